@@ -1,0 +1,599 @@
+// ba_device.cpp -- the seam between the BA C++ API and the HIP kernels.
+//
+// Everything here talks to the GPU only through the C-ABI of include/batotp_hip.h
+// (libbatotp_hip.so).  It covers the hot-path calls of the reference:
+//   * the final N->N spline build and the dynamics model of interpInputData
+//     (reference ba.cpp:299-305 -> evalSplineFullTraj ba.cpp:790-863, findDynModel ba.cpp:873-949),
+//   * sweep() (reference ba.cpp:979-1195),
+// plus the many-path extension optimizeBatch().  There is no host implementation to fall back to:
+// if the device layer fails the call returns -1 after printing the reason.
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+#include "ba.h"
+#include "batotp_hip.h"
+#include "util.h"
+
+namespace BATOTP
+{
+
+struct BA::Gpu
+{
+   batotp_ctx *ctx = nullptr;
+   ~Gpu()
+   {
+      if (ctx) batotp_hip_ctx_destroy(ctx);
+   }
+};
+
+namespace
+{
+// RAII for a device batch
+struct BatchGuard
+{
+   batotp_batch *b = nullptr;
+   ~BatchGuard()
+   {
+      if (b) batotp_hip_batch_destroy(b);
+   }
+};
+
+int fail(const char *what, int rc)
+{
+   printf("batotp device layer: %s failed (code %d) %s\n", what, rc, batotp_hip_last_error());
+   return -1;
+}
+
+void coeffsToVector(const Spline::splineCoeffs &C, size_t n, std::vector<double> &flat)
+{
+   flat.assign(4 * n, 0.0);
+   const std::vector<double> *src[4] = {&C.c0, &C.c1, &C.c2, &C.c3};
+   for (int k = 0; k < 4; ++k)
+   {
+      const size_t m = std::min(n, src[k]->size());
+      std::copy(src[k]->begin(), src[k]->begin() + m, flat.begin() + k * n);
+   }
+}
+
+void vectorToCoeffs(const std::vector<double> &flat, size_t n, Spline::splineCoeffs &C)
+{
+   C.c0.assign(flat.begin(), flat.begin() + n);
+   C.c1.assign(flat.begin() + n, flat.begin() + 2 * n);
+   C.c2.assign(flat.begin() + 2 * n, flat.begin() + 3 * n);
+   C.c3.assign(flat.begin() + 3 * n, flat.begin() + 4 * n);
+}
+} // namespace
+
+int BA::gpuAcquire()
+{
+   if (_gpu && _gpu->ctx) return 0;
+   _gpu = std::make_shared<Gpu>();
+   const int rc = batotp_hip_ctx_create(_deviceId, &_gpu->ctx);
+   if (rc != BATOTP_OK)
+   {
+      _gpu.reset();
+      printf("batotp: no usable HIP device (batotp_hip_ctx_create(%d) returned %d: %s).\n", _deviceId, rc,
+             batotp_hip_last_error());
+      printf("batotp: the sweep and the per-knot precompute run on the GPU only; there is no CPU fallback.\n");
+      return -1;
+   }
+   return 0;
+}
+
+// BA configuration -> the POD the kernels read
+void BA::fillProblem(void *out) const
+{
+   batotp_problem &P = *static_cast<batotp_problem *>(out);
+   std::memset(&P, 0, sizeof(P));
+   P.n_joints = (int32_t)_nJoints;
+   P.n_cart = (int32_t)_nCart;
+   P.robot_type = _robotType;
+   uint32_t f = 0;
+   if (_isJntAccConOn) f |= BATOTP_F_JNT_ACC_ON;
+   if (_isTrqConOn) f |= BATOTP_F_TRQ_ON;
+   if (_isCartVelConOn) f |= BATOTP_F_CART_VEL_ON;
+   if (_isCartAccConOn) f |= BATOTP_F_CART_ACC_ON;
+   if (_isParallelMechOrig) f |= BATOTP_F_PARALLEL;
+   if (_isPar2Ser) f |= BATOTP_F_PAR2SER;
+   if (_robotType == RR) f |= BATOTP_F_HOST_TRIG; // cos/sin from the host libm: bit parity with the reference
+   P.flags = f;
+   for (unsigned int j = 0; j < _nJoints && j < BATOTP_MAX_JOINTS; ++j)
+   {
+      if (j < _JntVelMax.size()) P.jnt_vel_max[j] = _JntVelMax[j];
+      if (j < _JntAccMax.size()) P.jnt_acc_max[j] = _JntAccMax[j];
+      if (j < _JntTrqMax.size()) P.jnt_trq_max[j] = _JntTrqMax[j];
+      if (j < _JntTrqMin.size()) P.jnt_trq_min[j] = _JntTrqMin[j];
+   }
+   P.cart_vel_max = _CartVelMax;
+   P.cart_acc_max = _CartAccMax;
+   P.jnt_thresh = _jntThresh;
+   P.quad_rad_thresh = _quadraticRadThresh;
+   P.integ_res = _integRes;
+   P.max_integ_time = _maxIntegTime;
+   if (_robotType == CSPR3DOF)
+   {
+      const std::vector<std::vector<double>> &A = const_cast<Robot &>(myRobot).cableAnchors();
+      for (int r = 0; r < 3; ++r)
+         for (int c = 0; c < 3; ++c) P.pmat[r * 3 + c] = A[r][c];
+   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// reference ba.cpp:299-305 on the GPU: evalSplineFullTraj(traj, sres, sres), sdot = DBL_MAX,
+// findDynModel
+// ---------------------------------------------------------------------------------------------
+int BA::deviceBuildKnotModel(Traj &traj)
+{
+   if (_nJoints > BATOTP_MAX_JOINTS || _nCart > BATOTP_MAX_CART)
+   {
+      printf("batotp: at most %d joints / %d Cartesian channels are supported on the device.\n",
+             BATOTP_MAX_JOINTS, BATOTP_MAX_CART);
+      return -1;
+   }
+   if (_isTrqConOn && !(_robotType == RR || _robotType == CSPR3DOF))
+   {
+      // the reference has no dynamics model for the other robots either (robot.cpp:349-360,452-463)
+      printf("No dynamics model provided for robotType=%s.\n", _robotTypeStr.c_str());
+      return -1;
+   }
+   if (gpuAcquire() != 0) return -1;
+
+   const int64_t N = traj.nPts;
+   if (N < 4)
+   {
+      printf("batotp: fewer than 4 knots after resampling.\n");
+      return -1;
+   }
+   const int nIn = (int)(_nJoints + _nCart);
+   batotp_problem prob;
+   fillProblem(&prob);
+
+   BatchGuard g;
+   int rc = batotp_hip_batch_create(_gpu->ctx, &prob, 1, &N, 4, &g.b);
+   if (rc) return fail("batch_create", rc);
+
+   std::vector<double> y((size_t)nIn * N, 0.0);
+   for (unsigned int j = 0; j < _nJoints; ++j) std::copy(traj.theta[j].begin(), traj.theta[j].begin() + N, y.begin() + (size_t)j * N);
+   for (unsigned int j = 0; j < _nCart; ++j)
+   {
+      if (j < traj.cart.size() && traj.cart[j].size() >= (size_t)N)
+         std::copy(traj.cart[j].begin(), traj.cart[j].begin() + N, y.begin() + (size_t)(_nJoints + j) * N);
+   }
+   const double sresIn = traj.sres;
+   rc = batotp_hip_upload_knots(g.b, 0, 1, y.data(), &sresIn);
+   if (rc) return fail("upload_knots", rc);
+   rc = batotp_hip_precompute(g.b, 1);
+   if (rc) return fail("precompute(kinematics)", rc);
+
+   // --- unmarshal what evalSplineFullTraj leaves in the Traj (reference ba.cpp:794-860) ---
+   traj.nPtsC = (int)N;
+   traj.sC.resize(N);
+   for (int64_t i = 0; i < N; ++i) traj.sC[i] = traj.sres * (double)i;
+   traj.sMVC.resize(N);
+   {
+      const double sScale = traj.sC[N - 1] / (double)(N - 1);
+      for (int64_t i = 0; i < N; ++i) traj.sMVC[i] = sScale * (double)i;
+   }
+   traj.sresC = traj.sres;
+   traj.vFact = 1 / traj.sresC;
+   traj.aFact = traj.vFact * traj.vFact;
+   traj.sres = sresIn * (double)(N - 1) / (double)(N - 1);
+   traj.nPts = (unsigned int)N;
+
+   std::vector<double> flat(4 * (size_t)N), samp(3 * (size_t)N);
+   traj.thetaC.resize(_nJoints);
+   traj.cartC.resize(_nCart);
+   traj.thetaD.resize(_nJoints);
+   traj.thetaD2.resize(_nJoints);
+   traj.cartD.resize(_nCart);
+   traj.cartD2.resize(_nCart);
+   traj.cart.resize(_nCart);
+   for (int ch = 0; ch < nIn; ++ch)
+   {
+      rc = batotp_hip_download_coeffs(g.b, 0, ch, flat.data());
+      if (rc) return fail("download_coeffs", rc);
+      rc = batotp_hip_download_samples(g.b, 0, ch, samp.data());
+      if (rc) return fail("download_samples", rc);
+      const bool isTheta = ch < (int)_nJoints;
+      const int j = isTheta ? ch : ch - (int)_nJoints;
+      vectorToCoeffs(flat, (size_t)N, isTheta ? traj.thetaC[j] : traj.cartC[j]);
+      std::vector<double> &v = isTheta ? traj.theta[j] : traj.cart[j];
+      std::vector<double> &vD = isTheta ? traj.thetaD[j] : traj.cartD[j];
+      std::vector<double> &vD2 = isTheta ? traj.thetaD2[j] : traj.cartD2[j];
+      v.assign(samp.begin(), samp.begin() + N);
+      vD.assign(samp.begin() + N, samp.begin() + 2 * N);
+      vD2.assign(samp.begin() + 2 * N, samp.begin() + 3 * N);
+   }
+   {
+      // the ptsOrig channel is bookkeeping of the resampler, nothing downstream reads it:
+      // kept on the host (reference ba.cpp:833,857-859)
+      mySpline.getSplineCoeffs(traj.ptsOrig, traj.ptsOrigC, "natural");
+      Spline::splineSegs where;
+      if (mySpline.findInterpSegs(traj.sC, traj.sMVC, where) == 0)
+      {
+         std::vector<double> d1, d2;
+         mySpline.interp1spline(traj.ptsOrig, d1, d2, traj.ptsOrigC, where, sresIn);
+      }
+   }
+   _isInterpolated = true;
+
+   // reference ba.cpp:300
+   traj.sdot.resize(traj.nPts, std::numeric_limits<double>::max());
+
+   if (!_isTrqConOn) return 0;
+
+   // --- findDynModel (reference ba.cpp:873-949) ---
+   _dynDim = _isParallelMech ? (int)_nCart : (int)_nJoints;
+   if (_isParallelMech)
+   {
+      traj.Apt.resize(_nCart);
+      for (unsigned int r = 0; r < _nCart; ++r) traj.Apt[r].resize(_nJoints);
+   }
+   traj.a1.resize(_dynDim); traj.a2.resize(_dynDim); traj.a3.resize(_dynDim); traj.a4.resize(_dynDim);
+   traj.a1C.resize(_dynDim); traj.a2C.resize(_dynDim); traj.a3C.resize(_dynDim); traj.a4C.resize(_dynDim);
+   traj.a1pt.resize(_dynDim); traj.a2pt.resize(_dynDim); traj.a3pt.resize(_dynDim); traj.a4pt.resize(_dynDim);
+
+   if (_robotType == RR)
+   {
+      // cos/sin of the knot samples with the host libm (reference robot.cpp:408-419), so that the
+      // device dynamics reproduce the reference bit for bit
+      std::vector<double> trig(4 * (size_t)N);
+      for (int64_t i = 0; i < N; ++i)
+      {
+         const double th1 = _DEG2RAD * traj.theta[0][i];
+         const double th2 = _DEG2RAD * traj.theta[1][i];
+         trig[i] = std::cos(th1);
+         trig[N + i] = std::cos(th2);
+         trig[2 * N + i] = std::cos(th1 + th2);
+         trig[3 * N + i] = sin(th2);
+      }
+      rc = batotp_hip_upload_rr_trig(g.b, 0, trig.data());
+      if (rc) return fail("upload_rr_trig", rc);
+   }
+   rc = batotp_hip_precompute(g.b, 2);
+   if (rc) return fail("precompute(dynamics)", rc);
+
+   std::vector<std::vector<double>> *ak[4] = {&traj.a1, &traj.a2, &traj.a3, &traj.a4};
+   std::vector<Spline::splineCoeffs> *akC[4] = {&traj.a1C, &traj.a2C, &traj.a3C, &traj.a4C};
+   for (int k = 0; k < 4; ++k)
+   {
+      for (int r = 0; r < _dynDim; ++r)
+      {
+         (*ak[k])[r].resize(N);
+         rc = batotp_hip_download_dyn(g.b, 0, k + 1, r, (*ak[k])[r].data());
+         if (rc) return fail("download_dyn", rc);
+         rc = batotp_hip_download_coeffs(g.b, 0, nIn + k * _dynDim + r, flat.data());
+         if (rc) return fail("download_coeffs(dyn)", rc);
+         vectorToCoeffs(flat, (size_t)N, (*akC[k])[r]);
+      }
+   }
+   if (_isParallelMech && _isPar2Ser) _isParallelMech = false; // reference ba.cpp:937
+   return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sweep (reference ba.cpp:979-1195) on the GPU, one path
+// ---------------------------------------------------------------------------------------------
+int BA::deviceSweep(Traj &traj)
+{
+   if (gpuAcquire() != 0) return -1;
+   const int64_t N = traj.nPtsC;
+   if (N < 2 || (int64_t)traj.sC.size() != N || traj.thetaC.size() < _nJoints)
+   {
+      printf("batotp: sweep() called on a trajectory without spline interpolants (call interpInputData first).\n");
+      return -1;
+   }
+   if (_integDir != 1 && _integDir != -1)
+   {
+      printf("batotp: setIntegDir() must be +1 or -1.\n");
+      return -1;
+   }
+
+   batotp_problem prob;
+   fillProblem(&prob);
+   const bool needCart = _isCartVelConOn || _isCartAccConOn;
+   const bool haveDyn = _isTrqConOn && traj.a1C.size() > 0;
+   prob.n_cart = needCart ? (int32_t)_nCart : 0;
+   if (!haveDyn) prob.flags &= ~(uint32_t)BATOTP_F_TRQ_ON;
+   if (needCart && traj.cartC.size() < _nCart)
+   {
+      printf("batotp: Cartesian constraints are on but the trajectory has no Cartesian interpolants.\n");
+      return -1;
+   }
+
+   const int64_t maxIntegSteps = (int64_t)std::floor(_maxIntegTime / _integRes) + 1;
+   const int64_t cap = maxIntegSteps + 2;
+
+   BatchGuard g;
+   int rc = batotp_hip_batch_create(_gpu->ctx, &prob, 1, &N, cap, &g.b);
+   if (rc) return fail("batch_create", rc);
+
+   rc = batotp_hip_upload_path_sites(g.b, 0, traj.sC.data(), traj.vFact, traj.aFact, _isParallelMech ? 1 : 0);
+   if (rc) return fail("upload_path_sites", rc);
+
+   std::vector<double> flat;
+   int ch = 0;
+   for (unsigned int j = 0; j < _nJoints; ++j, ++ch)
+   {
+      coeffsToVector(traj.thetaC[j], (size_t)N, flat);
+      rc = batotp_hip_upload_coeffs(g.b, 0, ch, flat.data());
+      if (rc) return fail("upload_coeffs(theta)", rc);
+   }
+   for (int j = 0; j < prob.n_cart; ++j, ++ch)
+   {
+      coeffsToVector(traj.cartC[j], (size_t)N, flat);
+      rc = batotp_hip_upload_coeffs(g.b, 0, ch, flat.data());
+      if (rc) return fail("upload_coeffs(cart)", rc);
+   }
+   if (haveDyn)
+   {
+      const int d = (int)traj.a1C.size();
+      const std::vector<Spline::splineCoeffs> *akC[4] = {&traj.a1C, &traj.a2C, &traj.a3C, &traj.a4C};
+      for (int k = 0; k < 4; ++k)
+         for (int r = 0; r < d; ++r, ++ch)
+         {
+            coeffsToVector((*akC[k])[r], (size_t)N, flat);
+            rc = batotp_hip_upload_coeffs(g.b, 0, ch, flat.data());
+            if (rc) return fail("upload_coeffs(dyn)", rc);
+         }
+   }
+   if (_integDir == 1)
+   {
+      if (traj.sMVC.size() < 2 || traj.sMVC.size() != traj.sdot.size() || traj.nPts != traj.sMVC.size())
+      {
+         printf("batotp: forward sweep needs the curve of the reverse sweep in traj.sMVC / traj.sdot.\n");
+         return -1;
+      }
+      rc = batotp_hip_upload_curve(g.b, 0, traj.sMVC.data(), traj.sdot.data(), (int64_t)traj.nPts);
+      if (rc) return fail("upload_curve", rc);
+   }
+
+   rc = batotp_hip_sweep(g.b, _integDir);
+   if (rc) return fail("sweep", rc);
+
+   batotp_path_result res;
+   rc = batotp_hip_get_results(g.b, &res);
+   if (rc) return fail("get_results", rc);
+
+   const bool fwd = (_integDir == 1);
+   const uint32_t status = fwd ? res.status_fwd : res.status_rev;
+   const int64_t nPts = fwd ? res.n_fwd : res.n_rev;
+   const int64_t steps = fwd ? res.steps_fwd : res.steps_rev;
+   const int nFailBisect = fwd ? res.n_bisect_fail_fwd : res.n_bisect_fail_rev;
+   const double tElapsed = fwd ? res.t_total : res.t_rev;
+
+   if (status & BATOTP_ST_MAX_INTEG_TIME)
+   {
+      printf("Error in sweep(): maxIntegTime of %.1f s was exceeded.\n", _maxIntegTime);
+      setErrorOptimization(MAX_INTEGRATION_TIME);
+      return -1;
+   }
+   if (status & (BATOTP_ST_CAPACITY | BATOTP_ST_NONFINITE))
+   {
+      printf("Error in sweep(): integration aborted on the device (status 0x%x).\n", status);
+      return -1;
+   }
+   if (nFailBisect > 0)
+   {
+      // the reference prints one message per failure and keeps integrating (ba.cpp:1307-1319)
+      printf("applyAccelConstraintsBisectionPt() error: %d point(s) did not respect accel constraints.\n", nFailBisect);
+   }
+
+   std::vector<double> sInteg((size_t)nPts), sdotInteg((size_t)nPts);
+   int64_t got = 0;
+   rc = batotp_hip_download_curve(g.b, 0, _integDir, sInteg.data(), sdotInteg.data(), nPts, &got);
+   if (rc || got != nPts) return fail("download_curve", rc);
+
+   printf("%s integ.: %4d steps; %5d ODE evals; %3d failed steps; traj time. %.3f sec.; avg. step size %f sec.\n",
+          fwd ? "fwd." : "rev.", (int)(steps + 1), (int)(4 * steps), 0, tElapsed, tElapsed / (double)(steps + 1));
+
+   // publish (reference ba.cpp:1154-1190)
+   std::vector<double> tInteg((size_t)nPts);
+   if (status & BATOTP_ST_SHORT)
+   {
+      const double tResNew = tElapsed / 3.;
+      for (int64_t k = 0; k < nPts; ++k) tInteg[k] = tResNew * (double)k;
+   }
+   else
+   {
+      for (int64_t k = 0; k < nPts; ++k) tInteg[k] = _integRes * (double)k;
+   }
+   traj.tTotalTraj = tElapsed;
+   if (is_sdotOut && traj.myMVChist.s.size() >= 2)
+   {
+      const int slot = _isLastSweep ? 1 : 0;
+      traj.myMVChist.s[slot] = sInteg;
+      traj.myMVChist.sdot[slot] = sdotInteg;
+      if (status & BATOTP_ST_SHORT)
+      {
+         // the reference stores the curve before the 4-point fix-up; with <4 points the history is
+         // not meaningful and is left as published
+      }
+   }
+   if (_isLastSweep) traj.tMVC = tInteg;
+   traj.sMVC = sInteg;
+   traj.sdot = sdotInteg;
+   traj.nPts = (unsigned int)nPts;
+   return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// extension: many independent paths, one device batch
+// ---------------------------------------------------------------------------------------------
+int BA::optimizeBatch(std::vector<Traj> &trajs)
+{
+   setErrorOptimization(NO_ERROR);
+   if (_isAutoIntegRes)
+   {
+      printf("optimizeBatch(): call setIsAutoIntegRes(false) first (one integration step per batch).\n");
+      return -1;
+   }
+   if (trajs.empty()) return 0;
+   if (gpuAcquire() != 0) return -1;
+
+   // host resampling of every path; the configuration fields it may rewrite are restored
+   // after each path so that all paths see the same problem
+   const std::vector<double> sWeights0 = _sWeights;
+   const int scaleType0 = _scaleType;
+   const unsigned int nCart0 = _nCart;
+   const bool par0 = _isParallelMech;
+   std::vector<int> ok(trajs.size(), 0);
+   std::vector<int64_t> nKnots;
+   std::vector<size_t> live;
+   unsigned int nCartRun = nCart0;
+   for (size_t p = 0; p < trajs.size(); ++p)
+   {
+      _sWeights = sWeights0; _scaleType = scaleType0; _nCart = nCart0; _isParallelMech = par0;
+      if (prepareKnots(trajs[p]) != 0 || trajs[p].nPts < 4) continue;
+      nCartRun = _nCart; // 6 -> 7 when poses were converted to quaternions
+      ok[p] = 1;
+      live.push_back(p);
+      nKnots.push_back((int64_t)trajs[p].nPts);
+   }
+   _nCart = nCartRun;
+   if (live.empty()) return (int)trajs.size();
+
+   batotp_problem prob;
+   fillProblem(&prob);
+   const int nIn = (int)(_nJoints + _nCart);
+   const int64_t maxIntegSteps = (int64_t)std::floor(_maxIntegTime / _integRes) + 1;
+   int64_t nMax = 0;
+   for (size_t k = 0; k < nKnots.size(); ++k) nMax = std::max(nMax, nKnots[k]);
+   const int64_t cap = std::min<int64_t>(maxIntegSteps + 2, 8 * nMax + 4096);
+
+   BatchGuard g;
+   int rc = batotp_hip_batch_create(_gpu->ctx, &prob, (int32_t)live.size(), nKnots.data(), cap, &g.b);
+   if (rc) return fail("batch_create", rc);
+
+   std::vector<double> y;
+   for (size_t k = 0; k < live.size(); ++k)
+   {
+      Traj &t = trajs[live[k]];
+      const int64_t N = nKnots[k];
+      y.assign((size_t)nIn * N, 0.0);
+      for (unsigned int j = 0; j < _nJoints; ++j) std::copy(t.theta[j].begin(), t.theta[j].begin() + N, y.begin() + (size_t)j * N);
+      for (unsigned int j = 0; j < _nCart && j < t.cart.size(); ++j)
+         if (t.cart[j].size() >= (size_t)N) std::copy(t.cart[j].begin(), t.cart[j].begin() + N, y.begin() + (size_t)(_nJoints + j) * N);
+      const double sres = t.sres;
+      rc = batotp_hip_upload_knots(g.b, (int32_t)k, 1, y.data(), &sres);
+      if (rc) return fail("upload_knots", rc);
+   }
+   rc = batotp_hip_precompute(g.b, 1);
+   if (rc) return fail("precompute(kinematics)", rc);
+   if (_isTrqConOn)
+   {
+      if (_robotType == RR)
+      {
+         std::vector<double> samp, trig;
+         for (size_t k = 0; k < live.size(); ++k)
+         {
+            const int64_t N = nKnots[k];
+            samp.resize(6 * (size_t)N);
+            trig.resize(4 * (size_t)N);
+            batotp_hip_download_samples(g.b, (int32_t)k, 0, samp.data());
+            batotp_hip_download_samples(g.b, (int32_t)k, 1, samp.data() + 3 * N);
+            for (int64_t i = 0; i < N; ++i)
+            {
+               const double th1 = _DEG2RAD * samp[i];
+               const double th2 = _DEG2RAD * samp[3 * N + i];
+               trig[i] = std::cos(th1);
+               trig[N + i] = std::cos(th2);
+               trig[2 * N + i] = std::cos(th1 + th2);
+               trig[3 * N + i] = sin(th2);
+            }
+            rc = batotp_hip_upload_rr_trig(g.b, (int32_t)k, trig.data());
+            if (rc) return fail("upload_rr_trig", rc);
+         }
+      }
+      rc = batotp_hip_precompute(g.b, 2);
+      if (rc) return fail("precompute(dynamics)", rc);
+   }
+   rc = batotp_hip_sweep(g.b, -1);
+   if (rc) return fail("sweep(-1)", rc);
+   rc = batotp_hip_sweep(g.b, +1);
+   if (rc) return fail("sweep(+1)", rc);
+
+   std::vector<batotp_path_result> res(live.size());
+   rc = batotp_hip_get_results(g.b, res.data());
+   if (rc) return fail("get_results", rc);
+
+   // unmarshal each path and finish it on the host
+   const double outRes0 = _outRes, outSmooth0 = _outSmoothFact;
+   std::vector<double> flat, samp;
+   for (size_t k = 0; k < live.size(); ++k)
+   {
+      Traj &t = trajs[live[k]];
+      const batotp_path_result &r = res[k];
+      const int64_t N = nKnots[k];
+      if ((r.status_rev | r.status_fwd) & (BATOTP_ST_MAX_INTEG_TIME | BATOTP_ST_CAPACITY | BATOTP_ST_NONFINITE))
+      {
+         if ((r.status_rev | r.status_fwd) & BATOTP_ST_MAX_INTEG_TIME) setErrorOptimization(MAX_INTEGRATION_TIME);
+         ok[live[k]] = 0;
+         continue;
+      }
+      const double sresIn = t.sres;
+      t.nPtsC = (int)N;
+      t.sC.resize(N);
+      for (int64_t i = 0; i < N; ++i) t.sC[i] = sresIn * (double)i;
+      t.sresC = sresIn;
+      t.vFact = 1 / t.sresC;
+      t.aFact = t.vFact * t.vFact;
+      t.thetaC.resize(_nJoints); t.cartC.resize(_nCart);
+      t.thetaD.resize(_nJoints); t.thetaD2.resize(_nJoints);
+      t.cartD.resize(_nCart); t.cartD2.resize(_nCart); t.cart.resize(_nCart);
+      flat.resize(4 * (size_t)N); samp.resize(3 * (size_t)N);
+      for (int ch = 0; ch < nIn; ++ch)
+      {
+         batotp_hip_download_coeffs(g.b, (int32_t)k, ch, flat.data());
+         batotp_hip_download_samples(g.b, (int32_t)k, ch, samp.data());
+         const bool isTheta = ch < (int)_nJoints;
+         const int j = isTheta ? ch : ch - (int)_nJoints;
+         vectorToCoeffs(flat, (size_t)N, isTheta ? t.thetaC[j] : t.cartC[j]);
+         (isTheta ? t.theta[j] : t.cart[j]).assign(samp.begin(), samp.begin() + N);
+         (isTheta ? t.thetaD[j] : t.cartD[j]).assign(samp.begin() + N, samp.begin() + 2 * N);
+         (isTheta ? t.thetaD2[j] : t.cartD2[j]).assign(samp.begin() + 2 * N, samp.begin() + 3 * N);
+      }
+      if (_isTrqConOn)
+      {
+         const int d = _isParallelMechOrig ? (int)_nCart : (int)_nJoints;
+         t.a1.assign(d, std::vector<double>()); t.a2 = t.a1; t.a3 = t.a1; t.a4 = t.a1;
+         if (_isParallelMechOrig)
+         {
+            t.Apt.resize(_nCart);
+            for (unsigned int q = 0; q < _nCart; ++q) t.Apt[q].resize(_nJoints);
+         }
+      }
+      t.sMVC.resize((size_t)r.n_fwd);
+      t.sdot.resize((size_t)r.n_fwd);
+      int64_t got = 0;
+      batotp_hip_download_curve(g.b, (int32_t)k, +1, t.sMVC.data(), t.sdot.data(), r.n_fwd, &got);
+      t.nPts = (unsigned int)r.n_fwd;
+      t.tTotalTraj = r.t_total;
+      t.tMVC.resize((size_t)r.n_fwd);
+      const double tStep = (r.status_fwd & BATOTP_ST_SHORT) ? r.t_total / 3. : _integRes;
+      for (int64_t i = 0; i < r.n_fwd; ++i) t.tMVC[i] = tStep * (double)i;
+      if (is_sdotOut)
+      {
+         t.myMVChist.s.assign(4, std::vector<double>());
+         t.myMVChist.sdot.assign(4, std::vector<double>());
+         t.myMVChist.s[0].resize((size_t)r.n_rev);
+         t.myMVChist.sdot[0].resize((size_t)r.n_rev);
+         batotp_hip_download_curve(g.b, (int32_t)k, -1, t.myMVChist.s[0].data(), t.myMVChist.sdot[0].data(), r.n_rev, &got);
+         t.myMVChist.s[1] = t.sMVC;
+         t.myMVChist.sdot[1] = t.sdot;
+      }
+      _outRes = outRes0;
+      _outSmoothFact = outSmooth0;
+      interpOutputData(t);
+   }
+   _outRes = outRes0;
+   _outSmoothFact = outSmooth0;
+   if (_isParallelMechOrig && _isPar2Ser && _isTrqConOn) _isParallelMech = false;
+
+   int failed = 0;
+   for (size_t p = 0; p < trajs.size(); ++p) failed += ok[p] ? 0 : 1;
+   return failed;
+}
+
+} // namespace BATOTP

@@ -1,0 +1,64 @@
+// robot.h -- the five built-in robot models of BA on the host side.
+//
+// Interface parity with reference batotp/robot.h:33-132: the robot/path id constants and the
+// public call_* methods of class Robot.  Host use: kinematics during path resampling
+// (BA::interpInputData / adjust_s) and torque recomputation in BA::interpOutputData.  The per-knot
+// dynamics of the hot path (dynRR, dynCSPR3DOF, setA) run on the GPU; this class only supplies
+// them to the host post-processing and hands the CSPR anchor matrix to the device problem.
+#ifndef BATOTP_AMD_ROBOT_H
+#define BATOTP_AMD_ROBOT_H
+
+#include <string>
+#include <vector>
+
+namespace BATOTP
+{
+
+// robot type
+static const int KUKA = 1;
+static const int UR = 2;
+static const int RR = 3;
+static const int CSPR3DOF = 4;
+static const int GENJNT = 5;
+
+// path type
+static const int JOINT = 1;
+static const int CART = 2;
+static const int BOTH = 3;
+
+class Robot
+{
+public:
+   typedef std::vector<std::vector<double>> Channels; // [channel][sample]
+
+   int call_set_robotType(const std::string &robotTypeStr);
+   int call_fwdKin(const Channels &theta, Channels &cart);
+   int call_invKin(Channels &theta, const Channels &cart);
+   int call_dynSerial(Channels &a1, Channels &a2, Channels &a3, Channels &a4,
+                      const Channels &theta, const Channels &thetaD, const Channels &thetaD2);
+   int call_dynParallel(Channels &a1, Channels &a2, Channels &a3, Channels &a4,
+                        const Channels &cart, const Channels &cartD, const Channels &cartD2);
+   int call_setA(const std::vector<double> &theta, const std::vector<double> &cart, Channels &A);
+
+   // extension: CSPR cable anchor matrix, row-major [3][3] (built on first use)
+   const std::vector<std::vector<double>> &cableAnchors();
+
+private:
+   int _kind = 0;
+   std::string _kindName;
+   Channels _anchors;
+
+   void kukaToolPoint(const Channels &theta, Channels &cart) const;
+   void planarRRToolPoint(const Channels &theta, Channels &cart) const;
+   void csprCableLengths(Channels &theta, const Channels &cart);
+   void buildCsprAnchors();
+   void planarRRDynamics(Channels &a1, Channels &a2, Channels &a3, Channels &a4,
+                         const Channels &theta, const Channels &thetaD,
+                         const Channels &thetaD2) const;
+   void csprDynamics(Channels &a1, Channels &a2, Channels &a3, Channels &a4, const Channels &cartD,
+                     const Channels &cartD2) const;
+};
+
+} // namespace BATOTP
+
+#endif // BATOTP_AMD_ROBOT_H

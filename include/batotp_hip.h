@@ -1,0 +1,193 @@
+/*
+ * batotp_hip.h -- C-ABI of the MI355X (gfx950) implementation of batotp's hot path:
+ * per-knot spline/dynamics precompute, per-knot max-admissible-sdot evaluation and the
+ * backward/forward constant-step sweep of (s, sdot) over a batch of independent paths.
+ *
+ * The reference (ebarnett2/batotp) has no FFI layer: its boundary is the C++ class BATOTP::BA
+ * (reference batotp/ba.h:168-255).  The host C++11 drop-in (batotp_amd/host/ba.h) keeps that
+ * class and calls the entry points below; nothing above this line of the stack knows about HIP.
+ * Every entry point takes plain pointers / sizes, returns an int status (BATOTP_OK == 0),
+ * never throws and never prints.
+ *
+ * Which reference routine each entry point replaces (file:line in /root/reference):
+ *   batotp_hip_precompute      BA::evalSplineFullTraj   batotp/ba.cpp:790-863  (final call, ba.cpp:299)
+ *                              Spline::getSplineCoeffs  batotp/spline.cpp:168-211
+ *                              Spline::solveTriDiagNatural batotp/spline.cpp:252-276
+ *                              Spline::findInterpSegs / interp1spline  spline.cpp:56-99,129-155
+ *                              BA::findDynModel         batotp/ba.cpp:873-949
+ *                              BA::dynCoeffs2Ser        batotp/ba.cpp:958-967
+ *                              Robot::dynRR / dynCSPR3DOF / setA  batotp/robot.cpp:377-431,487-517,534-558
+ *                              solveLinSys              batotp/util.cpp:413-442
+ *   batotp_hip_pointwise_mvc   BA::sdotLim + BA::applyAccelConstraintsBisectionPt evaluated at
+ *                              every knot               batotp/ba.cpp:1204-1236,1248-1332
+ *   batotp_hip_sweep           BA::sweep and everything it calls  batotp/ba.cpp:979-1195,
+ *                              1204-1236,1248-1332,1341-1413,1423-1439,1449-1581,1590-1652
+ *                              solveQuadratic           batotp/util.cpp:361-383
+ */
+#ifndef BATOTP_HIP_H
+#define BATOTP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BATOTP_MAX_JOINTS 8   /* lanes per path group; nJoints, dynDim <= 8            */
+#define BATOTP_MAX_CART   8   /* cart channels carried (only x,y,z enter constraints)   */
+
+/* status codes returned by every entry point */
+#define BATOTP_OK              0
+#define BATOTP_ERR_ARG        -1
+#define BATOTP_ERR_HIP        -2   /* a HIP runtime call failed; see batotp_hip_last_error */
+#define BATOTP_ERR_NO_DEVICE  -3
+#define BATOTP_ERR_STATE      -4   /* call sequence violated (e.g. sweep before precompute) */
+#define BATOTP_ERR_ALLOC      -5
+
+/* robot ids: reference batotp/robot.h:33-37 */
+#define BATOTP_ROBOT_KUKA     1
+#define BATOTP_ROBOT_UR       2
+#define BATOTP_ROBOT_RR       3
+#define BATOTP_ROBOT_CSPR3DOF 4
+#define BATOTP_ROBOT_GENJNT   5
+
+/* problem flags (reference BA private members, batotp/ba.h:262-302) */
+#define BATOTP_F_JNT_ACC_ON     (1u<<0)  /* _isJntAccConOn  */
+#define BATOTP_F_TRQ_ON         (1u<<1)  /* _isTrqConOn     */
+#define BATOTP_F_CART_VEL_ON    (1u<<2)  /* _isCartVelConOn */
+#define BATOTP_F_CART_ACC_ON    (1u<<3)  /* _isCartAccConOn */
+#define BATOTP_F_PARALLEL       (1u<<4)  /* _isParallelMechOrig: dynamics are A*tau = a1 sddot+... */
+#define BATOTP_F_PAR2SER        (1u<<5)  /* _isPar2Ser: convert a1..a4 with A^-1 per knot (ba.cpp:916-938) */
+#define BATOTP_F_HOST_TRIG      (1u<<6)  /* RR dynamics use host-supplied cos/sin (bit parity with glibc) */
+
+/* per-path status bits written by the sweep kernel (the reference only printf()s these) */
+#define BATOTP_ST_MAX_INTEG_TIME (1u<<0) /* ba.cpp:1117-1122 (MAX_INTEGRATION_TIME)        */
+#define BATOTP_ST_CAPACITY       (1u<<1) /* output capacity max_steps exhausted            */
+#define BATOTP_ST_BISECT_FAIL    (1u<<2) /* >=1 bisection failure, ba.cpp:1307-1319         */
+#define BATOTP_ST_NONFINITE      (1u<<3) /* NaN reached the segment search (reference would spin) */
+#define BATOTP_ST_SHORT          (1u<<4) /* nPts<4: re-interpolated to 4 points, ba.cpp:1171-1184 */
+#define BATOTP_ST_SEG_ERROR      (1u<<5) /* findInterpSegs division-by-zero error, spline.cpp:84-88 */
+
+/* Limits and switches shared by every path of a batch.
+ * Mirrors the subset of BA's private configuration the hot path reads (ba.h:262-302). */
+typedef struct batotp_problem {
+    int32_t  n_joints;                 /* _nJoints                                   */
+    int32_t  n_cart;                   /* cart channels uploaded (0 if none)         */
+    int32_t  robot_type;               /* BATOTP_ROBOT_*                             */
+    uint32_t flags;                    /* BATOTP_F_*                                 */
+    double   jnt_vel_max[BATOTP_MAX_JOINTS];  /* _JntVelMax */
+    double   jnt_acc_max[BATOTP_MAX_JOINTS];  /* _JntAccMax */
+    double   jnt_trq_max[BATOTP_MAX_JOINTS];  /* _JntTrqMax */
+    double   jnt_trq_min[BATOTP_MAX_JOINTS];  /* _JntTrqMin */
+    double   cart_vel_max;             /* _CartVelMax                                */
+    double   cart_acc_max;             /* _CartAccMax                                */
+    double   jnt_thresh;               /* _jntThresh                                 */
+    double   quad_rad_thresh;          /* _quadraticRadThresh = _cartThresh^2        */
+    double   integ_res;                /* _integRes  [s]                             */
+    double   max_integ_time;           /* _maxIntegTime [s]                          */
+    double   pmat[9];                  /* CSPR cable anchors, row-major [3][3] (robot.cpp:291-322) */
+} batotp_problem;
+
+/* per-path outcome of the two sweeps */
+typedef struct batotp_path_result {
+    double   t_rev;        /* traj.tTotalTraj after sweep(-1): integRes * steps (ba.cpp:1112,1156) */
+    double   t_total;      /* traj.tTotalTraj after sweep(+1)                               */
+    int64_t  n_rev;        /* points of the reverse curve (traj.nPts after sweep(-1))      */
+    int64_t  n_fwd;        /* points of the forward curve                                   */
+    int64_t  steps_rev;    /* integration steps taken (nPts-1 before the nPts<4 fix-up)     */
+    int64_t  steps_fwd;
+    uint32_t status_rev;   /* BATOTP_ST_*                                                   */
+    uint32_t status_fwd;
+    int32_t  n_bisect_fail_rev;
+    int32_t  n_bisect_fail_fwd;
+} batotp_path_result;
+
+typedef struct batotp_ctx   batotp_ctx;    /* one per GPU (device + stream)        */
+typedef struct batotp_batch batotp_batch;  /* B independent paths resident in HBM  */
+
+/* ---- device context --------------------------------------------------------------------- */
+int  batotp_hip_device_count(int *count);
+int  batotp_hip_ctx_create(int device, batotp_ctx **out);
+int  batotp_hip_ctx_destroy(batotp_ctx *ctx);
+/* message of the last HIP failure on this thread ("" if none) */
+const char *batotp_hip_last_error(void);
+/* device-side known-answer test of fp64 div / sqrt rounding (no contraction):
+ * computes q[i]=a[i]/b[i], r[i]=sqrt(a[i]), p[i]=a[i]*b[i]+q[i] on the GPU for n host values */
+int  batotp_hip_fp64_kat(batotp_ctx *ctx, int64_t n, const double *a, const double *b,
+                         double *q, double *r, double *p);
+
+/* ---- batch lifetime --------------------------------------------------------------------- */
+/* n_knots[b] = number of uniform-s knots of path b (>=4); max_steps = per-path capacity of each
+ * integrated curve (points).  Channels per path: n_joints theta + n_cart cart (+ 4*dynDim built
+ * on the device when BATOTP_F_TRQ_ON). */
+int  batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *prob, int32_t n_paths,
+                             const int64_t *n_knots, int64_t max_steps, batotp_batch **out);
+int  batotp_hip_batch_destroy(batotp_batch *batch);
+
+/* Upload the knot values of paths [path0, path0+n): for each path, channel-major doubles
+ * theta[n_joints][N] then cart[n_cart][N], paths concatenated; sres[n] = knot spacing
+ * (traj.sres at ba.cpp:299). */
+int  batotp_hip_upload_knots(batotp_batch *batch, int32_t path0, int32_t n,
+                             const double *y, const double *sres);
+/* same, from a device buffer (already resident in HBM) */
+int  batotp_hip_upload_knots_device(batotp_batch *batch, int32_t path0, int32_t n,
+                                    const double *y_dev, const double *sres_dev);
+/* RR only (BATOTP_F_HOST_TRIG): trig[4][N] = cos(th1), cos(th2), cos(th1+th2), sin(th2) of the
+ * knot samples of path p, evaluated with the host libm (robot.cpp:408-419). */
+int  batotp_hip_upload_rr_trig(batotp_batch *batch, int32_t path, const double *trig);
+
+/* Marshalling entry points used by BA::sweep (single path, B = 1), which like the reference reads
+ * whatever the caller left in the public Traj arrays (reference ba.h:140-152):
+ *   sites[N] = traj.sC, vfact/afact = traj.vFact/aFact, parallel_now = BA::_isParallelMech */
+int  batotp_hip_upload_path_sites(batotp_batch *batch, int32_t path, const double *sites,
+                                  double vfact, double afact, int32_t parallel_now);
+/* c[4][N] = c0,c1,c2,c3 of one channel (channel order as in batotp_hip_download_coeffs) */
+int  batotp_hip_upload_coeffs(batotp_batch *batch, int32_t path, int32_t channel, const double *c);
+/* the curve published by the reverse sweep (traj.sMVC / traj.sdot, n = traj.nPts) */
+int  batotp_hip_upload_curve(batotp_batch *batch, int32_t path, const double *s, const double *sdot,
+                             int64_t n);
+
+/* ---- the hot path ----------------------------------------------------------------------- */
+/* stage 1 = theta/cart spline coefficients + knot samples (evalSplineFullTraj);
+ * stage 2 = dynamics coefficients a1..a4 and their splines (findDynModel); stage 0 = both. */
+int  batotp_hip_precompute(batotp_batch *batch, int32_t stage);
+/* max admissible sdot and sddot interval at every knot (K3) */
+int  batotp_hip_pointwise_mvc(batotp_batch *batch);
+/* dir = -1: reverse sweep; dir = +1: forward sweep capped by the reverse curve */
+int  batotp_hip_sweep(batotp_batch *batch, int32_t dir);
+/* precompute + sweep(-1) + sweep(+1) */
+int  batotp_hip_optimize(batotp_batch *batch);
+int  batotp_hip_synchronize(batotp_ctx *ctx);
+
+/* ---- results ---------------------------------------------------------------------------- */
+int  batotp_hip_get_results(batotp_batch *batch, batotp_path_result *out /* [n_paths] */);
+/* which = -1 reverse curve, +1 forward curve; copies min(n, cap) points, *n = points available */
+int  batotp_hip_download_curve(batotp_batch *batch, int32_t path, int32_t which,
+                               double *s, double *sdot, int64_t cap, int64_t *n);
+/* spline coefficients of one channel of one path: c[4][N] (c0,c1,c2,c3).  Channel order:
+ * theta[0..nJ) cart[0..nC) a1[0..d) a2[0..d) a3[0..d) a4[0..d) */
+int  batotp_hip_download_coeffs(batotp_batch *batch, int32_t path, int32_t channel, double *c);
+/* knot samples value/first/second derivative of theta and cart channels: out[3][N] */
+int  batotp_hip_download_samples(batotp_batch *batch, int32_t path, int32_t channel, double *out);
+/* dynamics coefficients a_k (k=1..4) row r at the knots: out[N] */
+int  batotp_hip_download_dyn(batotp_batch *batch, int32_t path, int32_t k, int32_t row, double *out);
+/* K3 outputs of one path: sdot_max[N], sddot_l[N], sddot_h[N] (any pointer may be NULL) */
+int  batotp_hip_download_mvc(batotp_batch *batch, int32_t path, double *sdot_max,
+                             double *sddot_l, double *sddot_h);
+
+/* ---- plumbing for the Python / torch.distributed layer ---------------------------------- */
+/* device pointer + element count of the per-path result table (batotp_path_result[n_paths]) */
+int  batotp_hip_results_device_ptr(batotp_batch *batch, void **ptr, int64_t *bytes);
+/* Duration of the most recent launch of a kernel family, measured with HIP events on the
+ * stream the kernels were launched on.  which: 1 = precompute, 2 = pointwise_mvc,
+ * 3 = reverse sweep, 4 = forward sweep.  Synchronises on the stop event. */
+int  batotp_hip_last_kernel_ms(batotp_batch *batch, int32_t which, float *ms);
+/* bytes of HBM held by the batch */
+int  batotp_hip_batch_bytes(batotp_batch *batch, int64_t *bytes);
+/* tuning knob: lanes per path in the sweep kernel (8 or 16; default 8) */
+int  batotp_hip_set_sweep_group(batotp_ctx *ctx, int32_t lanes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BATOTP_HIP_H */

@@ -1,0 +1,312 @@
+/*
+ * abi_shim.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Implements the C-ABI of include/batotp_hip.h on top of the CPU oracle so that the host-side BA
+ * library (batotp_amd/host) can be exercised end to end on a machine without a GPU, and compared
+ * with the outputs of the reference itself (tests/test_reference_pin.py), and so that bench.py has
+ * a CPU baseline.  It is built only by oracle/Makefile into oracle/_build/ and linked only by test
+ * programs; the product links batotp_amd/csrc/libbatotp_hip.so instead and has no CPU path.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "batotp_hip.h"
+#include "batotp_oracle.h"
+
+struct batotp_ctx { int device; };
+
+struct batotp_batch {
+    batotp_problem prob;
+    int32_t n_paths;
+    int64_t cap;
+    bo_path **path;
+    double **in_y;       /* uploaded knot values per path */
+    double *in_sres;
+    double **trig;
+    double **rev_s, **rev_sd, **fwd_s, **fwd_sd;
+    batotp_path_result *res;
+    int kin_done;
+    float ms[5];
+};
+
+static double now_ms(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return 1e3 * (double)t.tv_sec + 1e-6 * (double)t.tv_nsec;
+}
+
+int batotp_hip_device_count(int *count) { if (count) *count = 1; return BATOTP_OK; }
+int batotp_hip_ctx_create(int device, batotp_ctx **out)
+{
+    if (!out) return BATOTP_ERR_ARG;
+    *out = (batotp_ctx *)calloc(1, sizeof(batotp_ctx));
+    (*out)->device = device;
+    return BATOTP_OK;
+}
+int batotp_hip_ctx_destroy(batotp_ctx *ctx) { free(ctx); return BATOTP_OK; }
+const char *batotp_hip_last_error(void) { return "(oracle shim)"; }
+int batotp_hip_fp64_kat(batotp_ctx *ctx, int64_t n, const double *a, const double *b, double *q, double *r, double *p)
+{
+    (void)ctx; (void)n; (void)a; (void)b; (void)q; (void)r; (void)p;
+    return BATOTP_ERR_NO_DEVICE;
+}
+int batotp_hip_synchronize(batotp_ctx *ctx) { (void)ctx; return BATOTP_OK; }
+int batotp_hip_set_sweep_group(batotp_ctx *ctx, int32_t lanes) { (void)ctx; (void)lanes; return BATOTP_OK; }
+
+int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *prob, int32_t n_paths,
+                            const int64_t *n_knots, int64_t max_steps, batotp_batch **out)
+{
+    batotp_batch *b;
+    int32_t p;
+    (void)ctx;
+    if (!prob || !n_knots || !out || n_paths < 1) return BATOTP_ERR_ARG;
+    b = (batotp_batch *)calloc(1, sizeof(*b));
+    b->prob = *prob;
+    b->n_paths = n_paths;
+    b->cap = max_steps;
+    b->path = (bo_path **)calloc((size_t)n_paths, sizeof(void *));
+    b->in_y = (double **)calloc((size_t)n_paths, sizeof(void *));
+    b->in_sres = (double *)calloc((size_t)n_paths, sizeof(double));
+    b->trig = (double **)calloc((size_t)n_paths, sizeof(void *));
+    b->rev_s = (double **)calloc((size_t)n_paths, sizeof(void *));
+    b->rev_sd = (double **)calloc((size_t)n_paths, sizeof(void *));
+    b->fwd_s = (double **)calloc((size_t)n_paths, sizeof(void *));
+    b->fwd_sd = (double **)calloc((size_t)n_paths, sizeof(void *));
+    b->res = (batotp_path_result *)calloc((size_t)n_paths, sizeof(batotp_path_result));
+    for (p = 0; p < n_paths; p++) {
+        if (n_knots[p] < 2) return BATOTP_ERR_ARG;
+        b->path[p] = bo_path_new(prob, n_knots[p]);
+        if (!b->path[p]) return BATOTP_ERR_ALLOC;
+    }
+    *out = b;
+    return BATOTP_OK;
+}
+
+int batotp_hip_batch_destroy(batotp_batch *b)
+{
+    int32_t p;
+    if (!b) return BATOTP_OK;
+    for (p = 0; p < b->n_paths; p++) {
+        bo_path_free(b->path[p]);
+        free(b->in_y[p]); free(b->trig[p]);
+        free(b->rev_s[p]); free(b->rev_sd[p]); free(b->fwd_s[p]); free(b->fwd_sd[p]);
+    }
+    free(b->path); free(b->in_y); free(b->in_sres); free(b->trig);
+    free(b->rev_s); free(b->rev_sd); free(b->fwd_s); free(b->fwd_sd); free(b->res);
+    free(b);
+    return BATOTP_OK;
+}
+
+int batotp_hip_upload_knots(batotp_batch *b, int32_t path0, int32_t n, const double *y, const double *sres)
+{
+    int32_t k;
+    const double *src = y;
+    if (!b || path0 < 0 || path0 + n > b->n_paths) return BATOTP_ERR_ARG;
+    for (k = 0; k < n; k++) {
+        bo_path *p = b->path[path0 + k];
+        size_t cnt = (size_t)(p->n_theta + p->n_cart) * (size_t)p->n;
+        free(b->in_y[path0 + k]);
+        b->in_y[path0 + k] = (double *)malloc(cnt * sizeof(double));
+        memcpy(b->in_y[path0 + k], src, cnt * sizeof(double));
+        b->in_sres[path0 + k] = sres[k];
+        src += cnt;
+    }
+    return BATOTP_OK;
+}
+int batotp_hip_upload_knots_device(batotp_batch *b, int32_t path0, int32_t n, const double *y, const double *sres)
+{
+    return batotp_hip_upload_knots(b, path0, n, y, sres);
+}
+int batotp_hip_upload_rr_trig(batotp_batch *b, int32_t path, const double *trig)
+{
+    size_t cnt;
+    if (!b || path < 0 || path >= b->n_paths) return BATOTP_ERR_ARG;
+    cnt = 4 * (size_t)b->path[path]->n;
+    free(b->trig[path]);
+    b->trig[path] = (double *)malloc(cnt * sizeof(double));
+    memcpy(b->trig[path], trig, cnt * sizeof(double));
+    return BATOTP_OK;
+}
+int batotp_hip_upload_path_sites(batotp_batch *b, int32_t path, const double *sites, double vfact, double afact, int32_t parallel_now)
+{
+    bo_path *p;
+    if (!b || path < 0 || path >= b->n_paths) return BATOTP_ERR_ARG;
+    p = b->path[path];
+    memcpy(p->sC, sites, sizeof(double) * (size_t)p->n);
+    p->vfact = vfact; p->afact = afact; p->parallel_now = parallel_now;
+    b->kin_done = 1;
+    return BATOTP_OK;
+}
+int batotp_hip_upload_coeffs(batotp_batch *b, int32_t path, int32_t channel, const double *c)
+{
+    bo_path *p;
+    if (!b || path < 0 || path >= b->n_paths) return BATOTP_ERR_ARG;
+    p = b->path[path];
+    if (channel < 0 || channel >= p->n_ch) return BATOTP_ERR_ARG;
+    memcpy(p->coef + (size_t)channel * 4 * (size_t)p->n, c, sizeof(double) * 4 * (size_t)p->n);
+    return BATOTP_OK;
+}
+static void set_curve(double **s, double **sd, int32_t path, const double *a, const double *c, int64_t n)
+{
+    free(s[path]); free(sd[path]);
+    s[path] = (double *)malloc(sizeof(double) * (size_t)n);
+    sd[path] = (double *)malloc(sizeof(double) * (size_t)n);
+    memcpy(s[path], a, sizeof(double) * (size_t)n);
+    memcpy(sd[path], c, sizeof(double) * (size_t)n);
+}
+int batotp_hip_upload_curve(batotp_batch *b, int32_t path, const double *s, const double *sdot, int64_t n)
+{
+    if (!b || path < 0 || path >= b->n_paths || n < 2) return BATOTP_ERR_ARG;
+    set_curve(b->rev_s, b->rev_sd, path, s, sdot, n);
+    b->res[path].n_rev = n;
+    return BATOTP_OK;
+}
+
+int batotp_hip_precompute(batotp_batch *b, int32_t stage)
+{
+    int32_t p;
+    double t0 = now_ms();
+    if (!b) return BATOTP_ERR_ARG;
+    for (p = 0; p < b->n_paths; p++) {
+        if (stage == 0 || stage == 1) {
+            if (!b->in_y[p]) return BATOTP_ERR_STATE;
+            if (bo_precompute_kin(&b->prob, b->path[p], b->in_y[p], b->in_sres[p]) != 0)
+                b->res[p].status_rev |= BATOTP_ST_SEG_ERROR;
+        }
+        if (stage == 0 || stage == 2) {
+            if (bo_precompute_dyn(&b->prob, b->path[p], b->trig[p]) != 0) return BATOTP_ERR_ARG;
+        }
+    }
+    b->kin_done = 1;
+    b->ms[1] = (float)(now_ms() - t0);
+    return BATOTP_OK;
+}
+
+int batotp_hip_pointwise_mvc(batotp_batch *b)
+{
+    int32_t p;
+    double t0 = now_ms();
+    if (!b || !b->kin_done) return BATOTP_ERR_STATE;
+    for (p = 0; p < b->n_paths; p++) bo_pointwise_mvc(&b->prob, b->path[p]);
+    b->ms[2] = (float)(now_ms() - t0);
+    return BATOTP_OK;
+}
+
+int batotp_hip_sweep(batotp_batch *b, int32_t dir)
+{
+    int32_t p;
+    double t0 = now_ms();
+    if (!b || !b->kin_done || (dir != 1 && dir != -1)) return BATOTP_ERR_STATE;
+    for (p = 0; p < b->n_paths; p++) {
+        double *s = (double *)malloc(sizeof(double) * (size_t)b->cap);
+        double *sd = (double *)malloc(sizeof(double) * (size_t)b->cap);
+        int64_t n = 0, steps = 0;
+        double T = 0;
+        uint32_t st = 0;
+        int32_t nf = 0;
+        batotp_path_result *r = &b->res[p];
+        if (dir == 1 && !b->rev_s[p]) { free(s); free(sd); return BATOTP_ERR_STATE; }
+        bo_sweep(&b->prob, b->path[p], dir, b->rev_s[p], b->rev_sd[p], r->n_rev, s, sd, b->cap, &n, &steps, &T, &st, &nf);
+        if (dir == -1) {
+            free(b->rev_s[p]); free(b->rev_sd[p]);
+            b->rev_s[p] = s; b->rev_sd[p] = sd;
+            r->n_rev = n; r->t_rev = T; r->status_rev = (r->status_rev & BATOTP_ST_SEG_ERROR) | st; r->n_bisect_fail_rev = nf;
+            r->steps_rev = steps;
+        } else {
+            free(b->fwd_s[p]); free(b->fwd_sd[p]);
+            b->fwd_s[p] = s; b->fwd_sd[p] = sd;
+            r->n_fwd = n; r->t_total = T; r->status_fwd = st; r->n_bisect_fail_fwd = nf;
+            r->steps_fwd = steps;
+        }
+    }
+    b->ms[dir == -1 ? 3 : 4] = (float)(now_ms() - t0);
+    return BATOTP_OK;
+}
+
+int batotp_hip_optimize(batotp_batch *b)
+{
+    int rc = batotp_hip_precompute(b, 0);
+    if (rc) return rc;
+    rc = batotp_hip_sweep(b, -1);
+    if (rc) return rc;
+    return batotp_hip_sweep(b, 1);
+}
+
+int batotp_hip_get_results(batotp_batch *b, batotp_path_result *out)
+{
+    if (!b || !out) return BATOTP_ERR_ARG;
+    memcpy(out, b->res, sizeof(batotp_path_result) * (size_t)b->n_paths);
+    return BATOTP_OK;
+}
+
+int batotp_hip_download_curve(batotp_batch *b, int32_t path, int32_t which, double *s, double *sdot, int64_t cap, int64_t *n)
+{
+    int64_t m, avail;
+    const double *ss, *sd;
+    if (!b || path < 0 || path >= b->n_paths) return BATOTP_ERR_ARG;
+    ss = which == 1 ? b->fwd_s[path] : b->rev_s[path];
+    sd = which == 1 ? b->fwd_sd[path] : b->rev_sd[path];
+    avail = which == 1 ? b->res[path].n_fwd : b->res[path].n_rev;
+    if (!ss) return BATOTP_ERR_STATE;
+    m = avail < cap ? avail : cap;
+    if (s) memcpy(s, ss, sizeof(double) * (size_t)m);
+    if (sdot) memcpy(sdot, sd, sizeof(double) * (size_t)m);
+    if (n) *n = avail;
+    return BATOTP_OK;
+}
+
+int batotp_hip_download_coeffs(batotp_batch *b, int32_t path, int32_t channel, double *c)
+{
+    bo_path *p;
+    if (!b || path < 0 || path >= b->n_paths) return BATOTP_ERR_ARG;
+    p = b->path[path];
+    if (channel < 0 || channel >= p->n_ch) return BATOTP_ERR_ARG;
+    memcpy(c, p->coef + (size_t)channel * 4 * (size_t)p->n, sizeof(double) * 4 * (size_t)p->n);
+    return BATOTP_OK;
+}
+int batotp_hip_download_samples(batotp_batch *b, int32_t path, int32_t channel, double *out)
+{
+    bo_path *p;
+    if (!b || path < 0 || path >= b->n_paths) return BATOTP_ERR_ARG;
+    p = b->path[path];
+    if (channel < 0 || channel >= p->n_theta + p->n_cart) return BATOTP_ERR_ARG;
+    memcpy(out, p->samp + (size_t)channel * 3 * (size_t)p->n, sizeof(double) * 3 * (size_t)p->n);
+    return BATOTP_OK;
+}
+int batotp_hip_download_dyn(batotp_batch *b, int32_t path, int32_t k, int32_t row, double *out)
+{
+    bo_path *p;
+    if (!b || path < 0 || path >= b->n_paths) return BATOTP_ERR_ARG;
+    p = b->path[path];
+    if (k < 1 || k > 4 || row < 0 || row >= p->dyn_dim) return BATOTP_ERR_ARG;
+    memcpy(out, p->dyn + ((size_t)(k - 1) * (size_t)p->dyn_dim + (size_t)row) * (size_t)p->n, sizeof(double) * (size_t)p->n);
+    return BATOTP_OK;
+}
+int batotp_hip_download_mvc(batotp_batch *b, int32_t path, double *sdot_max, double *sddot_l, double *sddot_h)
+{
+    bo_path *p;
+    size_t n;
+    if (!b || path < 0 || path >= b->n_paths) return BATOTP_ERR_ARG;
+    p = b->path[path]; n = (size_t)p->n;
+    if (sdot_max) memcpy(sdot_max, p->mvc, sizeof(double) * n);
+    if (sddot_l) memcpy(sddot_l, p->mvc + n, sizeof(double) * n);
+    if (sddot_h) memcpy(sddot_h, p->mvc + 2 * n, sizeof(double) * n);
+    return BATOTP_OK;
+}
+int batotp_hip_results_device_ptr(batotp_batch *b, void **ptr, int64_t *bytes)
+{
+    if (!b) return BATOTP_ERR_ARG;
+    if (ptr) *ptr = b->res;
+    if (bytes) *bytes = (int64_t)sizeof(batotp_path_result) * b->n_paths;
+    return BATOTP_OK;
+}
+int batotp_hip_last_kernel_ms(batotp_batch *b, int32_t which, float *ms)
+{
+    if (!b || which < 1 || which > 4 || !ms) return BATOTP_ERR_ARG;
+    *ms = b->ms[which];
+    return BATOTP_OK;
+}
+int batotp_hip_batch_bytes(batotp_batch *b, int64_t *bytes) { (void)b; if (bytes) *bytes = 0; return BATOTP_OK; }

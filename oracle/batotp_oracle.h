@@ -1,0 +1,93 @@
+/*
+ * batotp_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the batotp hot path (per-knot precompute, per-knot bisection and the
+ * reverse/forward sweep), written from scratch against the reference sources, every function
+ * citing the reference file:line it follows.  It exists to CHECK the HIP kernels:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call it.
+ * The product (batotp_amd/csrc, batotp_amd/host) never includes or links anything in oracle/.
+ *
+ * Pinning: see oracle/README.md -- the restatement is checked against the reference itself run in
+ * the build container (prebuilt /root/reference/bin/batest, real Eigen) on the five shipped
+ * examples and on synthetic inputs; fixtures are committed under tests/golden/.
+ *
+ * Arithmetic contract: IEEE-754 binary64, no FMA contraction (-ffp-contract=off), the reference's
+ * operation order.
+ */
+#ifndef BATOTP_ORACLE_H
+#define BATOTP_ORACLE_H
+
+#include <stdint.h>
+#include "batotp_hip.h" /* POD batotp_problem / batotp_path_result / flag macros only */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bo_path {
+    int64_t n;          /* knots (traj.nPtsC == traj.nPts at sweep entry)                 */
+    int32_t n_theta;    /* n_joints                                                       */
+    int32_t n_cart;     /* cart channels                                                  */
+    int32_t dyn_dim;    /* 0 if torque constraints off                                    */
+    int32_t n_ch;       /* n_theta + n_cart + 4*dyn_dim                                   */
+    int32_t parallel_now; /* _isParallelMech as seen by the sweep (cleared by par2ser)    */
+    double  sres_c;     /* traj.sresC                                                     */
+    double  sres;       /* traj.sres after evalSplineFullTraj (ba.cpp:798,818)            */
+    double  vfact;      /* 1/sresC                                                        */
+    double  afact;      /* vfact^2                                                        */
+    double *sC;         /* [n]  knot sites                                                */
+    double *sMVC;       /* [n]  output sites (ba.cpp:809-813)                             */
+    double *coef;       /* [n_ch][4][n]  c0,c1,c2,c3; row n-1 left 0 (spline.cpp:203-209) */
+    double *samp;       /* [n_theta+n_cart][3][n] value, d/ds, d2/ds2 at the sMVC sites   */
+    double *dyn;        /* [4][dyn_dim][n] a1..a4                                         */
+    double *mvc;        /* [3][n] pointwise sdot_max, sddotL, sddotH (bo_pointwise_mvc)   */
+} bo_path;
+
+/* allocate / free a path for problem prob with n knots */
+bo_path *bo_path_new(const batotp_problem *prob, int64_t n);
+void     bo_path_free(bo_path *p);
+
+/* Spline::getSplineCoeffs, "natural" and "clamped" (spline.cpp:168-211,225-243,252-276).
+ * c points to [4][n]. */
+void bo_spline_coeffs(const double *y, int64_t n, double *c, int clamped);
+/* Spline::findInterpSegs (spline.cpp:56-99); returns -1 on the division-by-zero error */
+int  bo_find_interp_segs(const double *a_in, int64_t n_in, const double *a_out, int64_t n_out,
+                         int32_t *seg, double *tau);
+/* Spline::interp1spline (spline.cpp:129-155) */
+void bo_interp1_spline(const double *c, int64_t n_c, const int32_t *seg, const double *tau,
+                       int64_t n_out, double tfact, double *b, double *bD, double *bD2);
+
+/* Robot::findCSPR3DOFpmat (robot.cpp:291-322), row-major [3][3] */
+void bo_cspr_pmat(double pmat[9]);
+/* solveLinSys, LU branch (util.cpp:413-442 -> Eigen PartialPivLU), dim <= 8 */
+void bo_solve_lin_sys(int dim, const double *A /* [dim][dim] row-major */, const double *b, double *x);
+/* solveQuadratic (util.cpp:361-383) */
+int  bo_solve_quadratic(double A, double B, double C, double *sol1, double *sol2);
+
+/* BA::evalSplineFullTraj as called at ba.cpp:299 (oldRes == newRes == sres):
+ * y = [n_theta+n_cart][n] knot values.  Fills sC, sMVC, coef (theta, cart), samp.  -1 on error. */
+int  bo_precompute_kin(const batotp_problem *prob, bo_path *p, const double *y, double sres);
+/* BA::findDynModel (ba.cpp:873-949): fills dyn and the a1..a4 channels of coef.
+ * trig: optional [4][n] host trig for RR (NULL -> libm). */
+int  bo_precompute_dyn(const batotp_problem *prob, bo_path *p, const double *trig);
+
+/* BA::sweep (ba.cpp:979-1195).  dir=-1 reverse / +1 forward.  For dir=+1, (mvc_s, mvc_sdot, n_mvc)
+ * is the curve published by the reverse sweep.  Output arrays have capacity cap points; ascending s.
+ * Returns 0, or -1 when the reference would return -1 (max integration time). */
+int  bo_sweep(const batotp_problem *prob, const bo_path *p, int dir,
+              const double *mvc_s, const double *mvc_sdot, int64_t n_mvc,
+              double *out_s, double *out_sdot, int64_t cap,
+              int64_t *n_out, int64_t *n_steps, double *t_total, uint32_t *status, int32_t *n_bisect_fail);
+
+/* sdotLim + applyAccelConstraintsBisectionPt at every knot (K3 definition) */
+void bo_pointwise_mvc(const batotp_problem *prob, bo_path *p);
+
+/* per-point known-answer hooks used by the tests: evaluate the constraint set at (s, sdot_in)
+ * from a cold cursor.  Outputs: sdot after sdotLim+bisection, sddotL, sddotH, nIter, rc. */
+void bo_point_eval(const batotp_problem *prob, const bo_path *p, int dir, double s, double sdot_in,
+                   double *sdot_out, double *sddot_l, double *sddot_h, int32_t *n_iter, int32_t *rc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
