@@ -1,0 +1,351 @@
+"""ctypes binding of the C-ABI in include/batotp_hip.h.
+
+The same binding serves two libraries with the same entry points:
+  * ``batotp_amd/csrc/libbatotp_hip.so`` -- the product (HIP kernels for gfx950);
+  * ``oracle/_build/libbatotp_oracle_abi.so`` -- the CPU oracle behind the same ABI, loaded ONLY
+    by tests, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg (see ``load_oracle``).
+
+Nothing in here falls back from one to the other: ``load_hip`` raises if the HIP library is
+missing or no GPU is usable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libbatotp_hip.so")
+ORACLE_ABI_LIB_PATH = os.path.join(_ROOT, "oracle", "_build", "libbatotp_oracle_abi.so")
+
+MAX_JOINTS = 8
+MAX_CART = 8
+
+# robot ids (reference batotp/robot.h:33-37)
+ROBOT_KUKA, ROBOT_UR, ROBOT_RR, ROBOT_CSPR3DOF, ROBOT_GENJNT = 1, 2, 3, 4, 5
+# problem flags
+F_JNT_ACC_ON, F_TRQ_ON, F_CART_VEL_ON, F_CART_ACC_ON = 1 << 0, 1 << 1, 1 << 2, 1 << 3
+F_PARALLEL, F_PAR2SER, F_HOST_TRIG = 1 << 4, 1 << 5, 1 << 6
+# per-path status bits
+ST_MAX_INTEG_TIME, ST_CAPACITY, ST_BISECT_FAIL = 1 << 0, 1 << 1, 1 << 2
+ST_NONFINITE, ST_SHORT, ST_SEG_ERROR = 1 << 3, 1 << 4, 1 << 5
+
+_d8 = C.c_double * 8
+
+
+class Problem(C.Structure):
+    """struct batotp_problem"""
+
+    _fields_ = [
+        ("n_joints", C.c_int32),
+        ("n_cart", C.c_int32),
+        ("robot_type", C.c_int32),
+        ("flags", C.c_uint32),
+        ("jnt_vel_max", _d8),
+        ("jnt_acc_max", _d8),
+        ("jnt_trq_max", _d8),
+        ("jnt_trq_min", _d8),
+        ("cart_vel_max", C.c_double),
+        ("cart_acc_max", C.c_double),
+        ("jnt_thresh", C.c_double),
+        ("quad_rad_thresh", C.c_double),
+        ("integ_res", C.c_double),
+        ("max_integ_time", C.c_double),
+        ("pmat", C.c_double * 9),
+    ]
+
+    @property
+    def dyn_dim(self) -> int:
+        if not (self.flags & F_TRQ_ON):
+            return 0
+        return self.n_cart if (self.flags & F_PARALLEL) else self.n_joints
+
+    @property
+    def n_channels(self) -> int:
+        return self.n_joints + self.n_cart + 4 * self.dyn_dim
+
+
+class PathResult(C.Structure):
+    """struct batotp_path_result"""
+
+    _fields_ = [
+        ("t_rev", C.c_double),
+        ("t_total", C.c_double),
+        ("n_rev", C.c_int64),
+        ("n_fwd", C.c_int64),
+        ("steps_rev", C.c_int64),
+        ("steps_fwd", C.c_int64),
+        ("status_rev", C.c_uint32),
+        ("status_fwd", C.c_uint32),
+        ("n_bisect_fail_rev", C.c_int32),
+        ("n_bisect_fail_fwd", C.c_int32),
+    ]
+
+
+RESULT_DTYPE = np.dtype(
+    [
+        ("t_rev", "<f8"), ("t_total", "<f8"), ("n_rev", "<i8"), ("n_fwd", "<i8"),
+        ("steps_rev", "<i8"), ("steps_fwd", "<i8"), ("status_rev", "<u4"), ("status_fwd", "<u4"),
+        ("n_bisect_fail_rev", "<i4"), ("n_bisect_fail_fwd", "<i4"),
+    ]
+)
+assert RESULT_DTYPE.itemsize == C.sizeof(PathResult)
+
+
+def make_problem(n_joints: int, n_cart: int = 0, robot_type: int = ROBOT_GENJNT, flags: int = 0,
+                 jnt_vel_max: Sequence[float] = (), jnt_acc_max: Sequence[float] = (),
+                 jnt_trq_max: Sequence[float] = (), jnt_trq_min: Sequence[float] = (),
+                 cart_vel_max: float = 0.0, cart_acc_max: float = 0.0, jnt_thresh: float = 1e-6,
+                 cart_thresh: float = 1e-6, integ_res: float = 0.01, max_integ_time: float = 6000.0,
+                 pmat: Optional[Sequence[float]] = None) -> Problem:
+    p = Problem()
+    p.n_joints, p.n_cart, p.robot_type, p.flags = n_joints, n_cart, robot_type, flags
+    for name, vals in (("jnt_vel_max", jnt_vel_max), ("jnt_acc_max", jnt_acc_max),
+                       ("jnt_trq_max", jnt_trq_max), ("jnt_trq_min", jnt_trq_min)):
+        arr = getattr(p, name)
+        for k, v in enumerate(vals):
+            arr[k] = float(v)
+    p.cart_vel_max, p.cart_acc_max = cart_vel_max, cart_acc_max
+    p.jnt_thresh = jnt_thresh
+    p.quad_rad_thresh = cart_thresh * cart_thresh  # reference ba.cpp:2048
+    p.integ_res, p.max_integ_time = integ_res, max_integ_time
+    if pmat is not None:
+        for k, v in enumerate(pmat):
+            p.pmat[k] = float(v)
+    return p
+
+
+class BatotpError(RuntimeError):
+    pass
+
+
+def _dptr(a: Optional[np.ndarray]):
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Library:
+    """One loaded implementation of the C-ABI."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise BatotpError(f"{path} is missing -- build it first (python -c 'import __graft_entry__ as g; g.build()')")
+        self.path = path
+        self.lib = C.CDLL(path)
+        L = self.lib
+        P, I32, I64, D = C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_double)
+        sig = {
+            "batotp_hip_device_count": [C.POINTER(C.c_int)],
+            "batotp_hip_ctx_create": [C.c_int, C.POINTER(P)],
+            "batotp_hip_ctx_destroy": [P],
+            "batotp_hip_fp64_kat": [P, I64, D, D, D, D, D],
+            "batotp_hip_batch_create": [P, C.POINTER(Problem), I32, C.POINTER(C.c_int64), I64, C.POINTER(P)],
+            "batotp_hip_batch_destroy": [P],
+            "batotp_hip_upload_knots": [P, I32, I32, D, D],
+            "batotp_hip_upload_knots_device": [P, I32, I32, P, D],
+            "batotp_hip_upload_rr_trig": [P, I32, D],
+            "batotp_hip_upload_path_sites": [P, I32, D, C.c_double, C.c_double, I32],
+            "batotp_hip_upload_coeffs": [P, I32, I32, D],
+            "batotp_hip_upload_curve": [P, I32, D, D, I64],
+            "batotp_hip_precompute": [P, I32],
+            "batotp_hip_pointwise_mvc": [P],
+            "batotp_hip_sweep": [P, I32],
+            "batotp_hip_optimize": [P],
+            "batotp_hip_synchronize": [P],
+            "batotp_hip_get_results": [P, C.c_void_p],
+            "batotp_hip_download_curve": [P, I32, I32, D, D, I64, C.POINTER(C.c_int64)],
+            "batotp_hip_download_coeffs": [P, I32, I32, D],
+            "batotp_hip_download_samples": [P, I32, I32, D],
+            "batotp_hip_download_dyn": [P, I32, I32, I32, D],
+            "batotp_hip_download_mvc": [P, I32, D, D, D],
+            "batotp_hip_results_device_ptr": [P, C.POINTER(P), C.POINTER(C.c_int64)],
+            "batotp_hip_last_kernel_ms": [P, I32, C.POINTER(C.c_float)],
+            "batotp_hip_batch_bytes": [P, C.POINTER(C.c_int64)],
+            "batotp_hip_set_sweep_group": [P, I32],
+        }
+        for name, argtypes in sig.items():
+            fn = getattr(L, name)  # raises AttributeError if the symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        L.batotp_hip_last_error.restype = C.c_char_p
+        L.batotp_hip_last_error.argtypes = []
+        self.symbols = sorted(list(sig) + ["batotp_hip_last_error"])
+
+    def check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.batotp_hip_last_error()
+            raise BatotpError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+    def device_count(self) -> int:
+        n = C.c_int(0)
+        self.lib.batotp_hip_device_count(C.byref(n))
+        return n.value
+
+
+class Context:
+    def __init__(self, library: Library, device: int = 0):
+        self.library = library
+        self.handle = C.c_void_p()
+        library.check(library.lib.batotp_hip_ctx_create(device, C.byref(self.handle)), "batotp_hip_ctx_create")
+
+    def close(self):
+        if self.handle:
+            self.library.lib.batotp_hip_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_sweep_group(self, lanes: int):
+        self.library.check(self.library.lib.batotp_hip_set_sweep_group(self.handle, lanes), "set_sweep_group")
+
+    def synchronize(self):
+        self.library.check(self.library.lib.batotp_hip_synchronize(self.handle), "synchronize")
+
+    def fp64_kat(self, a: np.ndarray, b: np.ndarray):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        q, r, p = np.empty_like(a), np.empty_like(a), np.empty_like(a)
+        self.library.check(self.library.lib.batotp_hip_fp64_kat(self.handle, a.size, _dptr(a), _dptr(b), _dptr(q), _dptr(r), _dptr(p)), "fp64_kat")
+        return q, r, p
+
+
+class Batch:
+    """B independent paths resident on one device."""
+
+    def __init__(self, ctx: Context, prob: Problem, n_knots: Sequence[int], max_steps: int):
+        self.ctx, self.lib, self.L = ctx, ctx.library.lib, ctx.library
+        self.prob = prob
+        self.n_knots = np.ascontiguousarray(n_knots, dtype=np.int64)
+        self.n_paths = int(self.n_knots.size)
+        self.max_steps = int(max_steps)
+        self.handle = C.c_void_p()
+        self.L.check(self.lib.batotp_hip_batch_create(ctx.handle, C.byref(prob), self.n_paths,
+                                                      self.n_knots.ctypes.data_as(C.POINTER(C.c_int64)), self.max_steps,
+                                                      C.byref(self.handle)), "batotp_hip_batch_create")
+
+    def close(self):
+        if self.handle:
+            self.lib.batotp_hip_batch_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- uploads -----------------------------------------------------------------------------
+    def upload_knots(self, path0: int, y_list: Sequence[np.ndarray], sres: Sequence[float]):
+        """y_list[k]: [n_joints+n_cart][N_k] knot values of path path0+k."""
+        flat = np.ascontiguousarray(np.concatenate([np.ascontiguousarray(y, dtype=np.float64).ravel() for y in y_list]))
+        sr = np.ascontiguousarray(sres, dtype=np.float64)
+        self.L.check(self.lib.batotp_hip_upload_knots(self.handle, path0, len(y_list), _dptr(flat), _dptr(sr)), "upload_knots")
+
+    def upload_knots_device(self, path0: int, n: int, dev_ptr: int, sres: Sequence[float]):
+        sr = np.ascontiguousarray(sres, dtype=np.float64)
+        self.L.check(self.lib.batotp_hip_upload_knots_device(self.handle, path0, n, C.c_void_p(dev_ptr), _dptr(sr)), "upload_knots_device")
+
+    def upload_rr_trig(self, path: int, trig: np.ndarray):
+        t = np.ascontiguousarray(trig, dtype=np.float64)
+        self.L.check(self.lib.batotp_hip_upload_rr_trig(self.handle, path, _dptr(t)), "upload_rr_trig")
+
+    def upload_path_sites(self, path: int, sites: np.ndarray, vfact: float, afact: float, parallel_now: int):
+        s = np.ascontiguousarray(sites, dtype=np.float64)
+        self.L.check(self.lib.batotp_hip_upload_path_sites(self.handle, path, _dptr(s), vfact, afact, parallel_now), "upload_path_sites")
+
+    def upload_coeffs(self, path: int, channel: int, c: np.ndarray):
+        a = np.ascontiguousarray(c, dtype=np.float64)
+        self.L.check(self.lib.batotp_hip_upload_coeffs(self.handle, path, channel, _dptr(a)), "upload_coeffs")
+
+    def upload_curve(self, path: int, s: np.ndarray, sdot: np.ndarray):
+        a = np.ascontiguousarray(s, dtype=np.float64)
+        b = np.ascontiguousarray(sdot, dtype=np.float64)
+        self.L.check(self.lib.batotp_hip_upload_curve(self.handle, path, _dptr(a), _dptr(b), a.size), "upload_curve")
+
+    # ---- hot path ----------------------------------------------------------------------------
+    def precompute(self, stage: int = 0):
+        self.L.check(self.lib.batotp_hip_precompute(self.handle, stage), "precompute")
+
+    def pointwise_mvc(self):
+        self.L.check(self.lib.batotp_hip_pointwise_mvc(self.handle), "pointwise_mvc")
+
+    def sweep(self, direction: int):
+        self.L.check(self.lib.batotp_hip_sweep(self.handle, direction), "sweep")
+
+    def optimize(self):
+        self.L.check(self.lib.batotp_hip_optimize(self.handle), "optimize")
+
+    # ---- results -----------------------------------------------------------------------------
+    def results(self) -> np.ndarray:
+        out = np.zeros(self.n_paths, dtype=RESULT_DTYPE)
+        self.L.check(self.lib.batotp_hip_get_results(self.handle, out.ctypes.data_as(C.c_void_p)), "get_results")
+        return out
+
+    def curve(self, path: int, which: int):
+        n = C.c_int64(0)
+        self.L.check(self.lib.batotp_hip_download_curve(self.handle, path, which, None, None, 0, C.byref(n)), "download_curve")
+        s = np.empty(max(n.value, 0)); sd = np.empty(max(n.value, 0))
+        if n.value > 0:
+            self.L.check(self.lib.batotp_hip_download_curve(self.handle, path, which, _dptr(s), _dptr(sd), n.value, C.byref(n)), "download_curve")
+        return s, sd
+
+    def coeffs(self, path: int, channel: int) -> np.ndarray:
+        out = np.empty((4, int(self.n_knots[path])))
+        self.L.check(self.lib.batotp_hip_download_coeffs(self.handle, path, channel, _dptr(out)), "download_coeffs")
+        return out
+
+    def samples(self, path: int, channel: int) -> np.ndarray:
+        out = np.empty((3, int(self.n_knots[path])))
+        self.L.check(self.lib.batotp_hip_download_samples(self.handle, path, channel, _dptr(out)), "download_samples")
+        return out
+
+    def dyn(self, path: int, k: int, row: int) -> np.ndarray:
+        out = np.empty(int(self.n_knots[path]))
+        self.L.check(self.lib.batotp_hip_download_dyn(self.handle, path, k, row, _dptr(out)), "download_dyn")
+        return out
+
+    def mvc(self, path: int):
+        n = int(self.n_knots[path])
+        a, b, c = np.empty(n), np.empty(n), np.empty(n)
+        self.L.check(self.lib.batotp_hip_download_mvc(self.handle, path, _dptr(a), _dptr(b), _dptr(c)), "download_mvc")
+        return a, b, c
+
+    def results_device_ptr(self):
+        ptr, nbytes = C.c_void_p(), C.c_int64(0)
+        self.L.check(self.lib.batotp_hip_results_device_ptr(self.handle, C.byref(ptr), C.byref(nbytes)), "results_device_ptr")
+        return ptr.value, nbytes.value
+
+    def kernel_ms(self, which: int) -> float:
+        ms = C.c_float(0)
+        self.L.check(self.lib.batotp_hip_last_kernel_ms(self.handle, which, C.byref(ms)), "last_kernel_ms")
+        return float(ms.value)
+
+    def nbytes(self) -> int:
+        n = C.c_int64(0)
+        self.L.check(self.lib.batotp_hip_batch_bytes(self.handle, C.byref(n)), "batch_bytes")
+        return n.value
+
+
+_hip_library: Optional[Library] = None
+
+
+def load_hip() -> Library:
+    """The product library.  Raises BatotpError when it has not been built."""
+    global _hip_library
+    if _hip_library is None:
+        _hip_library = Library(HIP_LIB_PATH)
+    return _hip_library
+
+
+def load_oracle() -> Library:
+    """TEST INFRASTRUCTURE: the CPU oracle behind the same ABI (tests / smoke / cpu_baseline only)."""
+    return Library(ORACLE_ABI_LIB_PATH)

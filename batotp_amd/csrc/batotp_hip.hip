@@ -1,0 +1,692 @@
+// batotp_hip.hip -- implementation of the C-ABI declared in include/batotp_hip.h for MI355X
+// (gfx950).  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see Makefile).
+// Host side: device context, batch memory management, launches, HIP-event timing.  The kernels
+// are in kernels.hip.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "batotp_hip.h"
+#include "kernels.hip.h"
+
+using namespace bk;
+
+// ---------------------------------------------------------------------------------------------
+// error bookkeeping
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int hipFail(hipError_t e, const char *what)
+{
+   snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+   return BATOTP_ERR_HIP;
+}
+#define HIP_TRY(call)                                              \
+   do                                                              \
+   {                                                               \
+      hipError_t e_ = (call);                                      \
+      if (e_ != hipSuccess) return hipFail(e_, #call);             \
+   } while (0)
+
+extern "C" const char *batotp_hip_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------
+// objects
+// ---------------------------------------------------------------------------------------------
+struct batotp_ctx
+{
+   int device = 0;
+   hipStream_t stream = nullptr;
+   int sweepGroup = 8;
+};
+
+struct batotp_batch
+{
+   batotp_ctx *ctx = nullptr;
+   batotp_problem prob;
+   DevProblem P;
+   int32_t B = 0;
+   int64_t cap = 0;
+   int64_t totalKnots = 0;
+   std::vector<PathInfo> pinfo; // host mirror
+   bool needPar = false;        // some path may run the parallel-mechanism torque branch
+   bool kinDone = false, dynDone = false, sitesSet = false, revDone = false, trigSet = false;
+
+   // device memory
+   DevProblem *dP = nullptr;
+   PathInfo *dPinfo = nullptr;
+   double *dY = nullptr, *dSC = nullptr, *dCoef = nullptr, *dSamp = nullptr, *dDyn = nullptr, *dTrig = nullptr, *dMvc = nullptr;
+   double2 *dRev = nullptr, *dFwd = nullptr;
+   batotp_path_result *dRes = nullptr;
+   double *dStage = nullptr; // staging for marshalling (4*maxN doubles)
+   int64_t maxN = 0;
+   int64_t bytes = 0;
+
+   hipEvent_t ev[5][2] = {};
+   bool evValid[5] = {};
+};
+
+static int devAlloc(batotp_batch *b, void **p, size_t bytes)
+{
+   if (bytes == 0) bytes = 8;
+   hipError_t e = hipMalloc(p, bytes);
+   if (e != hipSuccess) { hipFail(e, "hipMalloc"); return BATOTP_ERR_ALLOC; }
+   b->bytes += (int64_t)bytes;
+   return BATOTP_OK;
+}
+
+static int bind(batotp_ctx *ctx)
+{
+   HIP_TRY(hipSetDevice(ctx->device));
+   return BATOTP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device context
+// ---------------------------------------------------------------------------------------------
+extern "C" int batotp_hip_device_count(int *count)
+{
+   if (!count) return BATOTP_ERR_ARG;
+   int n = 0;
+   hipError_t e = hipGetDeviceCount(&n);
+   if (e != hipSuccess) { *count = 0; hipFail(e, "hipGetDeviceCount"); return BATOTP_ERR_NO_DEVICE; }
+   *count = n;
+   return BATOTP_OK;
+}
+
+static int uploadThomasTable()
+{
+   // super-diagonal of the eliminated (1,4,1) system, spline.cpp:256-266: c[1] = 1/4,
+   // c[i] = 1/(4 - c[i-1]); it reaches a fixed point in double precision after ~25 steps
+   double tab[64];
+   tab[0] = 0.0;
+   double c = 1.0;
+   c /= 4.0;
+   tab[1] = c;
+   int conv = -1;
+   for (int i = 2; i < 64; ++i)
+   {
+      double ci = 1.0;
+      ci /= 4.0 - 1.0 * tab[i - 1];
+      tab[i] = ci;
+      if (conv < 0 && tab[i] == tab[i - 1]) conv = i;
+   }
+   if (conv < 0 || conv > 60)
+   {
+      snprintf(g_err, sizeof(g_err), "Thomas coefficient table did not converge");
+      return BATOTP_ERR_STATE;
+   }
+   // verify it really is a fixed point (so that index 63 stands for every later row)
+   double chk = 1.0;
+   chk /= 4.0 - 1.0 * tab[63];
+   if (chk != tab[63])
+   {
+      snprintf(g_err, sizeof(g_err), "Thomas coefficient table is not a fixed point");
+      return BATOTP_ERR_STATE;
+   }
+   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_ctab), tab, sizeof(tab)));
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_ctx_create(int device, batotp_ctx **out)
+{
+   if (!out) return BATOTP_ERR_ARG;
+   *out = nullptr;
+   int n = 0;
+   hipError_t e = hipGetDeviceCount(&n);
+   if (e != hipSuccess || n <= 0)
+   {
+      snprintf(g_err, sizeof(g_err), "no HIP device (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+      return BATOTP_ERR_NO_DEVICE;
+   }
+   if (device < 0 || device >= n) return BATOTP_ERR_ARG;
+   batotp_ctx *c = new (std::nothrow) batotp_ctx;
+   if (!c) return BATOTP_ERR_ALLOC;
+   c->device = device;
+   e = hipSetDevice(device);
+   if (e != hipSuccess) { delete c; return hipFail(e, "hipSetDevice"); }
+   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+   if (e != hipSuccess) { delete c; return hipFail(e, "hipStreamCreate"); }
+   int rc = uploadThomasTable();
+   if (rc != BATOTP_OK) { hipStreamDestroy(c->stream); delete c; return rc; }
+   *out = c;
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_ctx_destroy(batotp_ctx *ctx)
+{
+   if (!ctx) return BATOTP_OK;
+   hipSetDevice(ctx->device);
+   if (ctx->stream) hipStreamDestroy(ctx->stream);
+   delete ctx;
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_synchronize(batotp_ctx *ctx)
+{
+   if (!ctx) return BATOTP_ERR_ARG;
+   int rc = bind(ctx);
+   if (rc) return rc;
+   HIP_TRY(hipStreamSynchronize(ctx->stream));
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_set_sweep_group(batotp_ctx *ctx, int32_t lanes)
+{
+   if (!ctx || !(lanes == 1 || lanes == 8 || lanes == 16)) return BATOTP_ERR_ARG;
+   ctx->sweepGroup = lanes;
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_fp64_kat(batotp_ctx *ctx, int64_t n, const double *a, const double *b, double *q, double *r, double *p)
+{
+   if (!ctx || n <= 0 || !a || !b || !q || !r || !p) return BATOTP_ERR_ARG;
+   int rc = bind(ctx);
+   if (rc) return rc;
+   double *d = nullptr;
+   const size_t sz = sizeof(double) * (size_t)n;
+   HIP_TRY(hipMalloc((void **)&d, 5 * sz));
+   hipMemcpyAsync(d, a, sz, hipMemcpyHostToDevice, ctx->stream);
+   hipMemcpyAsync(d + n, b, sz, hipMemcpyHostToDevice, ctx->stream);
+   const int bs = 256;
+   hipLaunchKernelGGL(k_kat, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, ctx->stream, n, d, d + n, d + 2 * n, d + 3 * n, d + 4 * n);
+   hipMemcpyAsync(q, d + 2 * n, sz, hipMemcpyDeviceToHost, ctx->stream);
+   hipMemcpyAsync(r, d + 3 * n, sz, hipMemcpyDeviceToHost, ctx->stream);
+   hipMemcpyAsync(p, d + 4 * n, sz, hipMemcpyDeviceToHost, ctx->stream);
+   hipError_t e = hipStreamSynchronize(ctx->stream);
+   hipFree(d);
+   if (e != hipSuccess) return hipFail(e, "fp64_kat");
+   return BATOTP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// batch lifetime
+// ---------------------------------------------------------------------------------------------
+static int dynDim(const batotp_problem *prob)
+{
+   if (!(prob->flags & BATOTP_F_TRQ_ON)) return 0;
+   return (prob->flags & BATOTP_F_PARALLEL) ? prob->n_cart : prob->n_joints; // ba.cpp:876-888
+}
+
+extern "C" int batotp_hip_batch_destroy(batotp_batch *b)
+{
+   if (!b) return BATOTP_OK;
+   if (b->ctx) hipSetDevice(b->ctx->device);
+   void *ptrs[] = {b->dP, b->dPinfo, b->dY, b->dSC, b->dCoef, b->dSamp, b->dDyn, b->dTrig, b->dMvc, b->dRev, b->dFwd, b->dRes, b->dStage};
+   for (void *p : ptrs)
+      if (p) hipFree(p);
+   for (int k = 0; k < 5; ++k)
+      for (int s = 0; s < 2; ++s)
+         if (b->ev[k][s]) hipEventDestroy(b->ev[k][s]);
+   delete b;
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *prob, int32_t n_paths, const int64_t *n_knots,
+                                       int64_t max_steps, batotp_batch **out)
+{
+   if (!ctx || !prob || !n_knots || !out || n_paths < 1 || max_steps < 4) return BATOTP_ERR_ARG;
+   *out = nullptr;
+   if (prob->n_joints < 1 || prob->n_joints > BATOTP_MAX_JOINTS || prob->n_cart < 0 || prob->n_cart > BATOTP_MAX_CART) return BATOTP_ERR_ARG;
+   const int d = dynDim(prob);
+   if (d != 0 && d != prob->n_joints) return BATOTP_ERR_ARG; // ba.cpp:940-946 iterates dynamics rows over nJoints
+   if ((prob->flags & (BATOTP_F_CART_VEL_ON | BATOTP_F_CART_ACC_ON)) && prob->n_cart < 3) return BATOTP_ERR_ARG;
+   if ((prob->flags & BATOTP_F_TRQ_ON) && (prob->flags & BATOTP_F_PARALLEL) && (prob->n_joints != 3 || prob->n_cart < 3)) return BATOTP_ERR_ARG;
+   int rc = bind(ctx);
+   if (rc) return rc;
+
+   batotp_batch *b = new (std::nothrow) batotp_batch;
+   if (!b) return BATOTP_ERR_ALLOC;
+   b->ctx = ctx;
+   b->prob = *prob;
+   b->B = n_paths;
+   b->cap = max_steps;
+   DevProblem &P = b->P;
+   memset(&P, 0, sizeof(P));
+   P.nJ = prob->n_joints; P.nC = prob->n_cart; P.d = d; P.robot = prob->robot_type;
+   P.flags = prob->flags;
+   P.Cin = P.nJ + P.nC;
+   P.C = P.Cin + 4 * d;
+   for (int k = 0; k < 8; ++k)
+   {
+      P.vmax[k] = prob->jnt_vel_max[k]; P.amax[k] = prob->jnt_acc_max[k];
+      P.tmax[k] = prob->jnt_trq_max[k]; P.tmin[k] = prob->jnt_trq_min[k];
+   }
+   P.cart_vel_max = prob->cart_vel_max; P.cart_acc_max = prob->cart_acc_max;
+   P.jnt_thresh = prob->jnt_thresh; P.quad_thresh = prob->quad_rad_thresh;
+   P.integ_res = prob->integ_res; P.max_integ_time = prob->max_integ_time;
+   for (int k = 0; k < 9; ++k) P.pmat[k] = prob->pmat[k];
+   b->needPar = (prob->flags & BATOTP_F_TRQ_ON) && (prob->flags & BATOTP_F_PARALLEL) && !(prob->flags & BATOTP_F_PAR2SER);
+
+   b->pinfo.resize(n_paths);
+   int64_t off = 0;
+   for (int p = 0; p < n_paths; ++p)
+   {
+      if (n_knots[p] < 2) { delete b; return BATOTP_ERR_ARG; }
+      PathInfo &pi = b->pinfo[p];
+      memset(&pi, 0, sizeof(pi));
+      pi.koff = off;
+      pi.n = n_knots[p];
+      pi.parallel_now = (prob->flags & BATOTP_F_PARALLEL) ? 1 : 0;
+      off += n_knots[p];
+      if (n_knots[p] > b->maxN) b->maxN = n_knots[p];
+   }
+   b->totalKnots = off;
+
+#define ALLOC(ptr, count, type)                                                        \
+   rc = devAlloc(b, (void **)&(ptr), sizeof(type) * (size_t)(count));                   \
+   if (rc) { batotp_hip_batch_destroy(b); return rc; }
+   ALLOC(b->dP, 1, DevProblem)
+   ALLOC(b->dPinfo, n_paths, PathInfo)
+   ALLOC(b->dY, off * P.Cin, double)
+   ALLOC(b->dSC, off, double)
+   ALLOC(b->dCoef, off * P.C * 4, double)
+   ALLOC(b->dSamp, off * P.Cin * 3, double)
+   ALLOC(b->dDyn, off * 4 * (d ? d : 0), double)
+   ALLOC(b->dTrig, (prob->robot_type == BATOTP_ROBOT_RR && d) ? off * 4 : 0, double)
+   ALLOC(b->dMvc, off * 3, double)
+   ALLOC(b->dRev, (int64_t)n_paths * max_steps, double2)
+   ALLOC(b->dFwd, (int64_t)n_paths * max_steps, double2)
+   ALLOC(b->dRes, n_paths, batotp_path_result)
+   ALLOC(b->dStage, 4 * b->maxN, double)
+#undef ALLOC
+   hipError_t e = hipMemcpyAsync(b->dP, &P, sizeof(P), hipMemcpyHostToDevice, ctx->stream);
+   if (e == hipSuccess) e = hipMemcpyAsync(b->dPinfo, b->pinfo.data(), sizeof(PathInfo) * n_paths, hipMemcpyHostToDevice, ctx->stream);
+   if (e == hipSuccess) e = hipMemsetAsync(b->dRes, 0, sizeof(batotp_path_result) * n_paths, ctx->stream);
+   if (e == hipSuccess) e = hipMemsetAsync(b->dCoef, 0, sizeof(double) * (size_t)(off * P.C * 4), ctx->stream);
+   for (int k = 0; k < 5 && e == hipSuccess; ++k)
+      for (int s = 0; s < 2 && e == hipSuccess; ++s) e = hipEventCreate(&b->ev[k][s]);
+   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+   if (e != hipSuccess) { batotp_hip_batch_destroy(b); return hipFail(e, "batch_create"); }
+   *out = b;
+   return BATOTP_OK;
+}
+
+static int pushPinfo(batotp_batch *b)
+{
+   HIP_TRY(hipMemcpyAsync(b->dPinfo, b->pinfo.data(), sizeof(PathInfo) * b->B, hipMemcpyHostToDevice, b->ctx->stream));
+   // the host vector may be modified again right after this call
+   HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+   return BATOTP_OK;
+}
+
+static void setSres(batotp_batch *b, int p, double sres)
+{
+   PathInfo &pi = b->pinfo[p];
+   const int64_t N = pi.n;
+   pi.sres_c = sres;                                        // ba.cpp:815
+   pi.vfact = 1 / pi.sres_c;                                // ba.cpp:816
+   pi.afact = pi.vfact * pi.vfact;                          // ba.cpp:817
+   pi.sres = sres * (double)(N - 1) / (double)(N - 1);      // ba.cpp:798,818 with nPtsNew == nPtsOld
+   pi.uniform = 1;
+}
+
+static int uploadKnotsImpl(batotp_batch *b, int32_t path0, int32_t n, const double *y, const double *sres, hipMemcpyKind kind)
+{
+   if (!b || !y || !sres || path0 < 0 || n < 1 || path0 + n > b->B) return BATOTP_ERR_ARG;
+   int rc = bind(b->ctx);
+   if (rc) return rc;
+   const int64_t first = b->pinfo[path0].koff;
+   const int64_t last = b->pinfo[path0 + n - 1].koff + b->pinfo[path0 + n - 1].n;
+   for (int k = 0; k < n; ++k)
+   {
+      if (b->pinfo[path0 + k].n < 4) return BATOTP_ERR_ARG;
+      setSres(b, path0 + k, sres[k]);
+   }
+   HIP_TRY(hipMemcpyAsync(b->dY + first * b->P.Cin, y, sizeof(double) * (size_t)((last - first) * b->P.Cin), kind, b->ctx->stream));
+   rc = pushPinfo(b);
+   b->kinDone = false; b->dynDone = false;
+   return rc;
+}
+
+extern "C" int batotp_hip_upload_knots(batotp_batch *b, int32_t path0, int32_t n, const double *y, const double *sres)
+{
+   return uploadKnotsImpl(b, path0, n, y, sres, hipMemcpyHostToDevice);
+}
+extern "C" int batotp_hip_upload_knots_device(batotp_batch *b, int32_t path0, int32_t n, const double *y_dev, const double *sres)
+{
+   return uploadKnotsImpl(b, path0, n, y_dev, sres, hipMemcpyDeviceToDevice);
+}
+
+extern "C" int batotp_hip_upload_rr_trig(batotp_batch *b, int32_t path, const double *trig)
+{
+   if (!b || !trig || path < 0 || path >= b->B || !b->dTrig || b->P.d == 0) return BATOTP_ERR_ARG;
+   int rc = bind(b->ctx);
+   if (rc) return rc;
+   const PathInfo &pi = b->pinfo[path];
+   HIP_TRY(hipMemcpyAsync(b->dTrig + pi.koff * 4, trig, sizeof(double) * 4 * (size_t)pi.n, hipMemcpyHostToDevice, b->ctx->stream));
+   HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+   b->trigSet = true;
+   return BATOTP_OK;
+}
+
+// ABI channel -> device channel (device order interleaves a1..a4 per dynamics row)
+static int devChannel(const batotp_batch *b, int ch)
+{
+   const int Cin = b->P.Cin, d = b->P.d;
+   if (ch < 0 || ch >= b->P.C) return -1;
+   if (ch < Cin) return ch;
+   const int k = (ch - Cin) / d, r = (ch - Cin) % d;
+   return Cin + r * 4 + k;
+}
+
+extern "C" int batotp_hip_upload_path_sites(batotp_batch *b, int32_t path, const double *sites, double vfact, double afact, int32_t parallel_now)
+{
+   if (!b || !sites || path < 0 || path >= b->B) return BATOTP_ERR_ARG;
+   int rc = bind(b->ctx);
+   if (rc) return rc;
+   PathInfo &pi = b->pinfo[path];
+   HIP_TRY(hipMemcpyAsync(b->dSC + pi.koff, sites, sizeof(double) * (size_t)pi.n, hipMemcpyHostToDevice, b->ctx->stream));
+   pi.vfact = vfact; pi.afact = afact;
+   pi.parallel_now = parallel_now;
+   pi.sres_c = sites[1] - sites[0];
+   pi.sres = pi.sres_c;
+   pi.uniform = 0;
+   if (parallel_now && (b->prob.flags & BATOTP_F_TRQ_ON))
+   {
+      if (b->P.nJ != 3 || b->P.nC < 3) return BATOTP_ERR_ARG;
+      b->needPar = true;
+   }
+   rc = pushPinfo(b);
+   b->sitesSet = true;
+   return rc;
+}
+
+extern "C" int batotp_hip_upload_coeffs(batotp_batch *b, int32_t path, int32_t channel, const double *c)
+{
+   if (!b || !c || path < 0 || path >= b->B) return BATOTP_ERR_ARG;
+   const int dc = devChannel(b, channel);
+   if (dc < 0) return BATOTP_ERR_ARG;
+   int rc = bind(b->ctx);
+   if (rc) return rc;
+   const PathInfo &pi = b->pinfo[path];
+   HIP_TRY(hipMemcpyAsync(b->dStage, c, sizeof(double) * 4 * (size_t)pi.n, hipMemcpyHostToDevice, b->ctx->stream));
+   const int bs = 256;
+   hipLaunchKernelGGL(k_coef_scatter, dim3((unsigned)((pi.n + bs - 1) / bs)), dim3(bs), 0, b->ctx->stream,
+                      b->dCoef + pi.koff * b->P.C * 4, b->P.C, dc, pi.n, b->dStage);
+   HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_upload_curve(batotp_batch *b, int32_t path, const double *s, const double *sdot, int64_t n)
+{
+   if (!b || !s || !sdot || path < 0 || path >= b->B || n < 2 || n > b->cap) return BATOTP_ERR_ARG;
+   int rc = bind(b->ctx);
+   if (rc) return rc;
+   double *tmp = nullptr;
+   HIP_TRY(hipMalloc((void **)&tmp, sizeof(double) * 2 * (size_t)n));
+   hipMemcpyAsync(tmp, s, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, b->ctx->stream);
+   hipMemcpyAsync(tmp + n, sdot, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, b->ctx->stream);
+   const int bs = 256;
+   hipLaunchKernelGGL(k_curve_pack, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, b->ctx->stream,
+                      b->dRev + (int64_t)path * b->cap + (b->cap - n), tmp, tmp + n, n);
+   // n_rev of the result row tells the forward kernel where the curve starts
+   batotp_path_result r;
+   hipMemcpyAsync(&r, b->dRes + path, sizeof(r), hipMemcpyDeviceToHost, b->ctx->stream);
+   hipError_t e = hipStreamSynchronize(b->ctx->stream);
+   if (e == hipSuccess)
+   {
+      r.n_rev = n;
+      e = hipMemcpy(b->dRes + path, &r, sizeof(r), hipMemcpyHostToDevice);
+   }
+   hipFree(tmp);
+   if (e != hipSuccess) return hipFail(e, "upload_curve");
+   b->revDone = true;
+   return BATOTP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the hot path
+// ---------------------------------------------------------------------------------------------
+static void evStart(batotp_batch *b, int which) { hipEventRecord(b->ev[which][0], b->ctx->stream); }
+static void evStop(batotp_batch *b, int which) { hipEventRecord(b->ev[which][1], b->ctx->stream); b->evValid[which] = true; }
+
+static int launchSpline(batotp_batch *b, int nch, int mode, const double *src, int64_t srcStridePerKnot)
+{
+   const int threads = b->B * nch;
+   const int bs = 64;
+   hipLaunchKernelGGL(k_spline, dim3((unsigned)((threads + bs - 1) / bs)), dim3(bs), 0, b->ctx->stream, b->dPinfo, b->B, nch, mode,
+                      b->P.C, b->P.Cin, b->P.d > 0 ? b->P.d : 1, src, srcStridePerKnot, b->dCoef);
+   HIP_TRY(hipGetLastError());
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_precompute(batotp_batch *b, int32_t stage)
+{
+   if (!b || stage < 0 || stage > 2) return BATOTP_ERR_ARG;
+   int rc = bind(b->ctx);
+   if (rc) return rc;
+   hipStream_t st = b->ctx->stream;
+   const int bs = 256;
+   const unsigned gridKnots = (unsigned)((b->totalKnots + bs - 1) / bs);
+   for (int p = 0; p < b->B; ++p)
+      if (b->pinfo[p].n < 4 || b->pinfo[p].sres_c == 0.0) return BATOTP_ERR_STATE; // knots not uploaded
+   if (stage == 0 || stage == 1) evStart(b, 1);
+   if (stage == 0 || stage == 1)
+   {
+      hipLaunchKernelGGL(k_sites, dim3(gridKnots), dim3(bs), 0, st, b->dPinfo, b->B, b->dSC, b->totalKnots);
+      rc = launchSpline(b, b->P.Cin, 0, b->dY, b->P.Cin);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_samples, dim3(gridKnots), dim3(bs), 0, st, b->dPinfo, b->B, b->P.C, b->P.Cin, b->dSC, b->dCoef, b->dSamp,
+                         b->dRes, b->totalKnots);
+      HIP_TRY(hipGetLastError());
+      b->kinDone = true;
+      b->sitesSet = true;
+   }
+   if ((stage == 0 || stage == 2) && b->P.d > 0)
+   {
+      if (!b->kinDone) return BATOTP_ERR_STATE;
+      if (!(b->prob.flags & BATOTP_F_PARALLEL) && b->prob.robot_type != BATOTP_ROBOT_RR) return BATOTP_ERR_ARG; // robot.cpp:349-360
+      if ((b->prob.flags & BATOTP_F_PARALLEL) && b->prob.robot_type != BATOTP_ROBOT_CSPR3DOF) return BATOTP_ERR_ARG; // robot.cpp:452-463
+      const bool hostTrig = (b->prob.flags & BATOTP_F_HOST_TRIG) && b->prob.robot_type == BATOTP_ROBOT_RR;
+      if (hostTrig && !b->trigSet) return BATOTP_ERR_STATE;
+      hipLaunchKernelGGL(k_dynamics, dim3(gridKnots), dim3(bs), 0, st, b->P, b->dP, b->dPinfo, b->B, b->dSamp,
+                         hostTrig ? b->dTrig : (const double *)nullptr, b->dDyn, b->totalKnots);
+      HIP_TRY(hipGetLastError());
+      rc = launchSpline(b, 4 * b->P.d, 1, b->dDyn, 4 * b->P.d);
+      if (rc) return rc;
+      if ((b->prob.flags & BATOTP_F_PARALLEL) && (b->prob.flags & BATOTP_F_PAR2SER))
+      {
+         for (int p = 0; p < b->B; ++p) b->pinfo[p].parallel_now = 0; // ba.cpp:937
+         rc = pushPinfo(b);
+         if (rc) return rc;
+      }
+      b->dynDone = true;
+   }
+   if (stage == 0 || stage == 1 || stage == 2) evStop(b, 1);
+   HIP_TRY(hipStreamSynchronize(st));
+   return BATOTP_OK;
+}
+
+static int readyForSweep(const batotp_batch *b)
+{
+   if (!b->sitesSet) return BATOTP_ERR_STATE;
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
+{
+   if (!b) return BATOTP_ERR_ARG;
+   int rc = readyForSweep(b);
+   if (rc) return rc;
+   rc = bind(b->ctx);
+   if (rc) return rc;
+   const int bs = 256;
+   const unsigned grid = (unsigned)((b->totalKnots + bs - 1) / bs);
+   evStart(b, 2);
+   if (b->needPar)
+      hipLaunchKernelGGL(k_pointwise<true>, dim3(grid), dim3(bs), 0, b->ctx->stream, b->P, b->dPinfo, b->B, b->dP, b->dSC, b->dCoef, b->dMvc, b->totalKnots);
+   else
+      hipLaunchKernelGGL(k_pointwise<false>, dim3(grid), dim3(bs), 0, b->ctx->stream, b->P, b->dPinfo, b->B, b->dP, b->dSC, b->dCoef, b->dMvc, b->totalKnots);
+   evStop(b, 2);
+   HIP_TRY(hipGetLastError());
+   HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+   return BATOTP_OK;
+}
+
+template <int G>
+static void launchSweep(batotp_batch *b, const SweepArgs &a)
+{
+   const int perBlock = 64 / G;
+   const unsigned grid = (unsigned)((b->B + perBlock - 1) / perBlock);
+   if (b->needPar) hipLaunchKernelGGL((k_sweep<G, true>), dim3(grid), dim3(64), 0, b->ctx->stream, a);
+   else hipLaunchKernelGGL((k_sweep<G, false>), dim3(grid), dim3(64), 0, b->ctx->stream, a);
+}
+
+extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
+{
+   if (!b || (dir != 1 && dir != -1)) return BATOTP_ERR_ARG;
+   int rc = readyForSweep(b);
+   if (rc) return rc;
+   if (dir == 1 && !b->revDone) return BATOTP_ERR_STATE;
+   rc = bind(b->ctx);
+   if (rc) return rc;
+   SweepArgs a;
+   a.P = b->P; a.dP = b->dP; a.pinfo = b->dPinfo; a.sC = b->dSC; a.coef = b->dCoef;
+   a.rev = b->dRev; a.fwd = b->dFwd; a.res = b->dRes; a.cap = b->cap; a.B = b->B; a.dir = dir;
+   const int which = dir == -1 ? 3 : 4;
+   evStart(b, which);
+   switch (b->ctx->sweepGroup)
+   {
+   case 1: launchSweep<1>(b, a); break;
+   case 16: launchSweep<16>(b, a); break;
+   default: launchSweep<8>(b, a); break;
+   }
+   evStop(b, which);
+   HIP_TRY(hipGetLastError());
+   HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+   if (dir == -1) b->revDone = true;
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_optimize(batotp_batch *b)
+{
+   int rc = batotp_hip_precompute(b, 0);
+   if (rc) return rc;
+   rc = batotp_hip_sweep(b, -1);
+   if (rc) return rc;
+   return batotp_hip_sweep(b, 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// results
+// ---------------------------------------------------------------------------------------------
+extern "C" int batotp_hip_get_results(batotp_batch *b, batotp_path_result *out)
+{
+   if (!b || !out) return BATOTP_ERR_ARG;
+   int rc = bind(b->ctx);
+   if (rc) return rc;
+   HIP_TRY(hipMemcpyAsync(out, b->dRes, sizeof(batotp_path_result) * b->B, hipMemcpyDeviceToHost, b->ctx->stream));
+   HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_download_curve(batotp_batch *b, int32_t path, int32_t which, double *s, double *sdot, int64_t cap, int64_t *n)
+{
+   if (!b || path < 0 || path >= b->B || (which != 1 && which != -1)) return BATOTP_ERR_ARG;
+   int rc = bind(b->ctx);
+   if (rc) return rc;
+   batotp_path_result r;
+   HIP_TRY(hipMemcpy(&r, b->dRes + path, sizeof(r), hipMemcpyDeviceToHost));
+   const int64_t avail = which == 1 ? r.n_fwd : r.n_rev;
+   if (n) *n = avail;
+   const int64_t m = avail < cap ? avail : cap;
+   if (m <= 0 || (!s && !sdot)) return BATOTP_OK;
+   const double2 *src = which == 1 ? b->dFwd + (int64_t)path * b->cap : b->dRev + (int64_t)path * b->cap + (b->cap - avail);
+   double *tmp = nullptr;
+   HIP_TRY(hipMalloc((void **)&tmp, sizeof(double) * 2 * (size_t)m));
+   const int bs = 256;
+   hipLaunchKernelGGL(k_curve_unpack, dim3((unsigned)((m + bs - 1) / bs)), dim3(bs), 0, b->ctx->stream, src, tmp, tmp + m, m);
+   if (s) hipMemcpyAsync(s, tmp, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, b->ctx->stream);
+   if (sdot) hipMemcpyAsync(sdot, tmp + m, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, b->ctx->stream);
+   hipError_t e = hipStreamSynchronize(b->ctx->stream);
+   hipFree(tmp);
+   if (e != hipSuccess) return hipFail(e, "download_curve");
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_download_coeffs(batotp_batch *b, int32_t path, int32_t channel, double *c)
+{
+   if (!b || !c || path < 0 || path >= b->B) return BATOTP_ERR_ARG;
+   const int dc = devChannel(b, channel);
+   if (dc < 0) return BATOTP_ERR_ARG;
+   int rc = bind(b->ctx);
+   if (rc) return rc;
+   const PathInfo &pi = b->pinfo[path];
+   const int bs = 256;
+   hipLaunchKernelGGL(k_coef_gather, dim3((unsigned)((pi.n + bs - 1) / bs)), dim3(bs), 0, b->ctx->stream,
+                      b->dCoef + pi.koff * b->P.C * 4, b->P.C, dc, pi.n, b->dStage);
+   HIP_TRY(hipMemcpyAsync(c, b->dStage, sizeof(double) * 4 * (size_t)pi.n, hipMemcpyDeviceToHost, b->ctx->stream));
+   HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_download_samples(batotp_batch *b, int32_t path, int32_t channel, double *out)
+{
+   if (!b || !out || path < 0 || path >= b->B || channel < 0 || channel >= b->P.Cin) return BATOTP_ERR_ARG;
+   int rc = bind(b->ctx);
+   if (rc) return rc;
+   const PathInfo &pi = b->pinfo[path];
+   HIP_TRY(hipMemcpyAsync(out, b->dSamp + pi.koff * b->P.Cin * 3 + (int64_t)channel * 3 * pi.n, sizeof(double) * 3 * (size_t)pi.n,
+                          hipMemcpyDeviceToHost, b->ctx->stream));
+   HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_download_dyn(batotp_batch *b, int32_t path, int32_t k, int32_t row, double *out)
+{
+   if (!b || !out || path < 0 || path >= b->B || k < 1 || k > 4 || row < 0 || row >= b->P.d) return BATOTP_ERR_ARG;
+   int rc = bind(b->ctx);
+   if (rc) return rc;
+   const PathInfo &pi = b->pinfo[path];
+   HIP_TRY(hipMemcpyAsync(out, b->dDyn + pi.koff * 4 * b->P.d + ((int64_t)(k - 1) * b->P.d + row) * pi.n, sizeof(double) * (size_t)pi.n,
+                          hipMemcpyDeviceToHost, b->ctx->stream));
+   HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_download_mvc(batotp_batch *b, int32_t path, double *sdot_max, double *sddot_l, double *sddot_h)
+{
+   if (!b || path < 0 || path >= b->B) return BATOTP_ERR_ARG;
+   int rc = bind(b->ctx);
+   if (rc) return rc;
+   const PathInfo &pi = b->pinfo[path];
+   const double *base = b->dMvc + pi.koff * 3;
+   const size_t sz = sizeof(double) * (size_t)pi.n;
+   if (sdot_max) HIP_TRY(hipMemcpyAsync(sdot_max, base, sz, hipMemcpyDeviceToHost, b->ctx->stream));
+   if (sddot_l) HIP_TRY(hipMemcpyAsync(sddot_l, base + pi.n, sz, hipMemcpyDeviceToHost, b->ctx->stream));
+   if (sddot_h) HIP_TRY(hipMemcpyAsync(sddot_h, base + 2 * pi.n, sz, hipMemcpyDeviceToHost, b->ctx->stream));
+   HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_results_device_ptr(batotp_batch *b, void **ptr, int64_t *bytes)
+{
+   if (!b) return BATOTP_ERR_ARG;
+   if (ptr) *ptr = b->dRes;
+   if (bytes) *bytes = (int64_t)sizeof(batotp_path_result) * b->B;
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_last_kernel_ms(batotp_batch *b, int32_t which, float *ms)
+{
+   if (!b || !ms || which < 1 || which > 4) return BATOTP_ERR_ARG;
+   if (!b->evValid[which]) return BATOTP_ERR_STATE;
+   int rc = bind(b->ctx);
+   if (rc) return rc;
+   HIP_TRY(hipEventSynchronize(b->ev[which][1]));
+   HIP_TRY(hipEventElapsedTime(ms, b->ev[which][0], b->ev[which][1]));
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_batch_bytes(batotp_batch *b, int64_t *bytes)
+{
+   if (!b || !bytes) return BATOTP_ERR_ARG;
+   *bytes = b->bytes;
+   return BATOTP_OK;
+}

@@ -1,0 +1,1133 @@
+// kernels.hip.h -- the gfx950 kernels of the batotp hot path (included by batotp_hip.hip).
+//
+//   k_sites / k_spline / k_samples / k_dynamics   per-knot precompute (K1, K2)
+//   k_pointwise                                    per-knot max admissible sdot (K3)
+//   k_sweep<G>                                     reverse / forward sweep, G lanes per path (K4)
+//
+// Reference routines restated here (file:line under /root/reference/batotp):
+//   Spline::getSplineCoeffs spline.cpp:168-211, solveTriDiagNatural spline.cpp:252-276,
+//   findInterpSegs spline.cpp:56-99, interp1spline spline.cpp:129-155,
+//   BA::evalSplineFullTraj ba.cpp:790-863, BA::findDynModel ba.cpp:873-949,
+//   Robot::dynRR robot.cpp:377-431, dynCSPR3DOF robot.cpp:487-517, setA robot.cpp:534-558,
+//   solveLinSys util.cpp:413-442 (Eigen PartialPivLU), solveQuadratic util.cpp:361-383,
+//   BA::sweep ba.cpp:979-1195, sdotLim ba.cpp:1204-1236, applyAccelConstraintsBisectionPt
+//   ba.cpp:1248-1332, evalSplinePartials ba.cpp:1341-1413, evalCartQuadCoeffs ba.cpp:1423-1439,
+//   verifySecondOrderConstraints ba.cpp:1449-1581, evalsdot ba.cpp:1590-1607,
+//   updateCurSeg ba.cpp:1617-1652.
+//
+// Data layout in HBM (all fp64), per path p with N knots starting at knot offset koff:
+//   yin   [Cin][N]          uploaded knot values, channel-major
+//   sC    [N]               knot sites
+//   coef  [N][C][4]         spline coefficients c0..c3, knot-major / channel-interleaved: the lanes
+//                           of a path group read 32 contiguous bytes each, C*32 contiguous bytes per
+//                           group and segment.  Device channel order: theta[nJ], cart[nC], then per
+//                           dynamics row r the four channels (a1_r, a2_r, a3_r, a4_r).
+//   samp  [Cin][3][N]       value, d/ds, d2/ds2 at the output sites
+//   dyn   [4][d][N]         a1..a4 at the knots
+//   curve [cap] double2     (s, sdot) of a sweep; the reverse sweep fills its curve from the end so
+//                           that it is ascending in s, as the reference leaves it after std::reverse
+#pragma once
+#include <stdint.h>
+#include "batotp_hip.h"
+#include "device_math.h"
+
+namespace bk
+{
+
+struct DevProblem
+{
+   int nJ, nC, d, robot;
+   unsigned flags;
+   int C;      // channels per knot in coef
+   int Cin;    // nJ + nC
+   int pad;
+   double vmax[8], amax[8], tmax[8], tmin[8];
+   double cart_vel_max, cart_acc_max, jnt_thresh, quad_thresh, integ_res, max_integ_time;
+   double pmat[9];
+};
+
+struct PathInfo
+{
+   int64_t koff;  // first knot of this path in the per-knot arrays
+   int64_t n;     // knots
+   double sres_c; // traj.sresC
+   double sres;   // traj.sres after evalSplineFullTraj
+   double vfact, afact;
+   int32_t parallel_now; // BA::_isParallelMech as seen by the sweep
+   int32_t uniform;      // sC[i] == sres_c * i exactly (sites can be computed instead of loaded)
+};
+
+struct alignas(32) Coef4
+{
+   double c0, c1, c2, c3;
+};
+
+__constant__ double c_ctab[64]; // Thomas super-diagonal c[i] of the (1,4,1) system; constant from c_conv on
+
+// ---------------------------------------------------------------------------------------------
+// K0: knot sites sC[i] = sres * i  (ba.cpp:800-806)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_sites(const PathInfo *__restrict__ pinfo, int B, double *__restrict__ sC, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   // locate the path by binary search over koff
+   int lo = 0, hi = B - 1;
+   while (lo < hi)
+   {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pinfo[mid].koff <= g) lo = mid; else hi = mid - 1;
+   }
+   const int64_t i = g - pinfo[lo].koff;
+   sC[g] = pinfo[lo].sres_c * (double)i;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: natural-spline coefficients of one channel per thread (Thomas recurrence is sequential in
+// the knot index; all channels of all paths run in parallel).
+// src: channel-major values; mode 0: yin channels (dev channel = c), mode 1: dyn channels
+// (c = k*d + r  ->  dev channel Cin + r*4 + k).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void emit_segment(double *__restrict__ cf, int64_t i, int C, int dc, double solL, double solR,
+                                             double yL, double yR)
+{
+   Coef4 o;
+   o.c3 = (solR - solL) / 6.0;
+   o.c2 = solL / 2.0;
+   o.c1 = yR - yL - (solR + 2 * solL) / 6.0;
+   o.c0 = yL;
+   *reinterpret_cast<Coef4 *>(cf + (i * C + dc) * 4) = o;
+}
+
+__global__ void k_spline(const PathInfo *__restrict__ pinfo, int B, int nch, int mode, int C, int Cin, int d,
+                         const double *__restrict__ src, int64_t src_stride_per_knot, double *__restrict__ coef)
+{
+   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+   if (t >= B * nch) return;
+   const int p = t / nch, c = t - p * nch;
+   const PathInfo pi = pinfo[p];
+   const int64_t N = pi.n;
+   const double *__restrict__ y = src + pi.koff * src_stride_per_knot + (int64_t)c * N;
+   double *__restrict__ cf = coef + pi.koff * C * 4;
+   const int dc = (mode == 0) ? c : (Cin + (c % d) * 4 + (c / d));
+   const int64_t n = N - 1;
+   const int conv = 63;
+
+   // forward elimination; d[i] parked in the c3 slot of knot i (spline.cpp:259-269)
+   double dprev = (6 * (y[0] - 2 * y[1] + y[2])) / 4.0;
+   cf[(1 * (int64_t)C + dc) * 4 + 3] = dprev;
+   double ym = y[1], y0 = y[2];
+   for (int64_t i = 2; i < n; ++i)
+   {
+      const double yp = y[i + 1];
+      const double rhs = 6 * (ym - 2 * y0 + yp);
+      const double cprev = c_ctab[(i - 1) < conv ? (i - 1) : conv];
+      const double di = (rhs - 1.0 * dprev) / (4.0 - 1.0 * cprev);
+      cf[(i * C + dc) * 4 + 3] = di;
+      dprev = di;
+      ym = y0; y0 = yp;
+   }
+   const double cl = c_ctab[(n - 1) < conv ? (n - 1) : conv];
+   double solR = (0.0 - 1.0 * dprev) / (4.0 - 1.0 * cl); // spline.cpp:269 (not forced to zero)
+
+   // row of the last knot stays zero (spline.cpp:203-209 never writes it)
+   Coef4 z; z.c0 = 0; z.c1 = 0; z.c2 = 0; z.c3 = 0;
+   *reinterpret_cast<Coef4 *>(cf + (n * C + dc) * 4) = z;
+
+   // back substitution fused with the coefficient formulas (spline.cpp:271-274, 203-209)
+   double yR = y[n];
+   for (int64_t i = n; i > 1; --i)
+   {
+      const double dcur = cf[((i - 1) * C + dc) * 4 + 3];
+      const double ci = c_ctab[(i - 1) < conv ? (i - 1) : conv];
+      const double solL = dcur - ci * solR;
+      const double yL = y[i - 1];
+      emit_segment(cf, i - 1, C, dc, solL, solR, yL, yR);
+      solR = solL;
+      yR = yL;
+   }
+   emit_segment(cf, 0, C, dc, 0.0, solR, y[0], yR);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2a: value / first / second derivative of every input channel at the output sites
+// sMVC[i] = sScale*i (ba.cpp:809-813, spline.cpp:56-99,129-155).  One thread per knot.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_samples(const PathInfo *__restrict__ pinfo, int B, int C, int Cin, const double *__restrict__ sC,
+                          const double *__restrict__ coef, double *__restrict__ samp, batotp_path_result *__restrict__ res,
+                          int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   int lo = 0, hi = B - 1;
+   while (lo < hi)
+   {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pinfo[mid].koff <= g) lo = mid; else hi = mid - 1;
+   }
+   const PathInfo pi = pinfo[lo];
+   const int64_t N = pi.n, i = g - pi.koff;
+   const double *__restrict__ s = sC + pi.koff;
+
+   // findInterpSegs aborts when two knots coincide (spline.cpp:81-89)
+   if (i < N - 1 && (s[i + 1] - s[i]) < 1e-20) atomicOr(&res[lo].status_rev, (unsigned)BATOTP_ST_SEG_ERROR);
+
+   const double sScale = s[N - 1] / (double)(N - 1);
+   const double site = sScale * (double)i;
+   // segment = first k with site < s[k+1], clipped to N-2 (cursor search of spline.cpp:70-79)
+   int64_t seg = (i < N - 1) ? i : N - 2;
+   while (seg > 0 && site < s[seg]) --seg;
+   while (seg < N - 2 && !(site < s[seg + 1])) ++seg;
+   const double tau = (site - s[seg]) / (s[seg + 1] - s[seg]);
+   const double tau2 = tau * tau, tau3 = tau2 * tau;
+   const double vfact = 1.0 / pi.sres_c;
+   const double afact = vfact * vfact;
+
+   const double *__restrict__ cf = coef + (pi.koff + seg) * C * 4;
+   double *__restrict__ o = samp + pi.koff * Cin * 3;
+   for (int c = 0; c < Cin; ++c)
+   {
+      const Coef4 k = *reinterpret_cast<const Coef4 *>(cf + c * 4);
+      o[((int64_t)c * 3 + 0) * N + i] = k.c3 * tau3 + k.c2 * tau2 + k.c1 * tau + k.c0;
+      o[((int64_t)c * 3 + 1) * N + i] = (3 * k.c3 * tau2 + 2 * k.c2 * tau + k.c1) * vfact;
+      o[((int64_t)c * 3 + 2) * N + i] = (6 * k.c3 * tau + 2 * k.c2) * afact;
+   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 dense solve as Eigen::PartialPivLU does it for util.cpp:432-438 (unblocked LU, first-max
+// pivot, true division of the sub-column, column-oriented substitutions).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void swap_d(double &a, double &b) { const double t = a; a = b; b = t; }
+
+__device__ void lu3_solve(const double *A /* row-major 3x3 */, const double *b, double *x)
+{
+   double m00 = A[0], m01 = A[1], m02 = A[2], m10 = A[3], m11 = A[4], m12 = A[5], m20 = A[6], m21 = A[7], m22 = A[8];
+   double r0 = b[0], r1 = b[1], r2 = b[2];
+   // k = 0
+   {
+      int piv = 0;
+      double best = fabs(m00);
+      if (fabs(m10) > best) { best = fabs(m10); piv = 1; }
+      if (fabs(m20) > best) { best = fabs(m20); piv = 2; }
+      if (best != 0.0)
+      {
+         if (piv == 1) { swap_d(m00, m10); swap_d(m01, m11); swap_d(m02, m12); }
+         if (piv == 2) { swap_d(m00, m20); swap_d(m01, m21); swap_d(m02, m22); }
+         m10 /= m00; m20 /= m00;
+      }
+      if (piv == 1) swap_d(r0, r1);
+      if (piv == 2) swap_d(r0, r2);
+      m11 -= m10 * m01; m12 -= m10 * m02;
+      m21 -= m20 * m01; m22 -= m20 * m02;
+   }
+   // k = 1
+   {
+      int piv = 1;
+      double best = fabs(m11);
+      if (fabs(m21) > best) { best = fabs(m21); piv = 2; }
+      if (best != 0.0)
+      {
+         if (piv == 2) { swap_d(m10, m20); swap_d(m11, m21); swap_d(m12, m22); }
+         m21 /= m11;
+      }
+      if (piv == 2) swap_d(r1, r2);
+      m22 -= m21 * m12;
+   }
+   // unit-lower forward substitution, column oriented
+   if (r0 != 0.0) { r1 -= r0 * m10; r2 -= r0 * m20; }
+   if (r1 != 0.0) { r2 -= r1 * m21; }
+   // upper back substitution, column oriented
+   if (r2 != 0.0) { r2 /= m22; r0 -= r2 * m02; r1 -= r2 * m12; }
+   if (r1 != 0.0) { r1 /= m11; r0 -= r1 * m01; }
+   if (r0 != 0.0) { r0 /= m00; }
+   x[0] = r0; x[1] = r1; x[2] = r2;
+}
+
+// Robot::setA (robot.cpp:534-558): A[i][j] = (cart[i] - pmat[i][j]) / theta[j]
+__device__ __forceinline__ void cspr_setA(const double *pmat, const double *th, const double *ca, double *A)
+{
+#pragma unroll
+   for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) A[i * 3 + j] = (ca[i] - pmat[i * 3 + j]) / th[j];
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2b: dynamics coefficients a1..a4 at the knots (ba.cpp:873-938).  One thread per knot.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_dynamics(DevProblem P, const DevProblem *__restrict__ dP, const PathInfo *__restrict__ pinfo, int B, const double *__restrict__ samp,
+                           const double *__restrict__ trig, double *__restrict__ dyn, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   int lo = 0, hi = B - 1;
+   while (lo < hi)
+   {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pinfo[mid].koff <= g) lo = mid; else hi = mid - 1;
+   }
+   const PathInfo pi = pinfo[lo];
+   const int64_t N = pi.n, i = g - pi.koff;
+   const double *__restrict__ sp = samp + pi.koff * P.Cin * 3;
+   double *__restrict__ dy = dyn + pi.koff * 4 * P.d;
+   const int d = P.d;
+
+   if (P.flags & BATOTP_F_PARALLEL)
+   {
+      // Robot::dynCSPR3DOF (robot.cpp:487-517)
+      double a1[3], a2[3], a3[3], a4[3];
+      const double *__restrict__ cs = sp + (int64_t)P.nJ * 3 * N;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+      {
+         a1[j] = -cs[((int64_t)j * 3 + 1) * N + i];
+         a2[j] = -cs[((int64_t)j * 3 + 2) * N + i];
+         a3[j] = 0.0;
+         a4[j] = 0.0;
+      }
+      a4[2] = 9.81;
+      if (P.flags & BATOTP_F_PAR2SER)
+      {
+         // ba.cpp:916-936: A^-1 a_k through four LU solves
+         double A[9], th[3], ca[3], xs[3];
+#pragma unroll
+         for (int j = 0; j < 3; ++j)
+         {
+            ca[j] = cs[((int64_t)j * 3) * N + i];
+            th[j] = sp[((int64_t)j * 3) * N + i];
+         }
+         cspr_setA(dP->pmat, th, ca, A);
+         lu3_solve(A, a1, xs); a1[0] = xs[0]; a1[1] = xs[1]; a1[2] = xs[2];
+         lu3_solve(A, a2, xs); a2[0] = xs[0]; a2[1] = xs[1]; a2[2] = xs[2];
+         lu3_solve(A, a3, xs); a3[0] = xs[0]; a3[1] = xs[1]; a3[2] = xs[2];
+         lu3_solve(A, a4, xs); a4[0] = xs[0]; a4[1] = xs[1]; a4[2] = xs[2];
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+      {
+         dy[((int64_t)0 * d + j) * N + i] = a1[j];
+         dy[((int64_t)1 * d + j) * N + i] = a2[j];
+         dy[((int64_t)2 * d + j) * N + i] = a3[j];
+         dy[((int64_t)3 * d + j) * N + i] = a4[j];
+      }
+      return;
+   }
+
+   // Robot::dynRR (robot.cpp:377-431), joint values in degrees
+   const double kDeg2Rad = 3.14159265358979323846 / 180.0;
+   const double kG = 9.81;
+   double A1 = .4, A2 = .6, m1 = 4, m2 = 8;
+   const double th1 = kDeg2Rad * sp[(0 * 3 + 0) * N + i];
+   const double th2 = kDeg2Rad * sp[((int64_t)1 * 3 + 0) * N + i];
+   const double dth1 = kDeg2Rad * sp[(0 * 3 + 1) * N + i];
+   const double dth2 = kDeg2Rad * sp[((int64_t)1 * 3 + 1) * N + i];
+   const double ddth1 = kDeg2Rad * sp[(0 * 3 + 2) * N + i];
+   const double ddth2 = kDeg2Rad * sp[((int64_t)1 * 3 + 2) * N + i];
+   double c1, c2, c12, s2;
+   if (trig != nullptr)
+   {
+      const double *__restrict__ tg = trig + pi.koff * 4;
+      c1 = tg[i]; c2 = tg[N + i]; c12 = tg[2 * N + i]; s2 = tg[3 * N + i];
+   }
+   else
+   {
+      // device libm: within an ulp of glibc but not bit-identical (RR trig policy)
+      c1 = cos(th1); c2 = cos(th2); c12 = cos(th1 + th2); s2 = sin(th2);
+   }
+   const double A11 = .25 * m1 * A1 * A1 + m2 * (A1 * A1 + .25 * A2 * A2 + A1 * A2 * c2);
+   const double A12 = .5 * m2 * (.5 * A2 * A2 + A1 * A2 * c2);
+   const double A22 = .25 * m2 * A2 * A2;
+   const double ccFact = m2 * A1 * A2 * s2;
+   dy[((int64_t)0 * d + 0) * N + i] = A11 * dth1 + A12 * dth2;
+   dy[((int64_t)0 * d + 1) * N + i] = A12 * dth1 + A22 * dth2;
+   dy[((int64_t)1 * d + 0) * N + i] = A11 * ddth1 + A12 * ddth2 - ccFact * dth2 * (dth1 + .5 * dth2);
+   dy[((int64_t)1 * d + 1) * N + i] = A12 * ddth1 + A22 * ddth2 - .5 * ccFact * dth1 * dth1;
+   dy[((int64_t)2 * d + 0) * N + i] = 10 * dth1;
+   dy[((int64_t)2 * d + 1) * N + i] = 10 * dth2;
+   dy[((int64_t)3 * d + 0) * N + i] = .5 * kG * (m1 * A1 * c1 + m2 * (2.0 * A1 * c1 + A2 * c12));
+   dy[((int64_t)3 * d + 1) * N + i] = .5 * kG * m2 * A2 * c12;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Point evaluation shared by K3 and K4.  A path is handled by a group of G lanes: lane j of the
+// group owns joint (and dynamics row) j; with G == 1 one lane loops over all joints.  Everything
+// that is one value per path (cursor, sdot, bisection bracket ...) is kept redundantly in every
+// lane of the group, so control flow is uniform inside a group and the only cross-lane traffic is
+// the min / max over joints (DPP butterflies, device_math.h).
+// ---------------------------------------------------------------------------------------------
+template <int G, bool PAR>
+struct Pt
+{
+   static constexpr int PER = (G == 1) ? BATOTP_MAX_JOINTS : 1;
+
+   // path constants
+   const double *__restrict__ sC;
+   const double *__restrict__ coef; // this path's [N][C][4]
+   int64_t n;
+   int C, nJ, nC, nIn;
+   unsigned flags;
+   int parallel_now;
+   double vfact, afact, thrV, thrA, quadA, quadA2, sdotCap, sddotMax, cartAccMaxSQ, cartVelMax, integRes;
+   const double *pmat;
+   // lane constants (limits of this lane's joints)
+   double vmax[PER], amax[PER], tmax[PER], tmin[PER];
+   // reverse curve (forward sweep only)
+   const double *__restrict__ mvc; // (s, sdot) pairs
+   int64_t nMvc;
+   int dir;
+   // cursor state (ba.h:94-103,144-145)
+   int64_t segC, segMVC;
+   double tauC, tauMVC, sCur, sdotCur, sddotL, sddotH, sdotMin;
+   // point buffers of this lane's joints
+   double thD[PER], thD2[PER], a1[PER], a2[PER], a3[PER], a4[PER];
+   double cq0, cq1, cq2; // CartAccCoeffs
+   // parallel mechanism (isPar2Ser = 0): everything, in every lane
+   double thp[PAR ? 3 : 1], cap[PAR ? 3 : 1], Am[PAR ? 9 : 1], pa1[PAR ? 3 : 1], pa2[PAR ? 3 : 1], pa3[PAR ? 3 : 1], pa4[PAR ? 3 : 1];
+   unsigned status;
+   int nfail;
+};
+
+// BA::updateCurSeg (ba.cpp:1617-1652) over sites s[k*STRIDE].  A NaN position, for which the
+// reference never terminates, sets BATOTP_ST_NONFINITE instead.
+template <int STRIDE>
+__device__ __forceinline__ void update_cur_seg(const double *__restrict__ s, int64_t n, double sCur, int64_t &curSeg,
+                                               double &tau, unsigned &status)
+{
+   const int64_t lastSeg = n - 2;
+   double sSeg, sNext;
+   for (;;)
+   {
+      sSeg = s[curSeg * STRIDE];
+      sNext = s[(curSeg + 1) * STRIDE];
+      if (sCur >= sSeg && sCur <= sNext) break;
+      bool moved = false;
+      if (sCur > sSeg)
+      {
+         if (curSeg >= lastSeg) { curSeg = lastSeg; break; }
+         ++curSeg; moved = true;
+      }
+      if (sCur < sSeg)
+      {
+         if (curSeg <= 0) { curSeg = 0; break; }
+         --curSeg; moved = true;
+      }
+      if (!moved) { status |= BATOTP_ST_NONFINITE; break; }
+   }
+   tau = (sCur - sSeg) / (sNext - sSeg);
+}
+
+// BA::evalSplinePartials + evalCartQuadCoeffs (ba.cpp:1341-1439)
+template <int G, bool PAR>
+__device__ __forceinline__ void eval_partials(Pt<G, PAR> &t, int j)
+{
+   update_cur_seg<1>(t.sC, t.n, t.sCur, t.segC, t.tauC, t.status);
+   const double tau = t.tauC, tau2 = tau * tau, tau3 = tau2 * tau;
+   const double *__restrict__ row = t.coef + t.segC * t.C * 4;
+
+#pragma unroll
+   for (int q = 0; q < Pt<G, PAR>::PER; ++q)
+   {
+      const int jj = j + q * G;
+      if (jj < t.nJ)
+      {
+         const Coef4 k = *reinterpret_cast<const Coef4 *>(row + jj * 4);
+         t.thD[q] = (3 * k.c3 * tau2 + 2 * k.c2 * tau + k.c1) * t.vfact;
+         t.thD2[q] = (6 * k.c3 * tau + 2 * k.c2) * t.afact;
+      }
+   }
+   if (t.flags & (BATOTP_F_CART_VEL_ON | BATOTP_F_CART_ACC_ON))
+   {
+      double v[3], a[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+      {
+         const Coef4 k = *reinterpret_cast<const Coef4 *>(row + (t.nJ + i) * 4);
+         if (PAR) t.cap[PAR ? i : 0] = k.c3 * tau3 + k.c2 * tau2 + k.c1 * tau + k.c0;
+         v[i] = (3 * k.c3 * tau2 + 2 * k.c2 * tau + k.c1) * t.vfact;
+         a[i] = (6 * k.c3 * tau + 2 * k.c2) * t.afact;
+      }
+      t.cq0 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+      t.cq1 = 2 * (v[0] * a[0] + v[1] * a[1] + v[2] * a[2]);
+      t.cq2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+   }
+   if (t.flags & BATOTP_F_TRQ_ON)
+   {
+      if (PAR && t.parallel_now)
+      {
+#pragma unroll
+         for (int r = 0; r < 3; ++r)
+         {
+            const Coef4 kt = *reinterpret_cast<const Coef4 *>(row + r * 4);
+            t.thp[PAR ? r : 0] = kt.c3 * tau3 + kt.c2 * tau2 + kt.c1 * tau + kt.c0;
+            const Coef4 *kd = reinterpret_cast<const Coef4 *>(row + (t.nIn + r * 4) * 4);
+            t.pa1[PAR ? r : 0] = kd[0].c3 * tau3 + kd[0].c2 * tau2 + kd[0].c1 * tau + kd[0].c0;
+            t.pa2[PAR ? r : 0] = kd[1].c3 * tau3 + kd[1].c2 * tau2 + kd[1].c1 * tau + kd[1].c0;
+            t.pa3[PAR ? r : 0] = kd[2].c3 * tau3 + kd[2].c2 * tau2 + kd[2].c1 * tau + kd[2].c0;
+            t.pa4[PAR ? r : 0] = kd[3].c3 * tau3 + kd[3].c2 * tau2 + kd[3].c1 * tau + kd[3].c0;
+         }
+         cspr_setA(t.pmat, t.thp, t.cap, t.Am); // ba.cpp:1407-1410
+      }
+      else
+      {
+#pragma unroll
+         for (int q = 0; q < Pt<G, PAR>::PER; ++q)
+         {
+            const int jj = j + q * G;
+            if (jj < t.nJ)
+            {
+               const Coef4 *kd = reinterpret_cast<const Coef4 *>(row + (t.nIn + jj * 4) * 4);
+               const Coef4 k1 = kd[0], k2 = kd[1], k3 = kd[2], k4 = kd[3];
+               t.a1[q] = k1.c3 * tau3 + k1.c2 * tau2 + k1.c1 * tau + k1.c0;
+               t.a2[q] = k2.c3 * tau3 + k2.c2 * tau2 + k2.c1 * tau + k2.c0;
+               t.a3[q] = k3.c3 * tau3 + k3.c2 * tau2 + k3.c1 * tau + k3.c0;
+               t.a4[q] = k4.c3 * tau3 + k4.c2 * tau2 + k4.c1 * tau + k4.c0;
+            }
+         }
+      }
+   }
+}
+
+// BA::evalsdot, "linear" (ba.cpp:1590-1607)
+template <int G, bool PAR>
+__device__ __forceinline__ double eval_sdot(Pt<G, PAR> &t)
+{
+   update_cur_seg<2>(t.mvc, t.nMvc, t.sCur, t.segMVC, t.tauMVC, t.status);
+   const double sd0 = t.mvc[t.segMVC * 2 + 1], sd1 = t.mvc[(t.segMVC + 1) * 2 + 1];
+   const double v = sd0 + t.tauMVC * (sd1 - sd0);
+   return dmax(v, t.sdotMin);
+}
+
+// BA::sdotLim (ba.cpp:1204-1236).  The joint-velocity limits use the theta' of the previous
+// evalSplinePartials call, exactly as the reference does.
+template <int G, bool PAR>
+__device__ __forceinline__ void sdot_lim(Pt<G, PAR> &t, int j, double &sdot)
+{
+   if (t.dir == 1)
+   {
+      const double sdotMVC = eval_sdot(t);
+      if (sdot > sdotMVC) sdot = sdotMVC;
+   }
+   sdot = dmin(sdot, t.sdotCap);
+   sdot = dmax(sdot, t.sdotMin);
+   double lim = kInf;
+#pragma unroll
+   for (int q = 0; q < Pt<G, PAR>::PER; ++q)
+   {
+      const int jj = j + q * G;
+      if (jj < t.nJ && fabs(t.thD[q]) > t.thrV) lim = dmin(lim, fabs(t.vmax[q] / t.thD[q]));
+   }
+   lim = grp_min<G>(lim);
+   sdot = dmin(sdot, lim);
+   if ((t.flags & BATOTP_F_CART_VEL_ON) && t.cq0 > t.quadA) sdot = dmin(sdot, t.cartVelMax / sqrt(t.cq0));
+}
+
+// solveQuadratic (util.cpp:361-383)
+__device__ __forceinline__ int solve_quadratic(double A, double B, double C, double &sol1, double &sol2)
+{
+   if (fabs(A) < 1e-308)
+   {
+      if (fabs(B) < 1e-308) return -2;
+      sol1 = -C / B; sol2 = sol1;
+      return 0;
+   }
+   const double rad = B * B - 4 * A * C;
+   if (rad < 0) return -1;
+   const double den = 2 * A;
+   const double F1 = -B / den, F2 = sqrt(rad) / den;
+   sol1 = F1 + F2;
+   sol2 = F1 - F2;
+   return 0;
+}
+
+// BA::verifySecondOrderConstraints (ba.cpp:1449-1581).  Each lane intersects the sddot intervals
+// of its own joints; the group then takes min(H) / max(L).  The reference leaves its joint loops
+// early as soon as L > H; since H only shrinks and L only grows along the loops, that is the same
+// predicate as L > H after the full reduction, and whenever the point is admissible both agree on
+// sddotL / sddotH bit for bit.
+template <int G, bool PAR>
+__device__ __forceinline__ bool verify_second_order(Pt<G, PAR> &t, int j, double sdotCur)
+{
+   const double sdotSQ = sdotCur * sdotCur;
+   double H = t.sddotMax, L = -t.sddotMax;
+   int force = 0;
+
+   if (t.flags & BATOTP_F_TRQ_ON)
+   {
+      if (PAR && t.parallel_now)
+      {
+         // ba.cpp:1463-1491: two 3x3 solves per joint
+         double cStar[3];
+#pragma unroll
+         for (int i = 0; i < 3; ++i) cStar[i] = sdotSQ * t.pa2[PAR ? i : 0] + sdotCur * t.pa3[PAR ? i : 0] + t.pa4[PAR ? i : 0];
+#pragma unroll
+         for (int q = 0; q < Pt<G, PAR>::PER; ++q)
+         {
+            const int jj = j + q * G;
+            if (jj < t.nJ)
+            {
+               double sol[2];
+#pragma unroll
+               for (int ii = 0; ii < 2; ++ii)
+               {
+                  const double lim = ii == 0 ? t.tmin[q] : t.tmax[q];
+                  double As[9], bs[3], xs[3];
+#pragma unroll
+                  for (int k = 0; k < 9; ++k) As[k] = t.Am[PAR ? k : 0];
+#pragma unroll
+                  for (int k = 0; k < 3; ++k)
+                  {
+                     // column jj of A replaced by -a1, rhs = cStar - A[:,jj]*limit
+                     const double akj = (jj == 0) ? t.Am[PAR ? k * 3 + 0 : 0] : (jj == 1) ? t.Am[PAR ? k * 3 + 1 : 0] : t.Am[PAR ? k * 3 + 2 : 0];
+                     bs[k] = cStar[k] - akj * lim;
+                     const double na1 = -t.pa1[PAR ? k : 0];
+                     if (jj == 0) As[k * 3 + 0] = na1;
+                     if (jj == 1) As[k * 3 + 1] = na1;
+                     if (jj == 2) As[k * 3 + 2] = na1;
+                  }
+                  lu3_solve(As, bs, xs);
+                  sol[ii] = (jj == 0) ? xs[0] : (jj == 1) ? xs[1] : xs[2];
+               }
+               H = dmin(H, dmax(sol[0], sol[1]));
+               L = dmax(L, dmin(sol[0], sol[1]));
+            }
+         }
+      }
+      else
+      {
+         // ba.cpp:1495-1509
+#pragma unroll
+         for (int q = 0; q < Pt<G, PAR>::PER; ++q)
+         {
+            const int jj = j + q * G;
+            if (jj < t.nJ)
+            {
+               const double a1pt = t.a1[q];
+               const double tmp1 = t.a3[q] * sdotCur + t.a4[q];
+               if (!(fabs(a1pt) < t.thrV))
+               {
+                  const double tmp2 = t.a2[q] * sdotSQ + tmp1;
+                  const double s0 = (t.tmax[q] - tmp2) / a1pt;
+                  const double s1 = (t.tmin[q] - tmp2) / a1pt;
+                  H = dmin(H, dmax(s0, s1));
+                  L = dmax(L, dmin(s0, s1));
+               }
+            }
+         }
+      }
+   }
+   if (t.flags & BATOTP_F_JNT_ACC_ON)
+   {
+      // ba.cpp:1514-1534
+#pragma unroll
+      for (int q = 0; q < Pt<G, PAR>::PER; ++q)
+      {
+         const int jj = j + q * G;
+         if (jj < t.nJ)
+         {
+            const double vpt = t.thD[q];
+            if (fabs(vpt) < t.thrV)
+            {
+               if (!(fabs(t.thD2[q]) < t.thrA))
+               {
+                  if (sdotSQ > t.amax[q] / fabs(t.thD2[q])) force = 1;
+               }
+            }
+            else
+            {
+               const int svpt = sgn(vpt);
+               const double vTerm = t.thD2[q] * sdotSQ;
+               H = dmin(H, (svpt * t.amax[q] - vTerm) / vpt);
+               L = dmax(L, (-svpt * t.amax[q] - vTerm) / vpt);
+            }
+         }
+      }
+   }
+   H = grp_min<G>(H);
+   L = grp_max<G>(L);
+   force = grp_or<G>(force);
+   t.sddotH = H;
+   t.sddotL = L;
+   if (force || L > H) return true;
+
+   if (t.flags & BATOTP_F_CART_ACC_ON)
+   {
+      // ba.cpp:1535-1579
+      const double A = t.cq0;
+      if (A > t.quadA)
+      {
+         const double Bq = t.cq1 * sdotSQ;
+         const double Cq = t.cq2 * sdotSQ * sdotSQ - t.cartAccMaxSQ;
+         double sol1 = 0, sol2 = 0;
+         const int ef = solve_quadratic(A, Bq, Cq, sol1, sol2);
+         if (ef == -1) return true;
+         const double cmax = dmax(sol1, sol2), cmin = dmin(sol1, sol2);
+         t.sddotH = dmin(t.sddotH, cmax);
+         t.sddotL = dmax(t.sddotL, cmin);
+         if (t.sddotL > t.sddotH) return true;
+      }
+      else
+      {
+         const double Cq = t.cq2;
+         if (Cq < t.quadA2) return false;
+         if (sdotSQ * sdotSQ > t.cartAccMaxSQ / Cq) return true;
+         return false;
+      }
+   }
+   return false;
+}
+
+// BA::applyAccelConstraintsBisectionPt (ba.cpp:1248-1332).  Returns 0, or -1 on the failure exits of
+// ba.cpp:1307-1319, in which case sddot is left untouched (the reference's caller ignores the code).
+template <int G, bool PAR>
+__device__ __forceinline__ int apply_accel_bisection(Pt<G, PAR> &t, int j, double &sddot, int &nIter)
+{
+   const double sdotErrThresh = .001;
+   double lowFact = .01;
+   const double sdotMin = 0;
+   double sdotGood = sdotMin, sdotGoodLast;
+   bool anyGoodIter = false;
+   double sdotL = sdotGood;
+   double sdotH = t.sdotCur;
+   double sdotCur = sdotH;
+   nIter = 0;
+
+   eval_partials(t, j);
+
+   for (;;)
+   {
+      const bool isViol = verify_second_order(t, j, sdotCur);
+      if (isViol)
+      {
+         sdotH = sdotCur;
+         if (!anyGoodIter)
+         {
+            lowFact *= 2.0;
+            sdotL = dmax(.999 * sdotMin, (1.0 - lowFact) * sdotH);
+         }
+      }
+      else
+      {
+         if (nIter == 0) break;
+         anyGoodIter = true;
+         sdotGoodLast = sdotGood;
+         sdotGood = sdotCur;
+         const double sdotErr = fabs(sdotGood - sdotGoodLast) / sdotGood;
+         if (sdotErr < sdotErrThresh || sdotCur < sdotMin)
+         {
+            t.sdotCur = sdotCur;
+            break;
+         }
+         sdotL = sdotCur;
+      }
+      nIter++;
+      if (nIter > 100) return -1;
+      if (sdotCur < 0 || ((sdotH - sdotL) / sdotH < 1e-20 && !anyGoodIter)) return -1;
+      sdotCur = .5 * (sdotH + sdotL);
+   }
+   sddot = (t.dir == 1) ? t.sddotH : t.sddotL;
+   return 0;
+}
+
+template <int G, bool PAR>
+__device__ __forceinline__ void accel_pt(Pt<G, PAR> &t, int j, double &sddot)
+{
+   int nIter;
+   if (apply_accel_bisection(t, j, sddot, nIter) != 0)
+   {
+      t.status |= BATOTP_ST_BISECT_FAIL;
+      t.nfail++;
+   }
+}
+
+// fill the constants of a path group
+template <int G, bool PAR>
+__device__ __forceinline__ void pt_init(Pt<G, PAR> &t, const DevProblem &P, const PathInfo &pi, const double *sC,
+                                        const double *coef, const double (*lim)[8], int j, int dir)
+{
+   t.sC = sC + pi.koff;
+   t.coef = coef + pi.koff * P.C * 4;
+   t.n = pi.n;
+   t.C = P.C; t.nJ = P.nJ; t.nC = P.nC; t.nIn = P.Cin;
+   t.flags = P.flags;
+   t.parallel_now = pi.parallel_now;
+   t.vfact = pi.vfact; t.afact = pi.afact;
+   t.thrV = P.jnt_thresh * pi.vfact;
+   t.thrA = P.jnt_thresh * pi.afact;
+   t.quadA = P.quad_thresh * pi.afact;
+   t.quadA2 = P.quad_thresh * P.quad_thresh * pi.afact * pi.afact;
+   t.integRes = P.integ_res;
+   const double sLastKnot = t.sC[pi.n - 1];
+   t.sdotCap = sLastKnot / P.integ_res;                      // ba.cpp:1216
+   t.sddotMax = 2 * sLastKnot / (P.integ_res * P.integ_res); // ba.cpp:1257
+   t.cartAccMaxSQ = P.cart_acc_max * P.cart_acc_max;
+   t.cartVelMax = P.cart_vel_max;
+   t.pmat = &lim[4][0];
+#pragma unroll
+   for (int q = 0; q < Pt<G, PAR>::PER; ++q)
+   {
+      const int jj = (j + q * G) & 7;
+      t.vmax[q] = lim[0][jj]; t.amax[q] = lim[1][jj]; t.tmax[q] = lim[2][jj]; t.tmin[q] = lim[3][jj];
+      t.thD[q] = 0; t.thD2[q] = 0; t.a1[q] = 0; t.a2[q] = 0; t.a3[q] = 0; t.a4[q] = 0;
+   }
+   t.cq0 = 0; t.cq1 = 0; t.cq2 = 0;
+   if (PAR)
+   {
+      for (int k = 0; k < 3; ++k) { t.thp[PAR ? k : 0] = 0; t.cap[PAR ? k : 0] = 0; t.pa1[PAR ? k : 0] = 0; t.pa2[PAR ? k : 0] = 0; t.pa3[PAR ? k : 0] = 0; t.pa4[PAR ? k : 0] = 0; }
+      for (int k = 0; k < 9; ++k) t.Am[PAR ? k : 0] = 0;
+   }
+   t.mvc = nullptr; t.nMvc = 0;
+   t.dir = dir;
+   t.segC = 0; t.segMVC = 0; t.tauC = 0; t.tauMVC = 0;
+   t.sCur = 0; t.sdotCur = 0; t.sddotL = 0; t.sddotH = 0; t.sdotMin = 0;
+   t.status = 0; t.nfail = 0;
+}
+
+// stage the limit tables of the problem in LDS (one copy per workgroup); row 4/5 = cable anchors
+__device__ __forceinline__ void stage_limits(const DevProblem *__restrict__ dP, double (*lim)[8])
+{
+   if (threadIdx.x < 32)
+   {
+      const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
+      const double *src = (r == 0) ? dP->vmax : (r == 1) ? dP->amax : (r == 2) ? dP->tmax : dP->tmin;
+      lim[r][c] = src[c];
+   }
+   else if (threadIdx.x < 41)
+   {
+      const int c = threadIdx.x - 32;
+      lim[4 + c / 8][c % 8] = dP->pmat[c];
+   }
+   __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: max admissible sdot and the sddot interval at every knot; one lane per (path, knot).
+// Definition: cursor on segment min(i, N-2); sdot starts from the clamp of ba.cpp:1216,
+// is cut by the velocity limits of ba.cpp:1219-1229 with THIS knot's derivatives, then by the
+// bisection of ba.cpp:1248-1332.
+// ---------------------------------------------------------------------------------------------
+template <bool PAR>
+__global__ void __launch_bounds__(256) k_pointwise(DevProblem P, const PathInfo *__restrict__ pinfo, int B,
+                                                   const DevProblem *__restrict__ dP,
+                                                   const double *__restrict__ sC, const double *__restrict__ coef,
+                                                   double *__restrict__ mvc, int64_t total)
+{
+   __shared__ double lim[6][8];
+   stage_limits(dP, lim);
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   int lo = 0, hi = B - 1;
+   while (lo < hi)
+   {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pinfo[mid].koff <= g) lo = mid; else hi = mid - 1;
+   }
+   const PathInfo pi = pinfo[lo];
+   const int64_t N = pi.n, i = g - pi.koff;
+
+   Pt<1, PAR> t;
+   pt_init(t, P, pi, sC, coef, lim, 0, -1);
+   t.segC = (i < N - 1) ? i : N - 2;
+   t.sCur = t.sC[i];
+   eval_partials(t, 0);
+   double sdot = t.sdotCap;
+   sdot_lim(t, 0, sdot);
+   t.sdotCur = sdot;
+   double sddot = 0;
+   int nIter;
+   (void)apply_accel_bisection(t, 0, sddot, nIter);
+   double *__restrict__ o = mvc + pi.koff * 3;
+   o[i] = t.sdotCur;
+   o[N + i] = t.sddotL;
+   o[2 * N + i] = t.sddotH;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: the sweep.  Wavefront = 64 lanes = 64/G paths.
+// ---------------------------------------------------------------------------------------------
+struct SweepArgs
+{
+   DevProblem P;
+   const DevProblem *dP;
+   const PathInfo *pinfo;
+   const double *sC;
+   const double *coef;
+   double2 *rev;  // [B][cap]
+   double2 *fwd;  // [B][cap]
+   batotp_path_result *res;
+   int64_t cap;
+   int B;
+   int dir;
+};
+
+// Butcher tableau of ba.cpp:58-63 (_B[k][j]; stage j+1 uses column j)
+#define BK_B00 (1. / 5)
+#define BK_B01 (3. / 40)
+#define BK_B02 (44. / 45)
+#define BK_B03 (19372. / 6561)
+#define BK_B04 (9017. / 3168)
+#define BK_B05 (35. / 384)
+#define BK_B11 (9. / 40)
+#define BK_B12 (-56. / 15)
+#define BK_B13 (-25360. / 2187)
+#define BK_B14 (-355. / 33)
+#define BK_B15 (0.)
+#define BK_B22 (32. / 9)
+#define BK_B23 (64448. / 6561)
+#define BK_B24 (46732. / 5247)
+#define BK_B25 (500. / 1113)
+#define BK_B33 (-212. / 729)
+#define BK_B34 (49. / 176)
+#define BK_B35 (125. / 192)
+#define BK_B44 (-5103. / 18656)
+#define BK_B45 (-2187. / 6784)
+#define BK_B55 (11. / 84)
+
+template <int G, bool PAR>
+__global__ void __launch_bounds__(64) k_sweep(SweepArgs a)
+{
+   __shared__ double lim[6][8];
+   stage_limits(a.dP, lim);
+
+   const int lane = threadIdx.x;
+   const int j = lane % G;
+   const int pRaw = blockIdx.x * (64 / G) + lane / G;
+   const bool valid = pRaw < a.B;
+   const int p = valid ? pRaw : a.B - 1;
+   const bool writer = valid && (j == 0);
+   const int dir = a.dir;
+   const PathInfo pi = a.pinfo[p];
+   const int64_t n = pi.n, cap = a.cap;
+
+   Pt<G, PAR> t;
+   pt_init(t, a.P, pi, a.sC, a.coef, lim, j, dir);
+
+   double2 *__restrict__ out = (dir == 1 ? a.fwd : a.rev) + (int64_t)p * cap;
+   batotp_path_result *__restrict__ r = a.res + p;
+   if (dir == 1)
+   {
+      const int64_t nRev = r->n_rev;
+      t.mvc = reinterpret_cast<const double *>(a.rev + (int64_t)p * cap + (cap - nRev));
+      t.nMvc = nRev;
+   }
+
+   const double absh = a.P.integ_res;
+   const double h = dir * absh;
+   const int64_t maxIntegSteps = (int64_t)floor(a.P.max_integ_time / a.P.integ_res) + 1;
+   double sLast;
+   double s0v, s1v, s2v, s3v, s4v, s5v, s6v;       // sArr
+   double v0, v1, v2, v3, v4, v5, v6;              // sdotArr
+   double w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, w6 = 0; // sddotArr
+
+   if (dir == 1) { t.segC = 0; t.tauC = 0; s0v = 0; t.segMVC = 0; t.tauMVC = 0; sLast = t.sC[n - 1]; }
+   else { t.segC = n - 2; t.tauC = 1; s0v = t.sC[n - 1]; t.segMVC = n - 2; t.tauMVC = 1; sLast = 0; }
+   t.sCur = s0v;
+   t.sdotCur = 0;
+
+   // bootstrap, ba.cpp:1024-1041 (two passes of [bisection, velocity limit]; kept as a loop so
+   // that the point evaluation is instantiated once here and once in the stage loop)
+#pragma unroll 1
+   for (int pass = 0; pass < 2; ++pass)
+   {
+      accel_pt(t, j, w0);
+      if (pass == 0) { v0 = .1 * h * w0; t.sdotMin = v0; }
+      else v0 = t.sdotCur;
+      sdot_lim(t, j, v0);
+      if (pass == 0) { t.sdotMin = v0; t.sdotCur = v0; }
+   }
+
+   // point 0
+   double sPrev = s0v, sdPrev = v0; // last two published points, for the end snap
+   double sCurPt = s0v, sdCurPt = v0;
+   if (writer) out[dir == 1 ? 0 : cap - 1] = make_double2(s0v, v0);
+
+   // ba.cpp:1050-1051: dsMin uses sArr.back() == 0, hence every dsMinV[j]/absh is +0
+   const double floorV = 0.0 / absh;
+
+   int64_t nPts = 0, i = 1;
+   unsigned endStatus = 0;
+   bool done = false;
+   while (!done)
+   {
+      if (i >= cap) { endStatus = BATOTP_ST_CAPACITY; break; }
+      const double sStart = t.sCur;
+      // st == 0: Euler predictor, of which only the MVC-cursor side effect survives
+      // (ba.cpp:1055-1065); st == 1..6: the six stages of ba.cpp:1068-1094.  A real loop (not
+      // unrolled) keeps the kernel inside the instruction cache.
+#pragma unroll 1
+      for (int st = 0; st < 7; ++st)
+      {
+         double sN, vN, sdotT = 0, sddotT = 0;
+         switch (st)
+         {
+         case 0: sN = s0v + h * v0; vN = v0 + h * w0; break;
+         case 1: sdotT += BK_B00 * v0; sddotT += BK_B00 * w0; break;
+         case 2: sdotT += BK_B01 * v0; sdotT += BK_B11 * v1; sddotT += BK_B01 * w0; sddotT += BK_B11 * w1; break;
+         case 3:
+            sdotT += BK_B02 * v0; sdotT += BK_B12 * v1; sdotT += BK_B22 * v2;
+            sddotT += BK_B02 * w0; sddotT += BK_B12 * w1; sddotT += BK_B22 * w2;
+            break;
+         case 4:
+            sdotT += BK_B03 * v0; sdotT += BK_B13 * v1; sdotT += BK_B23 * v2; sdotT += BK_B33 * v3;
+            sddotT += BK_B03 * w0; sddotT += BK_B13 * w1; sddotT += BK_B23 * w2; sddotT += BK_B33 * w3;
+            break;
+         case 5:
+            sdotT += BK_B04 * v0; sdotT += BK_B14 * v1; sdotT += BK_B24 * v2; sdotT += BK_B34 * v3; sdotT += BK_B44 * v4;
+            sddotT += BK_B04 * w0; sddotT += BK_B14 * w1; sddotT += BK_B24 * w2; sddotT += BK_B34 * w3; sddotT += BK_B44 * w4;
+            break;
+         default:
+            sdotT += BK_B05 * v0; sdotT += BK_B15 * v1; sdotT += BK_B25 * v2; sdotT += BK_B35 * v3; sdotT += BK_B45 * v4; sdotT += BK_B55 * v5;
+            sddotT += BK_B05 * w0; sddotT += BK_B15 * w1; sddotT += BK_B25 * w2; sddotT += BK_B35 * w3; sddotT += BK_B45 * w4; sddotT += BK_B55 * w5;
+            break;
+         }
+         if (st > 0)
+         {
+            sN = s0v + h * sdotT;
+            vN = v0 + h * sddotT;
+            vN = dmax(vN, floorV); // ba.cpp:1085
+         }
+         t.sCur = sN;
+         sdot_lim(t, j, vN);
+         if (st == 0) { t.sCur = sStart; continue; }
+         t.sdotCur = vN;
+         // sddotArr[st] keeps its previous value when the bisection fails (ba.cpp:1091 ignores the code)
+         double wN = (st == 1) ? w1 : (st == 2) ? w2 : (st == 3) ? w3 : (st == 4) ? w4 : (st == 5) ? w5 : w6;
+         accel_pt(t, j, wN);
+         vN = t.sdotCur;
+         switch (st)
+         {
+         case 1: s1v = sN; v1 = vN; w1 = wN; break;
+         case 2: s2v = sN; v2 = vN; w2 = wN; break;
+         case 3: s3v = sN; v3 = vN; w3 = wN; break;
+         case 4: s4v = sN; v4 = vN; w4 = wN; break;
+         case 5: s5v = sN; v5 = vN; w5 = wN; break;
+         default: s6v = sN; v6 = vN; w6 = wN; break;
+         }
+      }
+
+      // FSAL shift and publish, ba.cpp:1096-1100
+      s0v = s6v; v0 = v6; w0 = w6;
+      sPrev = sCurPt; sdPrev = sdCurPt;
+      sCurPt = s0v; sdCurPt = v0;
+      if (writer) out[dir == 1 ? i : cap - 1 - i] = make_double2(s0v, v0);
+
+      if (t.sCur * dir > sLast) { nPts = i + 1; done = true; } // ba.cpp:1109-1115
+      else if (i > maxIntegSteps) { endStatus = BATOTP_ST_MAX_INTEG_TIME; break; } // ba.cpp:1117-1122
+      else ++i;
+   }
+
+   unsigned status = t.status | endStatus;
+   if (endStatus != 0)
+   {
+      if (writer)
+      {
+         if (dir == 1) { r->n_fwd = 0; r->steps_fwd = i; r->t_total = 0; r->status_fwd = status; r->n_bisect_fail_fwd = t.nfail; }
+         else { r->n_rev = 0; r->steps_rev = i; r->t_rev = 0; r->status_rev = (r->status_rev & BATOTP_ST_SEG_ERROR) | status; r->n_bisect_fail_rev = t.nfail; }
+      }
+      return;
+   }
+
+   // end snap onto sLast, ba.cpp:1132-1134; forward: last sdot <- reverse curve's last sdot, ba.cpp:1140
+   {
+      const double sRat = (sLast - sPrev) / (sCurPt - sPrev);
+      sdCurPt = sdPrev + sRat * (sdCurPt - sdPrev);
+      sCurPt = sLast;
+      if (dir == 1) sdCurPt = t.mvc[(t.nMvc - 1) * 2 + 1];
+      if (writer) out[dir == 1 ? nPts - 1 : cap - nPts] = make_double2(sCurPt, sdCurPt);
+   }
+   const double tElapsed = absh * (double)(nPts - 1); // ba.cpp:1112
+   int64_t nOut = nPts;
+
+   if (nPts < 4 && writer)
+   {
+      // ba.cpp:1171-1184: re-interpolate linearly in time to four points
+      status |= BATOTP_ST_SHORT;
+      double ps[3], pd[3], tIn[3];
+      for (int k = 0; k < (int)nPts; ++k)
+      {
+         // ascending-in-time order == integration order
+         const double2 q = (k == (int)nPts - 1) ? make_double2(sCurPt, sdCurPt) : out[dir == 1 ? k : cap - 1 - k];
+         ps[k] = q.x; pd[k] = q.y;
+         tIn[k] = absh * (double)k;
+      }
+      if (dir != 1)
+      {
+         // the reference reversed the arrays before this step (ba.cpp:1145-1146)
+         for (int k = 0; k < (int)nPts / 2; ++k)
+         {
+            swap_d(ps[k], ps[nPts - 1 - k]);
+            swap_d(pd[k], pd[nPts - 1 - k]);
+         }
+      }
+      const double tResNew = tIn[nPts - 1] / 3.;
+      double ns[4], nd[4];
+      int cur = 0;
+      for (int k = 0; k < 4; ++k)
+      {
+         const double tn = tResNew * (double)k;
+         while (!(tn < tIn[cur + 1] || cur == (int)nPts - 2)) ++cur;
+         const double tau = (tn - tIn[cur]) / (tIn[cur + 1] - tIn[cur]);
+         ns[k] = ps[cur] + (ps[cur + 1] - ps[cur]) * tau;
+         nd[k] = pd[cur] + (pd[cur + 1] - pd[cur]) * tau;
+      }
+      for (int k = 0; k < 4; ++k) out[dir == 1 ? k : cap - 4 + k] = make_double2(ns[k], nd[k]);
+      nOut = 4;
+   }
+   if (nPts < 4) { status |= BATOTP_ST_SHORT; nOut = 4; }
+
+   if (writer)
+   {
+      if (dir == 1)
+      {
+         r->n_fwd = nOut; r->steps_fwd = nPts - 1; r->t_total = tElapsed; r->status_fwd = status; r->n_bisect_fail_fwd = t.nfail;
+      }
+      else
+      {
+         r->n_rev = nOut; r->steps_rev = nPts - 1; r->t_rev = tElapsed;
+         r->status_rev = (r->status_rev & BATOTP_ST_SEG_ERROR) | status; r->n_bisect_fail_rev = t.nfail;
+      }
+   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// marshalling helpers: one channel between [4][N] (C-ABI) and the interleaved device layout
+// ---------------------------------------------------------------------------------------------
+__global__ void k_coef_gather(const double *__restrict__ coefPath, int C, int dc, int64_t N, double *__restrict__ out)
+{
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= N) return;
+   const Coef4 k = *reinterpret_cast<const Coef4 *>(coefPath + (i * C + dc) * 4);
+   out[i] = k.c0; out[N + i] = k.c1; out[2 * N + i] = k.c2; out[3 * N + i] = k.c3;
+}
+__global__ void k_coef_scatter(double *__restrict__ coefPath, int C, int dc, int64_t N, const double *__restrict__ in)
+{
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= N) return;
+   Coef4 k;
+   k.c0 = in[i]; k.c1 = in[N + i]; k.c2 = in[2 * N + i]; k.c3 = in[3 * N + i];
+   *reinterpret_cast<Coef4 *>(coefPath + (i * C + dc) * 4) = k;
+}
+__global__ void k_curve_pack(double2 *__restrict__ dst, const double *__restrict__ s, const double *__restrict__ sd, int64_t n)
+{
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) dst[i] = make_double2(s[i], sd[i]);
+}
+__global__ void k_curve_unpack(const double2 *__restrict__ src, double *__restrict__ s, double *__restrict__ sd, int64_t n)
+{
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) { const double2 q = src[i]; s[i] = q.x; sd[i] = q.y; }
+}
+
+// fp64 known-answer test: q = a/b, r = sqrt(a), p = a*b + q (must NOT be contracted)
+__global__ void k_kat(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ q,
+                      double *__restrict__ r, double *__restrict__ p)
+{
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   q[i] = a[i] / b[i];
+   r[i] = sqrt(a[i]);
+   const double prod = a[i] * b[i];
+   p[i] = prod + q[i];
+}
+
+} // namespace bk

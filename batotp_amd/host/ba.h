@@ -162,6 +162,15 @@ public:
    int optimizeBatch(std::vector<Traj> &trajs);
    // Extension: select the HIP device used by this object (default 0).
    void setDevice(int device) { _deviceId = device; }
+   // Extension: the host half of interpInputData() only (everything before reference
+   // ba.cpp:299): leaves the final knot values in traj.theta / traj.cart, the knot spacing in
+   // traj.sres and the knot count in traj.nPts.  No device call.
+   int resampleToKnots(Traj &traj) { return prepareKnots(traj); }
+   // Extension: the POD description of the current configuration that is handed to the device
+   // layer (struct batotp_problem of include/batotp_hip.h).
+   void exportProblem(void *batotp_problem_out) const { fillProblem(batotp_problem_out); }
+   unsigned int getNumJoints() const { return _nJoints; }
+   unsigned int getNumCart() const { return _nCart; }
 
    // setters
    inline void setIsLastSweep(bool isLastSweep) { _isLastSweep = isLastSweep; }

@@ -1,0 +1,146 @@
+"""Shared helpers of the test-suite: golden-case loading and the knots -> curves pipeline."""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+from batotp_amd import capi, pathgen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+BUILD = os.path.join(ROOT, "oracle", "_build")
+
+FULL_CASES = sorted(d for d in os.listdir(GOLD) if os.path.exists(os.path.join(GOLD, d, "knots.npz")))
+DIGEST_CASES = sorted(d for d in os.listdir(GOLD) if os.path.exists(os.path.join(GOLD, d, "ref_curves_sampled.npz")))
+
+# how the digest-only inputs are regenerated (must match oracle/make_golden.py)
+DIGEST_INPUTS = {
+    "synth_gen7dof_s4_50k": lambda: (pathgen.gen7dof_fine(4, 871), None, 0.01),
+    "synth_ur_s7_100k": lambda: (pathgen.ur_like_fine(7, 500), None, 0.01),
+    "synth_cspr_s8_40k": lambda: (None, pathgen.cspr_fine(8, 200), 0.005),
+}
+
+
+def problem_from_bytes(raw: np.ndarray) -> capi.Problem:
+    assert raw.size == C.sizeof(capi.Problem), (raw.size, C.sizeof(capi.Problem))
+    return capi.Problem.from_buffer_copy(raw.tobytes())
+
+
+class Case:
+    def __init__(self, name):
+        self.name = name
+        self.dir = os.path.join(GOLD, name)
+        self.expected = json.load(open(os.path.join(self.dir, "expected.json")))
+        self.full = os.path.exists(os.path.join(self.dir, "knots.npz"))
+        if self.full:
+            z = np.load(os.path.join(self.dir, "knots.npz"))
+            self.y = np.ascontiguousarray(z["y"])
+            self.sres = float(z["sres"])
+            self.problem = problem_from_bytes(z["problem"])
+            self.ref = pathgen.read_s_sdot(os.path.join(self.dir, "ref_s-sdot.dat"))
+        else:
+            self._regen()
+
+    def _regen(self):
+        """digest-only case: rebuild the input from its seed, resample it with the host library"""
+        theta, cart, tres = DIGEST_INPUTS[self.name]()
+        with tempfile.TemporaryDirectory() as work:
+            pathgen.write_traj_bin(os.path.join(work, "path.dat"), tres, theta, cart)
+            with open(os.path.join(self.dir, "config.dat")) as f, open(os.path.join(work, "config.dat"), "w") as g:
+                g.write(f.read())
+            r = subprocess.run([os.path.join(BUILD, "dump_knots"), "config.dat"], cwd=work, capture_output=True, text=True)
+            assert r.returncode == 0, r.stdout[-2000:]
+            kb = open(os.path.join(work, "knots.bin"), "rb").read()
+            N, nJ, nC = (int(v) for v in np.frombuffer(kb, "<i8", 3, 0))
+            self.sres = float(np.frombuffer(kb, "<f8", 1, 24)[0])
+            self.y = np.frombuffer(kb, "<f8", (nJ + nC) * N, 32).reshape(nJ + nC, N).copy()
+            self.problem = problem_from_bytes(np.frombuffer(open(os.path.join(work, "problem.bin"), "rb").read(), np.uint8))
+        self.ref = None
+        self.sampled = np.load(os.path.join(self.dir, "ref_curves_sampled.npz"))
+
+    @property
+    def n(self):
+        return self.y.shape[1]
+
+    def max_steps(self):
+        return int(max(self.expected["n_rev"], self.expected["n_fwd"]) + 64)
+
+
+def rr_trig(theta_samples0, theta_samples1):
+    """cos/sin with the host libm, as the host layer does for RR (reference robot.cpp:401-419)"""
+    d2r = 3.14159265358979323846 / 180.0
+    th1, th2 = d2r * theta_samples0, d2r * theta_samples1
+    return np.stack([np.cos(th1), np.cos(th2), np.cos(th1 + th2), np.sin(th2)])
+
+
+def run_pipeline(ctx, cases, max_steps=None, mvc=True, details=True):
+    """knots -> precompute -> (pointwise) -> sweeps on the library behind `ctx`, as one batch.
+
+    All cases must share one problem description.  Returns a list of dicts, one per case."""
+    prob = cases[0].problem
+    cap = max_steps or max(c.max_steps() for c in cases)
+    b = capi.Batch(ctx, prob, [c.n for c in cases], cap)
+    for k, c in enumerate(cases):
+        b.upload_knots(k, [c.y], [c.sres])
+    b.precompute(1)
+    if prob.flags & capi.F_TRQ_ON:
+        if prob.robot_type == capi.ROBOT_RR and (prob.flags & capi.F_HOST_TRIG):
+            for k in range(len(cases)):
+                b.upload_rr_trig(k, rr_trig(b.samples(k, 0)[0], b.samples(k, 1)[0]))
+        b.precompute(2)
+    if mvc:
+        b.pointwise_mvc()
+    b.sweep(-1)
+    b.sweep(+1)
+    res = b.results()
+    out = []
+    for k, c in enumerate(cases):
+        d = {"result": res[k]}
+        d["rev"] = b.curve(k, -1)
+        d["fwd"] = b.curve(k, +1)
+        if details:
+            nch = prob.n_channels
+            d["coef"] = np.stack([b.coeffs(k, ch) for ch in range(nch)])
+            d["samp"] = np.stack([b.samples(k, ch) for ch in range(prob.n_joints + prob.n_cart)])
+            if prob.dyn_dim:
+                d["dyn"] = np.stack([np.stack([b.dyn(k, kk, r) for r in range(prob.dyn_dim)]) for kk in (1, 2, 3, 4)])
+        if mvc:
+            d["mvc"] = np.stack(b.mvc(k))
+        out.append(d)
+    b.close()
+    return out
+
+
+def f32_digest(s, sd):
+    return hashlib.sha256(np.asarray(s, dtype="<f4").tobytes() + np.asarray(sd, dtype="<f4").tobytes()).hexdigest()
+
+
+def assert_matches_reference(case, out):
+    """the curves, rounded to float32 exactly like the reference's sdotWrite (ba.cpp:2745-2748),
+    must reproduce the reference binary's s-sdot.dat bit for bit; step counts and T likewise"""
+    e = case.expected
+    r = out["result"]
+    assert int(r["n_rev"]) == e["n_rev"], (case.name, r, e)
+    assert int(r["n_fwd"]) == e["n_fwd"], (case.name, r, e)
+    assert abs(float(r["t_total"]) - e["t_total_print"]) < 5.1e-4  # the log prints %.3f
+    assert int(r["n_bisect_fail_rev"]) + int(r["n_bisect_fail_fwd"]) == e["ref_bisect_fail_msgs"]
+    assert f32_digest(*out["rev"]) == e["sha256_rev"], case.name
+    assert f32_digest(*out["fwd"]) == e["sha256_fwd"], case.name
+    if case.ref is not None:
+        for (sres, s, sd), (ms, msd) in zip(case.ref, (out["rev"], out["fwd"])):
+            assert np.array_equal(s, ms.astype(np.float32))
+            assert np.array_equal(sd, msd.astype(np.float32))
+
+
+def assert_bit_equal(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    same = (a.view(np.uint64) == b.view(np.uint64)) if a.dtype == np.float64 else (a == b)
+    if not np.all(same):
+        idx = np.argwhere(~same)[:5]
+        raise AssertionError(f"{what}: {np.count_nonzero(~same)} of {a.size} values differ, first at {idx.tolist()}: "
+                             f"{[ (a[tuple(i)], b[tuple(i)]) for i in idx ]}")

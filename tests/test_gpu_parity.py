@@ -1,0 +1,120 @@
+"""GPU (-m gpu): the HIP kernels against the oracle, through the C-ABI, bit for bit.
+
+fp64 parity contract: every value the hot path publishes (spline coefficients, knot samples,
+dynamics coefficients, pointwise sdot_max / sddot interval, both integrated curves, step counts,
+traversal time, status) is IDENTICAL to the oracle's -- tolerance 0 -- and, rounded to float32 the
+way the reference writes s-sdot.dat, identical to the reference binary's own output.
+"""
+import numpy as np
+import pytest
+
+import helpers
+from helpers import Case, run_pipeline, assert_matches_reference, assert_bit_equal
+from batotp_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fp64_div_sqrt_are_correctly_rounded_and_not_contracted(hip_ctx):
+    rng = np.random.default_rng(12345)
+    n = 1 << 16
+    a = np.abs(rng.standard_normal(n)) * 10.0 ** rng.integers(-30, 30, n)
+    b = rng.standard_normal(n) * 10.0 ** rng.integers(-30, 30, n)
+    b[b == 0] = 1.0
+    # a few hard cases
+    a[:4] = [1.0, 2.0, 0.1, 1e-310]
+    b[:4] = [3.0, 3.0, 0.3, 7.0]
+    q, r, p = hip_ctx.fp64_kat(a, b)
+    assert_bit_equal(q, a / b, "fp64 division")
+    assert_bit_equal(r, np.sqrt(a), "fp64 sqrt")
+    assert_bit_equal(p, (a * b) + (a / b), "a*b+q must be a separate multiply and add (no FMA contraction)")
+
+
+def _compare(case, ho, oo):
+    for key in ("coef", "samp", "dyn", "mvc"):
+        if key in oo:
+            assert_bit_equal(ho[key], oo[key], f"{case.name}:{key}")
+    for which in ("rev", "fwd"):
+        assert_bit_equal(ho[which][0], oo[which][0], f"{case.name}:{which}.s")
+        assert_bit_equal(ho[which][1], oo[which][1], f"{case.name}:{which}.sdot")
+    for f in ho["result"].dtype.names:
+        assert ho["result"][f] == oo["result"][f], (case.name, f, ho["result"], oo["result"])
+
+
+@pytest.mark.parametrize("name", helpers.FULL_CASES)
+def test_hip_matches_oracle_and_reference(hip_ctx, oracle_ctx, name):
+    case = Case(name)
+    ho = run_pipeline(hip_ctx, [case])[0]
+    oo = run_pipeline(oracle_ctx, [case])[0]
+    _compare(case, ho, oo)
+    assert_matches_reference(case, ho)
+
+
+@pytest.mark.parametrize("name", helpers.DIGEST_CASES)
+def test_hip_baseline_size_paths(hip_ctx, oracle_ctx, name):
+    case = Case(name)
+    ho = run_pipeline(hip_ctx, [case], mvc=True, details=False)[0]
+    oo = run_pipeline(oracle_ctx, [case], mvc=True, details=False)[0]
+    _compare(case, ho, oo)
+    assert_matches_reference(case, ho)
+
+
+@pytest.mark.parametrize("lanes", [1, 16])
+def test_other_lane_groupings_agree(hip_lib, oracle_ctx, lanes):
+    """the sweep kernel with 1 or 16 lanes per path publishes the same bits as the default 8"""
+    ctx = capi.Context(hip_lib, 0)
+    ctx.set_sweep_group(lanes)
+    for name in ("GEN7DOF", "CSPR3DOF", "UR5", "CSPR3DOF_par"):
+        case = Case(name)
+        ho = run_pipeline(ctx, [case], mvc=False, details=False)[0]
+        oo = run_pipeline(oracle_ctx, [case], mvc=False, details=False)[0]
+        _compare(case, ho, oo)
+    ctx.close()
+
+
+def test_ragged_batch_equals_single_paths(hip_ctx, oracle_ctx):
+    """a batch of paths of different length: every path equals its single-path run"""
+    names = ["synth_gen7dof_s0", "GEN7DOF", "synth_gen7dof_s0", "GEN7DOF", "GEN7DOF"]
+    cases = [Case(n) for n in names]
+    # same problem for the whole batch: take it from the first case (GEN7DOF example uses the same limits)
+    for c in cases:
+        c.problem = cases[0].problem
+    many = run_pipeline(hip_ctx, cases * 5, mvc=False, details=False)   # 25 paths: several waves
+    ref = {n: run_pipeline(oracle_ctx, [c], mvc=False, details=False)[0] for n, c in zip(names, cases)}
+    for k, c in enumerate(cases * 5):
+        _compare(c, many[k], ref[c.name])
+
+
+def test_capacity_and_max_time_status(hip_ctx, oracle_ctx):
+    case = Case("GEN7DOF")
+    for ctx in (hip_ctx, oracle_ctx):
+        out = run_pipeline(ctx, [case], max_steps=100, mvc=False, details=False)[0]
+        assert out["result"]["status_rev"] & capi.ST_CAPACITY
+        assert out["result"]["n_rev"] == 0
+    import copy
+    short = copy.copy(case)
+    short.problem = capi.Problem.from_buffer_copy(bytes(case.problem))
+    short.problem.max_integ_time = 1.0  # 100 steps of 0.01 s
+    a = run_pipeline(hip_ctx, [short], mvc=False, details=False)[0]
+    b = run_pipeline(oracle_ctx, [short], mvc=False, details=False)[0]
+    assert a["result"]["status_rev"] & capi.ST_MAX_INTEG_TIME
+    assert a["result"]["status_rev"] == b["result"]["status_rev"]
+
+
+def test_properties_at_full_size(hip_ctx):
+    """size-independent properties on a BASELINE-size batch (no oracle involved):
+    curves ascending in s and ending on the path end, forward curve never above the reverse curve
+    (evaluated on the forward sites), T = integRes * steps, identical paths give identical bits"""
+    case = Case("synth_ur_s7_100k")
+    outs = run_pipeline(hip_ctx, [case] * 9, mvc=False, details=False)
+    s_end = case.sres * (case.n - 1)
+    for o in outs:
+        r = o["result"]
+        assert r["status_rev"] == 0 and r["status_fwd"] == 0
+        for s, sd in (o["rev"], o["fwd"]):
+            assert s[0] == 0.0 and s[-1] == s_end and np.all(np.diff(s) > 0) and np.all(sd >= 0)
+        assert r["t_total"] == case.problem.integ_res * r["steps_fwd"]
+        rev_on_fwd = np.interp(o["fwd"][0], o["rev"][0], o["rev"][1])
+        assert np.all(o["fwd"][1] <= rev_on_fwd * (1 + 1e-12) + 1e-300)
+    for o in outs[1:]:
+        assert_bit_equal(o["fwd"][1], outs[0]["fwd"][1], "replicated path")

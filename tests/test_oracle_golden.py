@@ -1,0 +1,43 @@
+"""CPU: the oracle (behind the C-ABI shim) against golden vectors produced by the reference itself.
+
+Golden vectors = outputs of the reference's prebuilt bin/batest run in the build container by
+oracle/make_golden.py on the reference's five shipped examples, on edited configurations that
+reach the other constraint branches, and on synthetic inputs in the shapes of the BASELINE configs.
+"""
+import numpy as np
+import pytest
+
+import helpers
+from helpers import Case, run_pipeline, assert_matches_reference
+
+
+@pytest.mark.parametrize("name", helpers.FULL_CASES)
+def test_oracle_reproduces_reference_curves(oracle_ctx, name):
+    case = Case(name)
+    assert case.n == case.expected["n_knots"]
+    out = run_pipeline(oracle_ctx, [case])[0]
+    assert_matches_reference(case, out)
+    # sanity of the published curves
+    for s, sd in (out["rev"], out["fwd"]):
+        assert np.all(np.diff(s) >= 0) and s[0] == 0.0
+        assert np.all(np.isfinite(sd))
+
+
+@pytest.mark.parametrize("name", helpers.DIGEST_CASES)
+def test_oracle_reproduces_reference_digest(oracle_ctx, name):
+    """BASELINE-size single paths: step counts, T and the sha256 of the float32 curves"""
+    case = Case(name)
+    assert case.n == case.expected["n_knots"]
+    out = run_pipeline(oracle_ctx, [case], mvc=False, details=False)[0]
+    assert_matches_reference(case, out)
+    z = case.sampled
+    assert np.array_equal(z["fwd_s"], out["fwd"][0].astype(np.float32)[::64])
+    assert np.array_equal(z["fwd_sd"], out["fwd"][1].astype(np.float32)[::64])
+
+
+def test_bisection_failure_branch_is_pinned():
+    """one golden case makes the reference print a bisection failure (stale sddot, ignored -1)"""
+    assert Case.__init__  # keep import
+    import json, os
+    e = json.load(open(os.path.join(helpers.GOLD, "synth_cspr_s8_40k", "expected.json")))
+    assert e["ref_bisect_fail_msgs"] >= 1
