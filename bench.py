@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- constraint-evaluated waypoints/sec of the batotp hot path on MI355X.
+
+One "step" = one pass of the whole hot path over one batch of synthetic paths whose knot values are
+already resident in HBM:
+    per-knot precompute (spline coefficients, knot samples [, dynamics])      -> K1/K2
+    per-knot max-admissible-sdot evaluation with bisection                    -> K3
+    reverse sweep + forward sweep                                             -> K4
+Workload (BASELINE.json configs[1]): UR5-like 6-DOF path, joint velocity + acceleration limits only,
+N ~ 100k knots per path; the batch holds --paths such paths per GPU (north_star: "synthetic N-point,
+B-path batches"), weak scaling over GPUs, no collective in the hot path, one RCCL all_gather of the
+per-path result table at the end of every step.
+
+Prints ONE JSON line on rank 0.  Launch: python bench.py [--gpus N --steps K --warmup W], or through
+torch.distributed.run for N > 1.
+"""
+import argparse
+import concurrent.futures as cf
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from batotp_amd import capi, pathgen  # noqa: E402
+from batotp_amd import dist as bdist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+DUMP_KNOTS = os.path.join(ROOT, "oracle", "_build", "dump_knots")  # host resampler front end (no device code)
+
+WORKLOADS = {
+    # name: (fine-path generator, config kwargs, coarse points per 1000 knots)
+    "ur6": dict(C=6, gen=lambda seed, n: (pathgen.ur_like_fine(seed, n), None, 0.01), knots_per_coarse=210.8,
+                cfg=dict(robot="GENJNT", is_parallel=0, n_joints=6, n_cart=3, traj_file="path.dat", is_bin=1, path_type="JOINT",
+                         degrees=1, jnt_vel=[160] * 6, jnt_acc_on=1, jnt_acc=[573, 573, 573, 1146, 1146, 1146], integ_res=0.008,
+                         max_integ_time=2000000.0, theta_res=0.3, theta_res2=0.3)),
+    "gen7": dict(C=7, gen=lambda seed, n: (pathgen.gen7dof_fine(seed, n), None, 0.01), knots_per_coarse=58.2,
+                 cfg=dict(robot="GENJNT", is_parallel=0, n_joints=7, n_cart=3, traj_file="path.dat", is_bin=1, path_type="JOINT",
+                          degrees=0, jnt_vel=[5] * 7, jnt_acc_on=1, jnt_acc=[10] * 7, integ_res=0.01, max_integ_time=2000000.0,
+                          theta_res=0.1, theta_res2=0.1)),
+}
+
+
+def make_knots(workload: str, seed: int, n_target: int):
+    """one synthetic path -> (y [C_in][N], sres, problem) through the host resampler of the BA library"""
+    w = WORKLOADS[workload]
+    n_coarse = max(8, int(round(n_target / w["knots_per_coarse"])))
+    theta, cart, tres = w["gen"](seed, n_coarse)
+    with tempfile.TemporaryDirectory() as work:
+        pathgen.write_traj_bin(os.path.join(work, "path.dat"), tres, theta, cart)
+        pathgen.write_config(os.path.join(work, "config.dat"), **w["cfg"])
+        r = subprocess.run([DUMP_KNOTS, "config.dat"], cwd=work, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("host resampling failed: " + r.stdout[-1000:])
+        kb = open(os.path.join(work, "knots.bin"), "rb").read()
+        N, nJ, nC = (int(v) for v in np.frombuffer(kb, "<i8", 3, 0))
+        sres = float(np.frombuffer(kb, "<f8", 1, 24)[0])
+        y = np.frombuffer(kb, "<f8", (nJ + nC) * N, 32).reshape(nJ + nC, N)[:nJ].copy()  # joint channels only
+        prob = capi.Problem.from_buffer_copy(open(os.path.join(work, "problem.bin"), "rb").read())
+    prob.n_cart = 0  # vel+acc limits only: no Cartesian channels are carried
+    return y, sres, prob
+
+
+def run_step(batch, has_dyn):
+    batch.precompute(0)
+    batch.pointwise_mvc()
+    batch.sweep(-1)
+    batch.sweep(+1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="ur6", choices=sorted(WORKLOADS))
+    ap.add_argument("--paths", type=int, default=2048, help="paths per GPU")
+    ap.add_argument("--knots", type=int, default=100000, help="target knots per path")
+    ap.add_argument("--distinct", type=int, default=32, help="distinct seeded paths per GPU (tiled to --paths)")
+    ap.add_argument("--group", type=int, default=8, help="lanes per path in the sweep kernel")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    hip = capi.Context(capi.load_hip(), local_rank)  # raises if the HIP extension or the GPU is missing
+    hip.set_sweep_group(args.group)
+
+    # ---- synthetic inputs: K distinct host-resampled paths per GPU, tiled so that consecutive paths
+    # (the 64/G paths that share a wavefront) are all different
+    K = max(1, min(args.distinct, args.paths))
+    seeds = [1000 + rank * K + k for k in range(K)]
+    with cf.ThreadPoolExecutor(max_workers=min(K, os.cpu_count() or 1)) as ex:
+        base = list(ex.map(lambda s: make_knots(args.workload, s, args.knots), seeds))
+    prob = base[0][2]
+    B = args.paths
+    n_knots = [base[p % K][0].shape[1] for p in range(B)]
+    total_knots = int(sum(n_knots))
+    C = WORKLOADS[args.workload]["C"]
+    cap = int(max(n_knots) * (0.5 if args.workload == "ur6" else 2.2)) + 1024
+    batch = capi.Batch(hip, prob, n_knots, cap)
+    for p in range(B):
+        y, sres, _ = base[p % K]
+        batch.upload_knots(p, [y], [sres])
+    hip.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    gathered = None
+    for _ in range(args.warmup):
+        run_step(batch, False)
+        gathered = bdist.gather_results(batch.results(), dev if world > 1 else None)
+    res = batch.results()
+    bad = int(np.count_nonzero((res["status_rev"] | res["status_fwd"]) & ~np.uint32(capi.ST_BISECT_FAIL))) if args.warmup else 0
+    if bad:
+        raise RuntimeError(f"{bad} paths ended with an error status: raise the curve capacity")
+
+    kernel_ms = {1: 0.0, 2: 0.0, 3: 0.0, 4: 0.0}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step(batch, False)
+        for k in kernel_ms:
+            kernel_ms[k] += batch.kernel_ms(k)   # HIP events on the stream the kernels were launched on
+        gathered = bdist.gather_results(batch.results(), dev if world > 1 else None)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tk = torch.tensor([total_knots], dtype=torch.int64, device=dev)
+        dist.all_reduce(tk, op=dist.ReduceOp.SUM)
+        job_knots = int(tk.item())
+    else:
+        job_knots = total_knots
+    for k in kernel_ms:
+        kernel_ms[k] /= max(args.steps, 1)
+
+    res = batch.results()
+    steps_rev, steps_fwd = int(res["steps_rev"].sum()), int(res["steps_fwd"].sum())
+
+    # ---- roofline of the dominant kernel (algorithmic bytes of SURVEY.md 8d, compact (y, M) figure):
+    # a sweep reads the spline data of every knot once, 16*C bytes, and writes 16 bytes per integrated
+    # point; the forward sweep also reads the reverse curve, 16 bytes per point
+    bytes_rev = 16.0 * C * total_knots + 16.0 * (steps_rev + B)
+    bytes_fwd = 16.0 * C * total_knots + 16.0 * (steps_fwd + B) + 16.0 * (steps_rev + B)
+    dom = 4 if kernel_ms[4] >= kernel_ms[3] else 3
+    dom_bytes = bytes_fwd if dom == 4 else bytes_rev
+    achieved = dom_bytes / (kernel_ms[dom] * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_sweep_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "constraint-evaluated waypoints/sec + traversal-time err vs CPU ref",
+        "value": job_knots * args.steps / elapsed,
+        "unit": "waypoints/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": f"synthetic: {K} distinct seeded spline paths per GPU resampled by the host BA library, tiled to {B} paths",
+        "config": {"workload": f"cfg2 UR5-like 6-DOF vel+acc, N~{args.knots} knots/path, batch of independent paths"
+                   if args.workload == "ur6" else f"GEN7DOF 7-DOF vel+acc, N~{args.knots}",
+                   "paths_per_gpu": B, "knots_per_path_mean": total_knots / B, "channels": C, "lanes_per_path": args.group,
+                   "regions": "K1+K2 precompute, K3 pointwise, K4 reverse+forward sweep", "parallelism": f"paths sharded x{world}"},
+        "kernel_ms": {"precompute": kernel_ms[1], "pointwise_mvc": kernel_ms[2], "sweep_rev": kernel_ms[3], "sweep_fwd": kernel_ms[4]},
+        "steps_per_knot": {"rev": steps_rev / total_knots, "fwd": steps_fwd / total_knots},
+        "stage_evals_per_s": 7.0 * (steps_rev + steps_fwd) / ((kernel_ms[3] + kernel_ms[4]) * 1e-3),
+        "hbm_bytes_resident": batch.nbytes(),
+        "gathered_rows": int(gathered.shape[0]) if gathered is not None else 0,
+        "roofline": {"bound": "hbm", "kernel": "k_sweep (forward)" if dom == 4 else "k_sweep (reverse)", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": kernel_ms[dom]},
+    }
+
+    # ---- CPU baseline: the oracle (bit-identical port of the reference's path) on the host cores, on a
+    # bounded sample of the same workload, one path per thread
+    if rank == 0 and not args.no_cpu_baseline:
+        ora_lib = capi.load_oracle()
+        cores = os.cpu_count() or 1
+
+        def cpu_one(idx):
+            y, sres, pr = base[idx % K]
+            ctx = capi.Context(ora_lib, 0)
+            b = capi.Batch(ctx, pr, [y.shape[1]], cap)
+            b.upload_knots(0, [y], [sres])
+            t = time.perf_counter()
+            b.precompute(0); b.pointwise_mvc(); b.sweep(-1); b.sweep(+1)
+            dt = time.perf_counter() - t
+            r = b.results()[0]
+            b.close(); ctx.close()
+            return dt, y.shape[1], float(r["t_total"]), int(r["steps_fwd"])
+
+        t_one, n_one, T_one, _ = cpu_one(0)
+        n_sample = int(max(cores, min(64 * cores, (args.cpu_seconds / max(t_one, 1e-3)) * cores)))
+        n_sample = (n_sample // cores) * cores
+        t0 = time.perf_counter()
+        with cf.ThreadPoolExecutor(max_workers=cores) as ex:
+            rows = list(ex.map(cpu_one, range(n_sample)))
+        wall = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": sum(r[1] for r in rows) / wall, "unit": "waypoints/s", "cores": cores, "kind": "port",
+                               "single_thread_value": n_one / t_one,
+                               "sample": f"{n_sample} paths of the same workload (N~{n_one}), one path per thread, "
+                                         f"same regions (K1-K4), oracle/ C restatement at -O2 -ffp-contract=off"}
+        # traversal-time error vs the CPU reference on the sampled paths (T is quantised to integRes)
+        gpu_T = {idx: float(res["t_total"][idx]) for idx in range(min(K, B))}
+        err = max(abs(gpu_T[idx % K] - rows[idx][2]) for idx in range(min(n_sample, K)) if (idx % K) in gpu_T)
+        out["traversal_time_err_s"] = err
+
+    if rank == 0:
+        print(json.dumps(out))
+    batch.close()
+    hip.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Run the hot path once or a few times on the GPU for profiling (rocprofv3 -- python3 tools/run_hotpath.py ...)."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bench
+from batotp_amd import capi
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="ur6"); ap.add_argument("--paths", type=int, default=256)
+ap.add_argument("--knots", type=int, default=100000); ap.add_argument("--distinct", type=int, default=8)
+ap.add_argument("--reps", type=int, default=1); ap.add_argument("--group", type=int, default=8)
+ap.add_argument("--ppw", type=int, default=0)
+a = ap.parse_args()
+hip = capi.Context(capi.load_hip(), 0)
+hip.set_sweep_group(a.group)
+if a.ppw and hasattr(hip, "set_paths_per_wave"):
+    hip.set_paths_per_wave(a.ppw)
+base = [bench.make_knots(a.workload, 1000 + k, a.knots) for k in range(a.distinct)]
+nk = [base[p % a.distinct][0].shape[1] for p in range(a.paths)]
+cap = int(max(nk) * (0.5 if a.workload == "ur6" else 2.2)) + 1024
+b = capi.Batch(hip, base[0][2], nk, cap)
+for p in range(a.paths):
+    b.upload_knots(p, [base[p % a.distinct][0]], [base[p % a.distinct][1]])
+for _ in range(a.reps):
+    t = time.perf_counter(); b.precompute(0); b.pointwise_mvc(); b.sweep(-1); b.sweep(1); dt = time.perf_counter() - t
+    r = b.results()
+    print(f"step {dt*1e3:.1f} ms  pre {b.kernel_ms(1):.1f} mvc {b.kernel_ms(2):.1f} rev {b.kernel_ms(3):.1f} fwd {b.kernel_ms(4):.1f}  "
+          f"wp/s {sum(nk)/dt:.3e}  steps rev {int(r['steps_rev'].sum())} fwd {int(r['steps_fwd'].sum())} status {int((r['status_rev']|r['status_fwd']).max())}")
