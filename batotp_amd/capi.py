@@ -167,6 +167,7 @@ class Library:
             "batotp_hip_last_kernel_ms": [P, I32, C.POINTER(C.c_float)],
             "batotp_hip_batch_bytes": [P, C.POINTER(C.c_int64)],
             "batotp_hip_set_sweep_group": [P, I32],
+            "batotp_hip_set_paths_per_wave": [P, I32],
         }
         for name, argtypes in sig.items():
             fn = getattr(L, name)  # raises AttributeError if the symbol is not exported
@@ -206,6 +207,9 @@ class Context:
 
     def set_sweep_group(self, lanes: int):
         self.library.check(self.library.lib.batotp_hip_set_sweep_group(self.handle, lanes), "set_sweep_group")
+
+    def set_paths_per_wave(self, n: int):
+        self.library.check(self.library.lib.batotp_hip_set_paths_per_wave(self.handle, n), "set_paths_per_wave")
 
     def synchronize(self):
         self.library.check(self.library.lib.batotp_hip_synchronize(self.handle), "synchronize")

@@ -43,6 +43,7 @@ struct batotp_ctx
    int device = 0;
    hipStream_t stream = nullptr;
    int sweepGroup = 8;
+   int pathsPerWave = 0; // 0 = automatic
 };
 
 struct batotp_batch
@@ -64,6 +65,7 @@ struct batotp_batch
    double2 *dRev = nullptr, *dFwd = nullptr;
    batotp_path_result *dRes = nullptr;
    double *dStage = nullptr; // staging for marshalling (4*maxN doubles)
+   int *dSink = nullptr;     // consumer of the sweep kernel's prefetch touches
    int64_t maxN = 0;
    int64_t bytes = 0;
 
@@ -183,6 +185,13 @@ extern "C" int batotp_hip_set_sweep_group(batotp_ctx *ctx, int32_t lanes)
    return BATOTP_OK;
 }
 
+extern "C" int batotp_hip_set_paths_per_wave(batotp_ctx *ctx, int32_t n)
+{
+   if (!ctx || n < 0 || n > 64) return BATOTP_ERR_ARG;
+   ctx->pathsPerWave = n;
+   return BATOTP_OK;
+}
+
 extern "C" int batotp_hip_fp64_kat(batotp_ctx *ctx, int64_t n, const double *a, const double *b, double *q, double *r, double *p)
 {
    if (!ctx || n <= 0 || !a || !b || !q || !r || !p) return BATOTP_ERR_ARG;
@@ -217,7 +226,7 @@ extern "C" int batotp_hip_batch_destroy(batotp_batch *b)
 {
    if (!b) return BATOTP_OK;
    if (b->ctx) hipSetDevice(b->ctx->device);
-   void *ptrs[] = {b->dP, b->dPinfo, b->dY, b->dSC, b->dCoef, b->dSamp, b->dDyn, b->dTrig, b->dMvc, b->dRev, b->dFwd, b->dRes, b->dStage};
+   void *ptrs[] = {b->dP, b->dPinfo, b->dY, b->dSC, b->dCoef, b->dSamp, b->dDyn, b->dTrig, b->dMvc, b->dRev, b->dFwd, b->dRes, b->dStage, b->dSink};
    for (void *p : ptrs)
       if (p) hipFree(p);
    for (int k = 0; k < 5; ++k)
@@ -294,6 +303,7 @@ extern "C" int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *pr
    ALLOC(b->dFwd, (int64_t)n_paths * max_steps, double2)
    ALLOC(b->dRes, n_paths, batotp_path_result)
    ALLOC(b->dStage, 4 * b->maxN, double)
+   ALLOC(b->dSink, n_paths, int)
 #undef ALLOC
    hipError_t e = hipMemcpyAsync(b->dP, &P, sizeof(P), hipMemcpyHostToDevice, ctx->stream);
    if (e == hipSuccess) e = hipMemcpyAsync(b->dPinfo, b->pinfo.data(), sizeof(PathInfo) * n_paths, hipMemcpyHostToDevice, ctx->stream);
@@ -384,9 +394,11 @@ extern "C" int batotp_hip_upload_path_sites(batotp_batch *b, int32_t path, const
    HIP_TRY(hipMemcpyAsync(b->dSC + pi.koff, sites, sizeof(double) * (size_t)pi.n, hipMemcpyHostToDevice, b->ctx->stream));
    pi.vfact = vfact; pi.afact = afact;
    pi.parallel_now = parallel_now;
-   pi.sres_c = sites[1] - sites[0];
+   pi.sres_c = sites[1];
    pi.sres = pi.sres_c;
-   pi.uniform = 0;
+   pi.uniform = 1; // sites[k] == sites[1]*k bit for bit (what ba.cpp:800-806 produces)?
+   for (int64_t k = 0; k < pi.n; ++k)
+      if (sites[k] != pi.sres_c * (double)k) { pi.uniform = 0; break; }
    if (parallel_now && (b->prob.flags & BATOTP_F_TRQ_ON))
    {
       if (b->P.nJ != 3 || b->P.nC < 3) return BATOTP_ERR_ARG;
@@ -530,12 +542,33 @@ extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
 }
 
 template <int G>
-static void launchSweep(batotp_batch *b, const SweepArgs &a)
+static void launchSweep(batotp_batch *b, SweepArgs &a)
 {
-   const int perBlock = 64 / G;
-   const unsigned grid = (unsigned)((b->B + perBlock - 1) / perBlock);
-   if (b->needPar) hipLaunchKernelGGL((k_sweep<G, true>), dim3(grid), dim3(64), 0, b->ctx->stream, a);
-   else hipLaunchKernelGGL((k_sweep<G, false>), dim3(grid), dim3(64), 0, b->ctx->stream, a);
+   const int maxPpw = 64 / G;
+   int ppw = b->ctx->pathsPerWave;
+   if (ppw <= 0)
+   {
+      // automatic: with few paths spread them over more wavefronts (latency-bound regime), with many
+      // fill every lane (throughput-bound regime); aim at >= 2 wavefronts per SIMD (1024 SIMDs)
+      ppw = b->B / 2048;
+   }
+   if (ppw < 1) ppw = 1;
+   if (ppw > maxPpw) ppw = maxPpw;
+   a.ppw = ppw;
+   const unsigned grid = (unsigned)((b->B + ppw - 1) / ppw);
+   bool uni = true;
+   for (int p = 0; p < b->B; ++p) uni = uni && b->pinfo[p].uniform;
+   hipStream_t st = b->ctx->stream;
+   if (b->needPar)
+   {
+      if (uni) hipLaunchKernelGGL((k_sweep<G, true, true>), dim3(grid), dim3(64), 0, st, a);
+      else hipLaunchKernelGGL((k_sweep<G, true, false>), dim3(grid), dim3(64), 0, st, a);
+   }
+   else
+   {
+      if (uni) hipLaunchKernelGGL((k_sweep<G, false, true>), dim3(grid), dim3(64), 0, st, a);
+      else hipLaunchKernelGGL((k_sweep<G, false, false>), dim3(grid), dim3(64), 0, st, a);
+   }
 }
 
 extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
@@ -548,7 +581,7 @@ extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
    if (rc) return rc;
    SweepArgs a;
    a.P = b->P; a.dP = b->dP; a.pinfo = b->dPinfo; a.sC = b->dSC; a.coef = b->dCoef;
-   a.rev = b->dRev; a.fwd = b->dFwd; a.res = b->dRes; a.cap = b->cap; a.B = b->B; a.dir = dir;
+   a.rev = b->dRev; a.fwd = b->dFwd; a.res = b->dRes; a.sink = b->dSink; a.cap = b->cap; a.B = b->B; a.dir = dir; a.ppw = 1;
    const int which = dir == -1 ? 3 : 4;
    evStart(b, which);
    switch (b->ctx->sweepGroup)

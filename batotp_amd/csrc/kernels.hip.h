@@ -355,8 +355,11 @@ __global__ void k_dynamics(DevProblem P, const DevProblem *__restrict__ dP, cons
 // that is one value per path (cursor, sdot, bisection bracket ...) is kept redundantly in every
 // lane of the group, so control flow is uniform inside a group and the only cross-lane traffic is
 // the min / max over joints (DPP butterflies, device_math.h).
+//   PAR: the parallel-mechanism torque branch (isPar2Ser = 0) is compiled in.
+//   UNI: knot sites are sres*k exactly (every path built by batotp_hip_precompute): they are
+//        computed instead of loaded, which removes the dependent loads of the segment search.
 // ---------------------------------------------------------------------------------------------
-template <int G, bool PAR>
+template <int G, bool PAR, bool UNI>
 struct Pt
 {
    static constexpr int PER = (G == 1) ? BATOTP_MAX_JOINTS : 1;
@@ -364,20 +367,20 @@ struct Pt
    // path constants
    const double *__restrict__ sC;
    const double *__restrict__ coef; // this path's [N][C][4]
-   int64_t n;
+   int n;
    int C, nJ, nC, nIn;
    unsigned flags;
    int parallel_now;
-   double vfact, afact, thrV, thrA, quadA, quadA2, sdotCap, sddotMax, cartAccMaxSQ, cartVelMax, integRes;
+   double sresC, vfact, afact, thrV, thrA, quadA, quadA2, sdotCap, sddotMax, cartAccMaxSQ, cartVelMax;
    const double *pmat;
    // lane constants (limits of this lane's joints)
    double vmax[PER], amax[PER], tmax[PER], tmin[PER];
    // reverse curve (forward sweep only)
    const double *__restrict__ mvc; // (s, sdot) pairs
-   int64_t nMvc;
+   int nMvc;
    int dir;
    // cursor state (ba.h:94-103,144-145)
-   int64_t segC, segMVC;
+   int segC, segMVC;
    double tauC, tauMVC, sCur, sdotCur, sddotL, sddotH, sdotMin;
    // point buffers of this lane's joints
    double thD[PER], thD2[PER], a1[PER], a2[PER], a3[PER], a4[PER];
@@ -386,20 +389,30 @@ struct Pt
    double thp[PAR ? 3 : 1], cap[PAR ? 3 : 1], Am[PAR ? 9 : 1], pa1[PAR ? 3 : 1], pa2[PAR ? 3 : 1], pa3[PAR ? 3 : 1], pa4[PAR ? 3 : 1];
    unsigned status;
    int nfail;
+   int sink; // consumer of the prefetch touches (keeps them alive; written to the result row)
 };
 
-// BA::updateCurSeg (ba.cpp:1617-1652) over sites s[k*STRIDE].  A NaN position, for which the
-// reference never terminates, sets BATOTP_ST_NONFINITE instead.
-template <int STRIDE>
-__device__ __forceinline__ void update_cur_seg(const double *__restrict__ s, int64_t n, double sCur, int64_t &curSeg,
+// BA::updateCurSeg (ba.cpp:1617-1652).  KIND 0: sites computed as sres*k; 1: sites loaded from s[k];
+// 2: the (s, sdot) pairs of the reverse curve.  A NaN position, for which the reference never
+// terminates, sets BATOTP_ST_NONFINITE instead.
+template <int KIND>
+__device__ __forceinline__ double site_at(const double *__restrict__ s, double sres, int k)
+{
+   if (KIND == 0) return sres * (double)k;
+   if (KIND == 1) return s[k];
+   return s[2 * k];
+}
+
+template <int KIND>
+__device__ __forceinline__ void update_cur_seg(const double *__restrict__ s, double sres, int n, double sCur, int &curSeg,
                                                double &tau, unsigned &status)
 {
-   const int64_t lastSeg = n - 2;
+   const int lastSeg = n - 2;
    double sSeg, sNext;
    for (;;)
    {
-      sSeg = s[curSeg * STRIDE];
-      sNext = s[(curSeg + 1) * STRIDE];
+      sSeg = site_at<KIND>(s, sres, curSeg);
+      sNext = site_at<KIND>(s, sres, curSeg + 1);
       if (sCur >= sSeg && sCur <= sNext) break;
       bool moved = false;
       if (sCur > sSeg)
@@ -418,15 +431,15 @@ __device__ __forceinline__ void update_cur_seg(const double *__restrict__ s, int
 }
 
 // BA::evalSplinePartials + evalCartQuadCoeffs (ba.cpp:1341-1439)
-template <int G, bool PAR>
-__device__ __forceinline__ void eval_partials(Pt<G, PAR> &t, int j)
+template <int G, bool PAR, bool UNI>
+__device__ __forceinline__ void eval_partials(Pt<G, PAR, UNI> &t, int j)
 {
-   update_cur_seg<1>(t.sC, t.n, t.sCur, t.segC, t.tauC, t.status);
+   update_cur_seg<UNI ? 0 : 1>(t.sC, t.sresC, t.n, t.sCur, t.segC, t.tauC, t.status);
    const double tau = t.tauC, tau2 = tau * tau, tau3 = tau2 * tau;
-   const double *__restrict__ row = t.coef + t.segC * t.C * 4;
+   const double *__restrict__ row = t.coef + (unsigned)(t.segC * t.C * 4);
 
 #pragma unroll
-   for (int q = 0; q < Pt<G, PAR>::PER; ++q)
+   for (int q = 0; q < Pt<G, PAR, UNI>::PER; ++q)
    {
       const int jj = j + q * G;
       if (jj < t.nJ)
@@ -471,7 +484,7 @@ __device__ __forceinline__ void eval_partials(Pt<G, PAR> &t, int j)
       else
       {
 #pragma unroll
-         for (int q = 0; q < Pt<G, PAR>::PER; ++q)
+         for (int q = 0; q < Pt<G, PAR, UNI>::PER; ++q)
          {
             const int jj = j + q * G;
             if (jj < t.nJ)
@@ -489,10 +502,10 @@ __device__ __forceinline__ void eval_partials(Pt<G, PAR> &t, int j)
 }
 
 // BA::evalsdot, "linear" (ba.cpp:1590-1607)
-template <int G, bool PAR>
-__device__ __forceinline__ double eval_sdot(Pt<G, PAR> &t)
+template <int G, bool PAR, bool UNI>
+__device__ __forceinline__ double eval_sdot(Pt<G, PAR, UNI> &t)
 {
-   update_cur_seg<2>(t.mvc, t.nMvc, t.sCur, t.segMVC, t.tauMVC, t.status);
+   update_cur_seg<2>(t.mvc, 0.0, t.nMvc, t.sCur, t.segMVC, t.tauMVC, t.status);
    const double sd0 = t.mvc[t.segMVC * 2 + 1], sd1 = t.mvc[(t.segMVC + 1) * 2 + 1];
    const double v = sd0 + t.tauMVC * (sd1 - sd0);
    return dmax(v, t.sdotMin);
@@ -500,8 +513,8 @@ __device__ __forceinline__ double eval_sdot(Pt<G, PAR> &t)
 
 // BA::sdotLim (ba.cpp:1204-1236).  The joint-velocity limits use the theta' of the previous
 // evalSplinePartials call, exactly as the reference does.
-template <int G, bool PAR>
-__device__ __forceinline__ void sdot_lim(Pt<G, PAR> &t, int j, double &sdot)
+template <int G, bool PAR, bool UNI>
+__device__ __forceinline__ void sdot_lim(Pt<G, PAR, UNI> &t, int j, double &sdot)
 {
    if (t.dir == 1)
    {
@@ -512,7 +525,7 @@ __device__ __forceinline__ void sdot_lim(Pt<G, PAR> &t, int j, double &sdot)
    sdot = dmax(sdot, t.sdotMin);
    double lim = kInf;
 #pragma unroll
-   for (int q = 0; q < Pt<G, PAR>::PER; ++q)
+   for (int q = 0; q < Pt<G, PAR, UNI>::PER; ++q)
    {
       const int jj = j + q * G;
       if (jj < t.nJ && fabs(t.thD[q]) > t.thrV) lim = dmin(lim, fabs(t.vmax[q] / t.thD[q]));
@@ -544,13 +557,13 @@ __device__ __forceinline__ int solve_quadratic(double A, double B, double C, dou
 // of its own joints; the group then takes min(H) / max(L).  The reference leaves its joint loops
 // early as soon as L > H; since H only shrinks and L only grows along the loops, that is the same
 // predicate as L > H after the full reduction, and whenever the point is admissible both agree on
-// sddotL / sddotH bit for bit.
-template <int G, bool PAR>
-__device__ __forceinline__ bool verify_second_order(Pt<G, PAR> &t, int j, double sdotCur)
+// sddotL / sddotH bit for bit.  The unconditional "violated" exit of the zero-velocity case
+// (ba.cpp:1522) is folded into the H reduction as -inf (sddotL/H are never read after a violation).
+template <int G, bool PAR, bool UNI>
+__device__ __forceinline__ bool verify_second_order(Pt<G, PAR, UNI> &t, int j, double sdotCur)
 {
    const double sdotSQ = sdotCur * sdotCur;
    double H = t.sddotMax, L = -t.sddotMax;
-   int force = 0;
 
    if (t.flags & BATOTP_F_TRQ_ON)
    {
@@ -561,7 +574,7 @@ __device__ __forceinline__ bool verify_second_order(Pt<G, PAR> &t, int j, double
 #pragma unroll
          for (int i = 0; i < 3; ++i) cStar[i] = sdotSQ * t.pa2[PAR ? i : 0] + sdotCur * t.pa3[PAR ? i : 0] + t.pa4[PAR ? i : 0];
 #pragma unroll
-         for (int q = 0; q < Pt<G, PAR>::PER; ++q)
+         for (int q = 0; q < Pt<G, PAR, UNI>::PER; ++q)
          {
             const int jj = j + q * G;
             if (jj < t.nJ)
@@ -597,7 +610,7 @@ __device__ __forceinline__ bool verify_second_order(Pt<G, PAR> &t, int j, double
       {
          // ba.cpp:1495-1509
 #pragma unroll
-         for (int q = 0; q < Pt<G, PAR>::PER; ++q)
+         for (int q = 0; q < Pt<G, PAR, UNI>::PER; ++q)
          {
             const int jj = j + q * G;
             if (jj < t.nJ)
@@ -616,11 +629,12 @@ __device__ __forceinline__ bool verify_second_order(Pt<G, PAR> &t, int j, double
          }
       }
    }
+   bool force = false;
    if (t.flags & BATOTP_F_JNT_ACC_ON)
    {
       // ba.cpp:1514-1534
 #pragma unroll
-      for (int q = 0; q < Pt<G, PAR>::PER; ++q)
+      for (int q = 0; q < Pt<G, PAR, UNI>::PER; ++q)
       {
          const int jj = j + q * G;
          if (jj < t.nJ)
@@ -630,7 +644,7 @@ __device__ __forceinline__ bool verify_second_order(Pt<G, PAR> &t, int j, double
             {
                if (!(fabs(t.thD2[q]) < t.thrA))
                {
-                  if (sdotSQ > t.amax[q] / fabs(t.thD2[q])) force = 1;
+                  if (sdotSQ > t.amax[q] / fabs(t.thD2[q])) force = true;
                }
             }
             else
@@ -643,12 +657,11 @@ __device__ __forceinline__ bool verify_second_order(Pt<G, PAR> &t, int j, double
          }
       }
    }
-   H = grp_min<G>(H);
+   const double Hred = grp_min<G>(force ? -kInf : H);
    L = grp_max<G>(L);
-   force = grp_or<G>(force);
-   t.sddotH = H;
+   t.sddotH = Hred;
    t.sddotL = L;
-   if (force || L > H) return true;
+   if (L > Hred) return true; // also the folded "force" exit: L >= -sddotMax > -inf
 
    if (t.flags & BATOTP_F_CART_ACC_ON)
    {
@@ -679,8 +692,8 @@ __device__ __forceinline__ bool verify_second_order(Pt<G, PAR> &t, int j, double
 
 // BA::applyAccelConstraintsBisectionPt (ba.cpp:1248-1332).  Returns 0, or -1 on the failure exits of
 // ba.cpp:1307-1319, in which case sddot is left untouched (the reference's caller ignores the code).
-template <int G, bool PAR>
-__device__ __forceinline__ int apply_accel_bisection(Pt<G, PAR> &t, int j, double &sddot, int &nIter)
+template <int G, bool PAR, bool UNI>
+__device__ __forceinline__ int apply_accel_bisection(Pt<G, PAR, UNI> &t, int j, double &sddot, int &nIter)
 {
    const double sdotErrThresh = .001;
    double lowFact = .01;
@@ -729,8 +742,8 @@ __device__ __forceinline__ int apply_accel_bisection(Pt<G, PAR> &t, int j, doubl
    return 0;
 }
 
-template <int G, bool PAR>
-__device__ __forceinline__ void accel_pt(Pt<G, PAR> &t, int j, double &sddot)
+template <int G, bool PAR, bool UNI>
+__device__ __forceinline__ void accel_pt(Pt<G, PAR, UNI> &t, int j, double &sddot)
 {
    int nIter;
    if (apply_accel_bisection(t, j, sddot, nIter) != 0)
@@ -741,30 +754,30 @@ __device__ __forceinline__ void accel_pt(Pt<G, PAR> &t, int j, double &sddot)
 }
 
 // fill the constants of a path group
-template <int G, bool PAR>
-__device__ __forceinline__ void pt_init(Pt<G, PAR> &t, const DevProblem &P, const PathInfo &pi, const double *sC,
+template <int G, bool PAR, bool UNI>
+__device__ __forceinline__ void pt_init(Pt<G, PAR, UNI> &t, const DevProblem &P, const PathInfo &pi, const double *sC,
                                         const double *coef, const double (*lim)[8], int j, int dir)
 {
    t.sC = sC + pi.koff;
    t.coef = coef + pi.koff * P.C * 4;
-   t.n = pi.n;
+   t.n = (int)pi.n;
    t.C = P.C; t.nJ = P.nJ; t.nC = P.nC; t.nIn = P.Cin;
    t.flags = P.flags;
    t.parallel_now = pi.parallel_now;
+   t.sresC = pi.sres_c;
    t.vfact = pi.vfact; t.afact = pi.afact;
    t.thrV = P.jnt_thresh * pi.vfact;
    t.thrA = P.jnt_thresh * pi.afact;
    t.quadA = P.quad_thresh * pi.afact;
    t.quadA2 = P.quad_thresh * P.quad_thresh * pi.afact * pi.afact;
-   t.integRes = P.integ_res;
-   const double sLastKnot = t.sC[pi.n - 1];
+   const double sLastKnot = UNI ? pi.sres_c * (double)(t.n - 1) : t.sC[t.n - 1];
    t.sdotCap = sLastKnot / P.integ_res;                      // ba.cpp:1216
    t.sddotMax = 2 * sLastKnot / (P.integ_res * P.integ_res); // ba.cpp:1257
    t.cartAccMaxSQ = P.cart_acc_max * P.cart_acc_max;
    t.cartVelMax = P.cart_vel_max;
    t.pmat = &lim[4][0];
 #pragma unroll
-   for (int q = 0; q < Pt<G, PAR>::PER; ++q)
+   for (int q = 0; q < Pt<G, PAR, UNI>::PER; ++q)
    {
       const int jj = (j + q * G) & 7;
       t.vmax[q] = lim[0][jj]; t.amax[q] = lim[1][jj]; t.tmax[q] = lim[2][jj]; t.tmin[q] = lim[3][jj];
@@ -780,7 +793,7 @@ __device__ __forceinline__ void pt_init(Pt<G, PAR> &t, const DevProblem &P, cons
    t.dir = dir;
    t.segC = 0; t.segMVC = 0; t.tauC = 0; t.tauMVC = 0;
    t.sCur = 0; t.sdotCur = 0; t.sddotL = 0; t.sddotH = 0; t.sdotMin = 0;
-   t.status = 0; t.nfail = 0;
+   t.status = 0; t.nfail = 0; t.sink = 0;
 }
 
 // stage the limit tables of the problem in LDS (one copy per workgroup); row 4/5 = cable anchors
@@ -823,9 +836,9 @@ __global__ void __launch_bounds__(256) k_pointwise(DevProblem P, const PathInfo 
       if (pinfo[mid].koff <= g) lo = mid; else hi = mid - 1;
    }
    const PathInfo pi = pinfo[lo];
-   const int64_t N = pi.n, i = g - pi.koff;
+   const int N = (int)pi.n, i = (int)(g - pi.koff);
 
-   Pt<1, PAR> t;
+   Pt<1, PAR, false> t;
    pt_init(t, P, pi, sC, coef, lim, 0, -1);
    t.segC = (i < N - 1) ? i : N - 2;
    t.sCur = t.sC[i];
@@ -839,11 +852,12 @@ __global__ void __launch_bounds__(256) k_pointwise(DevProblem P, const PathInfo 
    double *__restrict__ o = mvc + pi.koff * 3;
    o[i] = t.sdotCur;
    o[N + i] = t.sddotL;
-   o[2 * N + i] = t.sddotH;
+   o[2 * (int64_t)N + i] = t.sddotH;
 }
 
 // ---------------------------------------------------------------------------------------------
-// K4: the sweep.  Wavefront = 64 lanes = 64/G paths.
+// K4: the sweep.  Wavefront = 64 lanes = up to 64/G paths (a.ppw of them are used: with few paths
+// in the batch it is faster to spread them over more wavefronts than to fill every lane).
 // ---------------------------------------------------------------------------------------------
 struct SweepArgs
 {
@@ -855,9 +869,11 @@ struct SweepArgs
    double2 *rev;  // [B][cap]
    double2 *fwd;  // [B][cap]
    batotp_path_result *res;
+   int *sink;     // [B] consumer of the prefetch touches
    int64_t cap;
    int B;
    int dir;
+   int ppw;       // paths per wavefront, 1 .. 64/G
 };
 
 // Butcher tableau of ba.cpp:58-63 (_B[k][j]; stage j+1 uses column j)
@@ -883,7 +899,35 @@ struct SweepArgs
 #define BK_B45 (-2187. / 6784)
 #define BK_B55 (11. / 84)
 
-template <int G, bool PAR>
+// Software prefetch: the walk over the spline rows (and over the reverse curve) is monotone, so
+// every stage each lane of the group touches one 128-byte line of the next kilobyte ahead of the
+// cursor.  The loaded word is consumed one stage later (t.sink), which keeps the load alive without
+// ever waiting on it, and by then the line sits in the vector L1 / L2 instead of HBM.
+template <int G, bool PAR, bool UNI>
+__device__ __forceinline__ int touch_ahead(const Pt<G, PAR, UNI> &t, int j)
+{
+   const int linesAhead = 1 + (j & 7);
+   const int rowDoubles = t.C * 4;
+   int v = 0;
+   {
+      // spline rows: byte offset of the current row, then +/- (1..8) lines
+      const int lastRow = t.n - 1;
+      int off = t.segC * rowDoubles + t.dir * linesAhead * 16; // in doubles (16 doubles = 128 B)
+      const int hi = lastRow * rowDoubles;
+      off = off < 0 ? 0 : (off > hi ? hi : off);
+      v = reinterpret_cast<const int *>(t.coef)[2 * (unsigned)off];
+   }
+   if (t.dir == 1)
+   {
+      int off = t.segMVC * 2 + linesAhead * 16;
+      const int hi = (t.nMvc - 1) * 2;
+      off = off > hi ? hi : off;
+      v ^= reinterpret_cast<const int *>(t.mvc)[2 * (unsigned)off];
+   }
+   return v;
+}
+
+template <int G, bool PAR, bool UNI>
 __global__ void __launch_bounds__(64) k_sweep(SweepArgs a)
 {
    __shared__ double lim[6][8];
@@ -891,15 +935,16 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a)
 
    const int lane = threadIdx.x;
    const int j = lane % G;
-   const int pRaw = blockIdx.x * (64 / G) + lane / G;
-   const bool valid = pRaw < a.B;
-   const int p = valid ? pRaw : a.B - 1;
-   const bool writer = valid && (j == 0);
+   const int slot = lane / G;
+   const int p = blockIdx.x * a.ppw + slot;
+   if (slot >= a.ppw || p >= a.B) return; // whole groups leave together; DPP never crosses groups
+   const bool writer = (j == 0);
    const int dir = a.dir;
    const PathInfo pi = a.pinfo[p];
-   const int64_t n = pi.n, cap = a.cap;
+   const int n = (int)pi.n;
+   const int64_t cap = a.cap;
 
-   Pt<G, PAR> t;
+   Pt<G, PAR, UNI> t;
    pt_init(t, a.P, pi, a.sC, a.coef, lim, j, dir);
 
    double2 *__restrict__ out = (dir == 1 ? a.fwd : a.rev) + (int64_t)p * cap;
@@ -907,20 +952,27 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a)
    if (dir == 1)
    {
       const int64_t nRev = r->n_rev;
+      if (nRev < 2)
+      {
+         // no reverse curve to follow (its sweep ended with an error status): nothing to integrate
+         if (writer) { r->n_fwd = 0; r->steps_fwd = 0; r->t_total = 0; r->status_fwd = r->status_rev | BATOTP_ST_CAPACITY; r->n_bisect_fail_fwd = 0; }
+         return;
+      }
       t.mvc = reinterpret_cast<const double *>(a.rev + (int64_t)p * cap + (cap - nRev));
-      t.nMvc = nRev;
+      t.nMvc = (int)nRev;
    }
 
    const double absh = a.P.integ_res;
    const double h = dir * absh;
    const int64_t maxIntegSteps = (int64_t)floor(a.P.max_integ_time / a.P.integ_res) + 1;
+   const double sEnd = UNI ? pi.sres_c * (double)(n - 1) : t.sC[n - 1];
    double sLast;
-   double s0v, s1v, s2v, s3v, s4v, s5v, s6v;       // sArr
-   double v0, v1, v2, v3, v4, v5, v6;              // sdotArr
+   double s0v, s6v = 0;                             // sArr[0], sArr[6] (the other stage positions are not reused)
+   double v0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0;   // sdotArr
    double w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, w6 = 0; // sddotArr
 
-   if (dir == 1) { t.segC = 0; t.tauC = 0; s0v = 0; t.segMVC = 0; t.tauMVC = 0; sLast = t.sC[n - 1]; }
-   else { t.segC = n - 2; t.tauC = 1; s0v = t.sC[n - 1]; t.segMVC = n - 2; t.tauMVC = 1; sLast = 0; }
+   if (dir == 1) { t.segC = 0; t.tauC = 0; s0v = 0; t.segMVC = 0; t.tauMVC = 0; sLast = sEnd; }
+   else { t.segC = n - 2; t.tauC = 1; s0v = sEnd; t.segMVC = n - 2; t.tauMVC = 1; sLast = 0; }
    t.sCur = s0v;
    t.sdotCur = 0;
 
@@ -947,20 +999,22 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a)
    int64_t nPts = 0, i = 1;
    unsigned endStatus = 0;
    bool done = false;
+   int pf = 0;
    while (!done)
    {
       if (i >= cap) { endStatus = BATOTP_ST_CAPACITY; break; }
       const double sStart = t.sCur;
-      // st == 0: Euler predictor, of which only the MVC-cursor side effect survives
-      // (ba.cpp:1055-1065); st == 1..6: the six stages of ba.cpp:1068-1094.  A real loop (not
-      // unrolled) keeps the kernel inside the instruction cache.
+      // st == 0: Euler predictor (ba.cpp:1055-1065).  Its sdot is overwritten by stage 6; all that
+      // survives is the move of the reverse-curve cursor inside evalsdot (forward sweep only).
+      // st == 1..6: the six stages of ba.cpp:1068-1094.  A real loop (not unrolled) keeps the
+      // kernel inside the instruction cache.
 #pragma unroll 1
-      for (int st = 0; st < 7; ++st)
+      for (int st = (dir == 1 ? 0 : 1); st < 7; ++st)
       {
          double sN, vN, sdotT = 0, sddotT = 0;
          switch (st)
          {
-         case 0: sN = s0v + h * v0; vN = v0 + h * w0; break;
+         case 0: break;
          case 1: sdotT += BK_B00 * v0; sddotT += BK_B00 * w0; break;
          case 2: sdotT += BK_B01 * v0; sdotT += BK_B11 * v1; sddotT += BK_B01 * w0; sddotT += BK_B11 * w1; break;
          case 3:
@@ -980,15 +1034,19 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a)
             sddotT += BK_B05 * w0; sddotT += BK_B15 * w1; sddotT += BK_B25 * w2; sddotT += BK_B35 * w3; sddotT += BK_B45 * w4; sddotT += BK_B55 * w5;
             break;
          }
-         if (st > 0)
+         if (st == 0)
          {
-            sN = s0v + h * sdotT;
-            vN = v0 + h * sddotT;
-            vN = dmax(vN, floorV); // ba.cpp:1085
+            // forward predictor: evalsdot's cursor walk at s0 + h*sdot0, nothing else is kept
+            t.sCur = s0v + h * v0;
+            update_cur_seg<2>(t.mvc, 0.0, t.nMvc, t.sCur, t.segMVC, t.tauMVC, t.status);
+            t.sCur = sStart;
+            continue;
          }
+         sN = s0v + h * sdotT;
+         vN = v0 + h * sddotT;
+         vN = dmax(vN, floorV); // ba.cpp:1085
          t.sCur = sN;
          sdot_lim(t, j, vN);
-         if (st == 0) { t.sCur = sStart; continue; }
          t.sdotCur = vN;
          // sddotArr[st] keeps its previous value when the bisection fails (ba.cpp:1091 ignores the code)
          double wN = (st == 1) ? w1 : (st == 2) ? w2 : (st == 3) ? w3 : (st == 4) ? w4 : (st == 5) ? w5 : w6;
@@ -996,13 +1054,16 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a)
          vN = t.sdotCur;
          switch (st)
          {
-         case 1: s1v = sN; v1 = vN; w1 = wN; break;
-         case 2: s2v = sN; v2 = vN; w2 = wN; break;
-         case 3: s3v = sN; v3 = vN; w3 = wN; break;
-         case 4: s4v = sN; v4 = vN; w4 = wN; break;
-         case 5: s5v = sN; v5 = vN; w5 = wN; break;
+         case 1: v1 = vN; w1 = wN; break;
+         case 2: v2 = vN; w2 = wN; break;
+         case 3: v3 = vN; w3 = wN; break;
+         case 4: v4 = vN; w4 = wN; break;
+         case 5: v5 = vN; w5 = wN; break;
          default: s6v = sN; v6 = vN; w6 = wN; break;
          }
+         // consume last stage's touch, issue the next one
+         t.sink += pf;
+         pf = touch_ahead(t, j);
       }
 
       // FSAL shift and publish, ba.cpp:1096-1100
@@ -1015,6 +1076,7 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a)
       else if (i > maxIntegSteps) { endStatus = BATOTP_ST_MAX_INTEG_TIME; break; } // ba.cpp:1117-1122
       else ++i;
    }
+   if (writer) a.sink[p] = t.sink + pf;
 
    unsigned status = t.status | endStatus;
    if (endStatus != 0)
@@ -1041,7 +1103,6 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a)
    if (nPts < 4 && writer)
    {
       // ba.cpp:1171-1184: re-interpolate linearly in time to four points
-      status |= BATOTP_ST_SHORT;
       double ps[3], pd[3], tIn[3];
       for (int k = 0; k < (int)nPts; ++k)
       {
@@ -1071,7 +1132,6 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a)
          nd[k] = pd[cur] + (pd[cur + 1] - pd[cur]) * tau;
       }
       for (int k = 0; k < 4; ++k) out[dir == 1 ? k : cap - 4 + k] = make_double2(ns[k], nd[k]);
-      nOut = 4;
    }
    if (nPts < 4) { status |= BATOTP_ST_SHORT; nOut = 4; }
 

@@ -129,9 +129,10 @@ int  batotp_hip_batch_destroy(batotp_batch *batch);
  * (traj.sres at ba.cpp:299). */
 int  batotp_hip_upload_knots(batotp_batch *batch, int32_t path0, int32_t n,
                              const double *y, const double *sres);
-/* same, from a device buffer (already resident in HBM) */
+/* same, with the knot values already resident in HBM (y_dev is a device pointer; sres stays a
+ * host array) */
 int  batotp_hip_upload_knots_device(batotp_batch *batch, int32_t path0, int32_t n,
-                                    const double *y_dev, const double *sres_dev);
+                                    const double *y_dev, const double *sres);
 /* RR only (BATOTP_F_HOST_TRIG): trig[4][N] = cos(th1), cos(th2), cos(th1+th2), sin(th2) of the
  * knot samples of path p, evaluated with the host libm (robot.cpp:408-419). */
 int  batotp_hip_upload_rr_trig(batotp_batch *batch, int32_t path, const double *trig);
@@ -186,6 +187,9 @@ int  batotp_hip_last_kernel_ms(batotp_batch *batch, int32_t which, float *ms);
 int  batotp_hip_batch_bytes(batotp_batch *batch, int64_t *bytes);
 /* tuning knob: lanes per path in the sweep kernel (8 or 16; default 8) */
 int  batotp_hip_set_sweep_group(batotp_ctx *ctx, int32_t lanes);
+/* tuning knob: paths per 64-lane wavefront in the sweep kernel, 1 .. 64/lanes (0 = automatic:
+ * few paths are spread over more wavefronts, many paths fill every lane) */
+int  batotp_hip_set_paths_per_wave(batotp_ctx *ctx, int32_t n);
 
 #ifdef __cplusplus
 }

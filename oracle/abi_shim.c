@@ -55,6 +55,7 @@ int batotp_hip_fp64_kat(batotp_ctx *ctx, int64_t n, const double *a, const doubl
 }
 int batotp_hip_synchronize(batotp_ctx *ctx) { (void)ctx; return BATOTP_OK; }
 int batotp_hip_set_sweep_group(batotp_ctx *ctx, int32_t lanes) { (void)ctx; (void)lanes; return BATOTP_OK; }
+int batotp_hip_set_paths_per_wave(batotp_ctx *ctx, int32_t n) { (void)ctx; (void)n; return BATOTP_OK; }
 
 int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *prob, int32_t n_paths,
                             const int64_t *n_knots, int64_t max_steps, batotp_batch **out)
@@ -209,6 +210,12 @@ int batotp_hip_sweep(batotp_batch *b, int32_t dir)
         int32_t nf = 0;
         batotp_path_result *r = &b->res[p];
         if (dir == 1 && !b->rev_s[p]) { free(s); free(sd); return BATOTP_ERR_STATE; }
+        if (dir == 1 && r->n_rev < 2) {
+            /* no reverse curve to follow: same convention as the HIP kernel */
+            free(s); free(sd);
+            r->n_fwd = 0; r->steps_fwd = 0; r->t_total = 0; r->status_fwd = r->status_rev | BATOTP_ST_CAPACITY; r->n_bisect_fail_fwd = 0;
+            continue;
+        }
         bo_sweep(&b->prob, b->path[p], dir, b->rev_s[p], b->rev_sd[p], r->n_rev, s, sd, b->cap, &n, &steps, &T, &st, &nf);
         if (dir == -1) {
             free(b->rev_s[p]); free(b->rev_sd[p]);
@@ -250,6 +257,7 @@ int batotp_hip_download_curve(batotp_batch *b, int32_t path, int32_t which, doub
     ss = which == 1 ? b->fwd_s[path] : b->rev_s[path];
     sd = which == 1 ? b->fwd_sd[path] : b->rev_sd[path];
     avail = which == 1 ? b->res[path].n_fwd : b->res[path].n_rev;
+    if (avail <= 0) { if (n) *n = 0; return BATOTP_OK; }
     if (!ss) return BATOTP_ERR_STATE;
     m = avail < cap ? avail : cap;
     if (s) memcpy(s, ss, sizeof(double) * (size_t)m);
