@@ -28,7 +28,7 @@ MAX_CART = 8
 ROBOT_KUKA, ROBOT_UR, ROBOT_RR, ROBOT_CSPR3DOF, ROBOT_GENJNT = 1, 2, 3, 4, 5
 # problem flags
 F_JNT_ACC_ON, F_TRQ_ON, F_CART_VEL_ON, F_CART_ACC_ON = 1 << 0, 1 << 1, 1 << 2, 1 << 3
-F_PARALLEL, F_PAR2SER, F_HOST_TRIG = 1 << 4, 1 << 5, 1 << 6
+F_PARALLEL, F_PAR2SER, F_HOST_TRIG, F_NO_SAMPLES = 1 << 4, 1 << 5, 1 << 6, 1 << 7
 # per-path status bits
 ST_MAX_INTEG_TIME, ST_CAPACITY, ST_BISECT_FAIL = 1 << 0, 1 << 1, 1 << 2
 ST_NONFINITE, ST_SHORT, ST_SEG_ERROR = 1 << 3, 1 << 4, 1 << 5

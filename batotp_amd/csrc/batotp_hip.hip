@@ -295,7 +295,8 @@ extern "C" int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *pr
    ALLOC(b->dY, off * P.Cin, double)
    ALLOC(b->dSC, off, double)
    ALLOC(b->dCoef, off * P.C * 4, double)
-   ALLOC(b->dSamp, off * P.Cin * 3, double)
+   if ((prob->flags & BATOTP_F_NO_SAMPLES) && d != 0) { batotp_hip_batch_destroy(b); return BATOTP_ERR_ARG; }
+   ALLOC(b->dSamp, (prob->flags & BATOTP_F_NO_SAMPLES) ? 0 : off * P.Cin * 3, double)
    ALLOC(b->dDyn, off * 4 * (d ? d : 0), double)
    ALLOC(b->dTrig, (prob->robot_type == BATOTP_ROBOT_RR && d) ? off * 4 : 0, double)
    ALLOC(b->dMvc, off * 3, double)
@@ -484,8 +485,9 @@ extern "C" int batotp_hip_precompute(batotp_batch *b, int32_t stage)
       hipLaunchKernelGGL(k_sites, dim3(gridKnots), dim3(bs), 0, st, b->dPinfo, b->B, b->dSC, b->totalKnots);
       rc = launchSpline(b, b->P.Cin, 0, b->dY, b->P.Cin);
       if (rc) return rc;
-      hipLaunchKernelGGL(k_samples, dim3(gridKnots), dim3(bs), 0, st, b->dPinfo, b->B, b->P.C, b->P.Cin, b->dSC, b->dCoef, b->dSamp,
-                         b->dRes, b->totalKnots);
+      if (!(b->prob.flags & BATOTP_F_NO_SAMPLES))
+         hipLaunchKernelGGL(k_samples, dim3(gridKnots), dim3(bs), 0, st, b->dPinfo, b->B, b->P.C, b->P.Cin, b->dSC, b->dCoef, b->dSamp,
+                            b->dRes, b->totalKnots);
       HIP_TRY(hipGetLastError());
       b->kinDone = true;
       b->sitesSet = true;
@@ -662,6 +664,7 @@ extern "C" int batotp_hip_download_coeffs(batotp_batch *b, int32_t path, int32_t
 extern "C" int batotp_hip_download_samples(batotp_batch *b, int32_t path, int32_t channel, double *out)
 {
    if (!b || !out || path < 0 || path >= b->B || channel < 0 || channel >= b->P.Cin) return BATOTP_ERR_ARG;
+   if (b->prob.flags & BATOTP_F_NO_SAMPLES) return BATOTP_ERR_STATE;
    int rc = bind(b->ctx);
    if (rc) return rc;
    const PathInfo &pi = b->pinfo[path];

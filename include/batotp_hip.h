@@ -59,6 +59,8 @@ extern "C" {
 #define BATOTP_F_PARALLEL       (1u<<4)  /* _isParallelMechOrig: dynamics are A*tau = a1 sddot+... */
 #define BATOTP_F_PAR2SER        (1u<<5)  /* _isPar2Ser: convert a1..a4 with A^-1 per knot (ba.cpp:916-938) */
 #define BATOTP_F_HOST_TRIG      (1u<<6)  /* RR dynamics use host-supplied cos/sin (bit parity with glibc) */
+#define BATOTP_F_NO_SAMPLES     (1u<<7)  /* do not keep traj.theta/thetaD/thetaD2-style knot samples (saves 24 B/knot/channel;
+                                            only valid without torque constraints; download_samples then fails) */
 
 /* per-path status bits written by the sweep kernel (the reference only printf()s these) */
 #define BATOTP_ST_MAX_INTEG_TIME (1u<<0) /* ba.cpp:1117-1122 (MAX_INTEGRATION_TIME)        */

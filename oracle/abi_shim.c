@@ -169,18 +169,22 @@ int batotp_hip_upload_curve(batotp_batch *b, int32_t path, const double *s, cons
 int batotp_hip_precompute(batotp_batch *b, int32_t stage)
 {
     int32_t p;
+    int bad = 0;
     double t0 = now_ms();
     if (!b) return BATOTP_ERR_ARG;
+    for (p = 0; p < b->n_paths; p++)
+        if ((stage == 0 || stage == 1) && !b->in_y[p]) return BATOTP_ERR_STATE;
+    #pragma omp parallel for schedule(dynamic, 1)
     for (p = 0; p < b->n_paths; p++) {
         if (stage == 0 || stage == 1) {
-            if (!b->in_y[p]) return BATOTP_ERR_STATE;
             if (bo_precompute_kin(&b->prob, b->path[p], b->in_y[p], b->in_sres[p]) != 0)
                 b->res[p].status_rev |= BATOTP_ST_SEG_ERROR;
         }
         if (stage == 0 || stage == 2) {
-            if (bo_precompute_dyn(&b->prob, b->path[p], b->trig[p]) != 0) return BATOTP_ERR_ARG;
+            if (bo_precompute_dyn(&b->prob, b->path[p], b->trig[p]) != 0) bad = 1;
         }
     }
+    if (bad) return BATOTP_ERR_ARG;
     b->kin_done = 1;
     b->ms[1] = (float)(now_ms() - t0);
     return BATOTP_OK;
@@ -191,6 +195,7 @@ int batotp_hip_pointwise_mvc(batotp_batch *b)
     int32_t p;
     double t0 = now_ms();
     if (!b || !b->kin_done) return BATOTP_ERR_STATE;
+    #pragma omp parallel for schedule(dynamic, 1)
     for (p = 0; p < b->n_paths; p++) bo_pointwise_mvc(&b->prob, b->path[p]);
     b->ms[2] = (float)(now_ms() - t0);
     return BATOTP_OK;
@@ -201,6 +206,9 @@ int batotp_hip_sweep(batotp_batch *b, int32_t dir)
     int32_t p;
     double t0 = now_ms();
     if (!b || !b->kin_done || (dir != 1 && dir != -1)) return BATOTP_ERR_STATE;
+    for (p = 0; p < b->n_paths; p++)
+        if (dir == 1 && !b->rev_s[p]) return BATOTP_ERR_STATE;
+    #pragma omp parallel for schedule(dynamic, 1)
     for (p = 0; p < b->n_paths; p++) {
         double *s = (double *)malloc(sizeof(double) * (size_t)b->cap);
         double *sd = (double *)malloc(sizeof(double) * (size_t)b->cap);
@@ -209,7 +217,6 @@ int batotp_hip_sweep(batotp_batch *b, int32_t dir)
         uint32_t st = 0;
         int32_t nf = 0;
         batotp_path_result *r = &b->res[p];
-        if (dir == 1 && !b->rev_s[p]) { free(s); free(sd); return BATOTP_ERR_STATE; }
         if (dir == 1 && r->n_rev < 2) {
             /* no reverse curve to follow: same convention as the HIP kernel */
             free(s); free(sd);
