@@ -1,0 +1,78 @@
+"""CPU: the multi-rank path (world_size 2, gloo).  Paths are sharded over ranks with no data-path
+collective; the only communication is the all_gather of the per-path result rows."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import helpers
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, names, q):
+    sys.path.insert(0, helpers.ROOT)
+    sys.path.insert(0, os.path.join(helpers.ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from batotp_amd import capi
+    from batotp_amd import dist as bdist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = bdist.shard_range(len(names), rank, world)
+        cases = [helpers.Case(n) for n in names[lo:hi]]
+        for c in cases:
+            c.problem = helpers.Case(names[0]).problem
+        ctx = capi.Context(capi.load_oracle(), 0)
+        outs = helpers.run_pipeline(ctx, cases, mvc=False, details=False) if cases else []
+        local = np.array([o["result"] for o in outs], dtype=capi.RESULT_DTYPE) if outs else np.zeros(0, dtype=capi.RESULT_DTYPE)
+        allres = bdist.gather_results(local)
+        if rank == 0:
+            q.put(allres.tobytes())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_partitions():
+    from batotp_amd import dist as bdist
+    for n in (0, 1, 5, 8, 1024, 4097):
+        for w in (1, 2, 3, 8):
+            spans = [bdist.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_ranks_gather_matches_single_rank(oracle_ctx):
+    import torch.multiprocessing as mp
+    from batotp_amd import capi
+    names = ["GEN7DOF", "synth_gen7dof_s0", "GEN7DOF", "synth_gen7dof_s0", "GEN7DOF"]  # 5 paths -> 3 + 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, names, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    raw = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    gathered = np.frombuffer(raw, dtype=capi.RESULT_DTYPE)
+    cases = [helpers.Case(n) for n in names]
+    for c in cases:
+        c.problem = cases[0].problem
+    single = helpers.run_pipeline(oracle_ctx, cases, mvc=False, details=False)
+    assert gathered.shape[0] == len(names)
+    for k, o in enumerate(single):
+        for f in capi.RESULT_DTYPE.names:
+            assert gathered[k][f] == o["result"][f], (k, f)

@@ -118,3 +118,78 @@ def test_properties_at_full_size(hip_ctx):
         assert np.all(o["fwd"][1] <= rev_on_fwd * (1 + 1e-12) + 1e-300)
     for o in outs[1:]:
         assert_bit_equal(o["fwd"][1], outs[0]["fwd"][1], "replicated path")
+
+
+def test_edge_minimum_knots_and_short_sweep(hip_ctx, oracle_ctx):
+    """4 knots (the minimum) and a path crossed in fewer than 4 steps (nPts<4 re-interpolation, ba.cpp:1171-1184)"""
+    prob = capi.make_problem(2, 0, flags=capi.F_JNT_ACC_ON, jnt_vel_max=[1e3, 1e3], jnt_acc_max=[1e6, 1e6], integ_res=0.05)
+    y = np.array([[0.0, 0.1, 0.2, 0.3], [0.0, 0.05, 0.1, 0.15]])
+    outs = []
+    for ctx in (hip_ctx, oracle_ctx):
+        b = capi.Batch(ctx, prob, [4, 4, 4], 64)
+        for k in range(3):
+            b.upload_knots(k, [y * (k + 1)], [0.1 * (k + 1)])
+        b.precompute(0); b.pointwise_mvc(); b.sweep(-1); b.sweep(1)
+        outs.append((b.results(), [b.curve(k, -1) for k in range(3)], [b.curve(k, 1) for k in range(3)], [np.stack(b.mvc(k)) for k in range(3)]))
+        b.close()
+    (rh, revh, fwdh, mh), (ro, revo, fwdo, mo) = outs
+    assert np.array_equal(rh, ro)
+    assert np.any(rh["status_fwd"] & capi.ST_SHORT) or np.all(rh["steps_fwd"] >= 3)
+    for k in range(3):
+        assert_bit_equal(revh[k][1], revo[k][1], "rev sdot"); assert_bit_equal(fwdh[k][0], fwdo[k][0], "fwd s")
+        assert_bit_equal(fwdh[k][1], fwdo[k][1], "fwd sdot"); assert_bit_equal(mh[k], mo[k], "mvc")
+
+
+def test_uploaded_sites_and_coefficients_path(hip_ctx, oracle_ctx):
+    """the marshalling entry points BA::sweep uses (sites / coefficients / curve uploaded from a Traj),
+    including non-uniform knot sites (loaded instead of computed)"""
+    case = Case("GEN7DOF")
+    oo = run_pipeline(oracle_ctx, [case])[0]
+    prob = case.problem
+    n = case.n
+    for stretch in (False, True):
+        res = []
+        for ctx in (hip_ctx, oracle_ctx):
+            b = capi.Batch(ctx, prob, [n], case.max_steps())
+            sites = case.sres * np.arange(n, dtype=np.float64)
+            if stretch:
+                sites = sites * (1.0 + 1e-3 * np.sin(np.arange(n)))   # no longer sres*k
+                sites[0] = 0.0
+            vf = 1.0 / case.sres
+            b.upload_path_sites(0, sites, vf, vf * vf, 0)
+            for ch in range(prob.n_channels):
+                b.upload_coeffs(0, ch, oo["coef"][ch])
+            b.sweep(-1)
+            s, sd = b.curve(0, -1)
+            b2 = capi.Batch(ctx, prob, [n], case.max_steps())
+            b2.upload_path_sites(0, sites, vf, vf * vf, 0)
+            for ch in range(prob.n_channels):
+                b2.upload_coeffs(0, ch, oo["coef"][ch])
+            b2.upload_curve(0, s, sd)
+            b2.sweep(+1)
+            res.append((s, sd, *b2.curve(0, 1), b2.results()[0]["t_total"]))
+            b.close(); b2.close()
+        for a, c in zip(res[0][:4], res[1][:4]):
+            assert_bit_equal(a, c, f"uploaded path (stretch={stretch})")
+        assert res[0][4] == res[1][4]
+        if not stretch:
+            assert_bit_equal(res[0][1], oo["rev"][1], "uploaded == precomputed")
+
+
+def test_product_batest_end_to_end_on_gpu(tmp_path):
+    """the real drop-in: batotp_amd/host/_build/batest (host BA library + HIP library) writes the same files
+    as the reference binary"""
+    import filecmp, os, shutil, subprocess
+    exe = os.path.join(helpers.ROOT, "batotp_amd", "host", "_build", "batest")
+    assert os.path.exists(exe), "build() must produce batest"
+    for name in helpers.FULL_CASES:
+        work = tmp_path / name
+        work.mkdir()
+        src = os.path.join(helpers.GOLD, name)
+        for f in os.listdir(src):
+            if not f.startswith("ref_") and f not in ("knots.npz", "expected.json"):
+                shutil.copy(os.path.join(src, f), work / f)
+        r = subprocess.run([exe, "config.dat"], cwd=work, capture_output=True, text=True)
+        assert r.returncode == 0, (name, r.stdout[-2000:])
+        assert filecmp.cmp(work / "s-sdot.dat", os.path.join(src, "ref_s-sdot.dat"), shallow=False), name
+        assert filecmp.cmp(work / "traj_out.dat", os.path.join(src, "ref_traj_out.dat"), shallow=False), name
