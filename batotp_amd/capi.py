@@ -18,7 +18,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libbatotp_hip.so")
+HIP_LIB_PATH = os.environ.get("BATOTP_HIP_LIB", os.path.join(_HERE, "csrc", "libbatotp_hip.so"))
 ORACLE_ABI_LIB_PATH = os.path.join(_ROOT, "oracle", "_build", "libbatotp_oracle_abi.so")
 
 MAX_JOINTS = 8

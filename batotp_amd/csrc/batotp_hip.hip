@@ -66,6 +66,7 @@ struct batotp_batch
    batotp_path_result *dRes = nullptr;
    double *dStage = nullptr; // staging for marshalling (4*maxN doubles)
    int *dSink = nullptr;     // consumer of the sweep kernel's prefetch touches
+   double *dElim = nullptr;  // Thomas elimination values of k_spline, [max(Cin,4d)][N] per path
    int64_t maxN = 0;
    int64_t bytes = 0;
 
@@ -226,7 +227,7 @@ extern "C" int batotp_hip_batch_destroy(batotp_batch *b)
 {
    if (!b) return BATOTP_OK;
    if (b->ctx) hipSetDevice(b->ctx->device);
-   void *ptrs[] = {b->dP, b->dPinfo, b->dY, b->dSC, b->dCoef, b->dSamp, b->dDyn, b->dTrig, b->dMvc, b->dRev, b->dFwd, b->dRes, b->dStage, b->dSink};
+   void *ptrs[] = {b->dP, b->dPinfo, b->dY, b->dSC, b->dCoef, b->dSamp, b->dDyn, b->dTrig, b->dMvc, b->dRev, b->dFwd, b->dRes, b->dStage, b->dSink, b->dElim};
    for (void *p : ptrs)
       if (p) hipFree(p);
    for (int k = 0; k < 5; ++k)
@@ -305,6 +306,7 @@ extern "C" int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *pr
    ALLOC(b->dRes, n_paths, batotp_path_result)
    ALLOC(b->dStage, 4 * b->maxN, double)
    ALLOC(b->dSink, n_paths, int)
+   ALLOC(b->dElim, off * (P.Cin > 4 * d ? P.Cin : 4 * d), double)
 #undef ALLOC
    hipError_t e = hipMemcpyAsync(b->dP, &P, sizeof(P), hipMemcpyHostToDevice, ctx->stream);
    if (e == hipSuccess) e = hipMemcpyAsync(b->dPinfo, b->pinfo.data(), sizeof(PathInfo) * n_paths, hipMemcpyHostToDevice, ctx->stream);
@@ -464,7 +466,7 @@ static int launchSpline(batotp_batch *b, int nch, int mode, const double *src, i
    const int threads = b->B * nch;
    const int bs = 64;
    hipLaunchKernelGGL(k_spline, dim3((unsigned)((threads + bs - 1) / bs)), dim3(bs), 0, b->ctx->stream, b->dPinfo, b->B, nch, mode,
-                      b->P.C, b->P.Cin, b->P.d > 0 ? b->P.d : 1, src, srcStridePerKnot, b->dCoef);
+                      b->P.C, b->P.Cin, b->P.d > 0 ? b->P.d : 1, src, srcStridePerKnot, b->dElim, b->dCoef);
    HIP_TRY(hipGetLastError());
    return BATOTP_OK;
 }
@@ -517,6 +519,15 @@ extern "C" int batotp_hip_precompute(batotp_batch *b, int32_t stage)
    return BATOTP_OK;
 }
 
+// which constraint families the kernels must carry (template parameter FEAT of kernels.hip.h)
+static int featureLevel(const batotp_batch *b)
+{
+   if (b->needPar) return 3;
+   if (b->prob.flags & BATOTP_F_TRQ_ON) return 2;
+   if (b->prob.flags & (BATOTP_F_CART_VEL_ON | BATOTP_F_CART_ACC_ON)) return 1;
+   return 0;
+}
+
 static int readyForSweep(const batotp_batch *b)
 {
    if (!b->sitesSet) return BATOTP_ERR_STATE;
@@ -530,13 +541,19 @@ extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
    if (rc) return rc;
    rc = bind(b->ctx);
    if (rc) return rc;
-   const int bs = 256;
+   const int bs = K3_BLOCK;
    const unsigned grid = (unsigned)((b->totalKnots + bs - 1) / bs);
+   const size_t ldsBytes = sizeof(double) * (size_t)bs * (size_t)(b->P.C * 4 + 2);
    evStart(b, 2);
-   if (b->needPar)
-      hipLaunchKernelGGL(k_pointwise<true>, dim3(grid), dim3(bs), 0, b->ctx->stream, b->P, b->dPinfo, b->B, b->dP, b->dSC, b->dCoef, b->dMvc, b->totalKnots);
-   else
-      hipLaunchKernelGGL(k_pointwise<false>, dim3(grid), dim3(bs), 0, b->ctx->stream, b->P, b->dPinfo, b->B, b->dP, b->dSC, b->dCoef, b->dMvc, b->totalKnots);
+#define LAUNCH_K3(F) hipLaunchKernelGGL(k_pointwise<F>, dim3(grid), dim3(bs), ldsBytes, b->ctx->stream, b->P, b->dPinfo, b->B, b->dP, b->dSC, b->dCoef, b->dMvc, b->totalKnots)
+   switch (featureLevel(b))
+   {
+   case 0: LAUNCH_K3(0); break;
+   case 1: LAUNCH_K3(1); break;
+   case 2: LAUNCH_K3(2); break;
+   default: LAUNCH_K3(3); break;
+   }
+#undef LAUNCH_K3
    evStop(b, 2);
    HIP_TRY(hipGetLastError());
    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
@@ -551,8 +568,11 @@ static void launchSweep(batotp_batch *b, SweepArgs &a)
    if (ppw <= 0)
    {
       // automatic: with few paths spread them over more wavefronts (latency-bound regime), with many
-      // fill every lane (throughput-bound regime); aim at >= 2 wavefronts per SIMD (1024 SIMDs)
-      ppw = b->B / 2048;
+      // fill every lane (throughput-bound regime); aim at ~2 wavefronts per SIMD (1024 SIMDs, the
+      // register budget of the kernel admits 2 per SIMD).  The reverse sweep runs more bisection
+      // iterations, whose count differs between the paths of a wavefront, so it prefers fewer
+      // paths per wavefront than the forward sweep (measured, B = 4096: rev best at 2, fwd at 4).
+      ppw = (a.dir == -1) ? b->B / 2048 : b->B / 1024;
    }
    if (ppw < 1) ppw = 1;
    if (ppw > maxPpw) ppw = maxPpw;
@@ -561,16 +581,19 @@ static void launchSweep(batotp_batch *b, SweepArgs &a)
    bool uni = true;
    for (int p = 0; p < b->B; ++p) uni = uni && b->pinfo[p].uniform;
    hipStream_t st = b->ctx->stream;
-   if (b->needPar)
+#define LAUNCH_K4(F)                                                                           \
+   do {                                                                                        \
+      if (uni) hipLaunchKernelGGL((k_sweep<G, F, true>), dim3(grid), dim3(64), 0, st, a);      \
+      else hipLaunchKernelGGL((k_sweep<G, F, false>), dim3(grid), dim3(64), 0, st, a);        \
+   } while (0)
+   switch (featureLevel(b))
    {
-      if (uni) hipLaunchKernelGGL((k_sweep<G, true, true>), dim3(grid), dim3(64), 0, st, a);
-      else hipLaunchKernelGGL((k_sweep<G, true, false>), dim3(grid), dim3(64), 0, st, a);
+   case 0: LAUNCH_K4(0); break;
+   case 1: LAUNCH_K4(1); break;
+   case 2: LAUNCH_K4(2); break;
+   default: LAUNCH_K4(3); break;
    }
-   else
-   {
-      if (uni) hipLaunchKernelGGL((k_sweep<G, false, true>), dim3(grid), dim3(64), 0, st, a);
-      else hipLaunchKernelGGL((k_sweep<G, false, false>), dim3(grid), dim3(64), 0, st, a);
-   }
+#undef LAUNCH_K4
 }
 
 extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)

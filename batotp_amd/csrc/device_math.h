@@ -23,18 +23,35 @@ constexpr int DPP_QUAD_XOR2 = 0x4E;        // quad_perm [2,3,0,1]
 constexpr int DPP_ROW_HALF_MIRROR = 0x141; // lane i <-> 7-i inside each 8-lane half row
 constexpr int DPP_ROW_MIRROR = 0x140;      // lane i <-> 15-i inside each 16-lane row
 
+// value of lane perm(i) of every lane i (all source lanes are active group members)
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v)
 {
-   int lo = __double2loint(v), hi = __double2hiint(v);
-   lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-   hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+   const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+   const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
    return __hiloint2double(hi, lo);
 }
 template <int CTRL>
 __device__ __forceinline__ int dpp_mov(int v)
 {
-   return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+   return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
+}
+
+// One-instruction min / max for the cross-lane reductions.  For the non-NaN values reduced here they
+// return the same number as the compare-and-select forms dmin / dmax; the only representational
+// difference is the sign of a zero result (v_min treats -0 < +0), which cannot propagate: the reduced
+// quantities are only compared (+0 == -0) or enter sums a + h*(+-0) whose result does not depend on it.
+__device__ __forceinline__ double vmin_f64(double a, double b)
+{
+   double r;
+   asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+   return r;
+}
+__device__ __forceinline__ double vmax_f64(double a, double b)
+{
+   double r;
+   asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+   return r;
 }
 
 // All-reduce over the G lanes of a path group (G = 1, 8 or 16; groups are aligned to G lanes, so
@@ -43,20 +60,20 @@ template <int G>
 __device__ __forceinline__ double grp_min(double v)
 {
    if (G == 1) return v;
-   v = dmin(v, dpp_mov<DPP_QUAD_XOR1>(v));
-   v = dmin(v, dpp_mov<DPP_QUAD_XOR2>(v));
-   v = dmin(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
-   if (G == 16) v = dmin(v, dpp_mov<DPP_ROW_MIRROR>(v));
+   v = vmin_f64(v, dpp_mov<DPP_QUAD_XOR1>(v));
+   v = vmin_f64(v, dpp_mov<DPP_QUAD_XOR2>(v));
+   v = vmin_f64(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+   if (G == 16) v = vmin_f64(v, dpp_mov<DPP_ROW_MIRROR>(v));
    return v;
 }
 template <int G>
 __device__ __forceinline__ double grp_max(double v)
 {
    if (G == 1) return v;
-   v = dmax(v, dpp_mov<DPP_QUAD_XOR1>(v));
-   v = dmax(v, dpp_mov<DPP_QUAD_XOR2>(v));
-   v = dmax(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
-   if (G == 16) v = dmax(v, dpp_mov<DPP_ROW_MIRROR>(v));
+   v = vmax_f64(v, dpp_mov<DPP_QUAD_XOR1>(v));
+   v = vmax_f64(v, dpp_mov<DPP_QUAD_XOR2>(v));
+   v = vmax_f64(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+   if (G == 16) v = vmax_f64(v, dpp_mov<DPP_ROW_MIRROR>(v));
    return v;
 }
 template <int G>

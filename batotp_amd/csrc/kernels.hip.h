@@ -99,49 +99,93 @@ __device__ __forceinline__ void emit_segment(double *__restrict__ cf, int64_t i,
    *reinterpret_cast<Coef4 *>(cf + (i * C + dc) * 4) = o;
 }
 
-__global__ void k_spline(const PathInfo *__restrict__ pinfo, int B, int nch, int mode, int C, int Cin, int d,
-                         const double *__restrict__ src, int64_t src_stride_per_knot, double *__restrict__ coef)
+__global__ void __launch_bounds__(64) k_spline(const PathInfo *__restrict__ pinfo, int B, int nch, int mode, int C, int Cin, int d,
+                                               const double *__restrict__ src, int64_t src_stride_per_knot,
+                                               double *__restrict__ scratch, double *__restrict__ coef)
 {
    const int t = blockIdx.x * blockDim.x + threadIdx.x;
    if (t >= B * nch) return;
    const int p = t / nch, c = t - p * nch;
    const PathInfo pi = pinfo[p];
-   const int64_t N = pi.n;
-   const double *__restrict__ y = src + pi.koff * src_stride_per_knot + (int64_t)c * N;
+   const int N = (int)pi.n;
+   const int64_t streamOff = pi.koff * src_stride_per_knot + (int64_t)c * N;
+   const double *__restrict__ y = src + streamOff;
+   double *__restrict__ dpark = scratch + streamOff; // eliminated right-hand sides d[i], contiguous per channel
    double *__restrict__ cf = coef + pi.koff * C * 4;
    const int dc = (mode == 0) ? c : (Cin + (c % d) * 4 + (c / d));
-   const int64_t n = N - 1;
-   const int conv = 63;
+   const int n = N - 1;
+   constexpr int CONV = 63;                    // c_ctab is constant from here on (checked by the host)
+   const double cInf = c_ctab[CONV];
+   const double denInf = 4.0 - 1.0 * cInf;
+   constexpr int CH = 16;                      // knots per batch of independent loads
 
-   // forward elimination; d[i] parked in the c3 slot of knot i (spline.cpp:259-269)
+   // forward elimination (spline.cpp:259-269).  The bulk runs in branch-free batches of CH knots
+   // whose loads are issued together (one memory round trip per CH dependent divide steps) and
+   // whose pivot is the converged constant; the first rows (table pivots) and the remainder take
+   // the simple loop.
    double dprev = (6 * (y[0] - 2 * y[1] + y[2])) / 4.0;
-   cf[(1 * (int64_t)C + dc) * 4 + 3] = dprev;
+   dpark[1] = dprev;
    double ym = y[1], y0 = y[2];
-   for (int64_t i = 2; i < n; ++i)
-   {
-      const double yp = y[i + 1];
+   int i = 2;
+   auto step_fwd = [&](int ii, double yp) {
       const double rhs = 6 * (ym - 2 * y0 + yp);
-      const double cprev = c_ctab[(i - 1) < conv ? (i - 1) : conv];
-      const double di = (rhs - 1.0 * dprev) / (4.0 - 1.0 * cprev);
-      cf[(i * C + dc) * 4 + 3] = di;
+      const double den = (ii - 1) < CONV ? (4.0 - 1.0 * c_ctab[ii - 1]) : denInf;
+      const double di = (rhs - 1.0 * dprev) / den;
+      dpark[ii] = di;
       dprev = di;
       ym = y0; y0 = yp;
+   };
+   for (; i < n && i <= CONV + 1; ++i) step_fwd(i, y[i + 1]);
+   for (; i + CH <= n; i += CH)
+   {
+      double yy[CH];
+#pragma unroll
+      for (int k = 0; k < CH; ++k) yy[k] = y[i + 1 + k];
+#pragma unroll
+      for (int k = 0; k < CH; ++k)
+      {
+         const double rhs = 6 * (ym - 2 * y0 + yy[k]);
+         const double di = (rhs - 1.0 * dprev) / denInf;
+         dpark[i + k] = di;
+         dprev = di;
+         ym = y0; y0 = yy[k];
+      }
    }
-   const double cl = c_ctab[(n - 1) < conv ? (n - 1) : conv];
+   for (; i < n; ++i) step_fwd(i, y[i + 1]);
+   const double cl = (n - 1) < CONV ? c_ctab[n - 1] : cInf;
    double solR = (0.0 - 1.0 * dprev) / (4.0 - 1.0 * cl); // spline.cpp:269 (not forced to zero)
 
    // row of the last knot stays zero (spline.cpp:203-209 never writes it)
    Coef4 z; z.c0 = 0; z.c1 = 0; z.c2 = 0; z.c3 = 0;
-   *reinterpret_cast<Coef4 *>(cf + (n * C + dc) * 4) = z;
+   *reinterpret_cast<Coef4 *>(cf + ((unsigned)n * (unsigned)C * 4 + dc * 4)) = z;
 
-   // back substitution fused with the coefficient formulas (spline.cpp:271-274, 203-209)
+   // back substitution fused with the coefficient formulas (spline.cpp:271-274, 203-209):
+   // reference loop index ii runs n .. 2 with d[ii-1] -= c[ii-1]*d[ii]
    double yR = y[n];
-   for (int64_t i = n; i > 1; --i)
+   i = n;
+   for (; i - CH >= CONV + 1; i -= CH)
    {
-      const double dcur = cf[((i - 1) * C + dc) * 4 + 3];
-      const double ci = c_ctab[(i - 1) < conv ? (i - 1) : conv];
-      const double solL = dcur - ci * solR;
+      double dd[CH], yy[CH];
+#pragma unroll
+      for (int k = 0; k < CH; ++k)
+      {
+         dd[k] = dpark[i - 1 - k];
+         yy[k] = y[i - 1 - k];
+      }
+#pragma unroll
+      for (int k = 0; k < CH; ++k)
+      {
+         const double solL = dd[k] - cInf * solR; // ii - 1 = i - k - 1 >= CONV
+         emit_segment(cf, i - k - 1, C, dc, solL, solR, yy[k], yR);
+         solR = solL;
+         yR = yy[k];
+      }
+   }
+   for (; i > 1; --i)
+   {
+      const double ci = (i - 1) < CONV ? c_ctab[i - 1] : cInf;
       const double yL = y[i - 1];
+      const double solL = dpark[i - 1] - ci * solR;
       emit_segment(cf, i - 1, C, dc, solL, solR, yL, yR);
       solR = solL;
       yR = yL;
@@ -355,14 +399,17 @@ __global__ void k_dynamics(DevProblem P, const DevProblem *__restrict__ dP, cons
 // that is one value per path (cursor, sdot, bisection bracket ...) is kept redundantly in every
 // lane of the group, so control flow is uniform inside a group and the only cross-lane traffic is
 // the min / max over joints (DPP butterflies, device_math.h).
-//   PAR: the parallel-mechanism torque branch (isPar2Ser = 0) is compiled in.
+//   FEAT: which constraint families are compiled in (0 joint velocity/acceleration only,
+//         1 + Cartesian, 2 + torque in serial form, 3 + torque of a parallel mechanism, isPar2Ser = 0);
+//         the narrow variants carry fewer registers and instructions.
 //   UNI: knot sites are sres*k exactly (every path built by batotp_hip_precompute): they are
 //        computed instead of loaded, which removes the dependent loads of the segment search.
 // ---------------------------------------------------------------------------------------------
-template <int G, bool PAR, bool UNI>
+template <int G, int FEAT, bool UNI>
 struct Pt
 {
    static constexpr int PER = (G == 1) ? BATOTP_MAX_JOINTS : 1;
+   static constexpr bool PAR = (FEAT == 3); // FEAT: 0 joint vel/acc only, 1 + Cartesian, 2 + torque (serial form), 3 + torque (parallel mechanism)
 
    // path constants
    const double *__restrict__ sC;
@@ -431,15 +478,14 @@ __device__ __forceinline__ void update_cur_seg(const double *__restrict__ s, dou
 }
 
 // BA::evalSplinePartials + evalCartQuadCoeffs (ba.cpp:1341-1439)
-template <int G, bool PAR, bool UNI>
-__device__ __forceinline__ void eval_partials(Pt<G, PAR, UNI> &t, int j)
+template <int G, int FEAT, bool UNI>
+__device__ __forceinline__ void eval_partials_row(Pt<G, FEAT, UNI> &t, int j, const double *__restrict__ row)
 {
-   update_cur_seg<UNI ? 0 : 1>(t.sC, t.sresC, t.n, t.sCur, t.segC, t.tauC, t.status);
+   constexpr bool PAR = (FEAT == 3);
    const double tau = t.tauC, tau2 = tau * tau, tau3 = tau2 * tau;
-   const double *__restrict__ row = t.coef + (unsigned)(t.segC * t.C * 4);
 
 #pragma unroll
-   for (int q = 0; q < Pt<G, PAR, UNI>::PER; ++q)
+   for (int q = 0; q < Pt<G, FEAT, UNI>::PER; ++q)
    {
       const int jj = j + q * G;
       if (jj < t.nJ)
@@ -449,7 +495,7 @@ __device__ __forceinline__ void eval_partials(Pt<G, PAR, UNI> &t, int j)
          t.thD2[q] = (6 * k.c3 * tau + 2 * k.c2) * t.afact;
       }
    }
-   if (t.flags & (BATOTP_F_CART_VEL_ON | BATOTP_F_CART_ACC_ON))
+   if (FEAT >= 1 && (t.flags & (BATOTP_F_CART_VEL_ON | BATOTP_F_CART_ACC_ON)))
    {
       double v[3], a[3];
 #pragma unroll
@@ -464,7 +510,7 @@ __device__ __forceinline__ void eval_partials(Pt<G, PAR, UNI> &t, int j)
       t.cq1 = 2 * (v[0] * a[0] + v[1] * a[1] + v[2] * a[2]);
       t.cq2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
    }
-   if (t.flags & BATOTP_F_TRQ_ON)
+   if (FEAT >= 2 && (t.flags & BATOTP_F_TRQ_ON))
    {
       if (PAR && t.parallel_now)
       {
@@ -484,7 +530,7 @@ __device__ __forceinline__ void eval_partials(Pt<G, PAR, UNI> &t, int j)
       else
       {
 #pragma unroll
-         for (int q = 0; q < Pt<G, PAR, UNI>::PER; ++q)
+         for (int q = 0; q < Pt<G, FEAT, UNI>::PER; ++q)
          {
             const int jj = j + q * G;
             if (jj < t.nJ)
@@ -501,9 +547,16 @@ __device__ __forceinline__ void eval_partials(Pt<G, PAR, UNI> &t, int j)
    }
 }
 
+template <int G, int FEAT, bool UNI>
+__device__ __forceinline__ void eval_partials(Pt<G, FEAT, UNI> &t, int j)
+{
+   update_cur_seg<UNI ? 0 : 1>(t.sC, t.sresC, t.n, t.sCur, t.segC, t.tauC, t.status);
+   eval_partials_row(t, j, t.coef + (unsigned)(t.segC * t.C * 4));
+}
+
 // BA::evalsdot, "linear" (ba.cpp:1590-1607)
-template <int G, bool PAR, bool UNI>
-__device__ __forceinline__ double eval_sdot(Pt<G, PAR, UNI> &t)
+template <int G, int FEAT, bool UNI>
+__device__ __forceinline__ double eval_sdot(Pt<G, FEAT, UNI> &t)
 {
    update_cur_seg<2>(t.mvc, 0.0, t.nMvc, t.sCur, t.segMVC, t.tauMVC, t.status);
    const double sd0 = t.mvc[t.segMVC * 2 + 1], sd1 = t.mvc[(t.segMVC + 1) * 2 + 1];
@@ -513,8 +566,8 @@ __device__ __forceinline__ double eval_sdot(Pt<G, PAR, UNI> &t)
 
 // BA::sdotLim (ba.cpp:1204-1236).  The joint-velocity limits use the theta' of the previous
 // evalSplinePartials call, exactly as the reference does.
-template <int G, bool PAR, bool UNI>
-__device__ __forceinline__ void sdot_lim(Pt<G, PAR, UNI> &t, int j, double &sdot)
+template <int G, int FEAT, bool UNI>
+__device__ __forceinline__ void sdot_lim(Pt<G, FEAT, UNI> &t, int j, double &sdot)
 {
    if (t.dir == 1)
    {
@@ -525,14 +578,14 @@ __device__ __forceinline__ void sdot_lim(Pt<G, PAR, UNI> &t, int j, double &sdot
    sdot = dmax(sdot, t.sdotMin);
    double lim = kInf;
 #pragma unroll
-   for (int q = 0; q < Pt<G, PAR, UNI>::PER; ++q)
+   for (int q = 0; q < Pt<G, FEAT, UNI>::PER; ++q)
    {
       const int jj = j + q * G;
       if (jj < t.nJ && fabs(t.thD[q]) > t.thrV) lim = dmin(lim, fabs(t.vmax[q] / t.thD[q]));
    }
    lim = grp_min<G>(lim);
    sdot = dmin(sdot, lim);
-   if ((t.flags & BATOTP_F_CART_VEL_ON) && t.cq0 > t.quadA) sdot = dmin(sdot, t.cartVelMax / sqrt(t.cq0));
+   if (FEAT >= 1 && (t.flags & BATOTP_F_CART_VEL_ON) && t.cq0 > t.quadA) sdot = dmin(sdot, t.cartVelMax / sqrt(t.cq0));
 }
 
 // solveQuadratic (util.cpp:361-383)
@@ -559,13 +612,14 @@ __device__ __forceinline__ int solve_quadratic(double A, double B, double C, dou
 // predicate as L > H after the full reduction, and whenever the point is admissible both agree on
 // sddotL / sddotH bit for bit.  The unconditional "violated" exit of the zero-velocity case
 // (ba.cpp:1522) is folded into the H reduction as -inf (sddotL/H are never read after a violation).
-template <int G, bool PAR, bool UNI>
-__device__ __forceinline__ bool verify_second_order(Pt<G, PAR, UNI> &t, int j, double sdotCur)
+template <int G, int FEAT, bool UNI>
+__device__ __forceinline__ bool verify_second_order(Pt<G, FEAT, UNI> &t, int j, double sdotCur)
 {
+   constexpr bool PAR = (FEAT == 3);
    const double sdotSQ = sdotCur * sdotCur;
    double H = t.sddotMax, L = -t.sddotMax;
 
-   if (t.flags & BATOTP_F_TRQ_ON)
+   if (FEAT >= 2 && (t.flags & BATOTP_F_TRQ_ON))
    {
       if (PAR && t.parallel_now)
       {
@@ -574,7 +628,7 @@ __device__ __forceinline__ bool verify_second_order(Pt<G, PAR, UNI> &t, int j, d
 #pragma unroll
          for (int i = 0; i < 3; ++i) cStar[i] = sdotSQ * t.pa2[PAR ? i : 0] + sdotCur * t.pa3[PAR ? i : 0] + t.pa4[PAR ? i : 0];
 #pragma unroll
-         for (int q = 0; q < Pt<G, PAR, UNI>::PER; ++q)
+         for (int q = 0; q < Pt<G, FEAT, UNI>::PER; ++q)
          {
             const int jj = j + q * G;
             if (jj < t.nJ)
@@ -610,7 +664,7 @@ __device__ __forceinline__ bool verify_second_order(Pt<G, PAR, UNI> &t, int j, d
       {
          // ba.cpp:1495-1509
 #pragma unroll
-         for (int q = 0; q < Pt<G, PAR, UNI>::PER; ++q)
+         for (int q = 0; q < Pt<G, FEAT, UNI>::PER; ++q)
          {
             const int jj = j + q * G;
             if (jj < t.nJ)
@@ -634,7 +688,7 @@ __device__ __forceinline__ bool verify_second_order(Pt<G, PAR, UNI> &t, int j, d
    {
       // ba.cpp:1514-1534
 #pragma unroll
-      for (int q = 0; q < Pt<G, PAR, UNI>::PER; ++q)
+      for (int q = 0; q < Pt<G, FEAT, UNI>::PER; ++q)
       {
          const int jj = j + q * G;
          if (jj < t.nJ)
@@ -663,7 +717,7 @@ __device__ __forceinline__ bool verify_second_order(Pt<G, PAR, UNI> &t, int j, d
    t.sddotL = L;
    if (L > Hred) return true; // also the folded "force" exit: L >= -sddotMax > -inf
 
-   if (t.flags & BATOTP_F_CART_ACC_ON)
+   if (FEAT >= 1 && (t.flags & BATOTP_F_CART_ACC_ON))
    {
       // ba.cpp:1535-1579
       const double A = t.cq0;
@@ -692,8 +746,8 @@ __device__ __forceinline__ bool verify_second_order(Pt<G, PAR, UNI> &t, int j, d
 
 // BA::applyAccelConstraintsBisectionPt (ba.cpp:1248-1332).  Returns 0, or -1 on the failure exits of
 // ba.cpp:1307-1319, in which case sddot is left untouched (the reference's caller ignores the code).
-template <int G, bool PAR, bool UNI>
-__device__ __forceinline__ int apply_accel_bisection(Pt<G, PAR, UNI> &t, int j, double &sddot, int &nIter)
+template <int G, int FEAT, bool UNI, bool DOEVAL = true>
+__device__ __forceinline__ int apply_accel_bisection(Pt<G, FEAT, UNI> &t, int j, double &sddot, int &nIter)
 {
    const double sdotErrThresh = .001;
    double lowFact = .01;
@@ -705,7 +759,7 @@ __device__ __forceinline__ int apply_accel_bisection(Pt<G, PAR, UNI> &t, int j, 
    double sdotCur = sdotH;
    nIter = 0;
 
-   eval_partials(t, j);
+   if (DOEVAL) eval_partials(t, j); // ba.cpp:1265
 
    for (;;)
    {
@@ -742,8 +796,8 @@ __device__ __forceinline__ int apply_accel_bisection(Pt<G, PAR, UNI> &t, int j, 
    return 0;
 }
 
-template <int G, bool PAR, bool UNI>
-__device__ __forceinline__ void accel_pt(Pt<G, PAR, UNI> &t, int j, double &sddot)
+template <int G, int FEAT, bool UNI>
+__device__ __forceinline__ void accel_pt(Pt<G, FEAT, UNI> &t, int j, double &sddot)
 {
    int nIter;
    if (apply_accel_bisection(t, j, sddot, nIter) != 0)
@@ -754,10 +808,11 @@ __device__ __forceinline__ void accel_pt(Pt<G, PAR, UNI> &t, int j, double &sddo
 }
 
 // fill the constants of a path group
-template <int G, bool PAR, bool UNI>
-__device__ __forceinline__ void pt_init(Pt<G, PAR, UNI> &t, const DevProblem &P, const PathInfo &pi, const double *sC,
+template <int G, int FEAT, bool UNI>
+__device__ __forceinline__ void pt_init(Pt<G, FEAT, UNI> &t, const DevProblem &P, const PathInfo &pi, const double *sC,
                                         const double *coef, const double (*lim)[8], int j, int dir)
 {
+   constexpr bool PAR = (FEAT == 3);
    t.sC = sC + pi.koff;
    t.coef = coef + pi.koff * P.C * 4;
    t.n = (int)pi.n;
@@ -777,7 +832,7 @@ __device__ __forceinline__ void pt_init(Pt<G, PAR, UNI> &t, const DevProblem &P,
    t.cartVelMax = P.cart_vel_max;
    t.pmat = &lim[4][0];
 #pragma unroll
-   for (int q = 0; q < Pt<G, PAR, UNI>::PER; ++q)
+   for (int q = 0; q < Pt<G, FEAT, UNI>::PER; ++q)
    {
       const int jj = (j + q * G) & 7;
       t.vmax[q] = lim[0][jj]; t.amax[q] = lim[1][jj]; t.tmax[q] = lim[2][jj]; t.tmin[q] = lim[3][jj];
@@ -819,15 +874,38 @@ __device__ __forceinline__ void stage_limits(const DevProblem *__restrict__ dP, 
 // is cut by the velocity limits of ba.cpp:1219-1229 with THIS knot's derivatives, then by the
 // bisection of ba.cpp:1248-1332.
 // ---------------------------------------------------------------------------------------------
-template <bool PAR>
-__global__ void __launch_bounds__(256) k_pointwise(DevProblem P, const PathInfo *__restrict__ pinfo, int B,
-                                                   const DevProblem *__restrict__ dP,
-                                                   const double *__restrict__ sC, const double *__restrict__ coef,
-                                                   double *__restrict__ mvc, int64_t total)
+constexpr int K3_BLOCK = 128;
+
+template <int FEAT>
+__global__ void __launch_bounds__(K3_BLOCK) k_pointwise(DevProblem P, const PathInfo *__restrict__ pinfo, int B,
+                                                        const DevProblem *__restrict__ dP,
+                                                        const double *__restrict__ sC, const double *__restrict__ coef,
+                                                        double *__restrict__ mvc, int64_t total)
 {
    __shared__ double lim[6][8];
+   extern __shared__ double tile[]; // K3_BLOCK rows of C*4 doubles, padded by 2 doubles per row
    stage_limits(dP, lim);
-   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+
+   // The coefficient rows of consecutive knots are contiguous in HBM (also across path boundaries):
+   // the workgroup copies its K3_BLOCK rows with fully coalesced 32-byte-per-lane loads into LDS,
+   // then every lane evaluates its own knot from LDS (row stride padded by 16 B: conflict-free b128 reads).
+   const int64_t g0 = (int64_t)blockIdx.x * K3_BLOCK;
+   const int rowD = P.C * 4, rowPad = rowD + 2;
+   const int rowsHere = (total - g0) < K3_BLOCK ? (int)(total - g0) : K3_BLOCK;
+   {
+      const Coef4 *__restrict__ srcp = reinterpret_cast<const Coef4 *>(coef + g0 * rowD);
+      const int chunks = rowsHere * P.C;
+      for (int k = threadIdx.x; k < chunks; k += K3_BLOCK)
+      {
+         const Coef4 v = srcp[k];
+         const int r = k / P.C, c = k - r * P.C;
+         double *dst = tile + r * rowPad + c * 4;
+         dst[0] = v.c0; dst[1] = v.c1; dst[2] = v.c2; dst[3] = v.c3;
+      }
+   }
+   __syncthreads();
+
+   const int64_t g = g0 + threadIdx.x;
    if (g >= total) return;
    int lo = 0, hi = B - 1;
    while (lo < hi)
@@ -838,17 +916,24 @@ __global__ void __launch_bounds__(256) k_pointwise(DevProblem P, const PathInfo 
    const PathInfo pi = pinfo[lo];
    const int N = (int)pi.n, i = (int)(g - pi.koff);
 
-   Pt<1, PAR, false> t;
+   Pt<1, FEAT, false> t;
    pt_init(t, P, pi, sC, coef, lim, 0, -1);
    t.segC = (i < N - 1) ? i : N - 2;
    t.sCur = t.sC[i];
-   eval_partials(t, 0);
+   // cursor already on its segment: updateCurSeg only computes tau (0 at a knot, 1 at the last knot)
+   {
+      const double sSeg = t.sC[t.segC], sNext = t.sC[t.segC + 1];
+      t.tauC = (t.sCur - sSeg) / (sNext - sSeg);
+   }
+   const int rowLocal = (int)threadIdx.x - (i - t.segC); // the last knot of a path uses the previous row
+   const double *row = (rowLocal >= 0) ? (tile + rowLocal * rowPad) : (t.coef + (unsigned)(t.segC * rowD));
+   eval_partials_row(t, 0, row);
    double sdot = t.sdotCap;
    sdot_lim(t, 0, sdot);
    t.sdotCur = sdot;
    double sddot = 0;
    int nIter;
-   (void)apply_accel_bisection(t, 0, sddot, nIter);
+   (void)apply_accel_bisection<1, FEAT, false, false>(t, 0, sddot, nIter);
    double *__restrict__ o = mvc + pi.koff * 3;
    o[i] = t.sdotCur;
    o[N + i] = t.sddotL;
@@ -903,8 +988,8 @@ struct SweepArgs
 // every stage each lane of the group touches one 128-byte line of the next kilobyte ahead of the
 // cursor.  The loaded word is consumed one stage later (t.sink), which keeps the load alive without
 // ever waiting on it, and by then the line sits in the vector L1 / L2 instead of HBM.
-template <int G, bool PAR, bool UNI>
-__device__ __forceinline__ int touch_ahead(const Pt<G, PAR, UNI> &t, int j)
+template <int G, int FEAT, bool UNI>
+__device__ __forceinline__ int touch_ahead(const Pt<G, FEAT, UNI> &t, int j)
 {
    const int linesAhead = 1 + (j & 7);
    const int rowDoubles = t.C * 4;
@@ -927,8 +1012,12 @@ __device__ __forceinline__ int touch_ahead(const Pt<G, PAR, UNI> &t, int j)
    return v;
 }
 
-template <int G, bool PAR, bool UNI>
-__global__ void __launch_bounds__(64) k_sweep(SweepArgs a)
+#ifndef BK_SWEEP_WPE
+#define BK_SWEEP_WPE 2
+#endif
+// waves per SIMD the register allocation of the narrow (FEAT <= 1) sweep kernels is tuned for
+template <int G, int FEAT, bool UNI>
+__global__ void __launch_bounds__(64, (FEAT <= 1 && G > 1) ? BK_SWEEP_WPE : 2) k_sweep(SweepArgs a)
 {
    __shared__ double lim[6][8];
    stage_limits(a.dP, lim);
@@ -944,7 +1033,7 @@ __global__ void __launch_bounds__(64) k_sweep(SweepArgs a)
    const int n = (int)pi.n;
    const int64_t cap = a.cap;
 
-   Pt<G, PAR, UNI> t;
+   Pt<G, FEAT, UNI> t;
    pt_init(t, a.P, pi, a.sC, a.coef, lim, j, dir);
 
    double2 *__restrict__ out = (dir == 1 ? a.fwd : a.rev) + (int64_t)p * cap;
