@@ -789,7 +789,11 @@ __device__ __forceinline__ int apply_accel_bisection(Pt<G, FEAT, UNI> &t, int j,
       }
       nIter++;
       if (nIter > 100) return -1;
-      if (sdotCur < 0 || ((sdotH - sdotL) / sdotH < 1e-20 && !anyGoodIter)) return -1;
+      if (sdotCur < 0) return -1;
+      if (!anyGoodIter)
+      {
+         if ((sdotH - sdotL) / sdotH < 1e-20) return -1; // only evaluated while no feasible point is known
+      }
       sdotCur = .5 * (sdotH + sdotL);
    }
    sddot = (t.dir == 1) ? t.sddotH : t.sddotL;
@@ -985,8 +989,8 @@ struct SweepArgs
 #define BK_B55 (11. / 84)
 
 // Software prefetch: the walk over the spline rows (and over the reverse curve) is monotone, so
-// every stage each lane of the group touches one 128-byte line of the next kilobyte ahead of the
-// cursor.  The loaded word is consumed one stage later (t.sink), which keeps the load alive without
+// every stage of the reverse sweep each lane of the group touches one 128-byte line of the next
+// kilobyte ahead of (below) the cursor.  The loaded word is consumed one stage later (t.sink), which keeps the load alive without
 // ever waiting on it, and by then the line sits in the vector L1 / L2 instead of HBM.
 template <int G, int FEAT, bool UNI>
 __device__ __forceinline__ int touch_ahead(const Pt<G, FEAT, UNI> &t, int j)
@@ -1001,13 +1005,6 @@ __device__ __forceinline__ int touch_ahead(const Pt<G, FEAT, UNI> &t, int j)
       const int hi = lastRow * rowDoubles;
       off = off < 0 ? 0 : (off > hi ? hi : off);
       v = reinterpret_cast<const int *>(t.coef)[2 * (unsigned)off];
-   }
-   if (t.dir == 1)
-   {
-      int off = t.segMVC * 2 + linesAhead * 16;
-      const int hi = (t.nMvc - 1) * 2;
-      off = off > hi ? hi : off;
-      v ^= reinterpret_cast<const int *>(t.mvc)[2 * (unsigned)off];
    }
    return v;
 }
@@ -1150,9 +1147,14 @@ __global__ void __launch_bounds__(64, (FEAT <= 1 && G > 1) ? BK_SWEEP_WPE : 2) k
          case 5: v5 = vN; w5 = wN; break;
          default: s6v = sN; v6 = vN; w6 = wN; break;
          }
-         // consume last stage's touch, issue the next one
-         t.sink += pf;
-         pf = touch_ahead(t, j);
+         // reverse sweep only (descending addresses; measured: -17 % there, +5 % on the forward sweep,
+         // whose ascending walk finds the next lines already on their way): consume last stage's touch,
+         // issue the next one
+         if (dir == -1)
+         {
+            t.sink += pf;
+            pf = touch_ahead(t, j);
+         }
       }
 
       // FSAL shift and publish, ba.cpp:1096-1100
