@@ -132,6 +132,19 @@ static int uploadThomasTable()
       snprintf(g_err, sizeof(g_err), "Thomas coefficient table is not a fixed point");
       return BATOTP_ERR_STATE;
    }
+   // slot 0 (unused by the recurrence) carries RN(1/(4 - c_inf)) for the reciprocal-based divide of
+   // k_spline; its preconditions are checked here: the divisor is not of the form 1.11..1 * 2^k
+   {
+      const double den = 4.0 - 1.0 * tab[63];
+      int e;
+      const double m = frexp(den, &e); // in [0.5, 1)
+      if (!(m < 1.0 - 1e-9))
+      {
+         snprintf(g_err, sizeof(g_err), "Thomas pivot unsuitable for the reciprocal divide");
+         return BATOTP_ERR_STATE;
+      }
+      tab[0] = 1.0 / den;
+   }
    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_ctab), tab, sizeof(tab)));
    return BATOTP_OK;
 }

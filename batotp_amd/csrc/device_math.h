@@ -44,13 +44,15 @@ __device__ __forceinline__ int dpp_mov(int v)
 __device__ __forceinline__ double vmin_f64(double a, double b)
 {
    double r;
-   asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+   // the trailing s_nop supplies the 2 wait states a DPP read of the result needs: hipcc does not
+   // pad hazards of instructions inside an asm statement (cdna_hip_programming.md 5.7 item 2)
+   asm("v_min_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
    return r;
 }
 __device__ __forceinline__ double vmax_f64(double a, double b)
 {
    double r;
-   asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+   asm("v_max_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
    return r;
 }
 

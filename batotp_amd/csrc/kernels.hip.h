@@ -88,6 +88,24 @@ __global__ void k_sites(const PathInfo *__restrict__ pinfo, int B, double *__res
 // src: channel-major values; mode 0: yin channels (dev channel = c), mode 1: dyn channels
 // (c = k*d + r  ->  dev channel Cin + r*4 + k).
 // ---------------------------------------------------------------------------------------------
+// Correctly rounded num/den for a loop-invariant divisor whose correctly rounded reciprocal rcp is
+// known (Markstein: q0 = RN(num*rcp); r = num - den*q0 exactly (one FMA); q = RN(q0 + r*rcp) is
+// RN(num/den) when rcp = RN(1/den), the mantissa of den is not all ones and nothing under/overflows).
+// This takes the divide's Newton iteration off the dependent chain of the Thomas recurrence
+// (4 dependent operations instead of 11).  The FMAs are explicit: they are the algorithm, not a
+// contraction.  Outside the safe magnitude window, and for zero (sign), the true division is used.
+__device__ __forceinline__ double div_by_const(double num, double den, double rcp)
+{
+   const double an = fabs(num);
+   if (an > 1e-280 && an < 1e280)
+   {
+      const double q0 = num * rcp;
+      const double r = __builtin_fma(-den, q0, num);
+      return __builtin_fma(r, rcp, q0);
+   }
+   return num / den;
+}
+
 __device__ __forceinline__ void emit_segment(double *__restrict__ cf, int64_t i, int C, int dc, double solL, double solR,
                                              double yL, double yR)
 {
@@ -117,7 +135,8 @@ __global__ void __launch_bounds__(64) k_spline(const PathInfo *__restrict__ pinf
    constexpr int CONV = 63;                    // c_ctab is constant from here on (checked by the host)
    const double cInf = c_ctab[CONV];
    const double denInf = 4.0 - 1.0 * cInf;
-   constexpr int CH = 16;                      // knots per batch of independent loads
+   const double rcpInf = c_ctab[0];            // RN(1/denInf), computed (and checked) by the host
+   constexpr int CH = 32;                      // knots per batch of independent loads
 
    // forward elimination (spline.cpp:259-269).  The bulk runs in branch-free batches of CH knots
    // whose loads are issued together (one memory round trip per CH dependent divide steps) and
@@ -145,7 +164,7 @@ __global__ void __launch_bounds__(64) k_spline(const PathInfo *__restrict__ pinf
       for (int k = 0; k < CH; ++k)
       {
          const double rhs = 6 * (ym - 2 * y0 + yy[k]);
-         const double di = (rhs - 1.0 * dprev) / denInf;
+         const double di = div_by_const(rhs - 1.0 * dprev, denInf, rcpInf);
          dpark[i + k] = di;
          dprev = di;
          ym = y0; y0 = yy[k];
@@ -437,6 +456,11 @@ struct Pt
    unsigned status;
    int nfail;
    int sink; // consumer of the prefetch touches (keeps them alive; written to the result row)
+   // register cache of the last spline row / reverse-curve segment read (dense-step paths stay on
+   // one segment for many consecutive evaluations)
+   int rowSeg, mvcSeg;
+   Coef4 rowTh[PER];
+   double mvcS0, mvcS1, mvcD0, mvcD1;
 };
 
 // BA::updateCurSeg (ba.cpp:1617-1652).  KIND 0: sites computed as sres*k; 1: sites loaded from s[k];
@@ -551,16 +575,73 @@ template <int G, int FEAT, bool UNI>
 __device__ __forceinline__ void eval_partials(Pt<G, FEAT, UNI> &t, int j)
 {
    update_cur_seg<UNI ? 0 : 1>(t.sC, t.sresC, t.n, t.sCur, t.segC, t.tauC, t.status);
-   eval_partials_row(t, j, t.coef + (unsigned)(t.segC * t.C * 4));
+   const double *__restrict__ row = t.coef + (unsigned)(t.segC * t.C * 4);
+#ifndef BK_NO_ROWCACHE
+   if (FEAT == 0)
+#else
+   if (false)
+#endif
+   {
+      // joint channels only: keep this lane's coefficients in registers while the cursor stays on
+      // the segment (group-uniform test)
+      if (t.segC != t.rowSeg)
+      {
+#pragma unroll
+         for (int q = 0; q < Pt<G, FEAT, UNI>::PER; ++q)
+         {
+            const int jj = j + q * G;
+            if (jj < t.nJ) t.rowTh[q] = *reinterpret_cast<const Coef4 *>(row + jj * 4);
+         }
+         t.rowSeg = t.segC;
+      }
+      const double tau = t.tauC, tau2 = tau * tau;
+#pragma unroll
+      for (int q = 0; q < Pt<G, FEAT, UNI>::PER; ++q)
+      {
+         const int jj = j + q * G;
+         if (jj < t.nJ)
+         {
+            const Coef4 k = t.rowTh[q];
+            t.thD[q] = (3 * k.c3 * tau2 + 2 * k.c2 * tau + k.c1) * t.vfact;
+            t.thD2[q] = (6 * k.c3 * tau + 2 * k.c2) * t.afact;
+         }
+      }
+      return;
+   }
+   eval_partials_row(t, j, row);
+}
+
+// BA::updateCurSeg on the reverse curve (ba.cpp:1592) with the current segment's two (s, sdot)
+// pairs cached in registers: the common case "still inside the cached segment" (dense-step paths)
+// costs no load; otherwise the literal walk runs and the cache is refilled.
+template <int G, int FEAT, bool UNI>
+__device__ __forceinline__ void mvc_walk(Pt<G, FEAT, UNI> &t)
+{
+   const double sCur = t.sCur;
+   if (t.mvcSeg == t.segMVC && sCur >= t.mvcS0 && sCur <= t.mvcS1)
+   {
+      t.tauMVC = (sCur - t.mvcS0) / (t.mvcS1 - t.mvcS0);
+      return;
+   }
+   update_cur_seg<2>(t.mvc, 0.0, t.nMvc, sCur, t.segMVC, t.tauMVC, t.status);
+   const double2 a = *reinterpret_cast<const double2 *>(t.mvc + 2 * t.segMVC);
+   const double2 b = *reinterpret_cast<const double2 *>(t.mvc + 2 * t.segMVC + 2);
+   t.mvcS0 = a.x; t.mvcD0 = a.y; t.mvcS1 = b.x; t.mvcD1 = b.y;
+   t.mvcSeg = t.segMVC;
 }
 
 // BA::evalsdot, "linear" (ba.cpp:1590-1607)
 template <int G, int FEAT, bool UNI>
 __device__ __forceinline__ double eval_sdot(Pt<G, FEAT, UNI> &t)
 {
+#ifdef BK_OLD_MVC
    update_cur_seg<2>(t.mvc, 0.0, t.nMvc, t.sCur, t.segMVC, t.tauMVC, t.status);
    const double sd0 = t.mvc[t.segMVC * 2 + 1], sd1 = t.mvc[(t.segMVC + 1) * 2 + 1];
    const double v = sd0 + t.tauMVC * (sd1 - sd0);
+#else
+   mvc_walk(t);
+   const double v = t.mvcD0 + t.tauMVC * (t.mvcD1 - t.mvcD0);
+#endif
    return dmax(v, t.sdotMin);
 }
 
@@ -853,6 +934,8 @@ __device__ __forceinline__ void pt_init(Pt<G, FEAT, UNI> &t, const DevProblem &P
    t.segC = 0; t.segMVC = 0; t.tauC = 0; t.tauMVC = 0;
    t.sCur = 0; t.sdotCur = 0; t.sddotL = 0; t.sddotH = 0; t.sdotMin = 0;
    t.status = 0; t.nfail = 0; t.sink = 0;
+   t.rowSeg = -1; t.mvcSeg = -1;
+   t.mvcS0 = 0; t.mvcS1 = 0; t.mvcD0 = 0; t.mvcD1 = 0;
 }
 
 // stage the limit tables of the problem in LDS (one copy per workgroup); row 4/5 = cable anchors
@@ -1124,7 +1207,11 @@ __global__ void __launch_bounds__(64, (FEAT <= 1 && G > 1) ? BK_SWEEP_WPE : 2) k
          {
             // forward predictor: evalsdot's cursor walk at s0 + h*sdot0, nothing else is kept
             t.sCur = s0v + h * v0;
+#ifdef BK_OLD_MVC
             update_cur_seg<2>(t.mvc, 0.0, t.nMvc, t.sCur, t.segMVC, t.tauMVC, t.status);
+#else
+            mvc_walk(t);
+#endif
             t.sCur = sStart;
             continue;
          }

@@ -43,6 +43,13 @@ WORKLOADS = {
                  cfg=dict(robot="GENJNT", is_parallel=0, n_joints=7, n_cart=3, traj_file="path.dat", is_bin=1, path_type="JOINT",
                           degrees=0, jnt_vel=[5] * 7, jnt_acc_on=1, jnt_acc=[10] * 7, integ_res=0.01, max_integ_time=2000000.0,
                           theta_res=0.1, theta_res2=0.1)),
+    # BASELINE configs[4]: cable robot, cable velocity/acceleration/tension limits + Cartesian speed, isPar2Ser=1
+    "cspr": dict(C=18, gen=lambda seed, n: (None, pathgen.cspr_fine(seed, n), 0.005), knots_per_coarse=217.0,
+                 cfg=dict(robot="CSPR3DOF", is_parallel=1, n_joints=3, n_cart=3, traj_file="path.dat", is_bin=1, path_type="CART",
+                          degrees=0, jnt_vel=[4] * 3, jnt_acc_on=1, jnt_acc=[8] * 3, trq_on=1, trq_max=[12] * 3, trq_min=[1] * 3,
+                          cart_vel_on=1, cart_vel=4.0, cart_acc_on=0, cart_acc=100.0, integ_res=0.01, max_integ_time=2000000.0,
+                          s_weights=(0, 0, 1), scale_type=2, theta_res=0.01, theta_res2=0.01, cart_res=0.01, cart_res2=0.01,
+                          par2ser=1)),
 }
 
 
@@ -60,11 +67,13 @@ def make_knots(workload: str, seed: int, n_target: int):
         kb = open(os.path.join(work, "knots.bin"), "rb").read()
         N, nJ, nC = (int(v) for v in np.frombuffer(kb, "<i8", 3, 0))
         sres = float(np.frombuffer(kb, "<f8", 1, 24)[0])
-        y = np.frombuffer(kb, "<f8", (nJ + nC) * N, 32).reshape(nJ + nC, N)[:nJ].copy()  # joint channels only
+        y = np.frombuffer(kb, "<f8", (nJ + nC) * N, 32).reshape(nJ + nC, N)
         prob = capi.Problem.from_buffer_copy(open(os.path.join(work, "problem.bin"), "rb").read())
-    prob.n_cart = 0  # vel+acc limits only: no Cartesian channels are carried
-    prob.flags |= capi.F_NO_SAMPLES  # the knot samples (traj.theta/thetaD/thetaD2) are not needed without a dynamics model
-    return y, sres, prob
+    if not (prob.flags & (capi.F_CART_VEL_ON | capi.F_CART_ACC_ON | capi.F_TRQ_ON)):
+        y = y[:nJ]           # vel+acc limits only: no Cartesian channels are carried
+        prob.n_cart = 0
+        prob.flags |= capi.F_NO_SAMPLES  # knot samples (traj.theta/thetaD/thetaD2) only feed the dynamics model
+    return np.ascontiguousarray(y), sres, prob
 
 
 def run_step(batch, has_dyn):
@@ -117,7 +126,7 @@ def main():
     n_knots = [base[p % K][0].shape[1] for p in range(B)]
     total_knots = int(sum(n_knots))
     C = WORKLOADS[args.workload]["C"]
-    cap = int(max(n_knots) * (0.5 if args.workload == "ur6" else 2.2)) + 1024
+    cap = int(max(n_knots) * {"ur6": 0.5, "gen7": 2.2, "cspr": 0.6}[args.workload]) + 1024
     batch = capi.Batch(hip, prob, n_knots, cap)
     for p in range(B):
         y, sres, _ = base[p % K]
@@ -192,8 +201,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": f"synthetic: {K} distinct seeded spline paths per GPU resampled by the host BA library, tiled to {B} paths",
-        "config": {"workload": f"cfg2 UR5-like 6-DOF vel+acc, N~{args.knots} knots/path, batch of independent paths"
-                   if args.workload == "ur6" else f"GEN7DOF 7-DOF vel+acc, N~{args.knots}",
+        "config": {"workload": {"ur6": f"cfg2 UR5-like 6-DOF vel+acc, N~{args.knots} knots/path, batch of independent paths",
+                                "gen7": f"cfg4 GEN7DOF 7-DOF vel+acc, N~{args.knots} knots/path, batch of independent paths",
+                                "cspr": f"cfg5 CSPR3DOF cable tensions + vel/acc + Cartesian speed, N~{args.knots} knots/path"}[args.workload],
                    "paths_per_gpu": B, "knots_per_path_mean": total_knots / B, "channels": C, "lanes_per_path": args.group,
                    "regions": "K1+K2 precompute, K3 pointwise, K4 reverse+forward sweep", "parallelism": f"paths sharded x{world}"},
         "kernel_ms": {"precompute": kernel_ms[1], "pointwise_mvc": kernel_ms[2], "sweep_rev": kernel_ms[3], "sweep_fwd": kernel_ms[4]},

@@ -18,7 +18,7 @@ if a.ppw and hasattr(hip, "set_paths_per_wave"):
     hip.set_paths_per_wave(a.ppw)
 base = [bench.make_knots(a.workload, 1000 + k, a.knots) for k in range(a.distinct)]
 nk = [base[p % a.distinct][0].shape[1] for p in range(a.paths)]
-cap = int(max(nk) * (0.5 if a.workload == "ur6" else 2.2)) + 1024
+cap = int(max(nk) * {"ur6": 0.5, "gen7": 2.2, "cspr": 0.6}[a.workload]) + 1024
 b = capi.Batch(hip, base[0][2], nk, cap)
 for p in range(a.paths):
     b.upload_knots(p, [base[p % a.distinct][0]], [base[p % a.distinct][1]])
