@@ -42,7 +42,7 @@ struct batotp_ctx
 {
    int device = 0;
    hipStream_t stream = nullptr;
-   int sweepGroup = 8;
+   int sweepGroup = 0; // lanes per path in the sweep kernel; 0 = automatic
    int pathsPerWave = 0; // 0 = automatic
 };
 
@@ -194,7 +194,7 @@ extern "C" int batotp_hip_synchronize(batotp_ctx *ctx)
 
 extern "C" int batotp_hip_set_sweep_group(batotp_ctx *ctx, int32_t lanes)
 {
-   if (!ctx || !(lanes == 1 || lanes == 8 || lanes == 16)) return BATOTP_ERR_ARG;
+   if (!ctx || !(lanes == 0 || lanes == 1 || lanes == 8 || lanes == 16 || lanes == 32)) return BATOTP_ERR_ARG;
    ctx->sweepGroup = lanes;
    return BATOTP_OK;
 }
@@ -590,14 +590,15 @@ static void launchSweep(batotp_batch *b, SweepArgs &a)
    if (ppw < 1) ppw = 1;
    if (ppw > maxPpw) ppw = maxPpw;
    a.ppw = ppw;
-   const unsigned grid = (unsigned)((b->B + ppw - 1) / ppw);
+   const unsigned waves = (unsigned)((b->B + ppw - 1) / ppw);
+   const unsigned grid = (waves + (K4_BLOCK / 64) - 1) / (K4_BLOCK / 64);
    bool uni = true;
    for (int p = 0; p < b->B; ++p) uni = uni && b->pinfo[p].uniform;
    hipStream_t st = b->ctx->stream;
 #define LAUNCH_K4(F)                                                                           \
    do {                                                                                        \
-      if (uni) hipLaunchKernelGGL((k_sweep<G, F, true>), dim3(grid), dim3(64), 0, st, a);      \
-      else hipLaunchKernelGGL((k_sweep<G, F, false>), dim3(grid), dim3(64), 0, st, a);        \
+      if (uni) hipLaunchKernelGGL((k_sweep<G, F, true>), dim3(grid), dim3(K4_BLOCK), 0, st, a);      \
+      else hipLaunchKernelGGL((k_sweep<G, F, false>), dim3(grid), dim3(K4_BLOCK), 0, st, a);        \
    } while (0)
    switch (featureLevel(b))
    {
@@ -619,11 +620,22 @@ extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
    if (rc) return rc;
    SweepArgs a;
    a.P = b->P; a.dP = b->dP; a.pinfo = b->dPinfo; a.sC = b->dSC; a.coef = b->dCoef;
-   a.rev = b->dRev; a.fwd = b->dFwd; a.res = b->dRes; a.sink = b->dSink; a.cap = b->cap; a.B = b->B; a.dir = dir; a.ppw = 1;
+   a.rev = b->dRev; a.fwd = b->dFwd; a.res = b->dRes; a.sink = b->dSink; a.prof = b->dMvc; a.cap = b->cap; a.B = b->B; a.dir = dir; a.ppw = 1;
    const int which = dir == -1 ? 3 : 4;
    evStart(b, which);
-   switch (b->ctx->sweepGroup)
+   int lanes = b->ctx->sweepGroup;
+   if (lanes == 0)
    {
+      // automatic: while the batch cannot fill the 8-lane layout anyway (<= 4 paths per SIMD), give a
+      // path 16 lanes and split the interval bounds over the two halves (fewer instructions per check)
+      // automatic (measured on UR6, N = 100k): up to ~2k paths the batch is latency-bound and the
+      // 32-lane layout (four bisection candidates per pass) wins; beyond that the 8-lane layout, which
+      // packs more paths per wavefront, has the higher throughput
+      lanes = (b->B <= (a.dir == -1 ? 2048 : 1024)) ? 32 : 8;
+   }
+   switch (lanes)
+   {
+   case 32: launchSweep<32>(b, a); break;
    case 1: launchSweep<1>(b, a); break;
    case 16: launchSweep<16>(b, a); break;
    default: launchSweep<8>(b, a); break;

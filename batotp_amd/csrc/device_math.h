@@ -22,6 +22,7 @@ constexpr int DPP_QUAD_XOR1 = 0xB1;        // quad_perm [1,0,3,2]
 constexpr int DPP_QUAD_XOR2 = 0x4E;        // quad_perm [2,3,0,1]
 constexpr int DPP_ROW_HALF_MIRROR = 0x141; // lane i <-> 7-i inside each 8-lane half row
 constexpr int DPP_ROW_MIRROR = 0x140;      // lane i <-> 15-i inside each 16-lane row
+constexpr int DPP_ROW_ROR8 = 0x128;        // lane i <-> i+-8 inside each 16-lane row
 
 // value of lane perm(i) of every lane i (all source lanes are active group members)
 template <int CTRL>

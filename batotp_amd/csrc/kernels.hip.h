@@ -31,6 +31,15 @@
 #include "batotp_hip.h"
 #include "device_math.h"
 
+// diagnostic build (-DBK_PROFILE_SECTIONS): cycle attribution inside k_sweep; no effect otherwise
+#ifdef BK_PROFILE_SECTIONS
+#define BK_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
+#define BK_ACC(acc, a, b) acc += (b) - (a)
+#else
+#define BK_TICK(var)
+#define BK_ACC(acc, a, b)
+#endif
+
 namespace bk
 {
 
@@ -428,6 +437,14 @@ template <int G, int FEAT, bool UNI>
 struct Pt
 {
    static constexpr int PER = (G == 1) ? BATOTP_MAX_JOINTS : 1;
+   // G == 16 (except for the parallel-mechanism variant): the group is two halves of 8 lanes; lane j and
+   // lane j+8 own the same joint, the lower half evaluates the upper bounds of the sddot interval, the
+   // upper half the lower bounds: one divide per lane and one reduction per constraint check.
+   static constexpr bool SPLIT = (G == 16 && FEAT != 3);
+   // G == 32: a path owns half a wavefront = 4 candidate slots x 8 joint lanes; the bisection evaluates
+   // four candidate sdot values per pass (speculation on its own, fully determined, candidate sequence)
+   static constexpr bool SPEC = (G == 32);
+   static constexpr int RED = (SPLIT || SPEC) ? 8 : G; // lanes one joint reduction spans
    static constexpr bool PAR = (FEAT == 3); // FEAT: 0 joint vel/acc only, 1 + Cartesian, 2 + torque (serial form), 3 + torque (parallel mechanism)
 
    // path constants
@@ -456,6 +473,11 @@ struct Pt
    unsigned status;
    int nfail;
    int sink; // consumer of the prefetch touches (keeps them alive; written to the result row)
+   int side; // SPLIT: 0 = upper-bound half, 1 = lower-bound half
+   int cslot, pbase; // SPEC: candidate slot 0..3 of this lane, first lane of the path in the wavefront
+#ifdef BK_PROFILE_SECTIONS
+   unsigned long long cycA, cycB, cycC, cycD; // diagnostic build: cycles in sdot_lim / eval_partials / bisection / rest
+#endif
    // register cache of the last spline row / reverse-curve segment read (dense-step paths stay on
    // one segment for many consecutive evaluations)
    int rowSeg, mvcSeg;
@@ -664,7 +686,7 @@ __device__ __forceinline__ void sdot_lim(Pt<G, FEAT, UNI> &t, int j, double &sdo
       const int jj = j + q * G;
       if (jj < t.nJ && fabs(t.thD[q]) > t.thrV) lim = dmin(lim, fabs(t.vmax[q] / t.thD[q]));
    }
-   lim = grp_min<G>(lim);
+   lim = grp_min<Pt<G, FEAT, UNI>::RED>(lim); // SPLIT / SPEC: every 8-lane part holds the same joints
    sdot = dmin(sdot, lim);
    if (FEAT >= 1 && (t.flags & BATOTP_F_CART_VEL_ON) && t.cq0 > t.quadA) sdot = dmin(sdot, t.cartVelMax / sqrt(t.cq0));
 }
@@ -755,10 +777,23 @@ __device__ __forceinline__ bool verify_second_order(Pt<G, FEAT, UNI> &t, int j, 
                if (!(fabs(a1pt) < t.thrV))
                {
                   const double tmp2 = t.a2[q] * sdotSQ + tmp1;
-                  const double s0 = (t.tmax[q] - tmp2) / a1pt;
-                  const double s1 = (t.tmin[q] - tmp2) / a1pt;
-                  H = dmin(H, dmax(s0, s1));
-                  L = dmax(L, dmin(s0, s1));
+                  if (Pt<G, FEAT, UNI>::SPLIT)
+                  {
+                     // max(s0, s1) and min(s0, s1) are each ONE of the two quotients: correctly rounded
+                     // subtraction and division are monotone, so the larger numerator over a positive a1
+                     // (the smaller one over a negative a1) is the maximum.  One divide per half.
+                     const double n0 = t.tmax[q] - tmp2, n1 = t.tmin[q] - tmp2;
+                     const bool firstIsMax = (n0 >= n1) == (a1pt > 0);
+                     if (t.side == 0) H = dmin(H, (firstIsMax ? n0 : n1) / a1pt);
+                     else L = dmax(L, (firstIsMax ? n1 : n0) / a1pt);
+                  }
+                  else
+                  {
+                     const double s0 = (t.tmax[q] - tmp2) / a1pt;
+                     const double s1 = (t.tmin[q] - tmp2) / a1pt;
+                     H = dmin(H, dmax(s0, s1));
+                     L = dmax(L, dmin(s0, s1));
+                  }
                }
             }
          }
@@ -786,14 +821,35 @@ __device__ __forceinline__ bool verify_second_order(Pt<G, FEAT, UNI> &t, int j, 
             {
                const int svpt = sgn(vpt);
                const double vTerm = t.thD2[q] * sdotSQ;
-               H = dmin(H, (svpt * t.amax[q] - vTerm) / vpt);
-               L = dmax(L, (-svpt * t.amax[q] - vTerm) / vpt);
+               if (Pt<G, FEAT, UNI>::SPLIT)
+               {
+                  if (t.side == 0) H = dmin(H, (svpt * t.amax[q] - vTerm) / vpt);
+                  else L = dmax(L, (-svpt * t.amax[q] - vTerm) / vpt);
+               }
+               else
+               {
+                  H = dmin(H, (svpt * t.amax[q] - vTerm) / vpt);
+                  L = dmax(L, (-svpt * t.amax[q] - vTerm) / vpt);
+               }
             }
          }
       }
    }
-   const double Hred = grp_min<G>(force ? -kInf : H);
-   L = grp_max<G>(L);
+   double Hred;
+   if (Pt<G, FEAT, UNI>::SPLIT)
+   {
+      // lower half reduces min(H), upper half min(-L) = -max(L) in the same three DPP steps, then the
+      // halves exchange their results (lane i <-> i +- 8 owns the same joint)
+      const double mine = grp_min<8>(t.side == 0 ? (force ? -kInf : H) : -L);
+      const double other = dpp_mov<DPP_ROW_ROR8>(mine);
+      Hred = t.side == 0 ? mine : other;
+      L = -(t.side == 0 ? other : mine);
+   }
+   else
+   {
+      Hred = grp_min<Pt<G, FEAT, UNI>::RED>(force ? -kInf : H);
+      L = grp_max<Pt<G, FEAT, UNI>::RED>(L);
+   }
    t.sddotH = Hred;
    t.sddotL = L;
    if (L > Hred) return true; // also the folded "force" exit: L >= -sddotMax > -inf
@@ -825,6 +881,21 @@ __device__ __forceinline__ bool verify_second_order(Pt<G, FEAT, UNI> &t, int j, 
    return false;
 }
 
+// (num / den) < thr, decided exactly as the correctly rounded division would decide it, without
+// performing the division unless num/den lies within 1e-14 (relative) of the threshold: the quotient
+// is a monotone function of num, so far from the threshold the comparison of num with thr*den is
+// decisive.  Takes two divisions off the dependent chain of every bisection iteration.
+__device__ __forceinline__ bool ratio_lt(double num, double den, double thr)
+{
+   const double p = thr * den;
+   if (den > 0.0 && num >= 0.0 && p > 1e-290 && p < 1e290)
+   {
+      if (num < p * (1.0 - 1e-14)) return true;
+      if (num > p * (1.0 + 1e-14)) return false;
+   }
+   return num / den < thr;
+}
+
 // BA::applyAccelConstraintsBisectionPt (ba.cpp:1248-1332).  Returns 0, or -1 on the failure exits of
 // ba.cpp:1307-1319, in which case sddot is left untouched (the reference's caller ignores the code).
 template <int G, int FEAT, bool UNI, bool DOEVAL = true>
@@ -840,7 +911,10 @@ __device__ __forceinline__ int apply_accel_bisection(Pt<G, FEAT, UNI> &t, int j,
    double sdotCur = sdotH;
    nIter = 0;
 
+   BK_TICK(tb0);
    if (DOEVAL) eval_partials(t, j); // ba.cpp:1265
+   BK_TICK(tb1);
+   BK_ACC(t.cycB, tb0, tb1);
 
    for (;;)
    {
@@ -860,8 +934,7 @@ __device__ __forceinline__ int apply_accel_bisection(Pt<G, FEAT, UNI> &t, int j,
          anyGoodIter = true;
          sdotGoodLast = sdotGood;
          sdotGood = sdotCur;
-         const double sdotErr = fabs(sdotGood - sdotGoodLast) / sdotGood;
-         if (sdotErr < sdotErrThresh || sdotCur < sdotMin)
+         if (ratio_lt(fabs(sdotGood - sdotGoodLast), sdotGood, sdotErrThresh) || sdotCur < sdotMin)
          {
             t.sdotCur = sdotCur;
             break;
@@ -873,10 +946,111 @@ __device__ __forceinline__ int apply_accel_bisection(Pt<G, FEAT, UNI> &t, int j,
       if (sdotCur < 0) return -1;
       if (!anyGoodIter)
       {
-         if ((sdotH - sdotL) / sdotH < 1e-20) return -1; // only evaluated while no feasible point is known
+         if (ratio_lt(sdotH - sdotL, sdotH, 1e-20)) return -1; // only evaluated while no feasible point is known
       }
       sdotCur = .5 * (sdotH + sdotL);
    }
+   sddot = (t.dir == 1) ? t.sddotH : t.sddotL;
+   return 0;
+}
+
+// The same bisection with four candidates evaluated per pass (SPEC lane layout).  The reference's loop
+// is replayed literally; the only thing speculated is WHICH sdot values it will ask for next, and a
+// speculated value is used only if it is bit-identical to the value the replay then really asks for,
+// so a wrong guess costs a pass, never a different result.  Guesses: while no feasible point is known
+// the next candidates follow from assuming "violated" (geometric shrink, ba.cpp:1281-1285,1320);
+// afterwards both children of the current midpoint.
+template <int G, int FEAT, bool UNI>
+__device__ __forceinline__ int apply_accel_bisection_spec(Pt<G, FEAT, UNI> &t, int j, double &sddot, int &nIter)
+{
+   const double sdotErrThresh = .001;
+   double lowFact = .01;
+   const double sdotMin = 0;
+   double sdotGood = sdotMin, sdotGoodLast;
+   bool anyGoodIter = false;
+   double sdotL = sdotGood;
+   double sdotH = t.sdotCur;
+   double sdotCur = sdotH;
+   nIter = 0;
+
+   BK_TICK(tb0);
+   eval_partials(t, j); // ba.cpp:1265
+   BK_TICK(tb1);
+   BK_ACC(t.cycB, tb0, tb1);
+
+   int rc = 0, lastSlot = 0;
+   bool finished = false;
+   while (!finished)
+   {
+      const double c0 = sdotCur;
+      double c1, c2, c3;
+      if (!anyGoodIter)
+      {
+         double lf = lowFact * 2.0;
+         c1 = .5 * (c0 + dmax(.999 * sdotMin, (1.0 - lf) * c0));
+         lf *= 2.0;
+         c2 = .5 * (c1 + dmax(.999 * sdotMin, (1.0 - lf) * c1));
+         lf *= 2.0;
+         c3 = .5 * (c2 + dmax(.999 * sdotMin, (1.0 - lf) * c2));
+      }
+      else
+      {
+         c1 = .5 * (c0 + sdotL); // next midpoint if c0 is violated (sdotH <- c0)
+         c2 = .5 * (sdotH + c0); // next midpoint if c0 is feasible (sdotL <- c0)
+         c3 = c0;
+      }
+      const double mine = (t.cslot == 0) ? c0 : (t.cslot == 1) ? c1 : (t.cslot == 2) ? c2 : c3;
+      const bool violMine = verify_second_order(t, j, mine); // this slot's sddotL / sddotH stay in t
+      const unsigned long long ballot = __ballot(violMine);
+
+      int k = 0;
+      for (int consumed = 0; consumed < 4; ++consumed)
+      {
+         const bool isViol = (ballot >> (t.pbase + 8 * k)) & 1ull;
+         lastSlot = k;
+         if (isViol)
+         {
+            sdotH = sdotCur;
+            if (!anyGoodIter)
+            {
+               lowFact *= 2.0;
+               sdotL = dmax(.999 * sdotMin, (1.0 - lowFact) * sdotH);
+            }
+         }
+         else
+         {
+            if (nIter == 0) { finished = true; break; }
+            anyGoodIter = true;
+            sdotGoodLast = sdotGood;
+            sdotGood = sdotCur;
+            if (ratio_lt(fabs(sdotGood - sdotGoodLast), sdotGood, sdotErrThresh) || sdotCur < sdotMin)
+            {
+               t.sdotCur = sdotCur;
+               finished = true;
+               break;
+            }
+            sdotL = sdotCur;
+         }
+         nIter++;
+         if (nIter > 100) { rc = -1; finished = true; break; }
+         if (sdotCur < 0) { rc = -1; finished = true; break; }
+         if (!anyGoodIter)
+         {
+            if (ratio_lt(sdotH - sdotL, sdotH, 1e-20)) { rc = -1; finished = true; break; }
+         }
+         sdotCur = .5 * (sdotH + sdotL);
+         // was this value evaluated in this pass?
+         if (sdotCur == c1) k = 1;
+         else if (sdotCur == c2) k = 2;
+         else if (sdotCur == c3 && !anyGoodIter) k = 3;
+         else break;
+      }
+   }
+   if (rc != 0) return -1;
+   // sddotL / sddotH of the last check the sequential loop performed live in the lanes of slot lastSlot
+   const int src = t.pbase + 8 * lastSlot;
+   t.sddotH = __shfl(t.sddotH, src);
+   t.sddotL = __shfl(t.sddotL, src);
    sddot = (t.dir == 1) ? t.sddotH : t.sddotL;
    return 0;
 }
@@ -885,7 +1059,8 @@ template <int G, int FEAT, bool UNI>
 __device__ __forceinline__ void accel_pt(Pt<G, FEAT, UNI> &t, int j, double &sddot)
 {
    int nIter;
-   if (apply_accel_bisection(t, j, sddot, nIter) != 0)
+   const int rc = Pt<G, FEAT, UNI>::SPEC ? apply_accel_bisection_spec(t, j, sddot, nIter) : apply_accel_bisection(t, j, sddot, nIter);
+   if (rc != 0)
    {
       t.status |= BATOTP_ST_BISECT_FAIL;
       t.nfail++;
@@ -933,7 +1108,10 @@ __device__ __forceinline__ void pt_init(Pt<G, FEAT, UNI> &t, const DevProblem &P
    t.dir = dir;
    t.segC = 0; t.segMVC = 0; t.tauC = 0; t.tauMVC = 0;
    t.sCur = 0; t.sdotCur = 0; t.sddotL = 0; t.sddotH = 0; t.sdotMin = 0;
-   t.status = 0; t.nfail = 0; t.sink = 0;
+   t.status = 0; t.nfail = 0; t.sink = 0; t.side = 0; t.cslot = 0; t.pbase = 0;
+#ifdef BK_PROFILE_SECTIONS
+   t.cycA = 0; t.cycB = 0; t.cycC = 0; t.cycD = 0;
+#endif
    t.rowSeg = -1; t.mvcSeg = -1;
    t.mvcS0 = 0; t.mvcS1 = 0; t.mvcD0 = 0; t.mvcD1 = 0;
 }
@@ -1042,6 +1220,7 @@ struct SweepArgs
    double2 *fwd;  // [B][cap]
    batotp_path_result *res;
    int *sink;     // [B] consumer of the prefetch touches
+   double *prof;  // diagnostic build (BK_PROFILE_SECTIONS): 4 doubles per path
    int64_t cap;
    int B;
    int dir;
@@ -1092,22 +1271,28 @@ __device__ __forceinline__ int touch_ahead(const Pt<G, FEAT, UNI> &t, int j)
    return v;
 }
 
+// A workgroup is 4 wavefronts (one per SIMD of a CU): with one-wavefront workgroups the dispatcher was
+// observed to stack several of them on the SIMDs of one CU while other CUs stayed empty.
+constexpr int K4_BLOCK = 256;
 #ifndef BK_SWEEP_WPE
 #define BK_SWEEP_WPE 2
 #endif
 // waves per SIMD the register allocation of the narrow (FEAT <= 1) sweep kernels is tuned for
 template <int G, int FEAT, bool UNI>
-__global__ void __launch_bounds__(64, (FEAT <= 1 && G > 1) ? BK_SWEEP_WPE : 2) k_sweep(SweepArgs a)
+__global__ void __launch_bounds__(K4_BLOCK, (FEAT <= 1 && G > 1) ? BK_SWEEP_WPE : 2) k_sweep(SweepArgs a)
 {
    __shared__ double lim[6][8];
    stage_limits(a.dP, lim);
 
-   const int lane = threadIdx.x;
-   const int j = lane % G;
+   const int lane = threadIdx.x & 63;
+   const int wave = blockIdx.x * (K4_BLOCK / 64) + (threadIdx.x >> 6);
+   constexpr bool SPLIT = Pt<G, FEAT, UNI>::SPLIT;
+   constexpr bool SPEC = Pt<G, FEAT, UNI>::SPEC;
+   const int j = (SPLIT || SPEC) ? (lane & 7) : lane % G;   // joint owned by this lane
    const int slot = lane / G;
-   const int p = blockIdx.x * a.ppw + slot;
+   const int p = wave * a.ppw + slot;
    if (slot >= a.ppw || p >= a.B) return; // whole groups leave together; DPP never crosses groups
-   const bool writer = (j == 0);
+   const bool writer = (lane % G == 0);
    const int dir = a.dir;
    const PathInfo pi = a.pinfo[p];
    const int n = (int)pi.n;
@@ -1115,6 +1300,9 @@ __global__ void __launch_bounds__(64, (FEAT <= 1 && G > 1) ? BK_SWEEP_WPE : 2) k
 
    Pt<G, FEAT, UNI> t;
    pt_init(t, a.P, pi, a.sC, a.coef, lim, j, dir);
+   t.side = SPLIT ? ((lane >> 3) & 1) : 0;
+   t.cslot = SPEC ? ((lane >> 3) & 3) : 0;
+   t.pbase = lane & ~(G - 1);
 
    double2 *__restrict__ out = (dir == 1 ? a.fwd : a.rev) + (int64_t)p * cap;
    batotp_path_result *__restrict__ r = a.res + p;
@@ -1165,6 +1353,9 @@ __global__ void __launch_bounds__(64, (FEAT <= 1 && G > 1) ? BK_SWEEP_WPE : 2) k
    // ba.cpp:1050-1051: dsMin uses sArr.back() == 0, hence every dsMinV[j]/absh is +0
    const double floorV = 0.0 / absh;
 
+#ifdef BK_PROFILE_SECTIONS
+   const unsigned long long tstart = __builtin_readcyclecounter();
+#endif
    int64_t nPts = 0, i = 1;
    unsigned endStatus = 0;
    bool done = false;
@@ -1219,11 +1410,17 @@ __global__ void __launch_bounds__(64, (FEAT <= 1 && G > 1) ? BK_SWEEP_WPE : 2) k
          vN = v0 + h * sddotT;
          vN = dmax(vN, floorV); // ba.cpp:1085
          t.sCur = sN;
+         BK_TICK(ta0);
          sdot_lim(t, j, vN);
+         BK_TICK(ta1);
+         BK_ACC(t.cycA, ta0, ta1);
          t.sdotCur = vN;
          // sddotArr[st] keeps its previous value when the bisection fails (ba.cpp:1091 ignores the code)
          double wN = (st == 1) ? w1 : (st == 2) ? w2 : (st == 3) ? w3 : (st == 4) ? w4 : (st == 5) ? w5 : w6;
+         BK_TICK(tc0);
          accel_pt(t, j, wN);
+         BK_TICK(tc1);
+         BK_ACC(t.cycC, tc0, tc1);
          vN = t.sdotCur;
          switch (st)
          {
@@ -1255,6 +1452,9 @@ __global__ void __launch_bounds__(64, (FEAT <= 1 && G > 1) ? BK_SWEEP_WPE : 2) k
       else ++i;
    }
    if (writer) a.sink[p] = t.sink + pf;
+#ifdef BK_PROFILE_SECTIONS
+   if (writer) { const unsigned long long tend = __builtin_readcyclecounter(); a.prof[4 * p + 0] = (double)t.cycA; a.prof[4 * p + 1] = (double)t.cycB; a.prof[4 * p + 2] = (double)(t.cycC - t.cycB); a.prof[4 * p + 3] = (double)(tend - tstart); }
+#endif
 
    unsigned status = t.status | endStatus;
    if (endStatus != 0)

@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--paths", type=int, default=4096, help="paths per GPU")
     ap.add_argument("--knots", type=int, default=100000, help="target knots per path")
     ap.add_argument("--distinct", type=int, default=32, help="distinct seeded paths per GPU (tiled to --paths)")
-    ap.add_argument("--group", type=int, default=8, help="lanes per path in the sweep kernel")
+    ap.add_argument("--group", type=int, default=0, help="lanes per path in the sweep kernel (0 = automatic)")
     ap.add_argument("--ppw", type=int, default=0, help="paths per wavefront in the sweep kernel (0 = automatic)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")

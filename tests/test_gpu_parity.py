@@ -59,12 +59,12 @@ def test_hip_baseline_size_paths(hip_ctx, oracle_ctx, name):
     assert_matches_reference(case, ho)
 
 
-@pytest.mark.parametrize("lanes", [1, 16])
+@pytest.mark.parametrize("lanes", [1, 8, 16, 32])
 def test_other_lane_groupings_agree(hip_lib, oracle_ctx, lanes):
     """the sweep kernel with 1 or 16 lanes per path publishes the same bits as the default 8"""
     ctx = capi.Context(hip_lib, 0)
     ctx.set_sweep_group(lanes)
-    for name in ("GEN7DOF", "CSPR3DOF", "UR5", "CSPR3DOF_par"):
+    for name in ("GEN7DOF", "CSPR3DOF", "UR5", "CSPR3DOF_par", "RR_acc", "synth_cspr_s5", "synth_ur_s2"):
         case = Case(name)
         ho = run_pipeline(ctx, [case], mvc=False, details=False)[0]
         oo = run_pipeline(oracle_ctx, [case], mvc=False, details=False)[0]

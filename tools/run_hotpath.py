@@ -9,7 +9,7 @@ from batotp_amd import capi
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="ur6"); ap.add_argument("--paths", type=int, default=256)
 ap.add_argument("--knots", type=int, default=100000); ap.add_argument("--distinct", type=int, default=8)
-ap.add_argument("--reps", type=int, default=1); ap.add_argument("--group", type=int, default=8)
+ap.add_argument("--reps", type=int, default=1); ap.add_argument("--group", type=int, default=0)
 ap.add_argument("--ppw", type=int, default=0)
 a = ap.parse_args()
 hip = capi.Context(capi.load_hip(), 0)
