@@ -28,7 +28,7 @@ def gather_results(local: np.ndarray, device=None) -> np.ndarray:
     import torch.distributed as dist
 
     assert local.dtype == capi.RESULT_DTYPE
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local.copy()
     world = dist.get_world_size()
     dev = device if device is not None else torch.device("cpu")

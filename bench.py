@@ -104,8 +104,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("BATOTP_BENCH_FORCE_DIST") == "1"   # the latter: exercise RCCL on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
     torch.cuda.set_device(local_rank)
@@ -134,14 +138,14 @@ def main():
     hip.synchronize()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     gathered = None
     for _ in range(args.warmup):
         run_step(batch, False)
-        gathered = bdist.gather_results(batch.results(), dev if world > 1 else None)
+        gathered = bdist.gather_results(batch.results(), dev if use_dist else None)
     res = batch.results()
     bad = int(np.count_nonzero((res["status_rev"] | res["status_fwd"]) & ~np.uint32(capi.ST_BISECT_FAIL))) if args.warmup else 0
     if bad:
@@ -154,10 +158,10 @@ def main():
         run_step(batch, False)
         for k in kernel_ms:
             kernel_ms[k] += batch.kernel_ms(k)   # HIP events on the stream the kernels were launched on
-        gathered = bdist.gather_results(batch.results(), dev if world > 1 else None)
+        gathered = bdist.gather_results(batch.results(), dev if use_dist else None)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -218,7 +222,7 @@ def main():
 
     # ---- CPU baseline: the oracle (bit-identical port of the reference's path) on the host cores, on a
     # bounded sample of the same workload, one path per thread
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         ora_lib = capi.load_oracle()
         cores = os.cpu_count() or 1
@@ -256,7 +260,7 @@ def main():
         print(json.dumps(out))
     batch.close()
     hip.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
