@@ -220,6 +220,21 @@ def main():
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": kernel_ms[dom]},
     }
 
+    # ---- the same workload as ONE trajectory (BASELINE configs[1] wording): inherently sequential,
+    # reported for transparency next to the batch figure
+    if rank == 0:
+        y1, sres1, _ = base[0]
+        b1 = capi.Batch(hip, prob, [y1.shape[1]], cap)
+        b1.upload_knots(0, [y1], [sres1])
+        run_step(b1, False)
+        t1 = time.perf_counter()
+        run_step(b1, False)
+        dt1 = time.perf_counter() - t1
+        out["single_trajectory"] = {"knots": int(y1.shape[1]), "ms": 1e3 * dt1, "waypoints_per_s": y1.shape[1] / dt1,
+                                    "kernel_ms": {"precompute": b1.kernel_ms(1), "pointwise_mvc": b1.kernel_ms(2),
+                                                  "sweep_rev": b1.kernel_ms(3), "sweep_fwd": b1.kernel_ms(4)}}
+        b1.close()
+
     # ---- CPU baseline: the oracle (bit-identical port of the reference's path) on the host cores, on a
     # bounded sample of the same workload, one path per thread
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
