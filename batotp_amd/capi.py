@@ -33,6 +33,10 @@ F_PARALLEL, F_PAR2SER, F_HOST_TRIG, F_NO_SAMPLES = 1 << 4, 1 << 5, 1 << 6, 1 << 
 ST_MAX_INTEG_TIME, ST_CAPACITY, ST_BISECT_FAIL = 1 << 0, 1 << 1, 1 << 2
 ST_NONFINITE, ST_SHORT, ST_SEG_ERROR = 1 << 3, 1 << 4, 1 << 5
 
+# path kinds / status bits of the resampler
+PATH_JOINT, PATH_CART = 1, 2
+RS_TOO_SHORT, RS_IDENTICAL, RS_CAPACITY, RS_SMALL_STEP, RS_SEG_ERROR = 1, 2, 4, 8, 16
+
 _d8 = C.c_double * 8
 
 
@@ -118,6 +122,19 @@ def make_problem(n_joints: int, n_cart: int = 0, robot_type: int = ROBOT_GENJNT,
     return p
 
 
+class ResampleParams(C.Structure):
+    """struct batotp_resample_params"""
+    _fields_ = [
+        ("n_joints", C.c_int32), ("n_cart", C.c_int32), ("robot_type", C.c_int32), ("path_type", C.c_int32),
+        ("scale_type", C.c_int32), ("flags", C.c_uint32),
+        ("s_weights", C.c_double * 3),
+        ("theta_norm_res", C.c_double), ("theta_norm_res2", C.c_double),
+        ("cart_norm_res", C.c_double), ("cart_norm_res2", C.c_double),
+        ("jnt_thresh", C.c_double), ("cart_thresh", C.c_double),
+        ("pmat", C.c_double * 9),
+    ]
+
+
 class BatotpError(RuntimeError):
     pass
 
@@ -168,6 +185,12 @@ class Library:
             "batotp_hip_batch_bytes": [P, C.POINTER(C.c_int64)],
             "batotp_hip_set_sweep_group": [P, I32],
             "batotp_hip_set_paths_per_wave": [P, I32],
+            "batotp_hip_resample": [P, C.POINTER(ResampleParams), I32, C.POINTER(C.c_int64), D, D, C.POINTER(P)],
+            "batotp_hip_resampled_destroy": [P],
+            "batotp_hip_resampled_info": [P, C.POINTER(C.c_int64), D, C.POINTER(C.c_uint32)],
+            "batotp_hip_resampled_knots_device": [P, C.POINTER(P), C.POINTER(C.c_int64)],
+            "batotp_hip_resampled_download": [P, I32, D],
+            "batotp_hip_resampled_ms": [P, C.POINTER(C.c_float)],
         }
         for name, argtypes in sig.items():
             fn = getattr(L, name)  # raises AttributeError if the symbol is not exported
@@ -220,6 +243,55 @@ class Context:
         q, r, p = np.empty_like(a), np.empty_like(a), np.empty_like(a)
         self.library.check(self.library.lib.batotp_hip_fp64_kat(self.handle, a.size, _dptr(a), _dptr(b), _dptr(q), _dptr(r), _dptr(p)), "fp64_kat")
         return q, r, p
+
+
+class Resampled:
+    """Uniform-s knots of a set of taught paths, produced by batotp_hip_resample and resident on the
+    device (feed them to Batch.upload_knots_device)."""
+
+    def __init__(self, ctx: Context, prm: ResampleParams, x_list: Sequence[np.ndarray], sres_in: Sequence[float]):
+        self.ctx, self.lib, self.L = ctx, ctx.library.lib, ctx.library
+        self.n_paths = len(x_list)
+        self.n_ch = prm.n_joints + prm.n_cart
+        n_in = np.ascontiguousarray([x.shape[1] for x in x_list], dtype=np.int64)
+        for x in x_list:
+            assert x.shape[0] == self.n_ch
+        flat = np.ascontiguousarray(np.concatenate([np.ascontiguousarray(x, dtype=np.float64).ravel() for x in x_list]))
+        sr = np.ascontiguousarray(sres_in, dtype=np.float64)
+        self.handle = C.c_void_p()
+        self.L.check(self.lib.batotp_hip_resample(ctx.handle, C.byref(prm), self.n_paths, n_in.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                  _dptr(flat), _dptr(sr), C.byref(self.handle)), "batotp_hip_resample")
+        self.n_knots = np.zeros(self.n_paths, dtype=np.int64)
+        self.sres = np.zeros(self.n_paths, dtype=np.float64)
+        self.status = np.zeros(self.n_paths, dtype=np.uint32)
+        self.L.check(self.lib.batotp_hip_resampled_info(self.handle, self.n_knots.ctypes.data_as(C.POINTER(C.c_int64)), _dptr(self.sres),
+                                                        self.status.ctypes.data_as(C.POINTER(C.c_uint32))), "resampled_info")
+
+    def close(self):
+        if self.handle:
+            self.lib.batotp_hip_resampled_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_ptr(self) -> int:
+        ptr, cnt = C.c_void_p(), C.c_int64(0)
+        self.L.check(self.lib.batotp_hip_resampled_knots_device(self.handle, C.byref(ptr), C.byref(cnt)), "resampled_knots_device")
+        return ptr.value
+
+    def knots(self, path: int) -> np.ndarray:
+        y = np.empty((self.n_ch, int(self.n_knots[path])), dtype=np.float64)
+        self.L.check(self.lib.batotp_hip_resampled_download(self.handle, path, _dptr(y)), "resampled_download")
+        return y
+
+    def ms(self) -> float:
+        v = C.c_float(0)
+        self.L.check(self.lib.batotp_hip_resampled_ms(self.handle, C.byref(v)), "resampled_ms")
+        return float(v.value)
 
 
 class Batch:

@@ -13,6 +13,7 @@
 
 #include "batotp_hip.h"
 #include "kernels.hip.h"
+#include "resample.hip.h"
 
 using namespace bk;
 
@@ -774,3 +775,5 @@ extern "C" int batotp_hip_batch_bytes(batotp_batch *b, int64_t *bytes)
    *bytes = b->bytes;
    return BATOTP_OK;
 }
+
+#include "resample_api.inc"

@@ -1,0 +1,389 @@
+// resample.hip.h -- GPU port of the path resampling that precedes the hot path:
+// remClosePts (util.cpp:452-524), the two adjust_s passes (ba.cpp:412-638), interpSpecial
+// (ba.cpp:651-781) and the N_old -> N_new evalSplineFullTraj (ba.cpp:790-863), for the path kinds of
+// BASELINE configs 2, 4 and 5: JOINT paths of a robot without kinematic model (GENJNT) and CART
+// paths of the cable robot (cable lengths by Robot::invKinCSPR3DOF, robot.cpp:243-278).
+// Included by batotp_hip.hip.  Arithmetic contract as everywhere: fp64, no contraction, the
+// reference's operation order; the host resampler (batotp_amd/host/ba_input.cpp), itself pinned by
+// the reference binary's outputs, is the checker (tests/test_gpu_resample.py).
+//
+// The walks are sequential per path (cumulative sums, data-dependent emission): one lane per path,
+// all paths in parallel; the spline builds reuse k_spline (one lane per channel), the uniform
+// re-evaluation runs one lane per output site.
+//
+// Stage arrays are channel-major per path: x[path base + c*n + i], path base = off*C.
+#pragma once
+#include "kernels.hip.h"
+
+namespace bk
+{
+
+struct RsParams
+{
+   int nJ, nC, C;
+   int pathType;  // 1 JOINT, 2 CART
+   int scaleType; // 0 input nodes, 1 joint-space arc length, 2 Cartesian arc length
+   int robot;
+   int cartEval;  // a Cartesian constraint is on: interpSpecial re-evaluates the Cartesian channels (ba.cpp:1362)
+   int pad;
+   double sW[3];
+   double thetaRes, cartRes; // of the current pass
+   double thresh;            // remClosePts threshold of the driving channel set
+   double pmat[9];
+};
+
+struct RsPath
+{
+   int64_t off;   // first point of this path in the stage arrays (points, not doubles)
+   int32_t n;     // points in the stage
+   int32_t status;
+   double sres;   // traj.sres entering the pass
+   double sLast, sResNew, tTeachFact, thetaFact, cartFact, sresNew; // set by k_rs_arclen
+   int32_t nOut;  // points the pass produces (special: emitted; regular: nPtsNew)
+   int32_t cap;   // capacity of the special pass' output rows
+   int64_t offOut;
+};
+
+// status bits of the resampler
+constexpr int RS_TOO_SHORT = 1;   // fewer than 4 points somewhere: the host path handles it (interpTrajLinear)
+constexpr int RS_IDENTICAL = 2;   // "all points identical" exit of adjust_s (ba.cpp:484-488)
+constexpr int RS_CAPACITY = 4;    // interpSpecial produced more points than planned for
+constexpr int RS_SMALL_STEP = 8;  // s-resolution too small between two points (ba.cpp:607-611)
+constexpr int RS_SEG_ERROR = 16;  // findInterpSegs division by zero (spline.cpp:84-88)
+
+// ---------------------------------------------------------------------------------------------
+// remClosePts (util.cpp:452-524): one lane per path, in place; repacks the channels when points
+// were dropped.  Driving set = theta channels (JOINT) or Cartesian channels (CART).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_rs_remclose(RsParams P, RsPath *__restrict__ paths, int B, double *__restrict__ x, unsigned char *__restrict__ drop)
+{
+   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+   if (p >= B) return;
+   RsPath &pp = paths[p];
+   const int n0 = pp.n;
+   double *__restrict__ xb = x + pp.off * P.C;
+   unsigned char *__restrict__ dr = drop + pp.off;
+   const int c0 = (P.pathType == 2) ? P.nJ : 0;
+   const int cN = (P.pathType == 2) ? P.nC : P.nJ;
+   const double thrSq = P.thresh * P.thresh;
+   int n = n0;
+   for (int i = 0; i < n; ++i) dr[i] = 0;
+   for (;;)
+   {
+      bool any = false;
+      for (int i = 1; i < n; ++i)
+      {
+         double sum = 0;
+         for (int j = 0; j < cN; ++j)
+         {
+            const double d = xb[(int64_t)(c0 + j) * n0 + i] - xb[(int64_t)(c0 + j) * n0 + i - 1];
+            sum += d * d;
+         }
+         if (sum < thrSq && !dr[i - 1]) { dr[i] = 1; any = true; }
+      }
+      if (dr[n - 1] && n > 2) { dr[n - 1] = 0; dr[n - 2] = 1; dr[n - 3] = 0; }
+      if (!any) break;
+      int keep = 0;
+      for (int i = 0; i < n; ++i)
+      {
+         if (dr[i]) continue;
+         for (int c = 0; c < P.C; ++c) xb[(int64_t)c * n0 + keep] = xb[(int64_t)c * n0 + i];
+         ++keep;
+      }
+      n = keep;
+      for (int i = 0; i < n; ++i) dr[i] = 0;
+   }
+   if (n != n0)
+   {
+      for (int c = 1; c < P.C; ++c)
+         for (int i = 0; i < n; ++i) xb[(int64_t)c * n + i] = xb[(int64_t)c * n0 + i];
+      pp.n = n;
+   }
+   if (n < 4) pp.status |= RS_TOO_SHORT;
+}
+
+// Robot::invKinCSPR3DOF (robot.cpp:243-278): cable lengths from the platform position; one lane per point
+__global__ void k_rs_invkin_cspr(RsParams P, const RsPath *__restrict__ paths, int B, double *__restrict__ x, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   int lo = 0, hi = B - 1;
+   while (lo < hi)
+   {
+      const int mid = (lo + hi + 1) >> 1;
+      if (paths[mid].off <= g) lo = mid; else hi = mid - 1;
+   }
+   const RsPath pp = paths[lo];
+   const int i = (int)(g - pp.off);
+   if (i >= pp.n) return;
+   double *__restrict__ xb = x + pp.off * P.C;
+   const int n = pp.n;
+   const double px = xb[(int64_t)(P.nJ + 0) * n + i], py = xb[(int64_t)(P.nJ + 1) * n + i], pz = xb[(int64_t)(P.nJ + 2) * n + i];
+#pragma unroll
+   for (int k = 0; k < 3; ++k)
+   {
+      const double dx = px - P.pmat[0 * 3 + k], dy = py - P.pmat[1 * 3 + k], dz = pz - P.pmat[2 * 3 + k];
+      double sq = 0.0;
+      sq += dx * dx;
+      sq += dy * dy;
+      sq += dz * dz;
+      xb[(int64_t)k * n + i] = sqrt(sq);
+   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// adjust_s up to the sC array (ba.cpp:430-590, _isAutoIntegRes = false): cumulative arc lengths,
+// scale factors, s of every point.  One lane per path.  Also decides the size of the pass' output.
+// special != 0: first pass (interpSpecial follows); 0: second pass (evalSplineFullTraj follows).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_rs_arclen(RsParams P, RsPath *__restrict__ paths, int B, const double *__restrict__ x, double *__restrict__ thetaArc,
+                            double *__restrict__ cartArc, double *__restrict__ sC, int special)
+{
+   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+   if (p >= B) return;
+   RsPath &pp = paths[p];
+   if (pp.status) return;
+   const int n = pp.n;
+   const double *__restrict__ xb = x + pp.off * P.C;
+   double *__restrict__ ta = thetaArc + pp.off, *__restrict__ ca = cartArc + pp.off, *__restrict__ s = sC + pp.off;
+   ta[0] = 0; ca[0] = 0;
+   double tacc = 0, cacc = 0;
+   for (int i = 0; i < n - 1; ++i)
+   {
+      double sq = 0;
+      for (int j = 0; j < P.nJ; ++j)
+      {
+         const double d = xb[(int64_t)j * n + i + 1] - xb[(int64_t)j * n + i];
+         sq += d * d;
+      }
+      tacc = tacc + sqrt(sq);
+      ta[i + 1] = tacc;
+      sq = 0;
+      for (int j = 0; j < 3; ++j)
+      {
+         const double d = xb[(int64_t)(P.nJ + j) * n + i + 1] - xb[(int64_t)(P.nJ + j) * n + i];
+         sq += d * d;
+      }
+      cacc = cacc + sqrt(sq);
+      ca[i + 1] = cacc;
+   }
+   if (ta[n - 1] < P.thetaRes) { pp.status |= RS_IDENTICAL; return; }
+
+   const double sResi = pp.sres;
+   const double ptsLast = (double)(n - 1); // traj.ptsOrig is 0,1,2,.. at both call sites
+   double sLast = 0, sResNew = 0;
+   switch (P.scaleType)
+   {
+   case 0: sLast = sResi * ptsLast; sResNew = sResi; break;
+   case 1: sLast = ta[n - 1]; sResNew = P.thetaRes; break;
+   default: sLast = ca[n - 1]; sResNew = P.cartRes; break;
+   }
+   double cartFact = 0;
+   if (ca[n - 1] >= P.cartRes) cartFact = P.sW[2] * sLast / ca[n - 1];
+   const double teachFact = P.sW[0] * sLast / (sResi * ptsLast);
+   const double thetaFact = P.sW[1] * sLast / ta[n - 1];
+   pp.sLast = sLast; pp.sResNew = sResNew; pp.tTeachFact = teachFact; pp.thetaFact = thetaFact; pp.cartFact = cartFact;
+   pp.sresNew = sLast / (n - 1); // traj.sres = sLast/(nPts-1), ba.cpp:585
+   for (int i = 0; i < n; ++i) s[i] = teachFact * sResi * (double)i + thetaFact * ta[i] + cartFact * ca[i];
+
+   if (special)
+   {
+      int nPts2 = (int)ceil(sLast / sResNew) + 1; // ba.cpp:666-667
+      if (nPts2 < 4) nPts2 = 4;
+      pp.nOut = nPts2; // planning figure; the walk reports the real count
+   }
+   else
+   {
+      const double sresRegular = pp.sresNew;
+      for (int i = 1; i < n; ++i)
+         if (s[i] - s[i - 1] < 1e-12 * sresRegular) { pp.status |= RS_SMALL_STEP; return; }
+      for (int i = 1; i < n; ++i)
+         if (s[i] - s[i - 1] < 1e-20) { pp.status |= RS_SEG_ERROR; return; } // findInterpSegs, spline.cpp:84-88
+      // evalSplineFullTraj(traj, traj.sres, sResNew): ba.cpp:796-798
+      int nNew = (int)ceil(sresRegular / sResNew * (n - 1)) + 1;
+      if (nNew < 4) nNew = 4;
+      pp.nOut = nNew;
+   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// interpSpecial (ba.cpp:651-781): walk along the original points and emit a new point every sResNew
+// of (weighted) distance from the last emitted one, by evaluating the splines of the original
+// points.  One lane per path.  Output rows are point-major [i][C] (the count is only known at the end).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_rs_special(RsParams P, RsPath *__restrict__ paths, int B, const double *__restrict__ x, const double *__restrict__ sC,
+                             const double *__restrict__ coef, double *__restrict__ rows)
+{
+   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+   if (p >= B) return;
+   RsPath &pp = paths[p];
+   if (pp.status) return;
+   const int n = pp.n, C = P.C, nJ = P.nJ, nC = P.nC;
+   const double *__restrict__ xb = x + pp.off * C;
+   const double *__restrict__ s = sC + pp.off;
+   const double *__restrict__ cf = coef + pp.off * C * 4;
+   double *__restrict__ out = rows + pp.offOut * C;
+   const int cap = pp.cap;
+   const double sResNew = pp.sResNew, teach = pp.tTeachFact * pp.sres, thF = pp.thetaFact, caF = pp.cartFact;
+
+   double cartpt[BATOTP_MAX_CART];
+   for (int c = 0; c < nC; ++c) cartpt[c] = 0.0; // traj.cartpt is zero until a Cartesian constraint evaluates it
+   for (int c = 0; c < C; ++c) out[c] = xb[(int64_t)c * n];
+   double sPrv = 0, prvDs = 0;
+   int newPt = 1, oldPt = 1, seg = 0;
+   const int lastSeg = n - 2;
+   bool done = false;
+   while (!done)
+   {
+      const double *prev = out + (int64_t)(newPt - 1) * C;
+      double thSq = 0;
+      for (int j = 0; j < nJ; ++j)
+      {
+         const double d = xb[(int64_t)j * n + oldPt] - prev[j];
+         thSq += d * d;
+      }
+      double caSq = 0;
+      for (int j = 0; j < 3; ++j)
+      {
+         const double d = xb[(int64_t)(nJ + j) * n + oldPt] - prev[nJ + j];
+         caSq += d * d;
+      }
+      const double ds = teach * (double)oldPt + thF * sqrt(thSq) + caF * sqrt(caSq);
+      if (ds > sResNew)
+      {
+         const double sNew = sPrv + sResNew - prvDs;
+         prvDs = 0;
+         sPrv = sNew;
+         if (sNew > s[n - 1]) done = true;
+         if (!done)
+         {
+            // evalSplinePartials: segment walk from the cached segment (ba.cpp:1617-1652), then the cubics
+            double sSeg;
+            for (;;)
+            {
+               sSeg = s[seg];
+               if (sNew >= sSeg && sNew <= s[seg + 1]) break;
+               bool moved = false;
+               if (sNew > sSeg) { if (seg >= lastSeg) { seg = lastSeg; break; } ++seg; moved = true; }
+               if (sNew < sSeg) { if (seg <= 0) { seg = 0; break; } --seg; moved = true; }
+               if (!moved) break;
+            }
+            const double tau = (sNew - sSeg) / (s[seg + 1] - sSeg);
+            const double tau2 = tau * tau, tau3 = tau2 * tau;
+            if (newPt >= cap) { pp.status |= RS_CAPACITY; return; }
+            double *o = out + (int64_t)newPt * C;
+            const double *row = cf + (int64_t)seg * C * 4;
+            for (int j = 0; j < nJ; ++j)
+            {
+               const Coef4 k = *reinterpret_cast<const Coef4 *>(row + j * 4);
+               o[j] = k.c3 * tau3 + k.c2 * tau2 + k.c1 * tau + k.c0;
+            }
+            if (P.cartEval)
+            {
+               for (int j = 0; j < nC; ++j)
+               {
+                  const Coef4 k = *reinterpret_cast<const Coef4 *>(row + (nJ + j) * 4);
+                  cartpt[j] = k.c3 * tau3 + k.c2 * tau2 + k.c1 * tau + k.c0;
+               }
+            }
+            for (int j = 0; j < nC; ++j) o[nJ + j] = cartpt[j];
+            oldPt = seg + 1;
+            ++newPt;
+         }
+      }
+      else if (oldPt == n - 1)
+      {
+         done = true;
+      }
+      else
+      {
+         prvDs = ds;
+         sPrv = s[oldPt];
+         ++oldPt;
+      }
+   }
+   if (newPt >= cap) { pp.status |= RS_CAPACITY; return; }
+   double *o = out + (int64_t)newPt * C;
+   for (int c = 0; c < C; ++c) o[c] = xb[(int64_t)c * n + n - 1]; // the original end point closes the path
+   pp.nOut = newPt + 1;
+   if (pp.nOut < 4) pp.status |= RS_TOO_SHORT;
+}
+
+// point-major rows [i][C] -> channel-major [C][n] of the next stage
+__global__ void k_rs_transpose(int C, const RsPath *__restrict__ src, const RsPath *__restrict__ dst, int B, const double *__restrict__ rows,
+                               double *__restrict__ x, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   int lo = 0, hi = B - 1;
+   while (lo < hi)
+   {
+      const int mid = (lo + hi + 1) >> 1;
+      if (dst[mid].off <= g) lo = mid; else hi = mid - 1;
+   }
+   const int i = (int)(g - dst[lo].off), n = dst[lo].n;
+   if (i >= n) return;
+   const double *r = rows + (src[lo].offOut + i) * C;
+   double *o = x + dst[lo].off * C;
+   for (int c = 0; c < C; ++c) o[(int64_t)c * n + i] = r[c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// evalSplineFullTraj N_old -> N_new (ba.cpp:790-863): values of every channel at the uniform sites
+// sMVC[i] = sScale*i.  One lane per output site; the segment is the one the reference's monotone
+// cursor ends on (first segment with site < sC[seg+1], clipped), found by bisection on sC.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_rs_regular(RsParams P, const RsPath *__restrict__ src, const RsPath *__restrict__ dst, int B, const double *__restrict__ sC,
+                             const double *__restrict__ coef, double *__restrict__ y, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   int lo = 0, hi = B - 1;
+   while (lo < hi)
+   {
+      const int mid = (lo + hi + 1) >> 1;
+      if (dst[mid].off <= g) lo = mid; else hi = mid - 1;
+   }
+   const RsPath sp = src[lo];
+   const int i = (int)(g - dst[lo].off), nNew = dst[lo].n, nOld = sp.n, C = P.C;
+   if (i >= nNew || sp.status) return;
+   const double *__restrict__ s = sC + sp.off;
+   const double sScale = s[nOld - 1] / (double)(nNew - 1);
+   const double site = sScale * (double)i;
+   // seg = number of interior knots <= site, clipped to nOld-2
+   int a = 0, b = nOld - 2; // invariant: answer in [a, b]
+   while (a < b)
+   {
+      const int m = (a + b) >> 1;
+      if (site < s[m + 1]) b = m; else a = m + 1;
+   }
+   const int seg = a;
+   const double tau = (site - s[seg]) / (s[seg + 1] - s[seg]);
+   const double tau2 = tau * tau, tau3 = tau2 * tau;
+   const double *row = coef + (sp.off + seg) * C * 4;
+   double *o = y + dst[lo].off * C;
+   for (int c = 0; c < C; ++c)
+   {
+      const Coef4 k = *reinterpret_cast<const Coef4 *>(row + c * 4);
+      o[(int64_t)c * nNew + i] = k.c3 * tau3 + k.c2 * tau2 + k.c1 * tau + k.c0;
+   }
+}
+
+// zero the Cartesian channels of a stage (robot without kinematic model: ba.cpp:618-625)
+__global__ void k_rs_zero_cart(RsParams P, const RsPath *__restrict__ paths, int B, double *__restrict__ x, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   int lo = 0, hi = B - 1;
+   while (lo < hi)
+   {
+      const int mid = (lo + hi + 1) >> 1;
+      if (paths[mid].off <= g) lo = mid; else hi = mid - 1;
+   }
+   const int i = (int)(g - paths[lo].off), n = paths[lo].n;
+   if (i >= n) return;
+   double *o = x + paths[lo].off * P.C;
+   for (int c = 0; c < P.nC; ++c) o[(int64_t)(P.nJ + c) * n + i] = 0.0;
+}
+
+} // namespace bk

@@ -169,6 +169,10 @@ public:
    // Extension: the POD description of the current configuration that is handed to the device
    // layer (struct batotp_problem of include/batotp_hip.h).
    void exportProblem(void *batotp_problem_out) const { fillProblem(batotp_problem_out); }
+   // Extension: the resampling parameters (struct batotp_resample_params) of the current
+   // configuration.  Returns 0 when the device resampler covers this configuration and `traj`
+   // (batotp_hip_resample, include/batotp_hip.h), -1 when the host resampler has to be used.
+   int exportResampleParams(const Traj &traj, void *batotp_resample_params_out) const;
    unsigned int getNumJoints() const { return _nJoints; }
    unsigned int getNumCart() const { return _nCart; }
 

@@ -119,6 +119,44 @@ void BA::fillProblem(void *out) const
    }
 }
 
+// Which configurations the device resampler takes over (the rest of prepareKnots' branches --
+// timestamps, decimation / smoothing, pose paths, robots with forward kinematics, automatic
+// integration resolution -- stay on the host).
+int BA::exportResampleParams(const Traj &traj, void *out) const
+{
+   batotp_resample_params &R = *static_cast<batotp_resample_params *>(out);
+   std::memset(&R, 0, sizeof(R));
+   R.n_joints = (int32_t)_nJoints;
+   R.n_cart = (int32_t)_nCart;
+   R.robot_type = _robotType;
+   R.path_type = (_pathType == JOINT) ? BATOTP_PATH_JOINT : (_pathType == CART ? BATOTP_PATH_CART : 0);
+   R.scale_type = _scaleType;
+   uint32_t f = 0;
+   if (_isCartVelConOn) f |= BATOTP_F_CART_VEL_ON;
+   if (_isCartAccConOn) f |= BATOTP_F_CART_ACC_ON;
+   R.flags = f;
+   for (int k = 0; k < 3; ++k) R.s_weights[k] = _sWeights[k];
+   R.theta_norm_res = _thetaNormRes; R.theta_norm_res2 = _thetaNormRes2;
+   R.cart_norm_res = _cartNormRes; R.cart_norm_res2 = _cartNormRes2;
+   R.jnt_thresh = _jntThresh; R.cart_thresh = _cartThresh;
+   if (_robotType == CSPR3DOF)
+   {
+      const std::vector<std::vector<double>> &A = const_cast<Robot &>(myRobot).cableAnchors();
+      for (int r = 0; r < 3; ++r)
+         for (int c = 0; c < 3; ++c) R.pmat[r * 3 + c] = A[r][c];
+   }
+
+   if (_isAutoIntegRes || _isInterpOnly) return -1;
+   if (traj.timestamp.size() > 0 || traj.nPts < 4) return -1;
+   if (_inputDecimFact > 1 || _smoothWindow > 1) return -1;
+   if (_sWeights[1] + _sWeights[2] < 1e-8) return -1;
+   if (_nJoints > BATOTP_MAX_JOINTS || _nCart > BATOTP_MAX_CART || _nCart < 3) return -1;
+   const bool joint = _pathType == JOINT && _robotType == GENJNT && !_isCartVelConOn && !_isCartAccConOn;
+   const bool cable = _pathType == CART && _robotType == CSPR3DOF && _nJoints == 3 && _nCart == 3 &&
+                      (_isJntVelConOn || _isJntAccConOn || _isTrqConOn);
+   return (joint || cable) ? 0 : -1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // reference ba.cpp:299-305 on the GPU: evalSplineFullTraj(traj, sres, sres), sdot = DBL_MAX,
 // findDynModel

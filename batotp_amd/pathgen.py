@@ -78,6 +78,24 @@ def write_traj_bin(path: str, tres: float, theta: Optional[np.ndarray], cart: Op
             f.write(np.ascontiguousarray(cart, dtype="<f4").tobytes())
 
 
+def read_traj_bin(path: str, n_joints: int, n_cart: int):
+    """inverse of write_traj_bin: (tres, theta or None, cart or None), values widened to float64"""
+    raw = open(path, "rb").read()
+    tres = float(np.frombuffer(raw, "<f4", 1, 0)[0])
+    n = int(np.frombuffer(raw, "<i4", 1, 4)[0])
+    pos = 8
+    out = []
+    for rows in (n_joints, n_cart):
+        has = int(np.frombuffer(raw, "<i4", 1, pos)[0])
+        pos += 4
+        if has == 1:
+            out.append(np.frombuffer(raw, "<f4", rows * n, pos).reshape(rows, n).astype(np.float64))
+            pos += 4 * rows * n
+        else:
+            out.append(None)
+    return tres, out[0], out[1]
+
+
 def _vec(v: Sequence[float]) -> str:
     return " ".join(repr(float(x)) if not (isinstance(x, float) and np.isnan(x)) else "NAN" for x in v)
 

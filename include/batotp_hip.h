@@ -20,6 +20,7 @@
  *                              solveLinSys              batotp/util.cpp:413-442
  *   batotp_hip_pointwise_mvc   BA::sdotLim + BA::applyAccelConstraintsBisectionPt evaluated at
  *                              every knot               batotp/ba.cpp:1204-1236,1248-1332
+ *   batotp_hip_resample        BA::adjust_s / interpSpecial / remClosePts  batotp/ba.cpp:412-781, util.cpp:452-524
  *   batotp_hip_sweep           BA::sweep and everything it calls  batotp/ba.cpp:979-1195,
  *                              1204-1236,1248-1332,1341-1413,1423-1439,1449-1581,1590-1652
  *                              solveQuadratic           batotp/util.cpp:361-383
@@ -193,6 +194,59 @@ int  batotp_hip_set_sweep_group(batotp_ctx *ctx, int32_t lanes);
 /* tuning knob: paths per 64-lane wavefront in the sweep kernel, 1 .. 64/lanes (0 = automatic:
  * few paths are spread over more wavefronts, many paths fill every lane) */
 int  batotp_hip_set_paths_per_wave(batotp_ctx *ctx, int32_t n);
+
+/* ---- path resampling before the hot path -------------------------------- */
+/* Replaces, for the path kinds listed below, everything BA::interpInputData does between loading
+ * the taught points and the final spline build: remClosePts (batotp/util.cpp:452-524), the two
+ * BA::adjust_s passes (batotp/ba.cpp:412-638) with BA::interpSpecial (ba.cpp:651-781) and the
+ * resampling BA::evalSplineFullTraj (ba.cpp:790-863), Robot::invKinCSPR3DOF (robot.cpp:243-278).
+ * Supported: path_type JOINT on a robot without kinematic model (GENJNT) and path_type CART on the
+ * cable robot (CSPR3DOF) with a joint constraint on; no timestamps, no decimation / smoothing, no
+ * automatic integration resolution.  Anything else returns BATOTP_ERR_ARG: the caller keeps using
+ * its host resampler for those. */
+#define BATOTP_PATH_JOINT 1   /* reference batotp/ba.h pathType JOINT */
+#define BATOTP_PATH_CART  2
+
+/* per-path status bits of the resampler (0 = resampled) */
+#define BATOTP_RS_TOO_SHORT   1u  /* a stage has fewer than 4 points (reference switches to interpTrajLinear) */
+#define BATOTP_RS_IDENTICAL   2u  /* "all points identical" exit, ba.cpp:484-488 */
+#define BATOTP_RS_CAPACITY    4u  /* interpSpecial emitted more points than planned for */
+#define BATOTP_RS_SMALL_STEP  8u  /* "s-resolution is too small between two points", ba.cpp:607-611 */
+#define BATOTP_RS_SEG_ERROR  16u  /* findInterpSegs division by zero, spline.cpp:84-88 */
+
+typedef struct batotp_resample_params {
+    int32_t  n_joints, n_cart;
+    int32_t  robot_type;             /* BATOTP_ROBOT_GENJNT or BATOTP_ROBOT_CSPR3DOF           */
+    int32_t  path_type;              /* BATOTP_PATH_*                                          */
+    int32_t  scale_type;             /* _scaleType 0 / 1 / 2                                   */
+    uint32_t flags;                  /* BATOTP_F_CART_VEL_ON / CART_ACC_ON decide whether interpSpecial
+                                        re-evaluates the Cartesian channels (ba.cpp:1362)      */
+    double   s_weights[3];           /* _sWeights                                              */
+    double   theta_norm_res, theta_norm_res2; /* _thetaNormRes, _thetaNormRes2                 */
+    double   cart_norm_res, cart_norm_res2;   /* _cartNormRes,  _cartNormRes2                  */
+    double   jnt_thresh, cart_thresh;         /* remClosePts thresholds                        */
+    double   pmat[9];                /* cable exit points (CSPR3DOF), row-major 3x3            */
+} batotp_resample_params;
+
+typedef struct batotp_resampled batotp_resampled;
+
+/* Resample n_paths taught paths.  x: the points of every path, path after path, each
+ * channel-major [n_joints + n_cart][n_in[p]] (theta rows then cart rows; for JOINT paths the cart
+ * rows are ignored and taken as zero, for CART paths the theta rows are overwritten by the inverse
+ * kinematics); sres_in[p] = traj.sres of the taught points.  The result stays in HBM. */
+int  batotp_hip_resample(batotp_ctx *ctx, const batotp_resample_params *prm, int32_t n_paths,
+                         const int64_t *n_in, const double *x, const double *sres_in,
+                         batotp_resampled **out);
+int  batotp_hip_resampled_destroy(batotp_resampled *r);
+/* knots per path, traj.sres per path, status bits per path (any pointer may be NULL) */
+int  batotp_hip_resampled_info(batotp_resampled *r, int64_t *n_knots, double *sres, uint32_t *status);
+/* device pointer of the knots, laid out as batotp_hip_upload_knots_device expects them (paths
+ * with a non-zero status hold 4 zero knots) */
+int  batotp_hip_resampled_knots_device(batotp_resampled *r, const double **y_dev, int64_t *n_doubles);
+/* knots of one path to the host: y[n_joints + n_cart][n_knots] */
+int  batotp_hip_resampled_download(batotp_resampled *r, int32_t path, double *y);
+/* milliseconds the resampling kernels of this object took (HIP events on the context's stream) */
+int  batotp_hip_resampled_ms(batotp_resampled *r, float *ms);
 
 #ifdef __cplusplus
 }

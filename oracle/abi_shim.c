@@ -325,3 +325,104 @@ int batotp_hip_last_kernel_ms(batotp_batch *b, int32_t which, float *ms)
     return BATOTP_OK;
 }
 int batotp_hip_batch_bytes(batotp_batch *b, int64_t *bytes) { (void)b; if (bytes) *bytes = 0; return BATOTP_OK; }
+
+/* ---- path resampling over bo_resample --------------------------------------- */
+struct batotp_resampled {
+    int32_t n_paths;
+    int C;
+    int64_t *n, *off;
+    double *sres;
+    uint32_t *status;
+    double *y; /* concatenated knots, the layout batotp_hip_upload_knots expects */
+    float ms;
+};
+
+int batotp_hip_resampled_destroy(batotp_resampled *r)
+{
+    if (!r) return BATOTP_OK;
+    free(r->n); free(r->off); free(r->sres); free(r->status); free(r->y);
+    free(r);
+    return BATOTP_OK;
+}
+
+int batotp_hip_resample(batotp_ctx *ctx, const batotp_resample_params *prm, int32_t n_paths, const int64_t *n_in, const double *x,
+                        const double *sres_in, batotp_resampled **out)
+{
+    batotp_resampled *r;
+    double **ys;
+    int64_t *xoff, total = 0;
+    int p, bad = 0, C;
+    struct timespec t0, t1;
+    if (!ctx || !prm || !n_in || !x || !sres_in || !out || n_paths < 1) return BATOTP_ERR_ARG;
+    *out = NULL;
+    C = prm->n_joints + prm->n_cart;
+    for (p = 0; p < n_paths; ++p)
+        if (n_in[p] < 4) return BATOTP_ERR_ARG;
+    r = (batotp_resampled *)calloc(1, sizeof(*r));
+    r->n_paths = n_paths; r->C = C;
+    r->n = (int64_t *)calloc((size_t)n_paths, sizeof(int64_t));
+    r->off = (int64_t *)calloc((size_t)n_paths, sizeof(int64_t));
+    r->sres = (double *)calloc((size_t)n_paths, sizeof(double));
+    r->status = (uint32_t *)calloc((size_t)n_paths, sizeof(uint32_t));
+    ys = (double **)calloc((size_t)n_paths, sizeof(double *));
+    xoff = (int64_t *)calloc((size_t)n_paths, sizeof(int64_t));
+    for (p = 1; p < n_paths; ++p) xoff[p] = xoff[p - 1] + n_in[p - 1] * C;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (p = 0; p < n_paths; ++p)
+        if (bo_resample(prm, n_in[p], x + xoff[p], sres_in[p], &ys[p], &r->n[p], &r->sres[p], &r->status[p]) != 0) {
+#pragma omp atomic write
+            bad = 1;
+        }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    r->ms = (float)((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6);
+    if (bad) {
+        for (p = 0; p < n_paths; ++p) free(ys[p]);
+        free(ys); free(xoff);
+        batotp_hip_resampled_destroy(r);
+        return BATOTP_ERR_ARG;
+    }
+    for (p = 0; p < n_paths; ++p) { r->off[p] = total; total += r->n[p]; }
+    r->y = (double *)malloc(sizeof(double) * (size_t)total * C);
+    for (p = 0; p < n_paths; ++p) {
+        memcpy(r->y + r->off[p] * C, ys[p], sizeof(double) * (size_t)r->n[p] * C);
+        free(ys[p]);
+    }
+    free(ys); free(xoff);
+    *out = r;
+    return BATOTP_OK;
+}
+
+int batotp_hip_resampled_info(batotp_resampled *r, int64_t *n_knots, double *sres, uint32_t *status)
+{
+    int p;
+    if (!r) return BATOTP_ERR_ARG;
+    for (p = 0; p < r->n_paths; ++p) {
+        if (n_knots) n_knots[p] = r->n[p];
+        if (sres) sres[p] = r->sres[p];
+        if (status) status[p] = r->status[p];
+    }
+    return BATOTP_OK;
+}
+
+int batotp_hip_resampled_knots_device(batotp_resampled *r, const double **y_dev, int64_t *n_doubles)
+{
+    if (!r || !y_dev) return BATOTP_ERR_ARG;
+    *y_dev = r->y;
+    if (n_doubles) *n_doubles = (r->off[r->n_paths - 1] + r->n[r->n_paths - 1]) * r->C;
+    return BATOTP_OK;
+}
+
+int batotp_hip_resampled_download(batotp_resampled *r, int32_t path, double *y)
+{
+    if (!r || !y || path < 0 || path >= r->n_paths) return BATOTP_ERR_ARG;
+    memcpy(y, r->y + r->off[path] * r->C, sizeof(double) * (size_t)r->n[path] * r->C);
+    return BATOTP_OK;
+}
+
+int batotp_hip_resampled_ms(batotp_resampled *r, float *ms)
+{
+    if (!r || !ms) return BATOTP_ERR_ARG;
+    *ms = r->ms;
+    return BATOTP_OK;
+}

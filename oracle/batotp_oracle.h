@@ -87,6 +87,15 @@ void bo_pointwise_mvc(const batotp_problem *prob, bo_path *p);
 void bo_point_eval(const batotp_problem *prob, const bo_path *p, int dir, double s, double sdot_in,
                    double *sdot_out, double *sddot_l, double *sddot_h, int32_t *n_iter, int32_t *rc);
 
+/* Path resampling before the hot path: remClosePts (util.cpp:452-524), the two
+ * BA::adjust_s passes (ba.cpp:412-638), BA::interpSpecial (ba.cpp:651-781), the resampling
+ * BA::evalSplineFullTraj (ba.cpp:790-863) and Robot::invKinCSPR3DOF (robot.cpp:243-278) for one path.
+ * x: [n_joints+n_cart][n_in].  *y_out is malloc'd [n_joints+n_cart][*n_out] (caller frees).
+ * Returns -1 for path kinds outside the device resampler's scope (see batotp_hip.h). */
+typedef batotp_resample_params bo_resample_params;
+int  bo_resample(const bo_resample_params *prm, int64_t n_in, const double *x, double sres_in,
+                 double **y_out, int64_t *n_out, double *sres_out, uint32_t *status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,281 @@
+/*
+ * batotp_oracle_resample.c -- TEST INFRASTRUCTURE ONLY (see batotp_oracle.h).
+ *
+ * Plain-C restatement of the path resampling that precedes the hot path, for the
+ * path kinds the device resampler covers: JOINT paths of a robot without kinematic model and CART
+ * paths of the 3-cable robot.  It is the checker of batotp_hip_resample.
+ *
+ * Pinning: tests/test_oracle_resample.py compares the knots it produces with the knots.npz
+ * fixtures under tests/golden/ -- the knots behind the s-sdot / trajectory outputs that are
+ * byte-identical to the reference binary's (oracle/README.md).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "batotp_oracle.h"
+
+typedef struct rs_traj {
+    int     nJ, nC, C;
+    int64_t n;
+    double *x;    /* [C][n] channel-major: theta rows then cart rows */
+    double  sres;
+} rs_traj;
+
+/* remClosePts (util.cpp:452-524) on the driving channels [c0, c0+cN) */
+static void rs_rem_close(rs_traj *t, int c0, int cN, double thresh)
+{
+    const int64_t n0 = t->n;
+    int64_t n = n0;
+    char *rem = (char *)calloc((size_t)n0, 1);
+    const double t2 = thresh * thresh;
+    for (;;) {
+        int found = 0;
+        for (int64_t i = 1; i < n; ++i) {
+            double sumsq = 0;
+            for (int j = 0; j < cN; ++j) {
+                const double dx = t->x[(c0 + j) * n0 + i] - t->x[(c0 + j) * n0 + i - 1];
+                sumsq += dx * dx;
+            }
+            if (sumsq < t2 && !rem[i - 1]) { rem[i] = 1; found = 1; }
+        }
+        if (rem[n - 1] && n > 2) { rem[n - 1] = 0; rem[n - 2] = 1; rem[n - 3] = 0; }
+        if (!found) break;
+        int64_t k = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            if (rem[i]) continue;
+            for (int c = 0; c < t->C; ++c) t->x[c * n0 + k] = t->x[c * n0 + i];
+            ++k;
+        }
+        n = k;
+        memset(rem, 0, (size_t)n);
+    }
+    free(rem);
+    if (n != n0) { /* repack rows to stride n */
+        for (int c = 1; c < t->C; ++c) memmove(t->x + c * n, t->x + c * n0, sizeof(double) * (size_t)n);
+        t->n = n;
+    }
+}
+
+/* Robot::invKinCSPR3DOF (robot.cpp:243-278) */
+static void rs_invkin_cspr(rs_traj *t, const double pmat[9])
+{
+    const int64_t n = t->n;
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            double sumSQ = 0.0;
+            for (int r = 0; r < 3; ++r) {
+                const double dlt = t->x[(t->nJ + r) * n + i] - pmat[r * 3 + k];
+                sumSQ += dlt * dlt;
+            }
+            t->x[k * n + i] = sqrt(sumSQ);
+        }
+}
+
+typedef struct rs_scale { double sLast, sResNew, teach, thetaF, cartF, sResi; } rs_scale;
+
+/* first half of adjust_s (ba.cpp:430-590): arc lengths, factors, sC.  0 ok / status bit */
+static unsigned rs_arclen(const bo_resample_params *prm, const rs_traj *t, int special, double *sC, rs_scale *sc)
+{
+    const int64_t n = t->n;
+    const double cartRes = special ? prm->cart_norm_res : prm->cart_norm_res2;
+    const double thetaRes = special ? prm->theta_norm_res : prm->theta_norm_res2;
+    double *th = (double *)calloc((size_t)n, sizeof(double)), *ca = (double *)calloc((size_t)n, sizeof(double));
+    for (int64_t i = 0; i < n - 1; ++i) {
+        double sq = 0;
+        for (int j = 0; j < t->nJ; ++j) {
+            const double d = t->x[j * n + i + 1] - t->x[j * n + i];
+            sq += d * d;
+        }
+        th[i + 1] = th[i] + sqrt(sq);
+        sq = 0;
+        for (int j = 0; j < 3; ++j) {
+            const double d = t->x[(t->nJ + j) * n + i + 1] - t->x[(t->nJ + j) * n + i];
+            sq += d * d;
+        }
+        ca[i + 1] = ca[i] + sqrt(sq);
+    }
+    unsigned st = 0;
+    if (th[n - 1] < thetaRes) st = BATOTP_RS_IDENTICAL; /* ba.cpp:484-488 */
+    if (!st) {
+        const double sResi = t->sres, last = (double)(n - 1);
+        double sLast = 0, sResNew = 0;
+        switch (prm->scale_type) { /* ba.cpp:558-572 */
+        case 0: sLast = sResi * last; sResNew = sResi; break;
+        case 1: sLast = th[n - 1]; sResNew = thetaRes; break;
+        default: sLast = ca[n - 1]; sResNew = cartRes; break;
+        }
+        double cartF = 0;
+        if (ca[n - 1] >= cartRes) cartF = prm->s_weights[2] * sLast / ca[n - 1];
+        const double teach = prm->s_weights[0] * sLast / (sResi * last);
+        const double thetaF = prm->s_weights[1] * sLast / th[n - 1];
+        for (int64_t i = 0; i < n; ++i) sC[i] = teach * sResi * (double)i + thetaF * th[i] + cartF * ca[i];
+        sc->sLast = sLast; sc->sResNew = sResNew; sc->teach = teach; sc->thetaF = thetaF; sc->cartF = cartF; sc->sResi = sResi;
+    }
+    free(th); free(ca);
+    return st;
+}
+
+/* spline coefficients of every channel: coef[c] -> [4][n] */
+static double *rs_all_coeffs(const rs_traj *t)
+{
+    double *coef = (double *)calloc((size_t)t->C * 4 * (size_t)t->n, sizeof(double));
+    for (int c = 0; c < t->C; ++c) bo_spline_coeffs(t->x + c * t->n, t->n, coef + (size_t)c * 4 * t->n, 0);
+    return coef;
+}
+
+/* interpSpecial (ba.cpp:651-781) */
+static unsigned rs_special(const bo_resample_params *prm, rs_traj *t, const double *sC, const rs_scale *sc)
+{
+    const int64_t n = t->n;
+    const int nJ = t->nJ, nC = t->nC, C = t->C;
+    const int cartEval = (prm->flags & (BATOTP_F_CART_VEL_ON | BATOTP_F_CART_ACC_ON)) != 0;
+    double *coef = rs_all_coeffs(t);
+    int64_t chunk = (int64_t)ceil(sc->sLast / sc->sResNew) + 1; /* ba.cpp:666-667 */
+    if (chunk < 4) chunk = 4;
+    int64_t cap = chunk;
+    double *out = (double *)calloc((size_t)cap * C, sizeof(double)); /* point-major rows */
+    double cartpt[BATOTP_MAX_CART] = {0};
+    for (int c = 0; c < C; ++c) out[c] = t->x[c * n];
+    double sPrv = 0, prvDs = 0;
+    int64_t newPt = 1, oldPt = 1, seg = 0;
+    int done = 0;
+    while (!done) {
+        double thSq = 0, caSq = 0;
+        for (int j = 0; j < nJ; ++j) {
+            const double d = t->x[j * n + oldPt] - out[(newPt - 1) * C + j];
+            thSq += d * d;
+        }
+        for (int j = 0; j < 3; ++j) {
+            const double d = t->x[(nJ + j) * n + oldPt] - out[(newPt - 1) * C + nJ + j];
+            caSq += d * d;
+        }
+        const double ds = sc->teach * sc->sResi * (double)oldPt + sc->thetaF * sqrt(thSq) + sc->cartF * sqrt(caSq);
+        if (ds > sc->sResNew) {
+            const double sNew = sPrv + sc->sResNew - prvDs;
+            prvDs = 0;
+            sPrv = sNew;
+            if (sNew > sC[n - 1]) done = 1;
+            if (!done) {
+                /* evalSplinePartials -> updateCurSeg (ba.cpp:1617-1652) from the cached segment */
+                double s0;
+                for (;;) {
+                    s0 = sC[seg];
+                    if (sNew >= s0 && sNew <= sC[seg + 1]) break;
+                    int moved = 0;
+                    if (sNew > s0) { if (seg >= n - 2) { seg = n - 2; break; } ++seg; moved = 1; }
+                    if (sNew < s0) { if (seg <= 0) { seg = 0; break; } --seg; moved = 1; }
+                    if (!moved) break;
+                }
+                const double tau = (sNew - s0) / (sC[seg + 1] - s0);
+                const double tau2 = tau * tau, tau3 = tau2 * tau;
+                double *o = out + newPt * C;
+                for (int j = 0; j < nJ; ++j) {
+                    const double *k = coef + (size_t)j * 4 * n;
+                    o[j] = k[3 * n + seg] * tau3 + k[2 * n + seg] * tau2 + k[1 * n + seg] * tau + k[seg];
+                }
+                if (cartEval)
+                    for (int j = 0; j < nC; ++j) {
+                        const double *k = coef + (size_t)(nJ + j) * 4 * n;
+                        cartpt[j] = k[3 * n + seg] * tau3 + k[2 * n + seg] * tau2 + k[1 * n + seg] * tau + k[seg];
+                    }
+                for (int j = 0; j < nC; ++j) o[nJ + j] = cartpt[j];
+                oldPt = seg + 1;
+                ++newPt;
+                if (newPt == cap) {
+                    cap += chunk;
+                    out = (double *)realloc(out, sizeof(double) * (size_t)cap * C);
+                }
+            }
+        } else if (oldPt == n - 1) {
+            done = 1;
+        } else {
+            prvDs = ds;
+            sPrv = sC[oldPt];
+            ++oldPt;
+        }
+    }
+    for (int c = 0; c < C; ++c) out[newPt * C + c] = t->x[c * n + n - 1];
+    const int64_t nNew = newPt + 1;
+    free(coef);
+    free(t->x);
+    t->x = (double *)malloc(sizeof(double) * (size_t)nNew * C);
+    for (int64_t i = 0; i < nNew; ++i)
+        for (int c = 0; c < C; ++c) t->x[c * nNew + i] = out[i * C + c];
+    free(out);
+    t->n = nNew;
+    t->sres = sc->sResNew;
+    return nNew < 4 ? BATOTP_RS_TOO_SHORT : 0;
+}
+
+/* second half of adjust_s "regularInterp" + evalSplineFullTraj (ba.cpp:601-613, 790-863) */
+static unsigned rs_regular(rs_traj *t, const double *sC, const rs_scale *sc)
+{
+    const int64_t n = t->n;
+    const int C = t->C;
+    const double oldRes = sc->sLast / (double)(n - 1); /* traj.sres, ba.cpp:585 */
+    for (int64_t i = 1; i < n; ++i)
+        if (sC[i] - sC[i - 1] < 1e-12 * oldRes) return BATOTP_RS_SMALL_STEP;
+    int64_t nNew = (int64_t)ceil(oldRes / sc->sResNew * (double)(n - 1)) + 1;
+    if (nNew < 4) nNew = 4;
+    const double newRes = oldRes * (double)(n - 1) / (double)(nNew - 1);
+    double *sites = (double *)malloc(sizeof(double) * (size_t)nNew);
+    const double sScale = sC[n - 1] / (double)(nNew - 1);
+    for (int64_t i = 0; i < nNew; ++i) sites[i] = sScale * (double)i;
+    int32_t *seg = (int32_t *)malloc(sizeof(int32_t) * (size_t)nNew);
+    double *tau = (double *)malloc(sizeof(double) * (size_t)nNew);
+    unsigned st = 0;
+    if (bo_find_interp_segs(sC, n, sites, nNew, seg, tau) != 0) st = BATOTP_RS_SEG_ERROR;
+    if (!st) {
+        double *coef = rs_all_coeffs(t);
+        double *y = (double *)malloc(sizeof(double) * (size_t)nNew * C);
+        double *d1 = (double *)malloc(sizeof(double) * (size_t)nNew), *d2 = (double *)malloc(sizeof(double) * (size_t)nNew);
+        for (int c = 0; c < C; ++c) bo_interp1_spline(coef + (size_t)c * 4 * n, n, seg, tau, nNew, oldRes, y + c * nNew, d1, d2);
+        free(d1); free(d2); free(coef);
+        free(t->x);
+        t->x = y;
+        t->n = nNew;
+        t->sres = newRes;
+    }
+    free(sites); free(seg); free(tau);
+    return st;
+}
+
+int bo_resample(const bo_resample_params *prm, int64_t n_in, const double *x, double sres_in, double **y_out, int64_t *n_out,
+                double *sres_out, uint32_t *status)
+{
+    const int joint = prm->path_type == BATOTP_PATH_JOINT && prm->robot_type == BATOTP_ROBOT_GENJNT;
+    const int cable = prm->path_type == BATOTP_PATH_CART && prm->robot_type == BATOTP_ROBOT_CSPR3DOF && prm->n_joints == 3;
+    if ((!joint && !cable) || n_in < 4 || prm->n_cart < 3) return -1;
+    if (prm->s_weights[1] + prm->s_weights[2] < 1e-8) return -1; /* ba.cpp:416: nothing to do */
+    rs_traj t;
+    t.nJ = prm->n_joints; t.nC = prm->n_cart; t.C = t.nJ + t.nC; t.n = n_in; t.sres = sres_in;
+    t.x = (double *)malloc(sizeof(double) * (size_t)n_in * t.C);
+    memcpy(t.x, x, sizeof(double) * (size_t)n_in * t.C);
+    if (joint) memset(t.x + (size_t)t.nJ * n_in, 0, sizeof(double) * (size_t)t.nC * n_in); /* ba.cpp:258-262 */
+    unsigned st = 0;
+    if (cable) rs_rem_close(&t, t.nJ, t.nC, prm->cart_thresh); /* ba.cpp:166-175 */
+    else rs_rem_close(&t, 0, t.nJ, prm->jnt_thresh);
+    if (t.n < 4) st |= BATOTP_RS_TOO_SHORT;
+    if (!st && cable) rs_invkin_cspr(&t, prm->pmat);
+    for (int pass = 0; pass < 2 && !st; ++pass) {
+        double *sC = (double *)malloc(sizeof(double) * (size_t)t.n);
+        rs_scale sc;
+        st |= rs_arclen(prm, &t, pass == 0, sC, &sc);
+        if (!st) st |= pass == 0 ? rs_special(prm, &t, sC, &sc) : rs_regular(&t, sC, &sc);
+        free(sC);
+        if (!st && cable) rs_invkin_cspr(&t, prm->pmat); /* ba.cpp:630 */
+    }
+    *status = st;
+    if (st) {
+        free(t.x);
+        *y_out = (double *)calloc((size_t)4 * t.C, sizeof(double));
+        *n_out = 4;
+        *sres_out = 0.0;
+    } else {
+        *y_out = t.x;
+        *n_out = t.n;
+        *sres_out = t.sres;
+    }
+    return 0;
+}

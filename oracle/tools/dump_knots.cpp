@@ -21,6 +21,25 @@ int main(int argc, char **argv)
    ba.setIsAutoIntegRes(false);
    if (ba.readConfigData((std::string("./") + argv[1]).c_str()) == -1) return 1;
    if (ba.loadTrajectoryData(tr) == -1) return 1;
+   {
+      // the taught points and the resampling parameters, for the device-resampler fixtures:
+      //   taught.bin   : int64 n, int64 nJ, int64 nCart, double sres, double x[nJ+nCart][n] (absent rows zero)
+      //   resample.bin : int32 supported (1/0), raw struct batotp_resample_params
+      batotp_resample_params R;
+      const int supported = ba.exportResampleParams(tr, &R) == 0 ? 1 : 0;
+      FILE *g = fopen("resample.bin", "wb");
+      fwrite(&supported, 4, 1, g); fwrite(&R, sizeof(R), 1, g);
+      fclose(g);
+      const long long n = tr.nPts, nJ = ba.getNumJoints(), nC = ba.getNumCart();
+      g = fopen("taught.bin", "wb");
+      fwrite(&n, 8, 1, g); fwrite(&nJ, 8, 1, g); fwrite(&nC, 8, 1, g); fwrite(&tr.sres, 8, 1, g);
+      std::vector<double> zeros(n, 0.0);
+      for (long long j = 0; j < nJ; ++j)
+         fwrite(((size_t)j < tr.theta.size() && tr.theta[j].size() >= (size_t)n) ? tr.theta[j].data() : zeros.data(), 8, n, g);
+      for (long long j = 0; j < nC; ++j)
+         fwrite(((size_t)j < tr.cart.size() && tr.cart[j].size() >= (size_t)n) ? tr.cart[j].data() : zeros.data(), 8, n, g);
+      fclose(g);
+   }
    if (ba.resampleToKnots(tr) != 0) return 1;
    const long long N = tr.nPts, nJ = ba.getNumJoints(), nC = ba.getNumCart();
    FILE *f = fopen("knots.bin", "wb");

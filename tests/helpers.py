@@ -17,6 +17,8 @@ BUILD = os.path.join(ROOT, "oracle", "_build")
 FULL_CASES = sorted(d for d in os.listdir(GOLD) if os.path.exists(os.path.join(GOLD, d, "knots.npz")))
 DIGEST_CASES = sorted(d for d in os.listdir(GOLD) if os.path.exists(os.path.join(GOLD, d, "ref_curves_sampled.npz")))
 
+RESAMPLE_CASES = sorted(d for d in os.listdir(GOLD) if os.path.exists(os.path.join(GOLD, d, "resample.npz")))
+
 # how the digest-only inputs are regenerated (must match oracle/make_golden.py)
 DIGEST_INPUTS = {
     "synth_gen7dof_s4_50k": lambda: (pathgen.gen7dof_fine(4, 871), None, 0.01),
@@ -68,6 +70,29 @@ class Case:
 
     def max_steps(self):
         return int(max(self.expected["n_rev"], self.expected["n_fwd"]) + 64)
+
+
+class ResampleCase:
+    """taught points + resampling parameters of a golden case; expected output = its knots.npz"""
+
+    def __init__(self, name):
+        self.name = name
+        d = os.path.join(GOLD, name)
+        z = np.load(os.path.join(d, "resample.npz"))
+        self.params = capi.ResampleParams.from_buffer_copy(z["params"].tobytes())
+        self.sres_in = float(z["sres_in"])
+        nJ, nC = self.params.n_joints, self.params.n_cart
+        tres, theta, cart = pathgen.read_traj_bin(os.path.join(d, str(z["traj_file"])), nJ, nC)
+        n = int(z["n_in"])
+        assert float(tres) == self.sres_in
+        self.x = np.zeros((nJ + nC, n))
+        if theta is not None:
+            self.x[:nJ] = theta
+        if cart is not None:
+            self.x[nJ:] = cart
+        k = np.load(os.path.join(d, "knots.npz"))
+        self.y = np.ascontiguousarray(k["y"])
+        self.sres = float(k["sres"])
 
 
 def rr_trig(theta_samples0, theta_samples1):

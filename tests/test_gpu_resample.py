@@ -1,0 +1,93 @@
+"""GPU (-m gpu): the device resampler against the golden knots and the oracle, through
+the C-ABI, bit for bit (fp64, tolerance 0)."""
+import numpy as np
+import pytest
+
+import helpers
+from helpers import RESAMPLE_CASES, ResampleCase, Case, assert_bit_equal
+from batotp_amd import capi, pathgen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", RESAMPLE_CASES)
+def test_hip_resample_matches_golden_knots(hip_ctx, name):
+    c = ResampleCase(name)
+    r = capi.Resampled(hip_ctx, c.params, [c.x], [c.sres_in])
+    assert int(r.status[0]) == 0
+    assert int(r.n_knots[0]) == c.y.shape[1]
+    assert r.sres[0] == c.sres
+    assert_bit_equal(r.knots(0), c.y, f"{name}: resampled knots")
+    r.close()
+
+
+def _same(h, o, what):
+    assert np.array_equal(h.status, o.status), what
+    assert np.array_equal(h.n_knots, o.n_knots), what
+    assert h.sres.tobytes() == o.sres.tobytes(), what
+    for k in range(h.n_paths):
+        assert_bit_equal(h.knots(k), o.knots(k), f"{what}: path {k}")
+
+
+def test_ragged_batch_with_failing_and_duplicated_paths(hip_ctx, oracle_ctx):
+    c = ResampleCase("synth_gen7dof_s0")
+    xs = [c.x, np.repeat(c.x[:, :1], 16, axis=1), np.repeat(c.x, 2, axis=1), c.x[:, :37].copy(), c.x[:, ::-1].copy()]
+    # a path whose last two points coincide (the tail rule of remClosePts)
+    t = c.x[:, :200].copy()
+    t[:, -1] = t[:, -2]
+    xs.append(t)
+    sr = [c.sres_in] * len(xs)
+    h = capi.Resampled(hip_ctx, c.params, xs, sr)
+    o = capi.Resampled(oracle_ctx, c.params, xs, sr)
+    assert int(h.status[1]) != 0  # all points identical: the reference performs no optimisation
+    _same(h, o, "ragged gen7dof batch")
+    assert_bit_equal(h.knots(2), c.y, "duplicated taught points are dropped first")
+
+
+@pytest.mark.parametrize("kind", ["gen7", "ur", "cspr"])
+def test_baseline_size_paths_match_oracle(hip_ctx, oracle_ctx, kind):
+    """BASELINE.json-sized taught paths (tens of thousands of points, ~1e5 knots), several seeds per batch"""
+    if kind == "gen7":
+        base = ResampleCase("synth_gen7dof_s0")
+        xs = [pathgen.gen7dof_fine(s, 400 + 50 * s) for s in (11, 12, 13)]
+    elif kind == "ur":
+        base = ResampleCase("synth_ur_s2")
+        xs = [pathgen.ur_like_fine(s, 300 + 40 * s) for s in (21, 22)]
+    else:
+        base = ResampleCase("synth_cspr_s3")
+        xs = [pathgen.cspr_fine(s, 100 + 20 * s) for s in (31, 32, 33)]
+    nJ, nC = base.params.n_joints, base.params.n_cart
+    full = []
+    for x in xs:
+        # the taught file stores float32: widen the way the reader does
+        x = x.astype(np.float32).astype(np.float64)
+        f = np.zeros((nJ + nC, x.shape[1]))
+        if kind == "cspr":
+            f[nJ:] = x
+        else:
+            f[:nJ] = x
+        full.append(f)
+    sr = [base.sres_in] * len(full)
+    h = capi.Resampled(hip_ctx, base.params, full, sr)
+    o = capi.Resampled(oracle_ctx, base.params, full, sr)
+    assert not h.status.any()
+    _same(h, o, f"{kind} baseline-size batch")
+
+
+def test_resampled_knots_feed_the_hot_path_on_the_device(hip_ctx):
+    """resample -> upload_knots_device -> precompute -> sweeps, nothing leaves HBM in between; the
+    traversal time and step counts are the golden case's"""
+    name = "synth_cspr_s3"
+    c, rc = Case(name), ResampleCase(name)
+    r = capi.Resampled(hip_ctx, rc.params, [rc.x, rc.x], [rc.sres_in] * 2)
+    b = capi.Batch(hip_ctx, c.problem, [int(n) for n in r.n_knots], c.max_steps())
+    b.upload_knots_device(0, 2, r.device_ptr(), list(r.sres))
+    b.optimize()
+    res = b.results()
+    for k in range(2):
+        assert int(res[k]["n_rev"]) == c.expected["n_rev"] and int(res[k]["n_fwd"]) == c.expected["n_fwd"]
+        assert f"{float(res[k]['t_total']):.2f}" == f"{c.expected['t_total_print']:.2f}"
+        s, sd = b.curve(k, +1)
+        assert helpers.f32_digest(s, sd) == c.expected["sha256_fwd"]
+    b.close()
+    r.close()

@@ -1,0 +1,56 @@
+"""Pins the oracle's restatement of the path resampling to the golden knots: the knots
+it produces from the taught points must be byte-identical to knots.npz -- the knots behind the
+s-sdot / trajectory outputs that match the reference binary byte for byte."""
+import numpy as np
+import pytest
+
+from batotp_amd import capi
+from helpers import RESAMPLE_CASES, ResampleCase
+
+
+@pytest.fixture(scope="module")
+def octx():
+    return capi.Context(capi.load_oracle(), 0)
+
+
+@pytest.mark.parametrize("name", RESAMPLE_CASES)
+def test_oracle_resample_matches_golden_knots(octx, name):
+    c = ResampleCase(name)
+    r = capi.Resampled(octx, c.params, [c.x], [c.sres_in])
+    assert int(r.status[0]) == 0
+    assert int(r.n_knots[0]) == c.y.shape[1]
+    assert r.sres[0] == c.sres
+    assert r.knots(0).tobytes() == c.y.tobytes()
+    r.close()
+
+
+def test_oracle_resample_batch_and_ragged(octx):
+    cs = [ResampleCase(n) for n in RESAMPLE_CASES if n.startswith("synth_cspr")]
+    r = capi.Resampled(octx, cs[0].params, [c.x for c in cs], [c.sres_in for c in cs])
+    for k, c in enumerate(cs):
+        assert r.knots(k).tobytes() == c.y.tobytes() and r.sres[k] == c.sres
+    r.close()
+
+
+def test_oracle_resample_status_paths(octx):
+    c = ResampleCase("synth_gen7dof_s0")
+    # all points identical -> the reference's "no optimization will be performed" exit
+    x = np.repeat(c.x[:, :1], 16, axis=1)
+    r = capi.Resampled(octx, c.params, [x, c.x], [c.sres_in, c.sres_in])
+    assert int(r.status[0]) != 0 and int(r.n_knots[0]) == 4
+    assert int(r.status[1]) == 0 and r.knots(1).tobytes() == c.y.tobytes()
+    r.close()
+    # close points are dropped before resampling: duplicating taught points must not change the result
+    xd = np.repeat(c.x, 2, axis=1)
+    r = capi.Resampled(octx, c.params, [xd], [c.sres_in])
+    assert int(r.status[0]) == 0
+    assert r.knots(0).tobytes() == c.y.tobytes()
+    r.close()
+
+
+def test_unsupported_kind_is_refused(octx):
+    c = ResampleCase("synth_gen7dof_s0")
+    p = capi.ResampleParams.from_buffer_copy(bytes(c.params))
+    p.robot_type = capi.ROBOT_UR
+    with pytest.raises(capi.BatotpError):
+        capi.Resampled(octx, p, [c.x], [c.sres_in])
