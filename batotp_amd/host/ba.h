@@ -162,6 +162,11 @@ public:
    int optimizeBatch(std::vector<Traj> &trajs);
    // Extension: select the HIP device used by this object (default 0).
    void setDevice(int device) { _deviceId = device; }
+   // Extension: optimizeBatch() resamples the taught paths on the device when the configuration is
+   // one batotp_hip_resample covers (exportResampleParams); false keeps the host resampler.
+   void setDeviceResample(bool on) { _deviceResample = on; }
+   // milliseconds the last optimizeBatch() spent resampling (device kernels, or host wall clock)
+   double getLastResampleMs() const { return _lastResampleMs; }
    // Extension: the host half of interpInputData() only (everything before reference
    // ba.cpp:299): leaves the final knot values in traj.theta / traj.cart, the knot spacing in
    // traj.sres and the knot count in traj.nPts.  No device call.
@@ -311,6 +316,8 @@ private:
    // ---- device seam ------------------------------------------------------------------------------
    struct Gpu; // owns the batotp_ctx (ba_device.cpp)
    std::shared_ptr<Gpu> _gpu;
+   bool _deviceResample = true;
+   double _lastResampleMs = 0;
    int _deviceId = 0;
    int gpuAcquire();                       // create the context on first use; -1 + message on failure
    void fillProblem(void *prob) const;     // BA configuration -> batotp_problem

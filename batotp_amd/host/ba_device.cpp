@@ -7,6 +7,7 @@
 //   * sweep() (reference ba.cpp:979-1195),
 // plus the many-path extension optimizeBatch().  There is no host implementation to fall back to:
 // if the device layer fails the call returns -1 after printing the reason.
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <numeric>
@@ -36,6 +37,14 @@ struct BatchGuard
    ~BatchGuard()
    {
       if (b) batotp_hip_batch_destroy(b);
+   }
+};
+struct ResampledGuard
+{
+   batotp_resampled *r = nullptr;
+   ~ResampledGuard()
+   {
+      if (r) batotp_hip_resampled_destroy(r);
    }
 };
 
@@ -470,26 +479,92 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
    if (trajs.empty()) return 0;
    if (gpuAcquire() != 0) return -1;
 
-   // host resampling of every path; the configuration fields it may rewrite are restored
-   // after each path so that all paths see the same problem
-   const std::vector<double> sWeights0 = _sWeights;
-   const int scaleType0 = _scaleType;
-   const unsigned int nCart0 = _nCart;
-   const bool par0 = _isParallelMech;
    std::vector<int> ok(trajs.size(), 0);
    std::vector<int64_t> nKnots;
    std::vector<size_t> live;
-   unsigned int nCartRun = nCart0;
-   for (size_t p = 0; p < trajs.size(); ++p)
+   unsigned int nCartRun = _nCart; // Cartesian channels during the run (6 -> 7 when poses become quaternions)
+   const int nInTaught = (int)(_nJoints + _nCart);
+   const std::chrono::steady_clock::time_point tResample0 = std::chrono::steady_clock::now();
+
+   // 1) resampling to uniform-s knots.  On the device when the configuration allows it
+   //    (batotp_hip_resample); the knots then never leave HBM.
+   ResampledGuard rs;
+   bool onDevice = _deviceResample;
+   batotp_resample_params rsp;
+   for (size_t p = 0; p < trajs.size() && onDevice; ++p)
+      if (exportResampleParams(trajs[p], &rsp) != 0) onDevice = false;
+   std::vector<double> sresKnots;
+   if (onDevice)
    {
-      _sWeights = sWeights0; _scaleType = scaleType0; _nCart = nCart0; _isParallelMech = par0;
-      if (prepareKnots(trajs[p]) != 0 || trajs[p].nPts < 4) continue;
-      nCartRun = _nCart; // 6 -> 7 when poses were converted to quaternions
-      ok[p] = 1;
-      live.push_back(p);
-      nKnots.push_back((int64_t)trajs[p].nPts);
+      std::vector<int64_t> nTaught(trajs.size());
+      std::vector<double> sresTaught(trajs.size());
+      size_t total = 0;
+      for (size_t p = 0; p < trajs.size(); ++p) { nTaught[p] = trajs[p].nPts; sresTaught[p] = trajs[p].sres; total += (size_t)trajs[p].nPts; }
+      std::vector<double> x(total * nInTaught, 0.0);
+      size_t at = 0;
+      for (size_t p = 0; p < trajs.size(); ++p)
+      {
+         const Traj &t = trajs[p];
+         const size_t n = (size_t)t.nPts;
+         for (unsigned int j = 0; j < _nJoints && j < t.theta.size(); ++j)
+            if (t.theta[j].size() >= n) std::copy(t.theta[j].begin(), t.theta[j].begin() + n, x.begin() + at + (size_t)j * n);
+         for (unsigned int j = 0; j < _nCart && j < t.cart.size(); ++j)
+            if (t.cart[j].size() >= n) std::copy(t.cart[j].begin(), t.cart[j].begin() + n, x.begin() + at + (size_t)(_nJoints + j) * n);
+         at += n * nInTaught;
+      }
+      int rcR = batotp_hip_resample(_gpu->ctx, &rsp, (int32_t)trajs.size(), nTaught.data(), x.data(), sresTaught.data(), &rs.r);
+      if (rcR) return fail("resample", rcR);
+      std::vector<int64_t> nK(trajs.size());
+      std::vector<double> sr(trajs.size());
+      std::vector<uint32_t> st(trajs.size());
+      batotp_hip_resampled_info(rs.r, nK.data(), sr.data(), st.data());
+      for (size_t p = 0; p < trajs.size(); ++p)
+         if (st[p] & (BATOTP_RS_TOO_SHORT | BATOTP_RS_CAPACITY)) onDevice = false; // rare branches: let the host resampler take them
+      if (onDevice)
+      {
+         for (size_t p = 0; p < trajs.size(); ++p)
+         {
+            if (st[p]) continue; // the reference returns -1 for this path (identical points / degenerate s)
+            ok[p] = 1;
+            live.push_back(p);
+            nKnots.push_back(nK[p]);
+            sresKnots.push_back(sr[p]);
+            trajs[p].sres = sr[p];
+            trajs[p].nPts = (int)nK[p];
+            trajs[p].sLastSec = -1;
+         }
+         _isInterpolated = true;
+         float ms = 0;
+         batotp_hip_resampled_ms(rs.r, &ms);
+         _lastResampleMs = ms;
+      }
+      else
+      {
+         batotp_hip_resampled_destroy(rs.r);
+         rs.r = nullptr;
+      }
    }
-   _nCart = nCartRun;
+   if (!onDevice)
+   {
+      // host resampling of every path; the configuration fields it may rewrite are restored
+      // after each path so that all paths see the same problem
+      const std::vector<double> sWeights0 = _sWeights;
+      const int scaleType0 = _scaleType;
+      const unsigned int nCart0 = _nCart;
+      const bool par0 = _isParallelMech;
+      nCartRun = nCart0;
+      for (size_t p = 0; p < trajs.size(); ++p)
+      {
+         _sWeights = sWeights0; _scaleType = scaleType0; _nCart = nCart0; _isParallelMech = par0;
+         if (prepareKnots(trajs[p]) != 0 || trajs[p].nPts < 4) continue;
+         nCartRun = _nCart; // 6 -> 7 when poses were converted to quaternions
+         ok[p] = 1;
+         live.push_back(p);
+         nKnots.push_back((int64_t)trajs[p].nPts);
+      }
+      _nCart = nCartRun;
+      _lastResampleMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tResample0).count();
+   }
    if (live.empty()) return (int)trajs.size();
 
    batotp_problem prob;
@@ -504,18 +579,42 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
    int rc = batotp_hip_batch_create(_gpu->ctx, &prob, (int32_t)live.size(), nKnots.data(), cap, &g.b);
    if (rc) return fail("batch_create", rc);
 
-   std::vector<double> y;
-   for (size_t k = 0; k < live.size(); ++k)
+   if (onDevice)
    {
-      Traj &t = trajs[live[k]];
-      const int64_t N = nKnots[k];
-      y.assign((size_t)nIn * N, 0.0);
-      for (unsigned int j = 0; j < _nJoints; ++j) std::copy(t.theta[j].begin(), t.theta[j].begin() + N, y.begin() + (size_t)j * N);
-      for (unsigned int j = 0; j < _nCart && j < t.cart.size(); ++j)
-         if (t.cart[j].size() >= (size_t)N) std::copy(t.cart[j].begin(), t.cart[j].begin() + N, y.begin() + (size_t)(_nJoints + j) * N);
-      const double sres = t.sres;
-      rc = batotp_hip_upload_knots(g.b, (int32_t)k, 1, y.data(), &sres);
-      if (rc) return fail("upload_knots", rc);
+      // runs of consecutive surviving paths are contiguous in the resampler's output
+      const double *yDev = nullptr;
+      batotp_hip_resampled_knots_device(rs.r, &yDev, nullptr);
+      std::vector<int64_t> nAll(trajs.size());
+      batotp_hip_resampled_info(rs.r, nAll.data(), nullptr, nullptr);
+      std::vector<int64_t> offAll(trajs.size(), 0);
+      for (size_t p = 1; p < trajs.size(); ++p) offAll[p] = offAll[p - 1] + nAll[p - 1];
+      size_t k = 0;
+      while (k < live.size())
+      {
+         size_t e = k + 1;
+         while (e < live.size() && live[e] == live[e - 1] + 1) ++e;
+         rc = batotp_hip_upload_knots_device(g.b, (int32_t)k, (int32_t)(e - k), yDev + offAll[live[k]] * nIn, sresKnots.data() + k);
+         if (rc) return fail("upload_knots_device", rc);
+         k = e;
+      }
+      batotp_hip_resampled_destroy(rs.r);
+      rs.r = nullptr;
+   }
+   else
+   {
+      std::vector<double> y;
+      for (size_t k = 0; k < live.size(); ++k)
+      {
+         Traj &t = trajs[live[k]];
+         const int64_t N = nKnots[k];
+         y.assign((size_t)nIn * N, 0.0);
+         for (unsigned int j = 0; j < _nJoints; ++j) std::copy(t.theta[j].begin(), t.theta[j].begin() + N, y.begin() + (size_t)j * N);
+         for (unsigned int j = 0; j < _nCart && j < t.cart.size(); ++j)
+            if (t.cart[j].size() >= (size_t)N) std::copy(t.cart[j].begin(), t.cart[j].begin() + N, y.begin() + (size_t)(_nJoints + j) * N);
+         const double sres = t.sres;
+         rc = batotp_hip_upload_knots(g.b, (int32_t)k, 1, y.data(), &sres);
+         if (rc) return fail("upload_knots", rc);
+      }
    }
    rc = batotp_hip_precompute(g.b, 1);
    if (rc) return fail("precompute(kinematics)", rc);
@@ -570,6 +669,7 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
          ok[live[k]] = 0;
          continue;
       }
+      _nCart = nCartRun; // interpOutputData of the previous path turned quaternions back into axis-angle
       const double sresIn = t.sres;
       t.nPtsC = (int)N;
       t.sC.resize(N);
@@ -579,7 +679,7 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
       t.aFact = t.vFact * t.vFact;
       t.thetaC.resize(_nJoints); t.cartC.resize(_nCart);
       t.thetaD.resize(_nJoints); t.thetaD2.resize(_nJoints);
-      t.cartD.resize(_nCart); t.cartD2.resize(_nCart); t.cart.resize(_nCart);
+      t.cartD.resize(_nCart); t.cartD2.resize(_nCart); t.cart.resize(_nCart); t.theta.resize(_nJoints);
       flat.resize(4 * (size_t)N); samp.resize(3 * (size_t)N);
       for (int ch = 0; ch < nIn; ++ch)
       {

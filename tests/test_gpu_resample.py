@@ -91,3 +91,21 @@ def test_resampled_knots_feed_the_hot_path_on_the_device(hip_ctx):
         assert helpers.f32_digest(s, sd) == c.expected["sha256_fwd"]
     b.close()
     r.close()
+
+
+@pytest.mark.parametrize("name", ["synth_cspr_s3", "synth_gen7dof_s0", "CSPR3DOF", "UR5"])
+def test_product_batch_driver_on_gpu(tmp_path, name):
+    """batotp_amd/host/_build/batest_batch (BA::optimizeBatch over the HIP library, device resampler where the
+    configuration allows it) writes the reference binary's files for every copy of the path"""
+    import filecmp, os, shutil, subprocess
+    exe = os.path.join(helpers.ROOT, "batotp_amd", "host", "_build", "batest_batch")
+    assert os.path.exists(exe), "build() must produce batest_batch"
+    src = os.path.join(helpers.GOLD, name)
+    for f in os.listdir(src):
+        if not f.startswith("ref_") and not f.endswith(".npz") and not f.endswith(".json"):
+            shutil.copy(os.path.join(src, f), tmp_path / f)
+    r = subprocess.run([exe, "config.dat", "5"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    for d in ("out_first", "out_last"):
+        assert filecmp.cmp(tmp_path / d / "s-sdot.dat", os.path.join(src, "ref_s-sdot.dat"), shallow=False), name
+        assert filecmp.cmp(tmp_path / d / "traj_out.dat", os.path.join(src, "ref_traj_out.dat"), shallow=False), name
