@@ -42,6 +42,8 @@ struct RsPath
    int32_t nOut;  // points the pass produces (special: emitted; regular: nPtsNew)
    int32_t cap;   // capacity of the special pass' output rows
    int64_t offOut;
+   int32_t n0;    // points the stage arrays reserve for this path (n <= n0; remClosePts shrinks n)
+   int32_t pad;
 };
 
 // status bits of the resampler
@@ -132,42 +134,81 @@ __global__ void k_rs_invkin_cspr(RsParams P, const RsPath *__restrict__ paths, i
 }
 
 // ---------------------------------------------------------------------------------------------
-// adjust_s up to the sC array (ba.cpp:430-590, _isAutoIntegRes = false): cumulative arc lengths,
-// scale factors, s of every point.  One lane per path.  Also decides the size of the pass' output.
+// adjust_s up to the sC array (ba.cpp:430-590, _isAutoIntegRes = false) in three kernels:
+//   k_rs_seglen  one lane per point: joint-space and Cartesian length of the step to each point
+//   k_rs_scan    one lane per path: the two running sums (sequential: fp addition order is the
+//                reference's), the scale factors, the size of the pass' output
+//   k_rs_sites   one lane per point: s of every point and, in the second pass, the spacing checks
 // special != 0: first pass (interpSpecial follows); 0: second pass (evalSplineFullTraj follows).
 // ---------------------------------------------------------------------------------------------
-__global__ void k_rs_arclen(RsParams P, RsPath *__restrict__ paths, int B, const double *__restrict__ x, double *__restrict__ thetaArc,
-                            double *__restrict__ cartArc, double *__restrict__ sC, int special)
+__device__ __forceinline__ int rs_find_path(const RsPath *__restrict__ paths, int B, int64_t g)
+{
+   int lo = 0, hi = B - 1;
+   while (lo < hi)
+   {
+      const int mid = (lo + hi + 1) >> 1;
+      if (paths[mid].off <= g) lo = mid; else hi = mid - 1;
+   }
+   return lo;
+}
+
+__global__ void k_rs_seglen(RsParams P, const RsPath *__restrict__ paths, int B, const double *__restrict__ x, double *__restrict__ thetaArc,
+                            double *__restrict__ cartArc, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   const int lo = rs_find_path(paths, B, g);
+   const RsPath pp = paths[lo];
+   const int i = (int)(g - pp.off), n = pp.n;
+   if (i >= n || pp.status) return;
+   if (i == 0) { thetaArc[g] = 0; cartArc[g] = 0; return; }
+   const double *__restrict__ xb = x + pp.off * P.C;
+   double sq = 0;
+   for (int j = 0; j < P.nJ; ++j)
+   {
+      const double d = xb[(int64_t)j * n + i] - xb[(int64_t)j * n + i - 1];
+      sq += d * d;
+   }
+   thetaArc[g] = sqrt(sq);
+   sq = 0;
+   for (int j = 0; j < 3; ++j)
+   {
+      const double d = xb[(int64_t)(P.nJ + j) * n + i] - xb[(int64_t)(P.nJ + j) * n + i - 1];
+      sq += d * d;
+   }
+   cartArc[g] = sqrt(sq);
+}
+
+__global__ void k_rs_scan(RsParams P, RsPath *__restrict__ paths, int B, double *__restrict__ thetaArc, double *__restrict__ cartArc, int special)
 {
    const int p = blockIdx.x * blockDim.x + threadIdx.x;
    if (p >= B) return;
    RsPath &pp = paths[p];
    if (pp.status) return;
    const int n = pp.n;
-   const double *__restrict__ xb = x + pp.off * P.C;
-   double *__restrict__ ta = thetaArc + pp.off, *__restrict__ ca = cartArc + pp.off, *__restrict__ s = sC + pp.off;
-   ta[0] = 0; ca[0] = 0;
+   double *__restrict__ ta = thetaArc + pp.off, *__restrict__ ca = cartArc + pp.off;
+   // thetaNorm[i+1] = thetaNorm[i] + dtheta (ba.cpp:452-470); step lengths are loaded a batch at a time
+   constexpr int CH = 16;
    double tacc = 0, cacc = 0;
-   for (int i = 0; i < n - 1; ++i)
+   int i = 1;
+   for (; i + CH <= n; i += CH)
    {
-      double sq = 0;
-      for (int j = 0; j < P.nJ; ++j)
+      double dt[CH], dc[CH];
+#pragma unroll
+      for (int k = 0; k < CH; ++k) { dt[k] = ta[i + k]; dc[k] = ca[i + k]; }
+#pragma unroll
+      for (int k = 0; k < CH; ++k)
       {
-         const double d = xb[(int64_t)j * n + i + 1] - xb[(int64_t)j * n + i];
-         sq += d * d;
+         tacc = tacc + dt[k]; ta[i + k] = tacc;
+         cacc = cacc + dc[k]; ca[i + k] = cacc;
       }
-      tacc = tacc + sqrt(sq);
-      ta[i + 1] = tacc;
-      sq = 0;
-      for (int j = 0; j < 3; ++j)
-      {
-         const double d = xb[(int64_t)(P.nJ + j) * n + i + 1] - xb[(int64_t)(P.nJ + j) * n + i];
-         sq += d * d;
-      }
-      cacc = cacc + sqrt(sq);
-      ca[i + 1] = cacc;
    }
-   if (ta[n - 1] < P.thetaRes) { pp.status |= RS_IDENTICAL; return; }
+   for (; i < n; ++i)
+   {
+      tacc = tacc + ta[i]; ta[i] = tacc;
+      cacc = cacc + ca[i]; ca[i] = cacc;
+   }
+   if (tacc < P.thetaRes) { pp.status |= RS_IDENTICAL; return; }
 
    const double sResi = pp.sres;
    const double ptsLast = (double)(n - 1); // traj.ptsOrig is 0,1,2,.. at both call sites
@@ -175,17 +216,15 @@ __global__ void k_rs_arclen(RsParams P, RsPath *__restrict__ paths, int B, const
    switch (P.scaleType)
    {
    case 0: sLast = sResi * ptsLast; sResNew = sResi; break;
-   case 1: sLast = ta[n - 1]; sResNew = P.thetaRes; break;
-   default: sLast = ca[n - 1]; sResNew = P.cartRes; break;
+   case 1: sLast = tacc; sResNew = P.thetaRes; break;
+   default: sLast = cacc; sResNew = P.cartRes; break;
    }
    double cartFact = 0;
-   if (ca[n - 1] >= P.cartRes) cartFact = P.sW[2] * sLast / ca[n - 1];
+   if (cacc >= P.cartRes) cartFact = P.sW[2] * sLast / cacc;
    const double teachFact = P.sW[0] * sLast / (sResi * ptsLast);
-   const double thetaFact = P.sW[1] * sLast / ta[n - 1];
+   const double thetaFact = P.sW[1] * sLast / tacc;
    pp.sLast = sLast; pp.sResNew = sResNew; pp.tTeachFact = teachFact; pp.thetaFact = thetaFact; pp.cartFact = cartFact;
    pp.sresNew = sLast / (n - 1); // traj.sres = sLast/(nPts-1), ba.cpp:585
-   for (int i = 0; i < n; ++i) s[i] = teachFact * sResi * (double)i + thetaFact * ta[i] + cartFact * ca[i];
-
    if (special)
    {
       int nPts2 = (int)ceil(sLast / sResNew) + 1; // ba.cpp:666-667
@@ -194,99 +233,143 @@ __global__ void k_rs_arclen(RsParams P, RsPath *__restrict__ paths, int B, const
    }
    else
    {
-      const double sresRegular = pp.sresNew;
-      for (int i = 1; i < n; ++i)
-         if (s[i] - s[i - 1] < 1e-12 * sresRegular) { pp.status |= RS_SMALL_STEP; return; }
-      for (int i = 1; i < n; ++i)
-         if (s[i] - s[i - 1] < 1e-20) { pp.status |= RS_SEG_ERROR; return; } // findInterpSegs, spline.cpp:84-88
       // evalSplineFullTraj(traj, traj.sres, sResNew): ba.cpp:796-798
-      int nNew = (int)ceil(sresRegular / sResNew * (n - 1)) + 1;
+      int nNew = (int)ceil(pp.sresNew / sResNew * (n - 1)) + 1;
       if (nNew < 4) nNew = 4;
       pp.nOut = nNew;
+   }
+}
+
+// RsPath::pad collects the spacing findings of the second pass: bit 0 "s-resolution is too small"
+// (ba.cpp:607-611), bit 1 findInterpSegs' zero width (spline.cpp:84-88); the host turns them into
+// the status the sequential code would have returned (the first check wins).
+__global__ void k_rs_sites(RsParams P, RsPath *__restrict__ paths, int B, const double *__restrict__ thetaArc, const double *__restrict__ cartArc,
+                           double *__restrict__ sC, int special, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   const int lo = rs_find_path(paths, B, g);
+   const RsPath pp = paths[lo];
+   const int i = (int)(g - pp.off), n = pp.n;
+   if (i >= n || pp.status) return;
+   const double a = pp.tTeachFact * pp.sres;
+   const double si = a * (double)i + pp.thetaFact * thetaArc[g] + pp.cartFact * cartArc[g];
+   sC[g] = si;
+   if (!special && i > 0)
+   {
+      const double sm = a * (double)(i - 1) + pp.thetaFact * thetaArc[g - 1] + pp.cartFact * cartArc[g - 1];
+      int f = 0;
+      if (si - sm < 1e-12 * pp.sresNew) f |= 1;
+      if (si - sm < 1e-20) f |= 2;
+      if (f) atomicOr(&paths[lo].pad, f);
    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // interpSpecial (ba.cpp:651-781): walk along the original points and emit a new point every sResNew
 // of (weighted) distance from the last emitted one, by evaluating the splines of the original
-// points.  One lane per path.  Output rows are point-major [i][C] (the count is only known at the end).
+// points.  Output rows are point-major [i][C] (the count is only known at the end).
+//
+// One WAVEFRONT per path, lane c = channel c.  The walk is a serial chain (every emitted point
+// depends on the previous one) with data-dependent control flow; with a lane per path the 64 paths
+// of a wavefront drag each other through both branches and through every memory wait.  With a
+// wavefront per path the control flow is uniform (scalar branches), the channel work of one step
+// runs across lanes, loads of a point / of a coefficient row are one coalesced access, and the
+// other wavefronts of the SIMD (other paths) hide the memory latency.  Values that all lanes
+// share (distances, s, tau) are computed redundantly in every lane from lane-broadcast operands, in
+// the reference's order of operations.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_rs_special(RsParams P, RsPath *__restrict__ paths, int B, const double *__restrict__ x, const double *__restrict__ sC,
-                             const double *__restrict__ coef, double *__restrict__ rows)
+__device__ __forceinline__ double readlane_f64(double v, int lane)
 {
-   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+   return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(64) k_rs_special(RsParams P, RsPath *__restrict__ paths, int B, const double *__restrict__ x,
+                                                   const double *__restrict__ sC, const double *__restrict__ coef, double *__restrict__ rows)
+{
+   const int p = blockIdx.x;
    if (p >= B) return;
    RsPath &pp = paths[p];
    if (pp.status) return;
-   const int n = pp.n, C = P.C, nJ = P.nJ, nC = P.nC;
-   const double *__restrict__ xb = x + pp.off * C;
+   const int lane = threadIdx.x;
+   const int n = pp.n, C = P.C, nJ = P.nJ;
+   const int c = lane < C ? lane : C - 1; // spare lanes shadow the last channel (they never store)
+   const bool owner = lane < C;
+   const double *__restrict__ xc = x + pp.off * C + (int64_t)c * n; // this lane's channel of the taught points
    const double *__restrict__ s = sC + pp.off;
-   const double *__restrict__ cf = coef + pp.off * C * 4;
-   double *__restrict__ out = rows + pp.offOut * C;
+   const double *__restrict__ cf = coef + pp.off * C * 4 + c * 4;
+   double *__restrict__ out = rows + pp.offOut * C + c;
    const int cap = pp.cap;
    const double sResNew = pp.sResNew, teach = pp.tTeachFact * pp.sres, thF = pp.thetaFact, caF = pp.cartFact;
+   const double sEnd = s[n - 1];
+   const bool cartCh = c >= nJ;
+   const bool evalCh = !cartCh || P.cartEval != 0; // Cartesian channels keep traj.cartpt (zero) unless a Cartesian constraint is on
 
-   double cartpt[BATOTP_MAX_CART];
-   for (int c = 0; c < nC; ++c) cartpt[c] = 0.0; // traj.cartpt is zero until a Cartesian constraint evaluates it
-   for (int c = 0; c < C; ++c) out[c] = xb[(int64_t)c * n];
+   double prev = xc[0], xo = xc[1];
+   Coef4 kk = *reinterpret_cast<const Coef4 *>(cf);
+   double cartpt = 0.0;
+   if (owner) out[0] = prev;
    double sPrv = 0, prvDs = 0;
-   int newPt = 1, oldPt = 1, seg = 0;
+   int newPt = 1, oldPt = 1, seg = 0, xoAt = 1, kAt = 0;
+   double sA = s[0], sB = s[1]; // s[seg], s[seg+1]
    const int lastSeg = n - 2;
    bool done = false;
    while (!done)
    {
-      const double *prev = out + (int64_t)(newPt - 1) * C;
-      double thSq = 0;
-      for (int j = 0; j < nJ; ++j)
+      if (xoAt != oldPt)
       {
-         const double d = xb[(int64_t)j * n + oldPt] - prev[j];
-         thSq += d * d;
+         xo = xc[oldPt];
+         xoAt = oldPt;
       }
-      double caSq = 0;
-      for (int j = 0; j < 3; ++j)
-      {
-         const double d = xb[(int64_t)(nJ + j) * n + oldPt] - prev[nJ + j];
-         caSq += d * d;
-      }
-      const double ds = teach * (double)oldPt + thF * sqrt(thSq) + caF * sqrt(caSq);
+      const double d = xo - prev;
+      const double d2 = d * d;
+      double thSq = 0, caSq = 0;
+      for (int j = 0; j < nJ; ++j) thSq += readlane_f64(d2, j);
+      for (int j = 0; j < 3; ++j) caSq += readlane_f64(d2, nJ + j);
+      // the two square roots side by side: lanes 0..31 take the joint-space one, lanes 32..63 the Cartesian one
+      const double root = sqrt(lane < 32 ? thSq : caSq);
+      const double ds = teach * (double)oldPt + thF * readlane_f64(root, 0) + caF * readlane_f64(root, 32);
       if (ds > sResNew)
       {
          const double sNew = sPrv + sResNew - prvDs;
          prvDs = 0;
          sPrv = sNew;
-         if (sNew > s[n - 1]) done = true;
+         if (sNew > sEnd) done = true;
          if (!done)
          {
             // evalSplinePartials: segment walk from the cached segment (ba.cpp:1617-1652), then the cubics
-            double sSeg;
             for (;;)
             {
-               sSeg = s[seg];
-               if (sNew >= sSeg && sNew <= s[seg + 1]) break;
+               if (sNew >= sA && sNew <= sB) break;
                bool moved = false;
-               if (sNew > sSeg) { if (seg >= lastSeg) { seg = lastSeg; break; } ++seg; moved = true; }
-               if (sNew < sSeg) { if (seg <= 0) { seg = 0; break; } --seg; moved = true; }
+               if (sNew > sA)
+               {
+                  if (seg >= lastSeg) break;
+                  ++seg; sA = sB; sB = s[seg + 1];
+                  moved = true;
+               }
+               else if (sNew < sA)
+               {
+                  if (seg <= 0) break;
+                  --seg; sB = sA; sA = s[seg];
+                  moved = true;
+               }
                if (!moved) break;
             }
-            const double tau = (sNew - sSeg) / (s[seg + 1] - sSeg);
+            if (kAt != seg)
+            {
+               kk = *reinterpret_cast<const Coef4 *>(cf + (int64_t)seg * C * 4);
+               kAt = seg;
+            }
+            const double tau = (sNew - sA) / (sB - sA);
             const double tau2 = tau * tau, tau3 = tau2 * tau;
-            if (newPt >= cap) { pp.status |= RS_CAPACITY; return; }
-            double *o = out + (int64_t)newPt * C;
-            const double *row = cf + (int64_t)seg * C * 4;
-            for (int j = 0; j < nJ; ++j)
-            {
-               const Coef4 k = *reinterpret_cast<const Coef4 *>(row + j * 4);
-               o[j] = k.c3 * tau3 + k.c2 * tau2 + k.c1 * tau + k.c0;
-            }
-            if (P.cartEval)
-            {
-               for (int j = 0; j < nC; ++j)
-               {
-                  const Coef4 k = *reinterpret_cast<const Coef4 *>(row + (nJ + j) * 4);
-                  cartpt[j] = k.c3 * tau3 + k.c2 * tau2 + k.c1 * tau + k.c0;
-               }
-            }
-            for (int j = 0; j < nC; ++j) o[nJ + j] = cartpt[j];
+            if (newPt >= cap) { if (lane == 0) pp.status |= RS_CAPACITY; return; }
+            const double v = kk.c3 * tau3 + kk.c2 * tau2 + kk.c1 * tau + kk.c0;
+            if (evalCh) cartpt = v; // (joint channels: simply the new value)
+            prev = cartpt;
+            if (owner) out[(int64_t)newPt * C] = prev;
             oldPt = seg + 1;
             ++newPt;
          }
@@ -302,11 +385,13 @@ __global__ void k_rs_special(RsParams P, RsPath *__restrict__ paths, int B, cons
          ++oldPt;
       }
    }
-   if (newPt >= cap) { pp.status |= RS_CAPACITY; return; }
-   double *o = out + (int64_t)newPt * C;
-   for (int c = 0; c < C; ++c) o[c] = xb[(int64_t)c * n + n - 1]; // the original end point closes the path
-   pp.nOut = newPt + 1;
-   if (pp.nOut < 4) pp.status |= RS_TOO_SHORT;
+   if (newPt >= cap) { if (lane == 0) pp.status |= RS_CAPACITY; return; }
+   if (owner) out[(int64_t)newPt * C] = xc[n - 1]; // the original end point closes the path
+   if (lane == 0)
+   {
+      pp.nOut = newPt + 1;
+      if (pp.nOut < 4) pp.status |= RS_TOO_SHORT;
+   }
 }
 
 // point-major rows [i][C] -> channel-major [C][n] of the next stage

@@ -109,3 +109,16 @@ def test_product_batch_driver_on_gpu(tmp_path, name):
     for d in ("out_first", "out_last"):
         assert filecmp.cmp(tmp_path / d / "s-sdot.dat", os.path.join(src, "ref_s-sdot.dat"), shallow=False), name
         assert filecmp.cmp(tmp_path / d / "traj_out.dat", os.path.join(src, "ref_traj_out.dat"), shallow=False), name
+
+
+def test_chunked_resampling_equals_one_chunk(hip_lib, oracle_ctx, monkeypatch):
+    """a tiny scratch budget forces several chunks of paths: the result must not depend on the chunking"""
+    c = ResampleCase("synth_cspr_s3")
+    xs = [c.x, c.x[:, :900].copy(), c.x[:, ::-1].copy(), c.x[:, 500:2500].copy(), c.x]
+    sr = [c.sres_in] * len(xs)
+    monkeypatch.setenv("BATOTP_RESAMPLE_BUDGET_MB", "6")
+    ctx = capi.Context(hip_lib, 0)
+    h = capi.Resampled(ctx, c.params, xs, sr)
+    o = capi.Resampled(oracle_ctx, c.params, xs, sr)
+    _same(h, o, "chunked cspr batch")
+    assert_bit_equal(h.knots(4), c.y, "last path of a chunked batch")
