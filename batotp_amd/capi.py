@@ -160,6 +160,7 @@ class Library:
             "batotp_hip_device_count": [C.POINTER(C.c_int)],
             "batotp_hip_ctx_create": [C.c_int, C.POINTER(P)],
             "batotp_hip_ctx_destroy": [P],
+            "batotp_hip_ctx_trim": [P],
             "batotp_hip_fp64_kat": [P, I64, D, D, D, D, D],
             "batotp_hip_batch_create": [P, C.POINTER(Problem), I32, C.POINTER(C.c_int64), I64, C.POINTER(P)],
             "batotp_hip_batch_destroy": [P],
@@ -236,6 +237,10 @@ class Context:
 
     def synchronize(self):
         self.library.check(self.library.lib.batotp_hip_synchronize(self.handle), "synchronize")
+
+    def trim(self):
+        """release the workspaces cached between resample calls (invalidates live Resampled objects)"""
+        self.library.check(self.library.lib.batotp_hip_ctx_trim(self.handle), "ctx_trim")
 
     def fp64_kat(self, a: np.ndarray, b: np.ndarray):
         a = np.ascontiguousarray(a, dtype=np.float64)

@@ -39,8 +39,18 @@ extern "C" const char *batotp_hip_last_error(void) { return g_err; }
 // ---------------------------------------------------------------------------------------------
 // objects
 // ---------------------------------------------------------------------------------------------
+// grow-only device workspace cached in the context: hipMalloc of tens of GB costs ~40 ms/GB on this
+// system, far more than the kernels that use the memory
+struct Arena
+{
+   void *p = nullptr;
+   size_t cap = 0;
+};
+
 struct batotp_ctx
 {
+   Arena ws[3]; // resampler: stage-0 arrays, per-chunk scratch, resampled knots
+   uint64_t rsEpoch = 0; // resample calls so far (a batotp_resampled is valid while its epoch is the current one)
    int device = 0;
    hipStream_t stream = nullptr;
    int sweepGroup = 0; // lanes per path in the sweep kernel; 0 = automatic
@@ -180,7 +190,24 @@ extern "C" int batotp_hip_ctx_destroy(batotp_ctx *ctx)
    if (!ctx) return BATOTP_OK;
    hipSetDevice(ctx->device);
    if (ctx->stream) hipStreamDestroy(ctx->stream);
+   for (Arena &a : ctx->ws)
+      if (a.p) hipFree(a.p);
    delete ctx;
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_ctx_trim(batotp_ctx *ctx)
+{
+   if (!ctx) return BATOTP_ERR_ARG;
+   int rc = bind(ctx);
+   if (rc) return rc;
+   HIP_TRY(hipStreamSynchronize(ctx->stream));
+   for (Arena &a : ctx->ws)
+   {
+      if (a.p) hipFree(a.p);
+      a.p = nullptr; a.cap = 0;
+   }
+   ++ctx->rsEpoch;
    return BATOTP_OK;
 }
 

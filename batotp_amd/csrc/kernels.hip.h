@@ -126,7 +126,11 @@ __device__ __forceinline__ void emit_segment(double *__restrict__ cf, int64_t i,
    *reinterpret_cast<Coef4 *>(cf + (i * C + dc) * 4) = o;
 }
 
-__global__ void __launch_bounds__(64) k_spline(const PathInfo *__restrict__ pinfo, int B, int nch, int mode, int C, int Cin, int d,
+// SOL = true (the resampler's spline builds): instead of the coefficient rows, the second
+// derivatives sol[0..N-1] of the channel are left in `scratch` (same layout as src); consumers
+// form c0..c3 of a segment from sol and y with emit_segment's formulas (coeffs_from_sol).
+template <bool SOL>
+__device__ __forceinline__ void spline_channel(const PathInfo *__restrict__ pinfo, int B, int nch, int mode, int C, int Cin, int d,
                                                const double *__restrict__ src, int64_t src_stride_per_knot,
                                                double *__restrict__ scratch, double *__restrict__ coef)
 {
@@ -183,9 +187,13 @@ __global__ void __launch_bounds__(64) k_spline(const PathInfo *__restrict__ pinf
    const double cl = (n - 1) < CONV ? c_ctab[n - 1] : cInf;
    double solR = (0.0 - 1.0 * dprev) / (4.0 - 1.0 * cl); // spline.cpp:269 (not forced to zero)
 
-   // row of the last knot stays zero (spline.cpp:203-209 never writes it)
-   Coef4 z; z.c0 = 0; z.c1 = 0; z.c2 = 0; z.c3 = 0;
-   *reinterpret_cast<Coef4 *>(cf + ((unsigned)n * (unsigned)C * 4 + dc * 4)) = z;
+   if (SOL) dpark[n] = solR;
+   else
+   {
+      // row of the last knot stays zero (spline.cpp:203-209 never writes it)
+      Coef4 z; z.c0 = 0; z.c1 = 0; z.c2 = 0; z.c3 = 0;
+      *reinterpret_cast<Coef4 *>(cf + ((unsigned)n * (unsigned)C * 4 + dc * 4)) = z;
+   }
 
    // back substitution fused with the coefficient formulas (spline.cpp:271-274, 203-209):
    // reference loop index ii runs n .. 2 with d[ii-1] -= c[ii-1]*d[ii]
@@ -204,7 +212,8 @@ __global__ void __launch_bounds__(64) k_spline(const PathInfo *__restrict__ pinf
       for (int k = 0; k < CH; ++k)
       {
          const double solL = dd[k] - cInf * solR; // ii - 1 = i - k - 1 >= CONV
-         emit_segment(cf, i - k - 1, C, dc, solL, solR, yy[k], yR);
+         if (SOL) dpark[i - k - 1] = solL;
+         else emit_segment(cf, i - k - 1, C, dc, solL, solR, yy[k], yR);
          solR = solL;
          yR = yy[k];
       }
@@ -214,11 +223,38 @@ __global__ void __launch_bounds__(64) k_spline(const PathInfo *__restrict__ pinf
       const double ci = (i - 1) < CONV ? c_ctab[i - 1] : cInf;
       const double yL = y[i - 1];
       const double solL = dpark[i - 1] - ci * solR;
-      emit_segment(cf, i - 1, C, dc, solL, solR, yL, yR);
+      if (SOL) dpark[i - 1] = solL;
+      else emit_segment(cf, i - 1, C, dc, solL, solR, yL, yR);
       solR = solL;
       yR = yL;
    }
-   emit_segment(cf, 0, C, dc, 0.0, solR, y[0], yR);
+   if (SOL) dpark[0] = 0.0;
+   else emit_segment(cf, 0, C, dc, 0.0, solR, y[0], yR);
+}
+
+__global__ void __launch_bounds__(64) k_spline(const PathInfo *__restrict__ pinfo, int B, int nch, int mode, int C, int Cin, int d,
+                                               const double *__restrict__ src, int64_t src_stride_per_knot,
+                                               double *__restrict__ scratch, double *__restrict__ coef)
+{
+   spline_channel<false>(pinfo, B, nch, mode, C, Cin, d, src, src_stride_per_knot, scratch, coef);
+}
+
+__global__ void __launch_bounds__(64) k_spline_sol(const PathInfo *__restrict__ pinfo, int B, int nch, int C, const double *__restrict__ src,
+                                                   double *__restrict__ sol)
+{
+   spline_channel<true>(pinfo, B, nch, 0, C, C, 1, src, (int64_t)C, sol, nullptr);
+}
+
+// coefficient row of segment i from the second derivatives and the values at its two ends
+// (emit_segment's formulas, spline.cpp:203-209)
+__device__ __forceinline__ Coef4 coeffs_from_sol(double solL, double solR, double yL, double yR)
+{
+   Coef4 o;
+   o.c3 = (solR - solL) / 6.0;
+   o.c2 = solL / 2.0;
+   o.c1 = yR - yL - (solR + 2 * solL) / 6.0;
+   o.c0 = yL;
+   return o;
 }
 
 // ---------------------------------------------------------------------------------------------

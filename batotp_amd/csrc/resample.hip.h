@@ -7,8 +7,7 @@
 // reference's operation order; the host resampler (batotp_amd/host/ba_input.cpp), itself pinned by
 // the reference binary's outputs, is the checker (tests/test_gpu_resample.py).
 //
-// The walks are sequential per path (cumulative sums, data-dependent emission): one lane per path,
-// all paths in parallel; the spline builds reuse k_spline (one lane per channel), the uniform
+// The walks are sequential per path (cumulative sums, data-dependent emission): the spline builds reuse the hot path's Thomas kernel (one lane per channel), the uniform
 // re-evaluation runs one lane per output site.
 //
 // Stage arrays are channel-major per path: x[path base + c*n + i], path base = off*C.
@@ -287,7 +286,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 }
 
 __global__ void __launch_bounds__(64) k_rs_special(RsParams P, RsPath *__restrict__ paths, int B, const double *__restrict__ x,
-                                                   const double *__restrict__ sC, const double *__restrict__ coef, double *__restrict__ rows)
+                                                   const double *__restrict__ sC, const double *__restrict__ sol, double *__restrict__ rows)
 {
    const int p = blockIdx.x;
    if (p >= B) return;
@@ -299,7 +298,7 @@ __global__ void __launch_bounds__(64) k_rs_special(RsParams P, RsPath *__restric
    const bool owner = lane < C;
    const double *__restrict__ xc = x + pp.off * C + (int64_t)c * n; // this lane's channel of the taught points
    const double *__restrict__ s = sC + pp.off;
-   const double *__restrict__ cf = coef + pp.off * C * 4 + c * 4;
+   const double *__restrict__ mc = sol + pp.off * C + (int64_t)c * n; // second derivatives of this lane's channel (k_spline_sol)
    double *__restrict__ out = rows + pp.offOut * C + c;
    const int cap = pp.cap;
    const double sResNew = pp.sResNew, teach = pp.tTeachFact * pp.sres, thF = pp.thetaFact, caF = pp.cartFact;
@@ -308,7 +307,7 @@ __global__ void __launch_bounds__(64) k_rs_special(RsParams P, RsPath *__restric
    const bool evalCh = !cartCh || P.cartEval != 0; // Cartesian channels keep traj.cartpt (zero) unless a Cartesian constraint is on
 
    double prev = xc[0], xo = xc[1];
-   Coef4 kk = *reinterpret_cast<const Coef4 *>(cf);
+   Coef4 kk = coeffs_from_sol(mc[0], mc[1], prev, xo);
    double cartpt = 0.0;
    if (owner) out[0] = prev;
    double sPrv = 0, prvDs = 0;
@@ -360,7 +359,7 @@ __global__ void __launch_bounds__(64) k_rs_special(RsParams P, RsPath *__restric
             }
             if (kAt != seg)
             {
-               kk = *reinterpret_cast<const Coef4 *>(cf + (int64_t)seg * C * 4);
+               kk = coeffs_from_sol(mc[seg], mc[seg + 1], xc[seg], xc[seg + 1]);
                kAt = seg;
             }
             const double tau = (sNew - sA) / (sB - sA);
@@ -419,7 +418,7 @@ __global__ void k_rs_transpose(int C, const RsPath *__restrict__ src, const RsPa
 // cursor ends on (first segment with site < sC[seg+1], clipped), found by bisection on sC.
 // ---------------------------------------------------------------------------------------------
 __global__ void k_rs_regular(RsParams P, const RsPath *__restrict__ src, const RsPath *__restrict__ dst, int B, const double *__restrict__ sC,
-                             const double *__restrict__ coef, double *__restrict__ y, int64_t total)
+                             const double *__restrict__ x, const double *__restrict__ sol, double *__restrict__ y, int64_t total)
 {
    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
    if (g >= total) return;
@@ -445,11 +444,12 @@ __global__ void k_rs_regular(RsParams P, const RsPath *__restrict__ src, const R
    const int seg = a;
    const double tau = (site - s[seg]) / (s[seg + 1] - s[seg]);
    const double tau2 = tau * tau, tau3 = tau2 * tau;
-   const double *row = coef + (sp.off + seg) * C * 4;
+   const double *xs = x + sp.off * C + seg, *ms = sol + sp.off * C + seg;
    double *o = y + dst[lo].off * C;
    for (int c = 0; c < C; ++c)
    {
-      const Coef4 k = *reinterpret_cast<const Coef4 *>(row + c * 4);
+      const int64_t at = (int64_t)c * nOld;
+      const Coef4 k = coeffs_from_sol(ms[at], ms[at + 1], xs[at], xs[at + 1]);
       o[(int64_t)c * nNew + i] = k.c3 * tau3 + k.c2 * tau2 + k.c1 * tau + k.c0;
    }
 }

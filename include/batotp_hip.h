@@ -112,6 +112,8 @@ typedef struct batotp_batch batotp_batch;  /* B independent paths resident in HB
 int  batotp_hip_device_count(int *count);
 int  batotp_hip_ctx_create(int device, batotp_ctx **out);
 int  batotp_hip_ctx_destroy(batotp_ctx *ctx);
+/* release the workspaces the context caches between batotp_hip_resample calls */
+int  batotp_hip_ctx_trim(batotp_ctx *ctx);
 /* message of the last HIP failure on this thread ("" if none) */
 const char *batotp_hip_last_error(void);
 /* device-side known-answer test of fp64 div / sqrt rounding (no contraction):
@@ -241,7 +243,10 @@ int  batotp_hip_resampled_destroy(batotp_resampled *r);
 /* knots per path, traj.sres per path, status bits per path (any pointer may be NULL) */
 int  batotp_hip_resampled_info(batotp_resampled *r, int64_t *n_knots, double *sres, uint32_t *status);
 /* device pointer of the knots, laid out as batotp_hip_upload_knots_device expects them (paths
- * with a non-zero status hold 4 zero knots) */
+ * with a non-zero status hold 4 zero knots).  The knots live in a workspace the context keeps
+ * between calls (allocating tens of GB per call costs more than the kernels): they stay valid until
+ * the next batotp_hip_resample on the same context, batotp_hip_ctx_trim or batotp_hip_ctx_destroy;
+ * after that this call and batotp_hip_resampled_download return BATOTP_ERR_STATE. */
 int  batotp_hip_resampled_knots_device(batotp_resampled *r, const double **y_dev, int64_t *n_doubles);
 /* knots of one path to the host: y[n_joints + n_cart][n_knots] */
 int  batotp_hip_resampled_download(batotp_resampled *r, int32_t path, double *y);

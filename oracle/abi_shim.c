@@ -337,6 +337,8 @@ struct batotp_resampled {
     float ms;
 };
 
+int batotp_hip_ctx_trim(batotp_ctx *ctx) { return ctx ? BATOTP_OK : BATOTP_ERR_ARG; }
+
 int batotp_hip_resampled_destroy(batotp_resampled *r)
 {
     if (!r) return BATOTP_OK;
