@@ -28,7 +28,7 @@ MAX_CART = 8
 ROBOT_KUKA, ROBOT_UR, ROBOT_RR, ROBOT_CSPR3DOF, ROBOT_GENJNT = 1, 2, 3, 4, 5
 # problem flags
 F_JNT_ACC_ON, F_TRQ_ON, F_CART_VEL_ON, F_CART_ACC_ON = 1 << 0, 1 << 1, 1 << 2, 1 << 3
-F_PARALLEL, F_PAR2SER, F_HOST_TRIG, F_NO_SAMPLES = 1 << 4, 1 << 5, 1 << 6, 1 << 7
+F_PARALLEL, F_PAR2SER, F_HOST_TRIG, F_NO_SAMPLES, F_COMPACT_SPLINES = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
 # per-path status bits
 ST_MAX_INTEG_TIME, ST_CAPACITY, ST_BISECT_FAIL = 1 << 0, 1 << 1, 1 << 2
 ST_NONFINITE, ST_SHORT, ST_SEG_ERROR = 1 << 3, 1 << 4, 1 << 5
@@ -162,6 +162,7 @@ class Library:
             "batotp_hip_ctx_destroy": [P],
             "batotp_hip_ctx_trim": [P],
             "batotp_hip_fp64_kat": [P, I64, D, D, D, D, D],
+            "batotp_hip_div6_kat": [P, I64, D, D],
             "batotp_hip_batch_create": [P, C.POINTER(Problem), I32, C.POINTER(C.c_int64), I64, C.POINTER(P)],
             "batotp_hip_batch_destroy": [P],
             "batotp_hip_upload_knots": [P, I32, I32, D, D],
@@ -297,6 +298,13 @@ class Resampled:
         v = C.c_float(0)
         self.L.check(self.lib.batotp_hip_resampled_ms(self.handle, C.byref(v)), "resampled_ms")
         return float(v.value)
+
+
+def div6_kat(ctx: "Context", a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    q = np.empty_like(a)
+    ctx.library.check(ctx.library.lib.batotp_hip_div6_kat(ctx.handle, a.size, _dptr(a), _dptr(q)), "div6_kat")
+    return q
 
 
 class Batch:

@@ -485,7 +485,9 @@ struct Pt
 
    // path constants
    const double *__restrict__ sC;
-   const double *__restrict__ coef; // this path's [N][C][4]
+   const double *__restrict__ coef; // this path's [N][C][4]   (FEAT >= 0)
+   const double *__restrict__ yk;   // FEAT == -1 (compact splines): this path's knot values [nJ][N] ...
+   const double *__restrict__ mk;   // ... and their second derivatives [nJ][N] (k_spline_sol)
    int n;
    int C, nJ, nC, nIn;
    unsigned flags;
@@ -629,44 +631,69 @@ __device__ __forceinline__ void eval_partials_row(Pt<G, FEAT, UNI> &t, int j, co
    }
 }
 
+// (x / 6.0) correctly rounded through the reciprocal (see div_by_const): the compact spline form
+// divides twice per coefficient row
+__device__ __forceinline__ double div6(double x) { return div_by_const(x, 6.0, 1.0 / 6.0); }
+
+// FEAT <= 0 (joint velocity / acceleration limits only): this lane's coefficients c1..c3 stay in
+// registers while the cursor stays on the segment (group-uniform test).  FEAT == 0 reads them from the
+// coefficient rows; FEAT == -1 forms them from the knot values and second derivatives with
+// emit_segment's formulas (spline.cpp:203-209) -- half the bytes per knot, no coefficient array.
 template <int G, int FEAT, bool UNI>
-__device__ __forceinline__ void eval_partials(Pt<G, FEAT, UNI> &t, int j)
+__device__ __forceinline__ void eval_partials_cached(Pt<G, FEAT, UNI> &t, int j)
 {
-   update_cur_seg<UNI ? 0 : 1>(t.sC, t.sresC, t.n, t.sCur, t.segC, t.tauC, t.status);
-   const double *__restrict__ row = t.coef + (unsigned)(t.segC * t.C * 4);
-#ifndef BK_NO_ROWCACHE
-   if (FEAT == 0)
-#else
-   if (false)
-#endif
+   if (t.segC != t.rowSeg)
    {
-      // joint channels only: keep this lane's coefficients in registers while the cursor stays on
-      // the segment (group-uniform test)
-      if (t.segC != t.rowSeg)
-      {
-#pragma unroll
-         for (int q = 0; q < Pt<G, FEAT, UNI>::PER; ++q)
-         {
-            const int jj = j + q * G;
-            if (jj < t.nJ) t.rowTh[q] = *reinterpret_cast<const Coef4 *>(row + jj * 4);
-         }
-         t.rowSeg = t.segC;
-      }
-      const double tau = t.tauC, tau2 = tau * tau;
 #pragma unroll
       for (int q = 0; q < Pt<G, FEAT, UNI>::PER; ++q)
       {
          const int jj = j + q * G;
          if (jj < t.nJ)
          {
-            const Coef4 k = t.rowTh[q];
-            t.thD[q] = (3 * k.c3 * tau2 + 2 * k.c2 * tau + k.c1) * t.vfact;
-            t.thD2[q] = (6 * k.c3 * tau + 2 * k.c2) * t.afact;
+            if (FEAT < 0)
+            {
+               const unsigned at = (unsigned)(jj * t.n + t.segC);
+               const double solL = t.mk[at], solR = t.mk[at + 1], yL = t.yk[at], yR = t.yk[at + 1];
+               Coef4 k;
+               k.c3 = div6(solR - solL);
+               k.c2 = solL / 2.0;
+               k.c1 = yR - yL - div6(solR + 2 * solL);
+               k.c0 = yL;
+               t.rowTh[q] = k;
+            }
+            else t.rowTh[q] = *reinterpret_cast<const Coef4 *>(t.coef + (unsigned)(t.segC * t.C * 4) + jj * 4);
          }
       }
+      t.rowSeg = t.segC;
+   }
+   const double tau = t.tauC, tau2 = tau * tau;
+#pragma unroll
+   for (int q = 0; q < Pt<G, FEAT, UNI>::PER; ++q)
+   {
+      const int jj = j + q * G;
+      if (jj < t.nJ)
+      {
+         const Coef4 k = t.rowTh[q];
+         t.thD[q] = (3 * k.c3 * tau2 + 2 * k.c2 * tau + k.c1) * t.vfact;
+         t.thD2[q] = (6 * k.c3 * tau + 2 * k.c2) * t.afact;
+      }
+   }
+}
+
+template <int G, int FEAT, bool UNI>
+__device__ __forceinline__ void eval_partials(Pt<G, FEAT, UNI> &t, int j)
+{
+   update_cur_seg<UNI ? 0 : 1>(t.sC, t.sresC, t.n, t.sCur, t.segC, t.tauC, t.status);
+#ifndef BK_NO_ROWCACHE
+   if (FEAT <= 0)
+#else
+   if (FEAT < 0)
+#endif
+   {
+      eval_partials_cached(t, j);
       return;
    }
-   eval_partials_row(t, j, row);
+   eval_partials_row(t, j, t.coef + (unsigned)(t.segC * t.C * 4));
 }
 
 // BA::updateCurSeg on the reverse curve (ba.cpp:1592) with the current segment's two (s, sdot)
@@ -1106,11 +1133,13 @@ __device__ __forceinline__ void accel_pt(Pt<G, FEAT, UNI> &t, int j, double &sdd
 // fill the constants of a path group
 template <int G, int FEAT, bool UNI>
 __device__ __forceinline__ void pt_init(Pt<G, FEAT, UNI> &t, const DevProblem &P, const PathInfo &pi, const double *sC,
-                                        const double *coef, const double (*lim)[8], int j, int dir)
+                                        const double *coef, const double *yk, const double *mk, const double (*lim)[8], int j, int dir)
 {
    constexpr bool PAR = (FEAT == 3);
    t.sC = sC + pi.koff;
-   t.coef = coef + pi.koff * P.C * 4;
+   t.coef = (FEAT < 0) ? nullptr : coef + pi.koff * P.C * 4;
+   t.yk = (FEAT < 0) ? yk + pi.koff * P.Cin : nullptr;
+   t.mk = (FEAT < 0) ? mk + pi.koff * P.Cin : nullptr;
    t.n = (int)pi.n;
    t.C = P.C; t.nJ = P.nJ; t.nC = P.nC; t.nIn = P.Cin;
    t.flags = P.flags;
@@ -1181,6 +1210,7 @@ template <int FEAT>
 __global__ void __launch_bounds__(K3_BLOCK) k_pointwise(DevProblem P, const PathInfo *__restrict__ pinfo, int B,
                                                         const DevProblem *__restrict__ dP,
                                                         const double *__restrict__ sC, const double *__restrict__ coef,
+                                                        const double *__restrict__ yk, const double *__restrict__ mk,
                                                         double *__restrict__ mvc, int64_t total)
 {
    __shared__ double lim[6][8];
@@ -1193,6 +1223,7 @@ __global__ void __launch_bounds__(K3_BLOCK) k_pointwise(DevProblem P, const Path
    const int64_t g0 = (int64_t)blockIdx.x * K3_BLOCK;
    const int rowD = P.C * 4, rowPad = rowD + 2;
    const int rowsHere = (total - g0) < K3_BLOCK ? (int)(total - g0) : K3_BLOCK;
+   if (FEAT >= 0) // (compact splines: adjacent lanes read adjacent knots of the channel-major arrays directly)
    {
       const Coef4 *__restrict__ srcp = reinterpret_cast<const Coef4 *>(coef + g0 * rowD);
       const int chunks = rowsHere * P.C;
@@ -1218,7 +1249,7 @@ __global__ void __launch_bounds__(K3_BLOCK) k_pointwise(DevProblem P, const Path
    const int N = (int)pi.n, i = (int)(g - pi.koff);
 
    Pt<1, FEAT, false> t;
-   pt_init(t, P, pi, sC, coef, lim, 0, -1);
+   pt_init(t, P, pi, sC, coef, yk, mk, lim, 0, -1);
    t.segC = (i < N - 1) ? i : N - 2;
    t.sCur = t.sC[i];
    // cursor already on its segment: updateCurSeg only computes tau (0 at a knot, 1 at the last knot)
@@ -1226,9 +1257,13 @@ __global__ void __launch_bounds__(K3_BLOCK) k_pointwise(DevProblem P, const Path
       const double sSeg = t.sC[t.segC], sNext = t.sC[t.segC + 1];
       t.tauC = (t.sCur - sSeg) / (sNext - sSeg);
    }
-   const int rowLocal = (int)threadIdx.x - (i - t.segC); // the last knot of a path uses the previous row
-   const double *row = (rowLocal >= 0) ? (tile + rowLocal * rowPad) : (t.coef + (unsigned)(t.segC * rowD));
-   eval_partials_row(t, 0, row);
+   if (FEAT < 0) eval_partials_cached(t, 0);
+   else
+   {
+      const int rowLocal = (int)threadIdx.x - (i - t.segC); // the last knot of a path uses the previous row
+      const double *row = (rowLocal >= 0) ? (tile + rowLocal * rowPad) : (t.coef + (unsigned)(t.segC * rowD));
+      eval_partials_row(t, 0, row);
+   }
    double sdot = t.sdotCap;
    sdot_lim(t, 0, sdot);
    t.sdotCur = sdot;
@@ -1239,6 +1274,59 @@ __global__ void __launch_bounds__(K3_BLOCK) k_pointwise(DevProblem P, const Path
    o[i] = t.sdotCur;
    o[N + i] = t.sddotL;
    o[2 * (int64_t)N + i] = t.sddotH;
+}
+
+// K3 with a lane group per knot (lane = joint, as in the sweep): one joint per lane keeps the register
+// footprint small (the lane-per-knot form carries all eight joints of a knot in one lane and runs at
+// low occupancy), the group reductions are DPP butterflies, and only the 8 knots of a wavefront share
+// a bisection loop instead of 64.  Same definition, same results as k_pointwise.
+constexpr int K3G_BLOCK = 256;
+
+template <int FEAT>
+__global__ void __launch_bounds__(K3G_BLOCK) k_pointwise_grp(DevProblem P, const PathInfo *__restrict__ pinfo, int B,
+                                                             const DevProblem *__restrict__ dP, const double *__restrict__ sC,
+                                                             const double *__restrict__ coef, const double *__restrict__ yk,
+                                                             const double *__restrict__ mk, double *__restrict__ mvc, int64_t first,
+                                                             int64_t total)
+{
+   __shared__ double lim[6][8];
+   stage_limits(dP, lim);
+   const int lane = threadIdx.x & 63, j = lane & 7;
+   // `first`: a launch covers at most 2^31 lanes (HIP limits grid x block to 32 bits), the host slices the knots
+   const int64_t g = first + ((int64_t)blockIdx.x * (K3G_BLOCK / 64) + (threadIdx.x >> 6)) * 8 + (lane >> 3);
+   if (g >= total) return; // whole groups leave together
+   int lo = 0, hi = B - 1;
+   while (lo < hi)
+   {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pinfo[mid].koff <= g) lo = mid; else hi = mid - 1;
+   }
+   const PathInfo pi = pinfo[lo];
+   const int N = (int)pi.n, i = (int)(g - pi.koff);
+
+   Pt<8, FEAT, false> t;
+   pt_init(t, P, pi, sC, coef, yk, mk, lim, j, -1);
+   t.segC = (i < N - 1) ? i : N - 2;
+   t.sCur = t.sC[i];
+   {
+      const double sSeg = t.sC[t.segC], sNext = t.sC[t.segC + 1];
+      t.tauC = (t.sCur - sSeg) / (sNext - sSeg);
+   }
+   if (FEAT < 0) eval_partials_cached(t, j);
+   else eval_partials_row(t, j, t.coef + (unsigned)(t.segC * t.C * 4));
+   double sdot = t.sdotCap;
+   sdot_lim(t, j, sdot);
+   t.sdotCur = sdot;
+   double sddot = 0;
+   int nIter;
+   (void)apply_accel_bisection<8, FEAT, false, false>(t, j, sddot, nIter);
+   if (j == 0)
+   {
+      double *__restrict__ o = mvc + pi.koff * 3;
+      o[i] = t.sdotCur;
+      o[N + i] = t.sddotL;
+      o[2 * (int64_t)N + i] = t.sddotH;
+   }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1252,6 +1340,7 @@ struct SweepArgs
    const PathInfo *pinfo;
    const double *sC;
    const double *coef;
+   const double *yk, *mk; // compact splines (FEAT == -1): knot values and second derivatives, [Cin][N] per path
    double2 *rev;  // [B][cap]
    double2 *fwd;  // [B][cap]
    batotp_path_result *res;
@@ -1296,6 +1385,16 @@ __device__ __forceinline__ int touch_ahead(const Pt<G, FEAT, UNI> &t, int j)
    const int linesAhead = 1 + (j & 7);
    const int rowDoubles = t.C * 4;
    int v = 0;
+   if (FEAT < 0)
+   {
+      // compact splines: every lane streams its own joint's two arrays, 16 knots per line: touch the next line of each
+      const int jj = j < t.nJ ? j : t.nJ - 1;
+      int k = t.segC + t.dir * 16;
+      k = k < 0 ? 0 : (k > t.n - 1 ? t.n - 1 : k);
+      const unsigned at = (unsigned)(jj * t.n + k);
+      v = reinterpret_cast<const int *>(t.yk)[2 * at] ^ reinterpret_cast<const int *>(t.mk)[2 * at];
+   }
+   else
    {
       // spline rows: byte offset of the current row, then +/- (1..8) lines
       const int lastRow = t.n - 1;
@@ -1335,7 +1434,7 @@ __global__ void __launch_bounds__(K4_BLOCK, (FEAT <= 1 && G > 1) ? BK_SWEEP_WPE 
    const int64_t cap = a.cap;
 
    Pt<G, FEAT, UNI> t;
-   pt_init(t, a.P, pi, a.sC, a.coef, lim, j, dir);
+   pt_init(t, a.P, pi, a.sC, a.coef, a.yk, a.mk, lim, j, dir);
    t.side = SPLIT ? ((lane >> 3) & 1) : 0;
    t.cslot = SPEC ? ((lane >> 3) & 3) : 0;
    t.pbase = lane & ~(G - 1);
@@ -1573,6 +1672,17 @@ __global__ void k_coef_gather(const double *__restrict__ coefPath, int C, int dc
    const Coef4 k = *reinterpret_cast<const Coef4 *>(coefPath + (i * C + dc) * 4);
    out[i] = k.c0; out[N + i] = k.c1; out[2 * N + i] = k.c2; out[3 * N + i] = k.c3;
 }
+// compact splines: the coefficient rows of one channel formed from (value, second derivative); the
+// row of the last knot is zero as in the coefficient layout (spline.cpp:203-209 never writes it)
+__global__ void k_coef_from_sol(const double *__restrict__ y, const double *__restrict__ sol, int64_t N, double *__restrict__ out)
+{
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= N) return;
+   Coef4 k;
+   k.c0 = 0; k.c1 = 0; k.c2 = 0; k.c3 = 0;
+   if (i < N - 1) k = coeffs_from_sol(sol[i], sol[i + 1], y[i], y[i + 1]);
+   out[i] = k.c0; out[N + i] = k.c1; out[2 * N + i] = k.c2; out[3 * N + i] = k.c3;
+}
 __global__ void k_coef_scatter(double *__restrict__ coefPath, int C, int dc, int64_t N, const double *__restrict__ in)
 {
    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1602,6 +1712,14 @@ __global__ void k_kat(int64_t n, const double *__restrict__ a, const double *__r
    r[i] = sqrt(a[i]);
    const double prod = a[i] * b[i];
    p[i] = prod + q[i];
+}
+
+// known-answer test of the reciprocal-based division by 6 the compact spline form uses
+__global__ void k_kat_div6(int64_t n, const double *__restrict__ a, double *__restrict__ q)
+{
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   q[i] = div6(a[i]);
 }
 
 } // namespace bk

@@ -89,14 +89,20 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="ur6", choices=sorted(WORKLOADS))
-    ap.add_argument("--paths", type=int, default=4096, help="paths per GPU")
+    ap.add_argument("--paths", type=int, default=0,
+                    help="paths per GPU (0 = what fills the GPU for the workload: 16384 ur6, 8192 gen7, 1024 cspr)")
     ap.add_argument("--knots", type=int, default=100000, help="target knots per path")
     ap.add_argument("--distinct", type=int, default=32, help="distinct seeded paths per GPU (tiled to --paths)")
     ap.add_argument("--group", type=int, default=0, help="lanes per path in the sweep kernel (0 = automatic)")
     ap.add_argument("--ppw", type=int, default=0, help="paths per wavefront in the sweep kernel (0 = automatic)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--coefficient-rows", action="store_true",
+                    help="keep four coefficients per knot and channel instead of the compact (value, second derivative) form")
     args = ap.parse_args()
+    if args.paths <= 0:
+        # ur6 / gen7: 8 paths in each of ~2048 wavefronts (2 per SIMD) is where the sweep kernel peaks, memory permitting
+        args.paths = {"ur6": 16384, "gen7": 8192, "cspr": 1024}[args.workload]
 
     import torch
     import torch.distributed as dist
@@ -126,6 +132,8 @@ def main():
     with cf.ThreadPoolExecutor(max_workers=min(K, os.cpu_count() or 1)) as ex:
         base = list(ex.map(lambda s: make_knots(args.workload, s, args.knots), seeds))
     prob = base[0][2]
+    if (prob.flags & capi.F_NO_SAMPLES) and not args.coefficient_rows:
+        prob.flags |= capi.F_COMPACT_SPLINES  # same results, half the spline bytes per knot: room for more paths per GPU
     B = args.paths
     n_knots = [base[p % K][0].shape[1] for p in range(B)]
     total_knots = int(sum(n_knots))

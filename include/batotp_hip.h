@@ -62,6 +62,11 @@ extern "C" {
 #define BATOTP_F_HOST_TRIG      (1u<<6)  /* RR dynamics use host-supplied cos/sin (bit parity with glibc) */
 #define BATOTP_F_NO_SAMPLES     (1u<<7)  /* do not keep traj.theta/thetaD/thetaD2-style knot samples (saves 24 B/knot/channel;
                                             only valid without torque constraints; download_samples then fails) */
+#define BATOTP_F_COMPACT_SPLINES (1u<<8) /* keep every spline as (knot value, second derivative) instead of the four
+                                            coefficients per segment: 16 instead of 32 bytes per knot and channel, the
+                                            coefficients are formed where they are used (same arithmetic, same results).
+                                            Joint velocity/acceleration-only problems with BATOTP_F_NO_SAMPLES;
+                                            upload_coeffs then fails, download_coeffs still works */
 
 /* per-path status bits written by the sweep kernel (the reference only printf()s these) */
 #define BATOTP_ST_MAX_INTEG_TIME (1u<<0) /* ba.cpp:1117-1122 (MAX_INTEGRATION_TIME)        */
@@ -120,6 +125,9 @@ const char *batotp_hip_last_error(void);
  * computes q[i]=a[i]/b[i], r[i]=sqrt(a[i]), p[i]=a[i]*b[i]+q[i] on the GPU for n host values */
 int  batotp_hip_fp64_kat(batotp_ctx *ctx, int64_t n, const double *a, const double *b,
                          double *q, double *r, double *p);
+/* q[i] = a[i] / 6.0 computed the way the compact spline form (BATOTP_F_COMPACT_SPLINES) divides:
+ * through the reciprocal with one exact residual correction; must equal the IEEE quotient */
+int  batotp_hip_div6_kat(batotp_ctx *ctx, int64_t n, const double *a, double *q);
 
 /* ---- batch lifetime --------------------------------------------------------------------- */
 /* n_knots[b] = number of uniform-s knots of path b (>=4); max_steps = per-path capacity of each

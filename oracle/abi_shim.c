@@ -48,6 +48,13 @@ int batotp_hip_ctx_create(int device, batotp_ctx **out)
 }
 int batotp_hip_ctx_destroy(batotp_ctx *ctx) { free(ctx); return BATOTP_OK; }
 const char *batotp_hip_last_error(void) { return "(oracle shim)"; }
+int batotp_hip_div6_kat(batotp_ctx *ctx, int64_t n, const double *a, double *q)
+{
+    int64_t i;
+    if (!ctx || n <= 0 || !a || !q) return BATOTP_ERR_ARG;
+    for (i = 0; i < n; ++i) q[i] = a[i] / 6.0;
+    return BATOTP_OK;
+}
 int batotp_hip_fp64_kat(batotp_ctx *ctx, int64_t n, const double *a, const double *b, double *q, double *r, double *p)
 {
     (void)ctx; (void)n; (void)a; (void)b; (void)q; (void)r; (void)p;

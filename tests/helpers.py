@@ -102,11 +102,14 @@ def rr_trig(theta_samples0, theta_samples1):
     return np.stack([np.cos(th1), np.cos(th2), np.cos(th1 + th2), np.sin(th2)])
 
 
-def run_pipeline(ctx, cases, max_steps=None, mvc=True, details=True):
+def run_pipeline(ctx, cases, max_steps=None, mvc=True, details=True, extra_flags=0):
     """knots -> precompute -> (pointwise) -> sweeps on the library behind `ctx`, as one batch.
 
     All cases must share one problem description.  Returns a list of dicts, one per case."""
     prob = cases[0].problem
+    if extra_flags:
+        prob = capi.Problem.from_buffer_copy(bytes(prob))
+        prob.flags |= extra_flags
     cap = max_steps or max(c.max_steps() for c in cases)
     b = capi.Batch(ctx, prob, [c.n for c in cases], cap)
     for k, c in enumerate(cases):
@@ -130,7 +133,8 @@ def run_pipeline(ctx, cases, max_steps=None, mvc=True, details=True):
         if details:
             nch = prob.n_channels
             d["coef"] = np.stack([b.coeffs(k, ch) for ch in range(nch)])
-            d["samp"] = np.stack([b.samples(k, ch) for ch in range(prob.n_joints + prob.n_cart)])
+            if not (prob.flags & capi.F_NO_SAMPLES):
+                d["samp"] = np.stack([b.samples(k, ch) for ch in range(prob.n_joints + prob.n_cart)])
             if prob.dyn_dim:
                 d["dyn"] = np.stack([np.stack([b.dyn(k, kk, r) for r in range(prob.dyn_dim)]) for kk in (1, 2, 3, 4)])
         if mvc:

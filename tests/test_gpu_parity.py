@@ -30,6 +30,19 @@ def test_fp64_div_sqrt_are_correctly_rounded_and_not_contracted(hip_ctx):
     assert_bit_equal(p, (a * b) + (a / b), "a*b+q must be a separate multiply and add (no FMA contraction)")
 
 
+def test_division_by_six_through_the_reciprocal_is_the_ieee_quotient(hip_ctx):
+    """the compact spline form divides by 6 with a reciprocal and one exact residual correction"""
+    rng = np.random.default_rng(777)
+    n = 1 << 20
+    a = rng.standard_normal(n) * 10.0 ** rng.integers(-40, 40, n)
+    # numerators next to exact multiples of 6 and to rounding boundaries of the quotient
+    k = rng.integers(1, 1 << 52, 1 << 16).astype(np.float64)
+    near = np.concatenate([6.0 * k, np.nextafter(6.0 * k, np.inf), np.nextafter(6.0 * k, -np.inf), k, k + 0.5, 3.0 * k])
+    edge = np.array([0.0, -0.0, 6.0, -6.0, 1e-300, -1e-300, 1e300, 5e-324, 1.7e308, 1e-290, 1e290])
+    a = np.concatenate([a, near, edge])
+    assert_bit_equal(capi.div6_kat(hip_ctx, a), a / 6.0, "x / 6.0")
+
+
 def _compare(case, ho, oo):
     for key in ("coef", "samp", "dyn", "mvc"):
         if key in oo:
@@ -48,6 +61,28 @@ def test_hip_matches_oracle_and_reference(hip_ctx, oracle_ctx, name):
     oo = run_pipeline(oracle_ctx, [case])[0]
     _compare(case, ho, oo)
     assert_matches_reference(case, ho)
+
+
+def _vel_acc_only(name):
+    f = Case(name).problem.flags if name in helpers.FULL_CASES else 0
+    return name in helpers.FULL_CASES and not (f & (capi.F_TRQ_ON | capi.F_CART_VEL_ON | capi.F_CART_ACC_ON))
+
+
+@pytest.mark.parametrize("lanes", [0, 1, 8, 16, 32])
+def test_compact_splines_give_identical_results(hip_lib, oracle_ctx, lanes):
+    """BATOTP_F_COMPACT_SPLINES (value + second derivative per knot instead of four coefficients): every
+    published quantity is bit-identical to the oracle's, for every lane grouping of the sweep"""
+    names = [n for n in helpers.FULL_CASES if _vel_acc_only(n)]
+    assert len(names) >= 3, names
+    ctx = capi.Context(hip_lib, 0)
+    ctx.set_sweep_group(lanes)
+    for name in names:
+        case = Case(name)
+        ho = run_pipeline(ctx, [case], extra_flags=capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES)[0]
+        oo = run_pipeline(oracle_ctx, [case])[0]
+        oo.pop("samp", None)
+        _compare(case, ho, oo)
+        assert_matches_reference(case, ho)
 
 
 @pytest.mark.parametrize("name", helpers.DIGEST_CASES)
@@ -118,6 +153,28 @@ def test_properties_at_full_size(hip_ctx):
         assert np.all(o["fwd"][1] <= rev_on_fwd * (1 + 1e-12) + 1e-300)
     for o in outs[1:]:
         assert_bit_equal(o["fwd"][1], outs[0]["fwd"][1], "replicated path")
+
+
+def test_pointwise_kernel_slices_batches_beyond_2_to_32_lanes(hip_lib, oracle_ctx):
+    """5600 paths x 1e5 knots x 8 lanes per knot is more than one launch may cover (grid x block is a 32-bit
+    quantity): the lane-group-per-knot kernel is launched in slices; first, middle and last path must all be right"""
+    hip_ctx = capi.Context(hip_lib, 0)
+    hip_ctx.set_sweep_group(8)
+    case = Case("synth_ur_s7_100k")
+    prob = capi.Problem.from_buffer_copy(bytes(case.problem))
+    prob.flags |= capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES
+    B = 5600
+    assert B * case.n * 8 > 2 ** 32
+    b = capi.Batch(hip_ctx, prob, [case.n] * B, 1024)
+    for p0 in range(0, B, 50):
+        k = min(50, B - p0)
+        b.upload_knots(p0, [case.y] * k, [case.sres] * k)
+    b.precompute(1)
+    b.pointwise_mvc()
+    o = run_pipeline(oracle_ctx, [case], details=False)[0]["mvc"]
+    for p in (0, 1, B // 2, 4097, B - 1):
+        assert_bit_equal(np.stack(b.mvc(p)), o, f"pointwise MVC of path {p}")
+    b.close()
 
 
 def test_edge_minimum_knots_and_short_sweep(hip_ctx, oracle_ctx):
