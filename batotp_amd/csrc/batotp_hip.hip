@@ -4,6 +4,7 @@
 // are in kernels.hip.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -79,6 +80,9 @@ struct batotp_batch
    double *dStage = nullptr; // staging for marshalling (4*maxN doubles)
    int *dSink = nullptr;     // consumer of the sweep kernel's prefetch touches
    double *dElim = nullptr;  // Thomas elimination values of k_spline, [max(Cin,4d)][N] per path
+   double *dKM = nullptr;    // compact splines: [N][Cin][2] (knot value, second derivative) per path; replaces dY, dElim and dCoef
+   double *dUp = nullptr;    // compact splines: staging of host knots on their way into dKM
+   int64_t upDoubles = 0;
    int64_t maxN = 0;
    int64_t bytes = 0;
 
@@ -286,7 +290,7 @@ extern "C" int batotp_hip_batch_destroy(batotp_batch *b)
 {
    if (!b) return BATOTP_OK;
    if (b->ctx) hipSetDevice(b->ctx->device);
-   void *ptrs[] = {b->dP, b->dPinfo, b->dY, b->dSC, b->dCoef, b->dSamp, b->dDyn, b->dTrig, b->dMvc, b->dRev, b->dFwd, b->dRes, b->dStage, b->dSink, b->dElim};
+   void *ptrs[] = {b->dP, b->dPinfo, b->dY, b->dSC, b->dCoef, b->dSamp, b->dDyn, b->dTrig, b->dMvc, b->dRev, b->dFwd, b->dRes, b->dStage, b->dSink, b->dElim, b->dKM, b->dUp};
    for (void *p : ptrs)
       if (p) hipFree(p);
    for (int k = 0; k < 5; ++k)
@@ -353,13 +357,6 @@ extern "C" int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *pr
       return BATOTP_ERR_ARG;
    }
 
-#define ALLOC(ptr, count, type)                                                        \
-   rc = devAlloc(b, (void **)&(ptr), sizeof(type) * (size_t)(count));                   \
-   if (rc) { batotp_hip_batch_destroy(b); return rc; }
-   ALLOC(b->dP, 1, DevProblem)
-   ALLOC(b->dPinfo, n_paths, PathInfo)
-   ALLOC(b->dY, off * P.Cin, double)
-   ALLOC(b->dSC, off, double)
    b->compact = (prob->flags & BATOTP_F_COMPACT_SPLINES) != 0;
    if (b->compact && (d != 0 || !(prob->flags & BATOTP_F_NO_SAMPLES) || (prob->flags & (BATOTP_F_CART_VEL_ON | BATOTP_F_CART_ACC_ON))))
    {
@@ -367,6 +364,14 @@ extern "C" int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *pr
       batotp_hip_batch_destroy(b);
       return BATOTP_ERR_ARG;
    }
+
+#define ALLOC(ptr, count, type)                                                        \
+   rc = devAlloc(b, (void **)&(ptr), sizeof(type) * (size_t)(count));                   \
+   if (rc) { batotp_hip_batch_destroy(b); return rc; }
+   ALLOC(b->dP, 1, DevProblem)
+   ALLOC(b->dPinfo, n_paths, PathInfo)
+   ALLOC(b->dY, b->compact ? 0 : off * P.Cin, double)
+   ALLOC(b->dSC, off, double)
    ALLOC(b->dCoef, b->compact ? 0 : off * P.C * 4, double)
    if ((prob->flags & BATOTP_F_NO_SAMPLES) && d != 0) { batotp_hip_batch_destroy(b); return BATOTP_ERR_ARG; }
    ALLOC(b->dSamp, (prob->flags & BATOTP_F_NO_SAMPLES) ? 0 : off * P.Cin * 3, double)
@@ -378,7 +383,8 @@ extern "C" int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *pr
    ALLOC(b->dRes, n_paths, batotp_path_result)
    ALLOC(b->dStage, 4 * b->maxN, double)
    ALLOC(b->dSink, n_paths, int)
-   ALLOC(b->dElim, off * (P.Cin > 4 * d ? P.Cin : 4 * d), double)
+   ALLOC(b->dElim, b->compact ? 0 : off * (P.Cin > 4 * d ? P.Cin : 4 * d), double)
+   ALLOC(b->dKM, b->compact ? off * P.Cin * 2 : 0, double)
 #undef ALLOC
    hipError_t e = hipMemcpyAsync(b->dP, &P, sizeof(P), hipMemcpyHostToDevice, ctx->stream);
    if (e == hipSuccess) e = hipMemcpyAsync(b->dPinfo, b->pinfo.data(), sizeof(PathInfo) * n_paths, hipMemcpyHostToDevice, ctx->stream);
@@ -423,7 +429,43 @@ static int uploadKnotsImpl(batotp_batch *b, int32_t path0, int32_t n, const doub
       if (b->pinfo[path0 + k].n < 4) return BATOTP_ERR_ARG;
       setSres(b, path0 + k, sres[k]);
    }
-   HIP_TRY(hipMemcpyAsync(b->dY + first * b->P.Cin, y, sizeof(double) * (size_t)((last - first) * b->P.Cin), kind, b->ctx->stream));
+   hipStream_t st = b->ctx->stream;
+   const int Cin = b->P.Cin, bs = 256;
+   if (!b->compact)
+      HIP_TRY(hipMemcpyAsync(b->dY + first * Cin, y, sizeof(double) * (size_t)((last - first) * Cin), kind, st));
+   else if (kind == hipMemcpyDeviceToDevice)
+   {
+      // compact splines: the values go straight from the caller's device buffer into the pair array
+      const int64_t total = last - first;
+      hipLaunchKernelGGL(k_pairs_from_rows, dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, st, b->dPinfo, path0, n, Cin, y, b->dKM, total);
+      HIP_TRY(hipGetLastError());
+   }
+   else
+   {
+      // host knots: through a bounded staging buffer, a run of whole paths at a time
+      const int64_t want = std::min<int64_t>((last - first) * Cin, std::max<int64_t>((int64_t)1 << 25, b->maxN * Cin));
+      if (b->upDoubles < want)
+      {
+         if (b->dUp) { hipFree(b->dUp); b->dUp = nullptr; b->upDoubles = 0; }
+         rc = devAlloc(b, (void **)&b->dUp, sizeof(double) * (size_t)want);
+         if (rc) return rc;
+         b->upDoubles = want;
+      }
+      int p = path0;
+      while (p < path0 + n)
+      {
+         int q = p;
+         int64_t knots = 0;
+         while (q < path0 + n && (knots + b->pinfo[q].n) * Cin <= b->upDoubles) { knots += b->pinfo[q].n; ++q; }
+         if (q == p) return BATOTP_ERR_STATE;
+         const int64_t off = b->pinfo[p].koff - first;
+         HIP_TRY(hipMemcpyAsync(b->dUp, y + off * Cin, sizeof(double) * (size_t)(knots * Cin), hipMemcpyHostToDevice, st));
+         hipLaunchKernelGGL(k_pairs_from_rows, dim3((unsigned)((knots + bs - 1) / bs)), dim3(bs), 0, st, b->dPinfo, p, q - p, Cin, b->dUp, b->dKM, knots);
+         HIP_TRY(hipGetLastError());
+         HIP_TRY(hipStreamSynchronize(st)); // the staging buffer is reused by the next run
+         p = q;
+      }
+   }
    rc = pushPinfo(b);
    b->kinDone = false; b->dynDone = false;
    return rc;
@@ -561,7 +603,7 @@ extern "C" int batotp_hip_precompute(batotp_batch *b, int32_t stage)
       if (b->compact)
       {
          const int threads = b->B * b->P.Cin;
-         hipLaunchKernelGGL(k_spline_sol, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, b->dPinfo, b->B, b->P.Cin, b->P.Cin, b->dY, b->dElim);
+         hipLaunchKernelGGL(k_spline_pairs, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, b->dPinfo, b->B, b->P.Cin, b->dKM);
       }
       else
       {
@@ -639,11 +681,11 @@ extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
          {                                                                                                                               \
             const int64_t cnt = (b->totalKnots - first) < sliceKnots ? (b->totalKnots - first) : sliceKnots;                            \
             hipLaunchKernelGGL(k_pointwise_grp<F>, dim3((unsigned)((cnt + knotsPerBlock - 1) / knotsPerBlock)), dim3(bs), 0,           \
-                               b->ctx->stream, b->P, b->dPinfo, b->B, b->dP, b->dSC, b->dCoef, b->dY, b->dElim, b->dMvc, first,         \
+                               b->ctx->stream, b->P, b->dPinfo, b->B, b->dP, b->dSC, b->dCoef, b->dKM, b->dMvc, first,         \
                                first + cnt);                                                                                             \
          }                                                                                                                               \
       else hipLaunchKernelGGL(k_pointwise<F>, dim3(grid), dim3(bs), ldsBytes, b->ctx->stream, b->P, b->dPinfo, b->B, b->dP, b->dSC,      \
-                              b->dCoef, b->dY, b->dElim, b->dMvc, b->totalKnots);                                                       \
+                              b->dCoef, b->dKM, b->dMvc, b->totalKnots);                                                       \
    } while (0)
    switch (featureLevel(b))
    {
@@ -707,7 +749,7 @@ extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
    rc = bind(b->ctx);
    if (rc) return rc;
    SweepArgs a;
-   a.P = b->P; a.dP = b->dP; a.pinfo = b->dPinfo; a.sC = b->dSC; a.coef = b->dCoef; a.yk = b->dY; a.mk = b->dElim;
+   a.P = b->P; a.dP = b->dP; a.pinfo = b->dPinfo; a.sC = b->dSC; a.coef = b->dCoef; a.km = b->dKM;
    a.rev = b->dRev; a.fwd = b->dFwd; a.res = b->dRes; a.sink = b->dSink; a.prof = b->dMvc; a.cap = b->cap; a.B = b->B; a.dir = dir; a.ppw = 1;
    const int which = dir == -1 ? 3 : 4;
    evStart(b, which);
@@ -792,7 +834,7 @@ extern "C" int batotp_hip_download_coeffs(batotp_batch *b, int32_t path, int32_t
    const int bs = 256;
    if (b->compact)
       hipLaunchKernelGGL(k_coef_from_sol, dim3((unsigned)((pi.n + bs - 1) / bs)), dim3(bs), 0, b->ctx->stream,
-                         b->dY + pi.koff * b->P.Cin + (int64_t)dc * pi.n, b->dElim + pi.koff * b->P.Cin + (int64_t)dc * pi.n, pi.n, b->dStage);
+                         b->dKM + pi.koff * b->P.Cin * 2, b->P.Cin, dc, pi.n, b->dStage);
    else
       hipLaunchKernelGGL(k_coef_gather, dim3((unsigned)((pi.n + bs - 1) / bs)), dim3(bs), 0, b->ctx->stream,
                          b->dCoef + pi.koff * b->P.C * 4, b->P.C, dc, pi.n, b->dStage);

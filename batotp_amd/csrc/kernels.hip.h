@@ -129,7 +129,7 @@ __device__ __forceinline__ void emit_segment(double *__restrict__ cf, int64_t i,
 // SOL = true (the resampler's spline builds): instead of the coefficient rows, the second
 // derivatives sol[0..N-1] of the channel are left in `scratch` (same layout as src); consumers
 // form c0..c3 of a segment from sol and y with emit_segment's formulas (coeffs_from_sol).
-template <bool SOL>
+template <bool SOL, bool PAIRS>
 __device__ __forceinline__ void spline_channel(const PathInfo *__restrict__ pinfo, int B, int nch, int mode, int C, int Cin, int d,
                                                const double *__restrict__ src, int64_t src_stride_per_knot,
                                                double *__restrict__ scratch, double *__restrict__ coef)
@@ -139,9 +139,12 @@ __device__ __forceinline__ void spline_channel(const PathInfo *__restrict__ pinf
    const int p = t / nch, c = t - p * nch;
    const PathInfo pi = pinfo[p];
    const int N = (int)pi.n;
-   const int64_t streamOff = pi.koff * src_stride_per_knot + (int64_t)c * N;
+   // PAIRS (compact splines): src = scratch = the knot-major array of (value, second derivative) pairs,
+   // [N][C][2]; the value of knot i of channel c is element (i*C + c)*2, its scratch slot the next one
+   const int ys = PAIRS ? 2 * C : 1, ds = PAIRS ? 2 * C : 1;
+   const int64_t streamOff = PAIRS ? pi.koff * C * 2 + (int64_t)c * 2 : pi.koff * src_stride_per_knot + (int64_t)c * N;
    const double *__restrict__ y = src + streamOff;
-   double *__restrict__ dpark = scratch + streamOff; // eliminated right-hand sides d[i], contiguous per channel
+   double *__restrict__ dpark = scratch + streamOff + (PAIRS ? 1 : 0); // eliminated right-hand sides d[i]
    double *__restrict__ cf = coef + pi.koff * C * 4;
    const int dc = (mode == 0) ? c : (Cin + (c % d) * 4 + (c / d));
    const int n = N - 1;
@@ -155,39 +158,39 @@ __device__ __forceinline__ void spline_channel(const PathInfo *__restrict__ pinf
    // whose loads are issued together (one memory round trip per CH dependent divide steps) and
    // whose pivot is the converged constant; the first rows (table pivots) and the remainder take
    // the simple loop.
-   double dprev = (6 * (y[0] - 2 * y[1] + y[2])) / 4.0;
-   dpark[1] = dprev;
-   double ym = y[1], y0 = y[2];
+   double dprev = (6 * (y[(0) * ys] - 2 * y[(1) * ys] + y[(2) * ys])) / 4.0;
+   dpark[(1) * ds] = dprev;
+   double ym = y[(1) * ys], y0 = y[(2) * ys];
    int i = 2;
    auto step_fwd = [&](int ii, double yp) {
       const double rhs = 6 * (ym - 2 * y0 + yp);
       const double den = (ii - 1) < CONV ? (4.0 - 1.0 * c_ctab[ii - 1]) : denInf;
       const double di = (rhs - 1.0 * dprev) / den;
-      dpark[ii] = di;
+      dpark[(ii) * ds] = di;
       dprev = di;
       ym = y0; y0 = yp;
    };
-   for (; i < n && i <= CONV + 1; ++i) step_fwd(i, y[i + 1]);
+   for (; i < n && i <= CONV + 1; ++i) step_fwd(i, y[(i + 1) * ys]);
    for (; i + CH <= n; i += CH)
    {
       double yy[CH];
 #pragma unroll
-      for (int k = 0; k < CH; ++k) yy[k] = y[i + 1 + k];
+      for (int k = 0; k < CH; ++k) yy[k] = y[(i + 1 + k) * ys];
 #pragma unroll
       for (int k = 0; k < CH; ++k)
       {
          const double rhs = 6 * (ym - 2 * y0 + yy[k]);
          const double di = div_by_const(rhs - 1.0 * dprev, denInf, rcpInf);
-         dpark[i + k] = di;
+         dpark[(i + k) * ds] = di;
          dprev = di;
          ym = y0; y0 = yy[k];
       }
    }
-   for (; i < n; ++i) step_fwd(i, y[i + 1]);
+   for (; i < n; ++i) step_fwd(i, y[(i + 1) * ys]);
    const double cl = (n - 1) < CONV ? c_ctab[n - 1] : cInf;
    double solR = (0.0 - 1.0 * dprev) / (4.0 - 1.0 * cl); // spline.cpp:269 (not forced to zero)
 
-   if (SOL) dpark[n] = solR;
+   if (SOL) dpark[(n) * ds] = solR;
    else
    {
       // row of the last knot stays zero (spline.cpp:203-209 never writes it)
@@ -197,7 +200,7 @@ __device__ __forceinline__ void spline_channel(const PathInfo *__restrict__ pinf
 
    // back substitution fused with the coefficient formulas (spline.cpp:271-274, 203-209):
    // reference loop index ii runs n .. 2 with d[ii-1] -= c[ii-1]*d[ii]
-   double yR = y[n];
+   double yR = y[(n) * ys];
    i = n;
    for (; i - CH >= CONV + 1; i -= CH)
    {
@@ -205,14 +208,14 @@ __device__ __forceinline__ void spline_channel(const PathInfo *__restrict__ pinf
 #pragma unroll
       for (int k = 0; k < CH; ++k)
       {
-         dd[k] = dpark[i - 1 - k];
-         yy[k] = y[i - 1 - k];
+         dd[k] = dpark[(i - 1 - k) * ds];
+         yy[k] = y[(i - 1 - k) * ys];
       }
 #pragma unroll
       for (int k = 0; k < CH; ++k)
       {
          const double solL = dd[k] - cInf * solR; // ii - 1 = i - k - 1 >= CONV
-         if (SOL) dpark[i - k - 1] = solL;
+         if (SOL) dpark[(i - k - 1) * ds] = solL;
          else emit_segment(cf, i - k - 1, C, dc, solL, solR, yy[k], yR);
          solR = solL;
          yR = yy[k];
@@ -221,28 +224,34 @@ __device__ __forceinline__ void spline_channel(const PathInfo *__restrict__ pinf
    for (; i > 1; --i)
    {
       const double ci = (i - 1) < CONV ? c_ctab[i - 1] : cInf;
-      const double yL = y[i - 1];
-      const double solL = dpark[i - 1] - ci * solR;
-      if (SOL) dpark[i - 1] = solL;
+      const double yL = y[(i - 1) * ys];
+      const double solL = dpark[(i - 1) * ds] - ci * solR;
+      if (SOL) dpark[(i - 1) * ds] = solL;
       else emit_segment(cf, i - 1, C, dc, solL, solR, yL, yR);
       solR = solL;
       yR = yL;
    }
-   if (SOL) dpark[0] = 0.0;
-   else emit_segment(cf, 0, C, dc, 0.0, solR, y[0], yR);
+   if (SOL) dpark[(0) * ds] = 0.0;
+   else emit_segment(cf, 0, C, dc, 0.0, solR, y[(0) * ys], yR);
 }
 
 __global__ void __launch_bounds__(64) k_spline(const PathInfo *__restrict__ pinfo, int B, int nch, int mode, int C, int Cin, int d,
                                                const double *__restrict__ src, int64_t src_stride_per_knot,
                                                double *__restrict__ scratch, double *__restrict__ coef)
 {
-   spline_channel<false>(pinfo, B, nch, mode, C, Cin, d, src, src_stride_per_knot, scratch, coef);
+   spline_channel<false, false>(pinfo, B, nch, mode, C, Cin, d, src, src_stride_per_knot, scratch, coef);
 }
 
 __global__ void __launch_bounds__(64) k_spline_sol(const PathInfo *__restrict__ pinfo, int B, int nch, int C, const double *__restrict__ src,
                                                    double *__restrict__ sol)
 {
-   spline_channel<true>(pinfo, B, nch, 0, C, C, 1, src, (int64_t)C, sol, nullptr);
+   spline_channel<true, false>(pinfo, B, nch, 0, C, C, 1, src, (int64_t)C, sol, nullptr);
+}
+
+// compact splines of the hot path: km = [N][C][2] (value, second derivative) pairs per path, solved in place
+__global__ void __launch_bounds__(64) k_spline_pairs(const PathInfo *__restrict__ pinfo, int B, int C, double *__restrict__ km)
+{
+   spline_channel<true, true>(pinfo, B, C, 0, C, C, 1, km, (int64_t)C, km, nullptr);
 }
 
 // coefficient row of segment i from the second derivatives and the values at its two ends
@@ -486,8 +495,7 @@ struct Pt
    // path constants
    const double *__restrict__ sC;
    const double *__restrict__ coef; // this path's [N][C][4]   (FEAT >= 0)
-   const double *__restrict__ yk;   // FEAT == -1 (compact splines): this path's knot values [nJ][N] ...
-   const double *__restrict__ mk;   // ... and their second derivatives [nJ][N] (k_spline_sol)
+   const double2 *__restrict__ km;  // FEAT == -1 (compact splines): this path's [N][Cin] (value, second derivative) pairs
    int n;
    int C, nJ, nC, nIn;
    unsigned flags;
@@ -652,8 +660,9 @@ __device__ __forceinline__ void eval_partials_cached(Pt<G, FEAT, UNI> &t, int j)
          {
             if (FEAT < 0)
             {
-               const unsigned at = (unsigned)(jj * t.n + t.segC);
-               const double solL = t.mk[at], solR = t.mk[at + 1], yL = t.yk[at], yR = t.yk[at + 1];
+               const unsigned at = (unsigned)(t.segC * t.nIn + jj);
+               const double2 kl = t.km[at], kr = t.km[at + t.nIn]; // knots segC and segC + 1 of this joint
+               const double solL = kl.y, solR = kr.y, yL = kl.x, yR = kr.x;
                Coef4 k;
                k.c3 = div6(solR - solL);
                k.c2 = solL / 2.0;
@@ -1133,13 +1142,12 @@ __device__ __forceinline__ void accel_pt(Pt<G, FEAT, UNI> &t, int j, double &sdd
 // fill the constants of a path group
 template <int G, int FEAT, bool UNI>
 __device__ __forceinline__ void pt_init(Pt<G, FEAT, UNI> &t, const DevProblem &P, const PathInfo &pi, const double *sC,
-                                        const double *coef, const double *yk, const double *mk, const double (*lim)[8], int j, int dir)
+                                        const double *coef, const double *km, const double (*lim)[8], int j, int dir)
 {
    constexpr bool PAR = (FEAT == 3);
    t.sC = sC + pi.koff;
    t.coef = (FEAT < 0) ? nullptr : coef + pi.koff * P.C * 4;
-   t.yk = (FEAT < 0) ? yk + pi.koff * P.Cin : nullptr;
-   t.mk = (FEAT < 0) ? mk + pi.koff * P.Cin : nullptr;
+   t.km = (FEAT < 0) ? reinterpret_cast<const double2 *>(km) + pi.koff * P.Cin : nullptr;
    t.n = (int)pi.n;
    t.C = P.C; t.nJ = P.nJ; t.nC = P.nC; t.nIn = P.Cin;
    t.flags = P.flags;
@@ -1210,7 +1218,7 @@ template <int FEAT>
 __global__ void __launch_bounds__(K3_BLOCK) k_pointwise(DevProblem P, const PathInfo *__restrict__ pinfo, int B,
                                                         const DevProblem *__restrict__ dP,
                                                         const double *__restrict__ sC, const double *__restrict__ coef,
-                                                        const double *__restrict__ yk, const double *__restrict__ mk,
+                                                        const double *__restrict__ km,
                                                         double *__restrict__ mvc, int64_t total)
 {
    __shared__ double lim[6][8];
@@ -1249,7 +1257,7 @@ __global__ void __launch_bounds__(K3_BLOCK) k_pointwise(DevProblem P, const Path
    const int N = (int)pi.n, i = (int)(g - pi.koff);
 
    Pt<1, FEAT, false> t;
-   pt_init(t, P, pi, sC, coef, yk, mk, lim, 0, -1);
+   pt_init(t, P, pi, sC, coef, km, lim, 0, -1);
    t.segC = (i < N - 1) ? i : N - 2;
    t.sCur = t.sC[i];
    // cursor already on its segment: updateCurSeg only computes tau (0 at a knot, 1 at the last knot)
@@ -1285,9 +1293,8 @@ constexpr int K3G_BLOCK = 256;
 template <int FEAT>
 __global__ void __launch_bounds__(K3G_BLOCK) k_pointwise_grp(DevProblem P, const PathInfo *__restrict__ pinfo, int B,
                                                              const DevProblem *__restrict__ dP, const double *__restrict__ sC,
-                                                             const double *__restrict__ coef, const double *__restrict__ yk,
-                                                             const double *__restrict__ mk, double *__restrict__ mvc, int64_t first,
-                                                             int64_t total)
+                                                             const double *__restrict__ coef, const double *__restrict__ km,
+                                                             double *__restrict__ mvc, int64_t first, int64_t total)
 {
    __shared__ double lim[6][8];
    stage_limits(dP, lim);
@@ -1305,7 +1312,7 @@ __global__ void __launch_bounds__(K3G_BLOCK) k_pointwise_grp(DevProblem P, const
    const int N = (int)pi.n, i = (int)(g - pi.koff);
 
    Pt<8, FEAT, false> t;
-   pt_init(t, P, pi, sC, coef, yk, mk, lim, j, -1);
+   pt_init(t, P, pi, sC, coef, km, lim, j, -1);
    t.segC = (i < N - 1) ? i : N - 2;
    t.sCur = t.sC[i];
    {
@@ -1340,7 +1347,7 @@ struct SweepArgs
    const PathInfo *pinfo;
    const double *sC;
    const double *coef;
-   const double *yk, *mk; // compact splines (FEAT == -1): knot values and second derivatives, [Cin][N] per path
+   const double *km; // compact splines (FEAT == -1): [N][Cin][2] (value, second derivative) per path
    double2 *rev;  // [B][cap]
    double2 *fwd;  // [B][cap]
    batotp_path_result *res;
@@ -1387,12 +1394,12 @@ __device__ __forceinline__ int touch_ahead(const Pt<G, FEAT, UNI> &t, int j)
    int v = 0;
    if (FEAT < 0)
    {
-      // compact splines: every lane streams its own joint's two arrays, 16 knots per line: touch the next line of each
-      const int jj = j < t.nJ ? j : t.nJ - 1;
-      int k = t.segC + t.dir * 16;
-      k = k < 0 ? 0 : (k > t.n - 1 ? t.n - 1 : k);
-      const unsigned at = (unsigned)(jj * t.n + k);
-      v = reinterpret_cast<const int *>(t.yk)[2 * at] ^ reinterpret_cast<const int *>(t.mk)[2 * at];
+      // compact splines: rows of Cin pairs; same scheme as below on the pair stream
+      const int rowD = t.nIn * 2;
+      int off = t.segC * rowD + t.dir * linesAhead * 16;
+      const int hi = (t.n - 1) * rowD;
+      off = off < 0 ? 0 : (off > hi ? hi : off);
+      v = reinterpret_cast<const int *>(t.km)[2 * (unsigned)off];
    }
    else
    {
@@ -1434,7 +1441,7 @@ __global__ void __launch_bounds__(K4_BLOCK, (FEAT <= 1 && G > 1) ? BK_SWEEP_WPE 
    const int64_t cap = a.cap;
 
    Pt<G, FEAT, UNI> t;
-   pt_init(t, a.P, pi, a.sC, a.coef, a.yk, a.mk, lim, j, dir);
+   pt_init(t, a.P, pi, a.sC, a.coef, a.km, lim, j, dir);
    t.side = SPLIT ? ((lane >> 3) & 1) : 0;
    t.cslot = SPEC ? ((lane >> 3) & 3) : 0;
    t.pbase = lane & ~(G - 1);
@@ -1674,14 +1681,34 @@ __global__ void k_coef_gather(const double *__restrict__ coefPath, int C, int dc
 }
 // compact splines: the coefficient rows of one channel formed from (value, second derivative); the
 // row of the last knot is zero as in the coefficient layout (spline.cpp:203-209 never writes it)
-__global__ void k_coef_from_sol(const double *__restrict__ y, const double *__restrict__ sol, int64_t N, double *__restrict__ out)
+__global__ void k_coef_from_sol(const double *__restrict__ kmPath, int C, int dc, int64_t N, double *__restrict__ out)
 {
    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
    if (i >= N) return;
    Coef4 k;
    k.c0 = 0; k.c1 = 0; k.c2 = 0; k.c3 = 0;
-   if (i < N - 1) k = coeffs_from_sol(sol[i], sol[i + 1], y[i], y[i + 1]);
+   const double *a = kmPath + (i * C + dc) * 2, *b = a + 2 * C;
+   if (i < N - 1) k = coeffs_from_sol(a[1], b[1], a[0], b[0]);
    out[i] = k.c0; out[N + i] = k.c1; out[2 * N + i] = k.c2; out[3 * N + i] = k.c3;
+}
+// knot values of paths [path0, path0+n) from the C-ABI layout (path after path, [C][N] each) into the value
+// slots of the pair array; one lane per knot
+__global__ void k_pairs_from_rows(const PathInfo *__restrict__ pinfo, int path0, int nPaths, int C, const double *__restrict__ rows,
+                                  double *__restrict__ km, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   const int64_t base = pinfo[path0].koff;
+   int lo = path0, hi = path0 + nPaths - 1;
+   while (lo < hi)
+   {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pinfo[mid].koff - base <= g) lo = mid; else hi = mid - 1;
+   }
+   const int64_t off = pinfo[lo].koff - base, N = pinfo[lo].n, i = g - off;
+   const double *src = rows + off * C + i;
+   double *dst = km + ((pinfo[lo].koff + i) * C) * 2;
+   for (int c = 0; c < C; ++c) dst[2 * c] = src[(int64_t)c * N];
 }
 __global__ void k_coef_scatter(double *__restrict__ coefPath, int C, int dc, int64_t N, const double *__restrict__ in)
 {

@@ -73,7 +73,58 @@ def make_knots(workload: str, seed: int, n_target: int):
         y = y[:nJ]           # vel+acc limits only: no Cartesian channels are carried
         prob.n_cart = 0
         prob.flags |= capi.F_NO_SAMPLES  # knot samples (traj.theta/thetaD/thetaD2) only feed the dynamics model
-    return np.ascontiguousarray(y), sres, prob
+    return np.ascontiguousarray(y), sres, prob, (theta, cart, tres)
+
+
+def resample_params(workload: str, prob) -> "capi.ResampleParams":
+    """struct batotp_resample_params of a workload's configuration (the fields write_config puts into config.dat)"""
+    cfg = WORKLOADS[workload]["cfg"]
+    r = capi.ResampleParams()
+    r.n_joints, r.n_cart = cfg["n_joints"], cfg["n_cart"]
+    r.robot_type = {"GENJNT": capi.ROBOT_GENJNT, "CSPR3DOF": capi.ROBOT_CSPR3DOF}[cfg["robot"]]
+    r.path_type = capi.PATH_JOINT if cfg["path_type"] == "JOINT" else capi.PATH_CART
+    r.scale_type = cfg.get("scale_type", 1)
+    r.flags = (capi.F_CART_VEL_ON if cfg.get("cart_vel_on") else 0) | (capi.F_CART_ACC_ON if cfg.get("cart_acc_on") else 0)
+    for i, w in enumerate(cfg.get("s_weights", (0, 1, 0))):
+        r.s_weights[i] = w
+    r.theta_norm_res, r.theta_norm_res2 = cfg.get("theta_res", 0.1), cfg.get("theta_res2", 0.1)
+    r.cart_norm_res, r.cart_norm_res2 = cfg.get("cart_res", 0.02), cfg.get("cart_res2", 0.02)
+    r.jnt_thresh, r.cart_thresh = cfg.get("jnt_thresh", 1e-6), cfg.get("cart_thresh", 1e-6)
+    for i in range(9):
+        r.pmat[i] = prob.pmat[i]
+    return r
+
+
+def measure_resampler(hip, workload, base, n_paths):
+    """SURVEY.md 8f-1 beside the hot path: the taught points of the bench paths through batotp_hip_resample;
+    its knots must be the ones the host resampler produced for the hot path (bit for bit)"""
+    cfg = WORKLOADS[workload]["cfg"]
+    nJ, nC = cfg["n_joints"], cfg["n_cart"]
+    prm = resample_params(workload, base[0][2])
+    xs = []
+    for _, _, _, (theta, cart, _) in base:
+        n = (theta if theta is not None else cart).shape[1]
+        x = np.zeros((nJ + nC, n))
+        if theta is not None:
+            x[:nJ] = theta.astype(np.float32).astype(np.float64)   # the taught file stores float32
+        if cart is not None:
+            x[nJ:] = cart.astype(np.float32).astype(np.float64)
+        xs.append(x)
+    K = len(base)
+    tiled = [xs[p % K] for p in range(n_paths)]
+    sres_in = [float(np.float32(base[0][3][2]))] * n_paths
+    best = None
+    for _ in range(2):   # the second call finds the context's workspaces allocated
+        r = capi.Resampled(hip, prm, tiled, sres_in)
+        ms = r.ms()
+        same = all(np.array_equal(r.knots(k)[: base[k][0].shape[0]], base[k][0]) and r.sres[k] == base[k][1] for k in range(min(K, 4)))
+        knots = int(r.n_knots.sum())
+        r.close()
+        best = ms if best is None else min(best, ms)
+    hip.trim()
+    return {"paths": n_paths, "knots": knots, "ms": best, "knots_per_s": knots / (best * 1e-3),
+            "identical_to_host_resampler": bool(same),
+            "what": "remClosePts + adjust_s x2 + interpSpecial + uniform re-evaluation on the device (taught points resident)"}
 
 
 def run_step(batch, has_dyn):
@@ -97,6 +148,7 @@ def main():
     ap.add_argument("--ppw", type=int, default=0, help="paths per wavefront in the sweep kernel (0 = automatic)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-resample", action="store_true", help="skip the side measurement of the device path resampler")
     ap.add_argument("--coefficient-rows", action="store_true",
                     help="keep four coefficients per knot and channel instead of the compact (value, second derivative) form")
     args = ap.parse_args()
@@ -132,6 +184,9 @@ def main():
     with cf.ThreadPoolExecutor(max_workers=min(K, os.cpu_count() or 1)) as ex:
         base = list(ex.map(lambda s: make_knots(args.workload, s, args.knots), seeds))
     prob = base[0][2]
+    resample_info = None
+    if rank == 0 and not args.no_resample:
+        resample_info = measure_resampler(hip, args.workload, base, min(args.paths, 1024))
     if (prob.flags & capi.F_NO_SAMPLES) and not args.coefficient_rows:
         prob.flags |= capi.F_COMPACT_SPLINES  # same results, half the spline bytes per knot: room for more paths per GPU
     B = args.paths
@@ -141,7 +196,7 @@ def main():
     cap = int(max(n_knots) * {"ur6": 0.5, "gen7": 2.2, "cspr": 0.6}[args.workload]) + 1024
     batch = capi.Batch(hip, prob, n_knots, cap)
     for p in range(B):
-        y, sres, _ = base[p % K]
+        y, sres = base[p % K][0], base[p % K][1]
         batch.upload_knots(p, [y], [sres])
     hip.synchronize()
 
@@ -231,7 +286,7 @@ def main():
     # ---- the same workload as ONE trajectory (BASELINE configs[1] wording): inherently sequential,
     # reported for transparency next to the batch figure
     if rank == 0:
-        y1, sres1, _ = base[0]
+        y1, sres1 = base[0][0], base[0][1]
         b1 = capi.Batch(hip, prob, [y1.shape[1]], cap)
         b1.upload_knots(0, [y1], [sres1])
         run_step(b1, False)
@@ -280,6 +335,8 @@ def main():
         out["step_count_mismatches"] = int(np.count_nonzero(res["steps_fwd"][:m] != rows["steps_fwd"][:m]))
 
     if rank == 0:
+        if resample_info is not None:
+            out["resample"] = resample_info
         print(json.dumps(out))
     batch.close()
     hip.close()

@@ -11,6 +11,7 @@ ap.add_argument("--workload", default="ur6"); ap.add_argument("--paths", type=in
 ap.add_argument("--knots", type=int, default=100000); ap.add_argument("--distinct", type=int, default=8)
 ap.add_argument("--reps", type=int, default=1); ap.add_argument("--group", type=int, default=0)
 ap.add_argument("--ppw", type=int, default=0)
+ap.add_argument("--coefficient-rows", action="store_true")
 a = ap.parse_args()
 hip = capi.Context(capi.load_hip(), 0)
 hip.set_sweep_group(a.group)
@@ -19,7 +20,10 @@ if a.ppw and hasattr(hip, "set_paths_per_wave"):
 base = [bench.make_knots(a.workload, 1000 + k, a.knots) for k in range(a.distinct)]
 nk = [base[p % a.distinct][0].shape[1] for p in range(a.paths)]
 cap = int(max(nk) * {"ur6": 0.5, "gen7": 2.2, "cspr": 0.6}[a.workload]) + 1024
-b = capi.Batch(hip, base[0][2], nk, cap)
+prob = base[0][2]
+if (prob.flags & capi.F_NO_SAMPLES) and not a.coefficient_rows:
+    prob.flags |= capi.F_COMPACT_SPLINES
+b = capi.Batch(hip, prob, nk, cap)
 for p in range(a.paths):
     b.upload_knots(p, [base[p % a.distinct][0]], [base[p % a.distinct][1]])
 for _ in range(a.reps):
