@@ -135,6 +135,12 @@ class ResampleParams(C.Structure):
     ]
 
 
+class OutputParams(C.Structure):
+    """struct batotp_output_params"""
+    _fields_ = [("n_joints", C.c_int32), ("reserved", C.c_int32), ("integ_res", C.c_double), ("out_res", C.c_double),
+                ("out_smooth_fact", C.c_double)]
+
+
 class BatotpError(RuntimeError):
     pass
 
@@ -193,6 +199,12 @@ class Library:
             "batotp_hip_resampled_knots_device": [P, C.POINTER(P), C.POINTER(C.c_int64)],
             "batotp_hip_resampled_download": [P, I32, D],
             "batotp_hip_resampled_ms": [P, C.POINTER(C.c_float)],
+            "batotp_hip_output": [P, C.POINTER(OutputParams), I32, I32, C.POINTER(P)],
+            "batotp_hip_output_destroy": [P],
+            "batotp_hip_output_info": [P, C.POINTER(C.c_int64), D],
+            "batotp_hip_output_download": [P, I32, D],
+            "batotp_hip_output_device": [P, C.POINTER(P), C.POINTER(C.c_int64)],
+            "batotp_hip_output_ms": [P, C.POINTER(C.c_float)],
         }
         for name, argtypes in sig.items():
             fn = getattr(L, name)  # raises AttributeError if the symbol is not exported
@@ -297,6 +309,41 @@ class Resampled:
     def ms(self) -> float:
         v = C.c_float(0)
         self.L.check(self.lib.batotp_hip_resampled_ms(self.handle, C.byref(v)), "resampled_ms")
+        return float(v.value)
+
+
+class Output:
+    """Constant-time output trajectories of a range of paths of a batch (batotp_hip_output), resident on the device."""
+
+    def __init__(self, batch: "Batch", prm: OutputParams, path0: int, n_paths: int):
+        self.lib, self.L = batch.lib, batch.L
+        self.n_paths, self.n_joints = n_paths, prm.n_joints
+        self.handle = C.c_void_p()
+        self.L.check(self.lib.batotp_hip_output(batch.handle, C.byref(prm), path0, n_paths, C.byref(self.handle)), "batotp_hip_output")
+        self.n_pts = np.zeros(n_paths, dtype=np.int64)
+        self.sres = np.zeros(n_paths, dtype=np.float64)
+        self.L.check(self.lib.batotp_hip_output_info(self.handle, self.n_pts.ctypes.data_as(C.POINTER(C.c_int64)), _dptr(self.sres)), "output_info")
+
+    def close(self):
+        if self.handle:
+            self.lib.batotp_hip_output_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def theta(self, k: int) -> np.ndarray:
+        out = np.empty((self.n_joints, int(self.n_pts[k])), dtype=np.float64)
+        if out.size:
+            self.L.check(self.lib.batotp_hip_output_download(self.handle, k, _dptr(out)), "output_download")
+        return out
+
+    def ms(self) -> float:
+        v = C.c_float(0)
+        self.L.check(self.lib.batotp_hip_output_ms(self.handle, C.byref(v)), "output_ms")
         return float(v.value)
 
 

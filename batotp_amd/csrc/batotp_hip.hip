@@ -15,6 +15,7 @@
 #include "batotp_hip.h"
 #include "kernels.hip.h"
 #include "resample.hip.h"
+#include "output.hip.h"
 
 using namespace bk;
 
@@ -910,3 +911,4 @@ extern "C" int batotp_hip_batch_bytes(batotp_batch *b, int64_t *bytes)
 }
 
 #include "resample_api.inc"
+#include "output_api.inc"

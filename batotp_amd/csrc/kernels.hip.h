@@ -126,27 +126,14 @@ __device__ __forceinline__ void emit_segment(double *__restrict__ cf, int64_t i,
    *reinterpret_cast<Coef4 *>(cf + (i * C + dc) * 4) = o;
 }
 
-// SOL = true (the resampler's spline builds): instead of the coefficient rows, the second
-// derivatives sol[0..N-1] of the channel are left in `scratch` (same layout as src); consumers
-// form c0..c3 of a segment from sol and y with emit_segment's formulas (coeffs_from_sol).
-template <bool SOL, bool PAIRS>
-__device__ __forceinline__ void spline_channel(const PathInfo *__restrict__ pinfo, int B, int nch, int mode, int C, int Cin, int d,
-                                               const double *__restrict__ src, int64_t src_stride_per_knot,
-                                               double *__restrict__ scratch, double *__restrict__ coef)
+// The Thomas solve of one series of N values (spline.cpp:252-276) and what follows it: SOL = false emits the
+// coefficient rows (emit_segment), SOL = true leaves the second derivatives sol[0..N-1] in dpark.
+// STRIDED = false: y and dpark are contiguous; true: element i of y is y[i*ys], of dpark dpark[i*ds].
+template <bool SOL, bool STRIDED>
+__device__ __forceinline__ void thomas_series(int N, const double *__restrict__ y, int ysIn, double *__restrict__ dpark, int dsIn,
+                                              double *__restrict__ cf, int C, int dc)
 {
-   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-   if (t >= B * nch) return;
-   const int p = t / nch, c = t - p * nch;
-   const PathInfo pi = pinfo[p];
-   const int N = (int)pi.n;
-   // PAIRS (compact splines): src = scratch = the knot-major array of (value, second derivative) pairs,
-   // [N][C][2]; the value of knot i of channel c is element (i*C + c)*2, its scratch slot the next one
-   const int ys = PAIRS ? 2 * C : 1, ds = PAIRS ? 2 * C : 1;
-   const int64_t streamOff = PAIRS ? pi.koff * C * 2 + (int64_t)c * 2 : pi.koff * src_stride_per_knot + (int64_t)c * N;
-   const double *__restrict__ y = src + streamOff;
-   double *__restrict__ dpark = scratch + streamOff + (PAIRS ? 1 : 0); // eliminated right-hand sides d[i]
-   double *__restrict__ cf = coef + pi.koff * C * 4;
-   const int dc = (mode == 0) ? c : (Cin + (c % d) * 4 + (c / d));
+   const int ys = STRIDED ? ysIn : 1, ds = STRIDED ? dsIn : 1;
    const int n = N - 1;
    constexpr int CONV = 63;                    // c_ctab is constant from here on (checked by the host)
    const double cInf = c_ctab[CONV];
@@ -235,6 +222,29 @@ __device__ __forceinline__ void spline_channel(const PathInfo *__restrict__ pinf
    else emit_segment(cf, 0, C, dc, 0.0, solR, y[(0) * ys], yR);
 }
 
+// SOL = true (the resampler's spline builds): instead of the coefficient rows, the second
+// derivatives sol[0..N-1] of the channel are left in `scratch` (same layout as src); consumers
+// form c0..c3 of a segment from sol and y with emit_segment's formulas (coeffs_from_sol).
+template <bool SOL, bool PAIRS>
+__device__ __forceinline__ void spline_channel(const PathInfo *__restrict__ pinfo, int B, int nch, int mode, int C, int Cin, int d,
+                                               const double *__restrict__ src, int64_t src_stride_per_knot,
+                                               double *__restrict__ scratch, double *__restrict__ coef)
+{
+   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+   if (t >= B * nch) return;
+   const int p = t / nch, c = t - p * nch;
+   const PathInfo pi = pinfo[p];
+   const int N = (int)pi.n;
+   // PAIRS (compact splines): src = scratch = the knot-major array of (value, second derivative) pairs,
+   // [N][C][2]; the value of knot i of channel c is element (i*C + c)*2, its scratch slot the next one
+   const int64_t streamOff = PAIRS ? pi.koff * C * 2 + (int64_t)c * 2 : pi.koff * src_stride_per_knot + (int64_t)c * N;
+   const double *__restrict__ y = src + streamOff;
+   double *__restrict__ dpark = scratch + streamOff + (PAIRS ? 1 : 0); // eliminated right-hand sides d[i]
+   double *__restrict__ cf = coef + pi.koff * C * 4;
+   const int dc = (mode == 0) ? c : (Cin + (c % d) * 4 + (c / d));
+   thomas_series<SOL, PAIRS>(N, y, 2 * C, dpark, 2 * C, cf, C, dc);
+}
+
 __global__ void __launch_bounds__(64) k_spline(const PathInfo *__restrict__ pinfo, int B, int nch, int mode, int C, int Cin, int d,
                                                const double *__restrict__ src, int64_t src_stride_per_knot,
                                                double *__restrict__ scratch, double *__restrict__ coef)
@@ -252,6 +262,17 @@ __global__ void __launch_bounds__(64) k_spline_sol(const PathInfo *__restrict__ 
 __global__ void __launch_bounds__(64) k_spline_pairs(const PathInfo *__restrict__ pinfo, int B, int C, double *__restrict__ km)
 {
    spline_channel<true, true>(pinfo, B, C, 0, C, C, 1, km, (int64_t)C, km, nullptr);
+}
+
+// natural-spline second derivatives of arbitrary series: series k has n[k] values y[yOff[k] + i*ys] and leaves its
+// second derivatives at sol[solOff[k] + i]; one lane per series (output stage: s(t) of a path, channels to re-sample)
+__global__ void __launch_bounds__(64) k_spline_series(int count, const int64_t *__restrict__ yOff, const int64_t *__restrict__ solOff,
+                                                      const int *__restrict__ n, const double *__restrict__ y, int ys,
+                                                      double *__restrict__ sol)
+{
+   const int k = blockIdx.x * blockDim.x + threadIdx.x;
+   if (k >= count || n[k] < 4) return;
+   thomas_series<true, true>(n[k], y + yOff[k], ys, sol + solOff[k], 1, nullptr, 1, 0);
 }
 
 // coefficient row of segment i from the second derivatives and the values at its two ends

@@ -178,6 +178,10 @@ public:
    // configuration.  Returns 0 when the device resampler covers this configuration and `traj`
    // (batotp_hip_resample, include/batotp_hip.h), -1 when the host resampler has to be used.
    int exportResampleParams(const Traj &traj, void *batotp_resample_params_out) const;
+   // Extension: the output-stage parameters (struct batotp_output_params).  Returns 0 when the device output
+   // stage covers this configuration (batotp_hip_output, include/batotp_hip.h), -1 when interpOutputData has
+   // to run on the host.
+   int exportOutputParams(void *batotp_output_params_out) const;
    unsigned int getNumJoints() const { return _nJoints; }
    unsigned int getNumCart() const { return _nCart; }
 

@@ -166,6 +166,22 @@ int BA::exportResampleParams(const Traj &traj, void *out) const
    return (joint || cable) ? 0 : -1;
 }
 
+// Which configurations the device output stage takes over: JOINT paths of a robot without kinematic model,
+// no torque recomputation (ba.cpp:1744-1827 stays on the host).
+int BA::exportOutputParams(void *out) const
+{
+   batotp_output_params &O = *static_cast<batotp_output_params *>(out);
+   std::memset(&O, 0, sizeof(O));
+   O.n_joints = (int32_t)_nJoints;
+   O.integ_res = _integRes;
+   O.out_res = _outRes;
+   O.out_smooth_fact = _outSmoothFact;
+   if (_isInterpOnly || _isTrqConOn) return -1;
+   if (!(_pathType == JOINT && _robotType == GENJNT)) return -1;
+   if (!(_outRes > 0) || !(_integRes > 0) || !(_outSmoothFact >= 1)) return -1;
+   return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // reference ba.cpp:299-305 on the GPU: evalSplineFullTraj(traj, sres, sres), sdot = DBL_MAX,
 // findDynModel

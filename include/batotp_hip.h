@@ -21,6 +21,7 @@
  *   batotp_hip_pointwise_mvc   BA::sdotLim + BA::applyAccelConstraintsBisectionPt evaluated at
  *                              every knot               batotp/ba.cpp:1204-1236,1248-1332
  *   batotp_hip_resample        BA::adjust_s / interpSpecial / remClosePts  batotp/ba.cpp:412-781, util.cpp:452-524
+ *   batotp_hip_output          BA::interpOutputData     batotp/ba.cpp:1661-1931
  *   batotp_hip_sweep           BA::sweep and everything it calls  batotp/ba.cpp:979-1195,
  *                              1204-1236,1248-1332,1341-1413,1423-1439,1449-1581,1590-1652
  *                              solveQuadratic           batotp/util.cpp:361-383
@@ -260,6 +261,36 @@ int  batotp_hip_resampled_knots_device(batotp_resampled *r, const double **y_dev
 int  batotp_hip_resampled_download(batotp_resampled *r, int32_t path, double *y);
 /* milliseconds the resampling kernels of this object took (HIP events on the context's stream) */
 int  batotp_hip_resampled_ms(batotp_resampled *r, float *ms);
+
+/* ---- output stage behind the hot path ------------------------------------ */
+/* Replaces BA::interpOutputData (batotp/ba.cpp:1661-1931) for JOINT paths of a robot without kinematic
+ * model and without torque constraints: the forward curve s(t) of every path is re-sampled at constant
+ * time steps, the joint splines are evaluated there, the result is smoothed and down-sampled by
+ * _outSmoothFact (smooth, batotp/util.cpp:263-290; Spline::interp1linear, spline.cpp:108-120) and, when
+ * out_res is finer than the integration step, re-interpolated (ba.cpp:1873-1919).  The batch must have
+ * completed the forward sweep.  Anything else returns BATOTP_ERR_ARG (the caller keeps its host code). */
+typedef struct batotp_output_params {
+    int32_t  n_joints;               /* joint channels to produce (the batch's n_joints)       */
+    int32_t  reserved;
+    double   integ_res;              /* _integRes                                              */
+    double   out_res;                /* _outRes                                                */
+    double   out_smooth_fact;        /* _outSmoothFact                                         */
+} batotp_output_params;
+
+typedef struct batotp_output batotp_output;
+
+/* constant-time trajectories of the paths [path0, path0 + n_paths) of the batch; they stay in HBM */
+int  batotp_hip_output(batotp_batch *batch, const batotp_output_params *prm, int32_t path0, int32_t n_paths,
+                       batotp_output **out);
+int  batotp_hip_output_destroy(batotp_output *o);
+/* points per path (0 for a path whose sweep ended with an error status) and traj.sres of the output */
+int  batotp_hip_output_info(batotp_output *o, int64_t *n_pts /* [n_paths] */, double *sres /* [n_paths] */);
+/* joint positions of path path0 + k: theta[n_joints][n_pts[k]] */
+int  batotp_hip_output_download(batotp_output *o, int32_t k, double *theta);
+/* device pointer of all trajectories, path after path, each [n_joints][n_pts] */
+int  batotp_hip_output_device(batotp_output *o, const double **theta_dev, int64_t *n_doubles);
+/* milliseconds of the stage's kernels (HIP events on the context's stream) */
+int  batotp_hip_output_ms(batotp_output *o, float *ms);
 
 #ifdef __cplusplus
 }

@@ -435,3 +435,101 @@ int batotp_hip_resampled_ms(batotp_resampled *r, float *ms)
     *ms = r->ms;
     return BATOTP_OK;
 }
+
+/* ---- output stage over bo_output ----------------------------------------------- */
+struct batotp_output {
+    int32_t n_paths;
+    int nJ;
+    int64_t *n, *off;
+    double *sres;
+    double *theta; /* path after path, [nJ][n] each */
+    float ms;
+};
+
+int batotp_hip_output_destroy(batotp_output *o)
+{
+    if (!o) return BATOTP_OK;
+    free(o->n); free(o->off); free(o->sres); free(o->theta);
+    free(o);
+    return BATOTP_OK;
+}
+
+int batotp_hip_output(batotp_batch *b, const batotp_output_params *prm, int32_t path0, int32_t n_paths, batotp_output **out)
+{
+    batotp_output *o;
+    double **th;
+    int64_t total = 0;
+    int k, bad = 0;
+    struct timespec t0, t1;
+    if (!b || !prm || !out || path0 < 0 || n_paths < 1 || path0 + n_paths > b->n_paths) return BATOTP_ERR_ARG;
+    *out = NULL;
+    if ((b->prob.flags & BATOTP_F_TRQ_ON) || prm->n_joints != b->prob.n_joints || !(prm->out_res > 0) || !(prm->integ_res > 0) ||
+        !(prm->out_smooth_fact >= 1))
+        return BATOTP_ERR_ARG;
+    o = (batotp_output *)calloc(1, sizeof(*o));
+    o->n_paths = n_paths; o->nJ = prm->n_joints;
+    o->n = (int64_t *)calloc((size_t)n_paths, sizeof(int64_t));
+    o->off = (int64_t *)calloc((size_t)n_paths, sizeof(int64_t));
+    o->sres = (double *)calloc((size_t)n_paths, sizeof(double));
+    th = (double **)calloc((size_t)n_paths, sizeof(double *));
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (k = 0; k < n_paths; ++k) {
+        const int p = path0 + k;
+        const batotp_path_result *r = &b->res[p];
+        const uint32_t st = r->status_rev | r->status_fwd;
+        if (r->n_fwd < 4 || (st & (BATOTP_ST_MAX_INTEG_TIME | BATOTP_ST_CAPACITY | BATOTP_ST_NONFINITE))) continue;
+        {
+            const double t_step = (r->status_fwd & BATOTP_ST_SHORT) ? r->t_total / 3. : prm->integ_res;
+            if (bo_output(prm, b->path[p], b->fwd_s[p], r->n_fwd, t_step, &th[k], &o->n[k], &o->sres[k]) != 0) {
+#pragma omp atomic write
+                bad = 1;
+            }
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    o->ms = (float)((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6);
+    for (k = 0; k < n_paths; ++k) { o->off[k] = total; total += o->n[k] * o->nJ; }
+    o->theta = (double *)malloc(sizeof(double) * (size_t)(total ? total : 1));
+    for (k = 0; k < n_paths; ++k) {
+        if (th[k]) memcpy(o->theta + o->off[k], th[k], sizeof(double) * (size_t)(o->n[k] * o->nJ));
+        free(th[k]);
+    }
+    free(th);
+    if (bad) { batotp_hip_output_destroy(o); return BATOTP_ERR_ARG; }
+    *out = o;
+    return BATOTP_OK;
+}
+
+int batotp_hip_output_info(batotp_output *o, int64_t *n_pts, double *sres)
+{
+    int k;
+    if (!o) return BATOTP_ERR_ARG;
+    for (k = 0; k < o->n_paths; ++k) {
+        if (n_pts) n_pts[k] = o->n[k];
+        if (sres) sres[k] = o->sres[k];
+    }
+    return BATOTP_OK;
+}
+
+int batotp_hip_output_download(batotp_output *o, int32_t k, double *theta)
+{
+    if (!o || !theta || k < 0 || k >= o->n_paths) return BATOTP_ERR_ARG;
+    memcpy(theta, o->theta + o->off[k], sizeof(double) * (size_t)(o->n[k] * o->nJ));
+    return BATOTP_OK;
+}
+
+int batotp_hip_output_device(batotp_output *o, const double **theta_dev, int64_t *n_doubles)
+{
+    if (!o || !theta_dev) return BATOTP_ERR_ARG;
+    *theta_dev = o->theta;
+    if (n_doubles) *n_doubles = o->off[o->n_paths - 1] + o->n[o->n_paths - 1] * o->nJ;
+    return BATOTP_OK;
+}
+
+int batotp_hip_output_ms(batotp_output *o, float *ms)
+{
+    if (!o || !ms) return BATOTP_ERR_ARG;
+    *ms = o->ms;
+    return BATOTP_OK;
+}

@@ -96,6 +96,12 @@ typedef batotp_resample_params bo_resample_params;
 int  bo_resample(const bo_resample_params *prm, int64_t n_in, const double *x, double sres_in,
                  double **y_out, int64_t *n_out, double *sres_out, uint32_t *status);
 
+/* Output stage behind the hot path: BA::interpOutputData (ba.cpp:1661-1931) for JOINT paths
+ * without kinematic model and without torque constraints.  p: the path as precomputed for the sweep;
+ * fwd_s[n_fwd]: s of the forward curve; t_step: its time step.  *theta_out is malloc'd [n_joints][*n_out]. */
+int  bo_output(const batotp_output_params *prm, const bo_path *p, const double *fwd_s, int64_t n_fwd, double t_step,
+               double **theta_out, int64_t *n_out, double *sres_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,151 @@
+/*
+ * batotp_oracle_output.c -- TEST INFRASTRUCTURE ONLY (see batotp_oracle.h).
+ *
+ * Plain-C restatement of the output stage behind the hot path:
+ * BA::interpOutputData (ba.cpp:1661-1931) for the configurations the device output stage covers --
+ * JOINT paths of a robot without kinematic model, no torque constraints: the optimised s(t) is
+ * re-sampled at constant time steps, the joint splines are evaluated there, the result is smoothed
+ * and down-sampled (_outSmoothFact) and, when the output resolution is finer than the integration
+ * step, re-interpolated.  It is the checker of batotp_hip_output.
+ *
+ * Pinning: tests/test_oracle_output.py -- the trajectories it produces, rounded to float32 the way
+ * BA::trajWriteBIN writes them, are byte-identical to the reference binary's traj_out.dat of the
+ * covered golden cases.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "batotp_oracle.h"
+
+/* util.cpp:263-290 smooth(): centred moving average, shrinking windows at both ends */
+static void out_smooth(double *x, int64_t n, int w)
+{
+    if (w > n) w = (int)n;
+    const int half = w / 2 + w % 2 - 1;
+    w = 2 * half + 1;
+    double *y = (double *)malloc(sizeof(double) * (size_t)n);
+    y[0] = x[0];
+    y[n - 1] = x[n - 1];
+    for (int i = 1; i < half; ++i) {
+        const int span = 2 * i + 1;
+        double head = 0, tail = 0;
+        for (int j = 0; j < span; ++j) { head += x[j]; tail += x[n - j - 1]; }
+        y[i] = head / span;
+        y[n - i - 1] = tail / span;
+    }
+    for (int64_t i = half; i < n - half; ++i) {
+        double acc = 0;
+        for (int64_t j = i - half; j < i + half + 1; ++j) acc += x[j];
+        y[i] = acc / w;
+    }
+    memcpy(x, y, sizeof(double) * (size_t)n);
+    free(y);
+}
+
+int bo_output(const batotp_output_params *prm, const bo_path *p, const double *fwd_s, int64_t n_fwd, double t_step,
+              double **theta_out, int64_t *n_out, double *sres_out)
+{
+    const int nJ = prm->n_joints;
+    if (nJ < 1 || nJ > p->n_theta || n_fwd < 4) return -1;
+    double outRes = prm->out_res, smoothFact = prm->out_smooth_fact;
+    const double outResUser = outRes;
+    int reinterp = 0;
+    if (outRes < prm->integ_res) { /* ba.cpp:1668-1675 */
+        reinterp = 1;
+        outRes = prm->integ_res;
+        const double r = outResUser / outRes;
+        smoothFact *= (r > 1. ? r : 1.);
+    }
+
+    /* tMVC[i] = t_step*i */
+    double *tMVC = (double *)malloc(sizeof(double) * (size_t)n_fwd);
+    for (int64_t i = 0; i < n_fwd; ++i) tMVC[i] = t_step * (double)i;
+    double tLast = tMVC[n_fwd - 1];
+    int64_t nOut = (int64_t)(int)(smoothFact * ceil(tMVC[n_fwd - 1] / outRes + 1.));
+    if (nOut < 4) nOut = 4;
+
+    /* output times (ba.cpp:1691-1699) */
+    double *tOut = (double *)malloc(sizeof(double) * (size_t)nOut);
+    for (int64_t i = 0; i < nOut; ++i) tOut[i] = (double)(i - 1);
+    tOut[0] = 0;
+    tOut[1] = 1.0 / 3.0;
+    tOut[nOut - 1] = tOut[nOut - 2];
+    tOut[nOut - 2] = tOut[nOut - 2] - 1.0 / 3.0;
+    {
+        const double c = tMVC[n_fwd - 1] / tOut[nOut - 1];
+        for (int64_t i = 0; i < nOut; ++i) tOut[i] = c * tOut[i];
+    }
+
+    /* s at the output times: natural spline of sMVC over the step index */
+    int32_t *seg = (int32_t *)malloc(sizeof(int32_t) * (size_t)nOut);
+    double *tau = (double *)malloc(sizeof(double) * (size_t)nOut);
+    double *sOut = (double *)malloc(sizeof(double) * (size_t)nOut);
+    double *d1 = (double *)malloc(sizeof(double) * (size_t)nOut), *d2 = (double *)malloc(sizeof(double) * (size_t)nOut);
+    double *cS = (double *)calloc((size_t)4 * (size_t)n_fwd, sizeof(double));
+    bo_find_interp_segs(tMVC, n_fwd, tOut, nOut, seg, tau);
+    bo_spline_coeffs(fwd_s, n_fwd, cS, 0);
+    bo_interp1_spline(cS, n_fwd, seg, tau, nOut, p->sres / smoothFact, sOut, d1, d2);
+    free(cS);
+
+    /* joint values at those s */
+    bo_find_interp_segs(p->sC, p->n, sOut, nOut, seg, tau);
+    int64_t n = nOut;
+    double *th = (double *)malloc(sizeof(double) * (size_t)nJ * (size_t)n);
+    for (int j = 0; j < nJ; ++j)
+        bo_interp1_spline(p->coef + (size_t)j * 4 * (size_t)p->n, p->n, seg, tau, nOut, outRes, th + (size_t)j * n, d1, d2);
+    free(seg); free(tau); free(sOut); free(d1); free(d2); free(tOut); free(tMVC);
+
+    if (smoothFact > 1.5) { /* ba.cpp:1838-1871 */
+        const int64_t nIn = n;
+        int64_t nDown = (int64_t)(int)((double)(nIn - 1) / smoothFact) + 1;
+        if (nDown < 4) nDown = 4;
+        const double sc = (double)(nIn - 1) / (double)(nDown - 1);
+        const int window = (int)smoothFact;
+        double *dn = (double *)malloc(sizeof(double) * (size_t)nJ * (size_t)nDown);
+        for (int j = 0; j < nJ; ++j) {
+            double *b = th + (size_t)j * nIn;
+            out_smooth(b, nIn, window);
+            int64_t cursor = 0;
+            for (int64_t i = 0; i < nDown; ++i) { /* findInterpSegs(0..nIn-1, sc*i) + interp1linear */
+                const double site = sc * (double)i;
+                while (!(site < (double)(cursor + 1) || cursor == nIn - 2)) ++cursor;
+                const double width = (double)(cursor + 1) - (double)cursor;
+                const double t = (site - (double)cursor) / width;
+                dn[(size_t)j * nDown + i] = b[cursor] + (b[cursor + 1] - b[cursor]) * t;
+            }
+        }
+        free(th);
+        th = dn;
+        n = nDown;
+    }
+
+    if (reinterp) { /* ba.cpp:1873-1919 */
+        int64_t nUser = (int64_t)(int)ceil(tLast / outResUser);
+        if (nUser < 4) nUser = 4;
+        const double c1 = 1. / (double)(n - 1), c2 = 1. / (double)(nUser - 1);
+        double *g1 = (double *)malloc(sizeof(double) * (size_t)n), *g2 = (double *)malloc(sizeof(double) * (size_t)nUser);
+        for (int64_t i = 0; i < n; ++i) g1[i] = c1 * (double)i;
+        for (int64_t i = 0; i < nUser; ++i) g2[i] = c2 * (double)i;
+        int32_t *sg = (int32_t *)malloc(sizeof(int32_t) * (size_t)nUser);
+        double *tu = (double *)malloc(sizeof(double) * (size_t)nUser);
+        double *e1 = (double *)malloc(sizeof(double) * (size_t)nUser), *e2 = (double *)malloc(sizeof(double) * (size_t)nUser);
+        bo_find_interp_segs(g1, n, g2, nUser, sg, tu);
+        double *up = (double *)malloc(sizeof(double) * (size_t)nJ * (size_t)nUser);
+        double *c = (double *)calloc((size_t)4 * (size_t)n, sizeof(double));
+        for (int j = 0; j < nJ; ++j) {
+            memset(c, 0, sizeof(double) * 4 * (size_t)n);
+            bo_spline_coeffs(th + (size_t)j * n, n, c, 0);
+            bo_interp1_spline(c, n, sg, tu, nUser, outResUser, up + (size_t)j * nUser, e1, e2);
+        }
+        free(c); free(g1); free(g2); free(sg); free(tu); free(e1); free(e2);
+        free(th);
+        th = up;
+        n = nUser;
+        outRes = outResUser;
+    }
+    *theta_out = th;
+    *n_out = n;
+    *sres_out = outRes;
+    return 0;
+}

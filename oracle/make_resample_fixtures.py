@@ -8,6 +8,8 @@ the configuration is in the device resampler's scope and dumps struct batotp_res
 script checks that the knots it gets are byte-identical to the committed knots.npz, then writes
    resample.npz : params (raw struct bytes), traj_file (name of the taught-path file in the case
                   directory), n_in, sres_in
+and, for the configurations the device output stage covers,
+   output.npz   : params (raw struct batotp_output_params); expected output = the case's ref_traj_out.dat
 The expected output of the resampler is knots.npz itself (y, sres) -- the knots behind the s-sdot /
 trajectory outputs that are byte-identical to the reference binary's.
 
@@ -45,6 +47,10 @@ def main():
             y = np.frombuffer(kb, "<f8", (nJ + nC) * N, 32).reshape(nJ + nC, N)
             z = np.load(os.path.join(d, "knots.npz"))
             assert y.tobytes() == np.ascontiguousarray(z["y"]).tobytes() and sres == float(z["sres"]), case
+            oraw = open(os.path.join(work, "output.bin"), "rb").read()
+            if int(np.frombuffer(oraw, "<i4", 1, 0)[0]):
+                np.savez(os.path.join(d, "output.npz"), params=np.frombuffer(oraw[4:], np.uint8))
+                print(f"{case:28s} output stage fixture written")
             if not supported:
                 print(f"{case:28s} host resampler only")
                 continue

@@ -30,6 +30,12 @@ int main(int argc, char **argv)
       FILE *g = fopen("resample.bin", "wb");
       fwrite(&supported, 4, 1, g); fwrite(&R, sizeof(R), 1, g);
       fclose(g);
+      //   output.bin   : int32 supported (1/0), raw struct batotp_output_params
+      batotp_output_params O;
+      const int outSupported = ba.exportOutputParams(&O) == 0 ? 1 : 0;
+      g = fopen("output.bin", "wb");
+      fwrite(&outSupported, 4, 1, g); fwrite(&O, sizeof(O), 1, g);
+      fclose(g);
       const long long n = tr.nPts, nJ = ba.getNumJoints(), nC = ba.getNumCart();
       g = fopen("taught.bin", "wb");
       fwrite(&n, 8, 1, g); fwrite(&nJ, 8, 1, g); fwrite(&nC, 8, 1, g); fwrite(&tr.sres, 8, 1, g);

@@ -19,6 +19,8 @@ DIGEST_CASES = sorted(d for d in os.listdir(GOLD) if os.path.exists(os.path.join
 
 RESAMPLE_CASES = sorted(d for d in os.listdir(GOLD) if os.path.exists(os.path.join(GOLD, d, "resample.npz")))
 
+OUTPUT_CASES = sorted(d for d in os.listdir(GOLD) if os.path.exists(os.path.join(GOLD, d, "output.npz")))
+
 # how the digest-only inputs are regenerated (must match oracle/make_golden.py)
 DIGEST_INPUTS = {
     "synth_gen7dof_s4_50k": lambda: (pathgen.gen7dof_fine(4, 871), None, 0.01),
@@ -93,6 +95,42 @@ class ResampleCase:
         k = np.load(os.path.join(d, "knots.npz"))
         self.y = np.ascontiguousarray(k["y"])
         self.sres = float(k["sres"])
+
+
+def read_traj_out(path, n_joints):
+    """traj_out.dat as BA::trajWriteBIN writes it: float32 sres; int32 nPts; int32 1; float32 theta[nJ][nPts]; ..."""
+    raw = open(path, "rb").read()
+    sres = np.frombuffer(raw, "<f4", 1, 0)[0]
+    n = int(np.frombuffer(raw, "<i4", 1, 4)[0])
+    assert int(np.frombuffer(raw, "<i4", 1, 8)[0]) == 1
+    theta = np.frombuffer(raw, "<f4", n_joints * n, 12).reshape(n_joints, n)
+    return sres, n, theta
+
+
+def output_params(name):
+    z = np.load(os.path.join(GOLD, name, "output.npz"))
+    return capi.OutputParams.from_buffer_copy(z["params"].tobytes())
+
+
+def run_to_output(ctx, cases, extra_flags=0):
+    """knots -> hot path -> output stage on the library behind ctx; returns (Output, Batch)"""
+    prob = cases[0].problem
+    if extra_flags:
+        prob = capi.Problem.from_buffer_copy(bytes(prob))
+        prob.flags |= extra_flags
+    b = capi.Batch(ctx, prob, [c.n for c in cases], max(c.max_steps() for c in cases))
+    for k, c in enumerate(cases):
+        b.upload_knots(k, [c.y], [c.sres])
+    b.optimize()
+    return capi.Output(b, output_params(cases[0].name), 0, len(cases)), b
+
+
+def assert_output_equals_reference_file(case, out, k=0):
+    """the trajectory of path k rounded to float32 = the reference binary's traj_out.dat, byte for byte"""
+    sres32, n, theta32 = read_traj_out(os.path.join(case.dir, "ref_traj_out.dat"), case.problem.n_joints)
+    assert int(out.n_pts[k]) == n, (case.name, int(out.n_pts[k]), n)
+    assert np.float32(out.sres[k]) == sres32
+    assert out.theta(k).astype("<f4").tobytes() == theta32.tobytes(), case.name
 
 
 def rr_trig(theta_samples0, theta_samples1):

@@ -1,0 +1,101 @@
+"""GPU (-m gpu): the device output stage against the reference binary's traj_out.dat and against the
+oracle, through the C-ABI, bit for bit (fp64, tolerance 0)."""
+import numpy as np
+import pytest
+
+import helpers
+from helpers import OUTPUT_CASES, Case, run_to_output, assert_output_equals_reference_file, assert_bit_equal, output_params
+from batotp_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("flags", [0, capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES])
+@pytest.mark.parametrize("name", OUTPUT_CASES)
+def test_hip_output_matches_reference_traj_out(hip_ctx, oracle_ctx, name, flags):
+    case = Case(name)
+    if flags and (case.problem.flags & (capi.F_CART_VEL_ON | capi.F_CART_ACC_ON | capi.F_TRQ_ON)):
+        pytest.skip("compact splines need a velocity/acceleration-only problem")
+    ho, hb = run_to_output(hip_ctx, [case], extra_flags=flags)
+    oo, ob = run_to_output(oracle_ctx, [case])
+    assert_output_equals_reference_file(case, ho)
+    assert int(ho.n_pts[0]) == int(oo.n_pts[0]) and ho.sres[0] == oo.sres[0]
+    assert_bit_equal(ho.theta(0), oo.theta(0), f"{name}: output trajectory (fp64)")
+    for x in (ho, oo):
+        x.close()
+    hb.close(); ob.close()
+
+
+def _variants(base):
+    """parameter sets reaching every branch: plain, smoothing only, re-interpolation only, both, even / large windows"""
+    out = []
+    for out_res, smooth in ((base.integ_res, 1.0), (base.integ_res, 5.0), (base.integ_res * 0.8, 1.0), (base.integ_res * 0.8, 5.0),
+                            (base.integ_res * 2.5, 4.0), (base.integ_res * 0.5, 9.0), (base.integ_res, 1.6)):
+        out.append(capi.OutputParams(base.n_joints, 0, base.integ_res, out_res, smooth))
+    return out
+
+
+def test_every_branch_and_a_ragged_batch_match_the_oracle(hip_ctx, oracle_ctx):
+    cases = [Case("synth_gen7dof_s0"), Case("synth_gen7dof_s0")]
+    short = Case("synth_gen7dof_s0")
+    short.y = np.ascontiguousarray(short.y[:, :400])   # a shorter path in the same batch
+    cases.insert(1, short)
+    base = output_params("synth_gen7dof_s0")
+    outs = []
+    for ctx in (hip_ctx, oracle_ctx):
+        b = capi.Batch(ctx, cases[0].problem, [c.n for c in cases], max(c.max_steps() for c in cases))
+        for k, c in enumerate(cases):
+            b.upload_knots(k, [c.y], [c.sres])
+        b.optimize()
+        outs.append(b)
+    hb, ob = outs
+    for prm in _variants(base):
+        h, o = capi.Output(hb, prm, 0, 3), capi.Output(ob, prm, 0, 3)
+        what = f"out_res={prm.out_res} smooth={prm.out_smooth_fact}"
+        assert np.array_equal(h.n_pts, o.n_pts), what
+        assert h.sres.tobytes() == o.sres.tobytes(), what
+        for k in range(3):
+            assert_bit_equal(h.theta(k), o.theta(k), f"{what}: path {k}")
+        # a sub-range of the batch gives the same trajectories
+        h1 = capi.Output(hb, prm, 1, 2)
+        assert_bit_equal(h1.theta(1), o.theta(2), f"{what}: sub-range")
+        for x in (h, o, h1):
+            x.close()
+    hb.close(); ob.close()
+
+
+def test_chunked_output_equals_one_chunk(hip_lib, oracle_ctx, monkeypatch):
+    """a tiny scratch budget forces one chunk per path: the result must not depend on the chunking"""
+    case = Case("synth_ur_s2")
+    monkeypatch.setenv("BATOTP_OUTPUT_BUDGET_MB", "1")
+    ctx = capi.Context(hip_lib, 0)
+    ho, hb = run_to_output(ctx, [case, case, case])
+    oo, ob = run_to_output(oracle_ctx, [case])
+    for k in range(3):
+        assert_bit_equal(ho.theta(k), oo.theta(0), f"chunked output, path {k}")
+    assert_output_equals_reference_file(case, ho, 2)
+    ho.close(); oo.close(); hb.close(); ob.close()
+
+
+def test_baseline_size_path_and_failed_paths(hip_ctx, oracle_ctx):
+    """a 1e5-knot path (hundreds of thousands of output points) and a path whose sweep hit the curve capacity"""
+    case = Case("synth_ur_s7_100k")
+    prm = capi.OutputParams(case.problem.n_joints, 0, case.problem.integ_res, 0.008, 5.0)
+    outs = []
+    for ctx in (hip_ctx, oracle_ctx):
+        b = capi.Batch(ctx, case.problem, [case.n], case.max_steps())
+        b.upload_knots(0, [case.y], [case.sres])
+        b.optimize()
+        outs.append((capi.Output(b, prm, 0, 1), b))
+    (h, hb), (o, ob) = outs
+    assert int(h.n_pts[0]) == int(o.n_pts[0]) > 10000
+    assert_bit_equal(h.theta(0), o.theta(0), "1e5-knot path")
+    for x in (h, o, hb, ob):
+        x.close()
+    small = Case("synth_gen7dof_s0")
+    b = capi.Batch(hip_ctx, small.problem, [small.n], 64)   # capacity far too small: the sweep reports it
+    b.upload_knots(0, [small.y], [small.sres])
+    b.optimize()
+    out = capi.Output(b, output_params("synth_gen7dof_s0"), 0, 1)
+    assert int(out.n_pts[0]) == 0 and out.theta(0).size == 0
+    out.close(); b.close()
