@@ -167,6 +167,12 @@ public:
    void setDeviceResample(bool on) { _deviceResample = on; }
    // milliseconds the last optimizeBatch() spent resampling (device kernels, or host wall clock)
    double getLastResampleMs() const { return _lastResampleMs; }
+   // Extension: optimizeBatch() runs the output stage (interpOutputData) on the device when the configuration is
+   // one batotp_hip_output covers (exportOutputParams); false keeps the host code.
+   void setDeviceOutput(bool on) { _deviceOutput = on; }
+   // milliseconds the last optimizeBatch() spent in the output stage: wall clock incl. downloads, and device kernels
+   double getLastOutputMs() const { return _lastOutputMs; }
+   double getLastOutputKernelMs() const { return _lastOutputKernelMs; }
    // Extension: the host half of interpInputData() only (everything before reference
    // ba.cpp:299): leaves the final knot values in traj.theta / traj.cart, the knot spacing in
    // traj.sres and the knot count in traj.nPts.  No device call.
@@ -322,6 +328,8 @@ private:
    std::shared_ptr<Gpu> _gpu;
    bool _deviceResample = true;
    double _lastResampleMs = 0;
+   bool _deviceOutput = true;
+   double _lastOutputMs = 0, _lastOutputKernelMs = 0;
    int _deviceId = 0;
    int gpuAcquire();                       // create the context on first use; -1 + message on failure
    void fillProblem(void *prob) const;     // BA configuration -> batotp_problem

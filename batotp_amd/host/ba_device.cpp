@@ -39,6 +39,14 @@ struct BatchGuard
       if (b) batotp_hip_batch_destroy(b);
    }
 };
+struct OutputGuard
+{
+   batotp_output *o = nullptr;
+   ~OutputGuard()
+   {
+      if (o) batotp_hip_output_destroy(o);
+   }
+};
 struct ResampledGuard
 {
    batotp_resampled *r = nullptr;
@@ -671,7 +679,79 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
    rc = batotp_hip_get_results(g.b, res.data());
    if (rc) return fail("get_results", rc);
 
+   // 3) output stage.  On the device when the configuration allows it (batotp_hip_output): only the finished
+   //    trajectories come back, in ranges of paths so that their device copy stays small.
+   batotp_output_params outPrm;
+   if (_deviceOutput && exportOutputParams(&outPrm) == 0)
+   {
+      const std::chrono::steady_clock::time_point tOut0 = std::chrono::steady_clock::now();
+      double kernelMs = 0;
+      const size_t range = 1024;
+      std::vector<double> flatTh;
+      std::vector<int64_t> nPtsOut;
+      std::vector<double> sresOut;
+      for (size_t k0 = 0; k0 < live.size(); k0 += range)
+      {
+         const size_t cnt = std::min(range, live.size() - k0);
+         OutputGuard og;
+         rc = batotp_hip_output(g.b, &outPrm, (int32_t)k0, (int32_t)cnt, &og.o);
+         if (rc) return fail("output", rc);
+         nPtsOut.assign(cnt, 0);
+         sresOut.assign(cnt, 0.0);
+         batotp_hip_output_info(og.o, nPtsOut.data(), sresOut.data());
+         float ms = 0;
+         batotp_hip_output_ms(og.o, &ms);
+         kernelMs += ms;
+         for (size_t q = 0; q < cnt; ++q)
+         {
+            const size_t k = k0 + q;
+            Traj &t = trajs[live[k]];
+            const batotp_path_result &r = res[k];
+            if ((r.status_rev | r.status_fwd) & BATOTP_ST_MAX_INTEG_TIME) setErrorOptimization(MAX_INTEGRATION_TIME);
+            const int64_t n = nPtsOut[q];
+            if (n == 0) { ok[live[k]] = 0; continue; }
+            flatTh.resize((size_t)n * _nJoints);
+            rc = batotp_hip_output_download(og.o, (int32_t)q, flatTh.data());
+            if (rc) return fail("output_download", rc);
+            t.theta.assign(_nJoints, std::vector<double>());
+            for (unsigned int j = 0; j < _nJoints; ++j) t.theta[j].assign(flatTh.begin() + (size_t)j * n, flatTh.begin() + (size_t)(j + 1) * n);
+            {
+               // no kinematic model: the Cartesian rows are zeros that interpOutputData sizes (ba.cpp:1829-1836),
+               // smooths and down-samples with the joints (ba.cpp:1861-1869) but does not re-interpolate
+               // (ba.cpp:1899); the writer keeps them only if their length ends up equal to the joints'
+               double outResEff = _outRes, smoothEff = _outSmoothFact;
+               if (_outRes < _integRes) { outResEff = _integRes; smoothEff *= std::max(_outRes / outResEff, 1.); }
+               const double tStep = (r.status_fwd & BATOTP_ST_SHORT) ? r.t_total / 3. : _integRes;
+               const double tLast = tStep * (double)(r.n_fwd - 1);
+               int nCartPts = std::max((int)(smoothEff * std::ceil(tLast / outResEff + 1.)), 4);
+               if (smoothEff > 1.5) nCartPts = std::max((int)((nCartPts - 1) / smoothEff) + 1, 4);
+               t.cart.assign(_nCart, std::vector<double>((size_t)nCartPts, 0.0));
+            }
+            t.trq.clear();
+            t.nPts = (unsigned int)n;
+            t.sres = sresOut[q];
+            t.tTotalTraj = r.t_total;
+            if (is_sdotOut)
+            {
+               int64_t got = 0;
+               t.myMVChist.s.assign(4, std::vector<double>());
+               t.myMVChist.sdot.assign(4, std::vector<double>());
+               t.myMVChist.s[0].resize((size_t)r.n_rev); t.myMVChist.sdot[0].resize((size_t)r.n_rev);
+               t.myMVChist.s[1].resize((size_t)r.n_fwd); t.myMVChist.sdot[1].resize((size_t)r.n_fwd);
+               batotp_hip_download_curve(g.b, (int32_t)k, -1, t.myMVChist.s[0].data(), t.myMVChist.sdot[0].data(), r.n_rev, &got);
+               batotp_hip_download_curve(g.b, (int32_t)k, +1, t.myMVChist.s[1].data(), t.myMVChist.sdot[1].data(), r.n_fwd, &got);
+            }
+         }
+      }
+      _lastOutputKernelMs = kernelMs;
+      _lastOutputMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tOut0).count();
+      int failedDev = 0;
+      for (size_t p = 0; p < trajs.size(); ++p) failedDev += ok[p] ? 0 : 1;
+      return failedDev;
+   }
+
    // unmarshal each path and finish it on the host
+   const std::chrono::steady_clock::time_point tHostOut0 = std::chrono::steady_clock::now();
    const double outRes0 = _outRes, outSmooth0 = _outSmoothFact;
    std::vector<double> flat, samp;
    for (size_t k = 0; k < live.size(); ++k)
@@ -744,6 +824,8 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
    _outRes = outRes0;
    _outSmoothFact = outSmooth0;
    if (_isParallelMechOrig && _isPar2Ser && _isTrqConOn) _isParallelMech = false;
+   _lastOutputKernelMs = 0;
+   _lastOutputMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tHostOut0).count();
 
    int failed = 0;
    for (size_t p = 0; p < trajs.size(); ++p) failed += ok[p] ? 0 : 1;

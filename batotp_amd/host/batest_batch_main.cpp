@@ -1,6 +1,6 @@
 // batest_batch_main.cpp -- command-line driver of the many-path extension BA::optimizeBatch().
 //
-//   batest_batch config.dat nPaths [--host-resample]
+//   batest_batch config.dat nPaths [--host-resample] [--host-output]
 //
 // Loads the trajectory named by the configuration nPaths times, optimises all copies as one device
 // batch and writes, for the first and the last path, the same files the single-path driver writes
@@ -20,14 +20,17 @@ int main(int argc, char *argv[])
 {
    if (argc < 3)
    {
-      fprintf(stderr, "usage: batest_batch config.dat nPaths [--host-resample]\n");
+      fprintf(stderr, "usage: batest_batch config.dat nPaths [--host-resample] [--host-output]\n");
       return 2;
    }
    const int nPaths = atoi(argv[2]);
    if (nPaths < 1) return 2;
-   bool hostResample = false;
+   bool hostResample = false, hostOutput = false;
    for (int k = 3; k < argc; ++k)
+   {
       if (std::string(argv[k]) == "--host-resample") hostResample = true;
+      if (std::string(argv[k]) == "--host-output") hostOutput = true;
+   }
 
    BA planner;
    planner.setHomeFolder("./");
@@ -35,6 +38,7 @@ int main(int argc, char *argv[])
    planner.setOutputFolder("./");
    planner.setIsAutoIntegRes(false);
    planner.setDeviceResample(!hostResample);
+   planner.setDeviceOutput(!hostOutput);
    if (planner.readConfigData((std::string("./") + argv[1]).c_str()) == -1) return 1;
 
    std::vector<Traj> paths(nPaths);
@@ -44,8 +48,9 @@ int main(int argc, char *argv[])
    const Time t0 = getTime();
    const int failed = planner.optimizeBatch(paths);
    const Time t1 = getTime();
-   printf("\noptimizeBatch: %d paths, %d failed, %.3f s (resampling %s: %.3f ms)\n", nPaths, failed, diffTime(t1, t0),
-          hostResample ? "host" : "device", planner.getLastResampleMs());
+   printf("\noptimizeBatch: %d paths, %d failed, %.3f s (resampling %s: %.3f ms; output stage %s: %.3f ms, kernels %.3f ms)\n", nPaths, failed,
+          diffTime(t1, t0), hostResample ? "host" : "device", planner.getLastResampleMs(), hostOutput ? "host" : "device (where covered)",
+          planner.getLastOutputMs(), planner.getLastOutputKernelMs());
    if (failed < 0 || failed == nPaths) return 1;
 
    const char *dirs[2] = {"./out_first/", "./out_last/"};

@@ -30,15 +30,16 @@ def _stage(src, dst):
             shutil.copy(os.path.join(src, f), dst / f)
 
 
-@pytest.mark.parametrize("mode", ["device-resample", "host-resample"])
-@pytest.mark.parametrize("name", ["synth_cspr_s3", "synth_gen7dof_s1_vel", "UR5", "RR"])
+@pytest.mark.parametrize("mode", ["device-resample", "host-resample", "host-output"])
+@pytest.mark.parametrize("name", ["synth_cspr_s3", "synth_gen7dof_s1_vel", "synth_ur_s2", "GEN7DOF", "UR5", "RR"])
 def test_batch_driver_files_equal_reference(tmp_path, oracle_lib, name, mode):
     """BA::optimizeBatch (the many-path extension) writes, for every copy of the path, the files the
     reference binary wrote for the single path -- with the resampling done behind the C-ABI
-    (batotp_hip_resample, configurations it covers) and by the host resampler"""
+    (batotp_hip_resample, configurations it covers) and by the host resampler, the output stage behind the C-ABI
+    (batotp_hip_output, configurations it covers) and by the host code"""
     src = os.path.join(helpers.GOLD, name)
     _stage(src, tmp_path)
-    cmd = [os.path.join(helpers.BUILD, "batest_batch_oracle"), "config.dat", "3"] + (["--host-resample"] if mode == "host-resample" else [])
+    cmd = [os.path.join(helpers.BUILD, "batest_batch_oracle"), "config.dat", "3"] + (["--" + mode] if mode.startswith("host-") else [])
     r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
     for d in ("out_first", "out_last"):

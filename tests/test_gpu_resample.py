@@ -93,10 +93,10 @@ def test_resampled_knots_feed_the_hot_path_on_the_device(hip_ctx):
     r.close()
 
 
-@pytest.mark.parametrize("name", ["synth_cspr_s3", "synth_gen7dof_s0", "CSPR3DOF", "UR5"])
+@pytest.mark.parametrize("name", ["synth_cspr_s3", "synth_gen7dof_s0", "synth_ur_s2", "GEN7DOF", "CSPR3DOF", "UR5"])
 def test_product_batch_driver_on_gpu(tmp_path, name):
-    """batotp_amd/host/_build/batest_batch (BA::optimizeBatch over the HIP library, device resampler where the
-    configuration allows it) writes the reference binary's files for every copy of the path"""
+    """batotp_amd/host/_build/batest_batch (BA::optimizeBatch over the HIP library, device resampler and device output
+    stage where the configuration allows them) writes the reference binary's files for every copy of the path"""
     import filecmp, os, shutil, subprocess
     exe = os.path.join(helpers.ROOT, "batotp_amd", "host", "_build", "batest_batch")
     assert os.path.exists(exe), "build() must produce batest_batch"
