@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-resample", action="store_true", help="skip the side measurement of the device path resampler")
+    ap.add_argument("--no-output", action="store_true", help="skip the side measurement of the device output stage")
     ap.add_argument("--coefficient-rows", action="store_true",
                     help="keep four coefficients per knot and channel instead of the compact (value, second derivative) form")
     args = ap.parse_args()
@@ -283,6 +284,24 @@ def main():
                      "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": kernel_ms[dom]},
     }
 
+    # ---- SURVEY.md 8f-2 beside the hot path: the output stage (constant-time trajectories from the forward curves)
+    # of the first paths of the batch on the device; untimed side measurement
+    out_prm = capi.OutputParams(prob.n_joints, 0, prob.integ_res, 0.008, 5.0)
+    hip_out_theta0 = None
+    if rank == 0 and not args.no_output and not (prob.flags & capi.F_TRQ_ON) and WORKLOADS[args.workload]["cfg"]["robot"] == "GENJNT":
+        n_out_paths = min(B, 512)
+        best = None
+        for _ in range(2):  # the second call finds the context's workspace allocated
+            o = capi.Output(batch, out_prm, 0, n_out_paths)
+            ms, pts = o.ms(), int(o.n_pts.sum())
+            hip_out_theta0 = o.theta(0)
+            o.close()
+            best = ms if best is None else min(best, ms)
+        out["output_stage"] = {"paths": n_out_paths, "points": pts, "ms": best, "points_per_s": pts / (best * 1e-3),
+                               "out_res": out_prm.out_res, "out_smooth_fact": out_prm.out_smooth_fact,
+                               "what": "s(t) spline + re-sampling at constant time steps + joint spline evaluation + smoothing / "
+                                       "down-sampling (+ re-interpolation when out_res < integ_res) on the device"}
+
     # ---- the same workload as ONE trajectory (BASELINE configs[1] wording): inherently sequential,
     # reported for transparency next to the batch figure
     if rank == 0:
@@ -318,13 +337,20 @@ def main():
                 b.precompute(0); b.pointwise_mvc(); b.sweep(-1); b.sweep(+1)
                 dt = time.perf_counter() - t
             rr = b.results()
+            th0 = None
+            if hip_out_theta0 is not None:
+                oo = capi.Output(b, out_prm, 0, 1)
+                th0 = oo.theta(0)
+                oo.close()
             b.close()
-            return dt, sum(nk), rr
+            return dt, sum(nk), rr, th0
 
-        t_one, n_one, _ = cpu_batch(1, passes=2)           # one path = one busy thread
+        t_one, n_one, _, th0 = cpu_batch(1, passes=2)      # one path = one busy thread
         n_sample = int(max(cores, min(2 * cores, (args.cpu_seconds / max(t_one, 1e-3)) * cores)))
         n_sample = max(cores, (n_sample // cores) * cores)
-        wall, n_wp, rows = cpu_batch(n_sample, passes=2)
+        wall, n_wp, rows, _ = cpu_batch(n_sample, passes=2)
+        if th0 is not None:
+            out["output_stage"]["identical_to_oracle"] = bool(th0.tobytes() == hip_out_theta0.tobytes())
         out["cpu_baseline"] = {"value": n_wp / wall, "unit": "waypoints/s", "cores": cores, "kind": "port",
                                "single_thread_value": n_one / t_one,
                                "sample": f"{n_sample} paths of the same workload (N~{n_one}), OpenMP one path per thread on {cores} "
