@@ -245,9 +245,11 @@ def main():
     # point; the forward sweep also reads the reverse curve, 16 bytes per point
     bytes_rev = 16.0 * C * total_knots + 16.0 * (steps_rev + B)
     bytes_fwd = 16.0 * C * total_knots + 16.0 * (steps_fwd + B) + 16.0 * (steps_rev + B)
-    dom = 4 if kernel_ms[4] >= kernel_ms[3] else 3
-    dom_bytes = bytes_fwd if dom == 4 else bytes_rev
-    achieved = dom_bytes / (kernel_ms[dom] * 1e-3) / 1e9
+    # the dominant kernel is k_sweep; a step launches it twice (reverse, forward): per-launch averages, which is what
+    # a rocprofv3 --stats summary of this command shows for the kernel (profiles/)
+    dom_bytes = 0.5 * (bytes_rev + bytes_fwd)
+    dom_ms = 0.5 * (kernel_ms[3] + kernel_ms[4])
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_sweep_traffic.json")
     if os.path.exists(pmc_path):
@@ -279,9 +281,10 @@ def main():
         "stage_evals_per_s": 7.0 * (steps_rev + steps_fwd) / ((kernel_ms[3] + kernel_ms[4]) * 1e-3),
         "hbm_bytes_resident": batch.nbytes(),
         "gathered_rows": int(gathered.shape[0]) if gathered is not None else 0,
-        "roofline": {"bound": "hbm", "kernel": "k_sweep (forward)" if dom == 4 else "k_sweep (reverse)", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": "k_sweep (2 launches per step: reverse, forward; per-launch averages)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": kernel_ms[dom]},
+                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
+                     "reverse": {"ms": kernel_ms[3], "algorithmic_bytes": bytes_rev}, "forward": {"ms": kernel_ms[4], "algorithmic_bytes": bytes_fwd}},
     }
 
     # ---- SURVEY.md 8f-2 beside the hot path: the output stage (constant-time trajectories from the forward curves)
