@@ -137,7 +137,7 @@ class ResampleParams(C.Structure):
 
 class OutputParams(C.Structure):
     """struct batotp_output_params"""
-    _fields_ = [("n_joints", C.c_int32), ("reserved", C.c_int32), ("integ_res", C.c_double), ("out_res", C.c_double),
+    _fields_ = [("n_joints", C.c_int32), ("path_type", C.c_int32), ("integ_res", C.c_double), ("out_res", C.c_double),
                 ("out_smooth_fact", C.c_double)]
 
 
@@ -202,6 +202,7 @@ class Library:
             "batotp_hip_output": [P, C.POINTER(OutputParams), I32, I32, C.POINTER(P)],
             "batotp_hip_output_destroy": [P],
             "batotp_hip_output_info": [P, C.POINTER(C.c_int64), D],
+            "batotp_hip_output_channels": [P, C.POINTER(I32), C.POINTER(I32), C.POINTER(I32)],
             "batotp_hip_output_download": [P, I32, D],
             "batotp_hip_output_device": [P, C.POINTER(P), C.POINTER(C.c_int64)],
             "batotp_hip_output_ms": [P, C.POINTER(C.c_float)],
@@ -323,6 +324,10 @@ class Output:
         self.n_pts = np.zeros(n_paths, dtype=np.int64)
         self.sres = np.zeros(n_paths, dtype=np.float64)
         self.L.check(self.lib.batotp_hip_output_info(self.handle, self.n_pts.ctypes.data_as(C.POINTER(C.c_int64)), _dptr(self.sres)), "output_info")
+        a, b_, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self.L.check(self.lib.batotp_hip_output_channels(self.handle, C.byref(a), C.byref(b_), C.byref(c)), "output_channels")
+        self.n_theta, self.n_cart, self.n_trq = a.value, b_.value, c.value
+        self.n_rows = a.value + b_.value + c.value
 
     def close(self):
         if self.handle:
@@ -335,11 +340,15 @@ class Output:
         except Exception:
             pass
 
-    def theta(self, k: int) -> np.ndarray:
-        out = np.empty((self.n_joints, int(self.n_pts[k])), dtype=np.float64)
+    def rows(self, k: int) -> np.ndarray:
+        """[n_theta + n_cart + n_trq][n_pts] of path k of the range"""
+        out = np.empty((self.n_rows, int(self.n_pts[k])), dtype=np.float64)
         if out.size:
             self.L.check(self.lib.batotp_hip_output_download(self.handle, k, _dptr(out)), "output_download")
         return out
+
+    def theta(self, k: int) -> np.ndarray:
+        return self.rows(k)[: self.n_theta]
 
     def ms(self) -> float:
         v = C.c_float(0)

@@ -29,12 +29,15 @@ struct OutPath
 
 struct OutParams
 {
-   int nJ;
+   int nJ;          // joint rows
+   int R;           // rows per output point: joints (+ 3 Cartesian + 3 torque rows for the cable robot)
    int window;      // (int)_outSmoothFact when smoothing, else 0
    int reinterp;
    int compact;     // the batch keeps (value, second derivative) pairs instead of coefficient rows
    int C, Cin;
    double outRes;
+   double vfactT, afactT; // cable robot: 1/tfact and its square, tfact = outRes/smoothFact (ba.cpp:1754)
+   double pmat[9];
 };
 
 __device__ __forceinline__ int out_find_path(const OutPath *__restrict__ paths, int K, int64_t g, int which)
@@ -142,10 +145,12 @@ __global__ void k_out_segmax(const OutPath *__restrict__ paths, int K, int *__re
    }
 }
 
-// joint values at the output sites (ba.cpp:1709-1722): th1[nJ][n1] per path
+// path values at the output sites (ba.cpp:1709-1742): channels [c0, c0+cn) of the path splines go to rows
+// [r0, r0+cn) of th1[R][n1] (joint rows of a JOINT path; Cartesian rows of a CART path)
 __global__ void k_out_eval(OutParams P, const OutPath *__restrict__ paths, int K, const PathInfo *__restrict__ pinfo,
                            const double *__restrict__ sC, const double *__restrict__ coef, const double *__restrict__ km,
-                           const double *__restrict__ sOut, const int *__restrict__ segK, double *__restrict__ th1, int64_t total)
+                           const double *__restrict__ sOut, const int *__restrict__ segK, double *__restrict__ th1, int c0, int cn, int r0,
+                           int64_t total)
 {
    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
    if (g >= total) return;
@@ -160,9 +165,10 @@ __global__ void k_out_eval(OutParams P, const OutPath *__restrict__ paths, int K
    else { s0 = sC[pi.koff + seg]; s1 = sC[pi.koff + seg + 1]; }
    const double tau = (s - s0) / (s1 - s0);
    const double tau2 = tau * tau, tau3 = tau2 * tau;
-   double *__restrict__ o = th1 + op.off1 * P.nJ + i;
-   for (int c = 0; c < P.nJ; ++c)
+   double *__restrict__ o = th1 + op.off1 * P.R + (int64_t)r0 * n1 + i;
+   for (int cc = 0; cc < cn; ++cc)
    {
+      const int c = c0 + cc;
       Coef4 k;
       if (P.compact)
       {
@@ -170,8 +176,71 @@ __global__ void k_out_eval(OutParams P, const OutPath *__restrict__ paths, int K
          k = coeffs_from_sol(a[1], b[1], a[0], b[0]);
       }
       else k = *reinterpret_cast<const Coef4 *>(coef + ((pi.koff + seg) * P.C + c) * 4);
-      o[(int64_t)c * n1] = k.c3 * tau3 + k.c2 * tau2 + k.c1 * tau + k.c0;
+      o[(int64_t)cc * n1] = k.c3 * tau3 + k.c2 * tau2 + k.c1 * tau + k.c0;
    }
+}
+
+// CART path of the cable robot: cable lengths from the platform position (Robot::invKinCSPR3DOF, robot.cpp:243-278):
+// rows 0..2 from rows 3..5
+__global__ void k_out_invkin(OutParams P, const OutPath *__restrict__ paths, int K, double *__restrict__ th1, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   const OutPath op = paths[out_find_path(paths, K, g, 1)];
+   const int i = (int)(g - op.off1), n1 = op.n1;
+   if (i >= n1) return;
+   double *__restrict__ x = th1 + op.off1 * P.R + i;
+   const double px = x[(int64_t)3 * n1], py = x[(int64_t)4 * n1], pz = x[(int64_t)5 * n1];
+#pragma unroll
+   for (int k = 0; k < 3; ++k)
+   {
+      const double dx = px - P.pmat[0 * 3 + k], dy = py - P.pmat[1 * 3 + k], dz = pz - P.pmat[2 * 3 + k];
+      double sq = 0.0;
+      sq += dx * dx;
+      sq += dy * dy;
+      sq += dz * dz;
+      x[(int64_t)k * n1] = sqrt(sq);
+   }
+}
+
+// torque recomputation of the cable robot (ba.cpp:1744-1790): natural splines through the output samples themselves
+// (second derivatives in sol1), every site evaluated at the END of the previous segment (site 0: start of segment 0) --
+// the VALUES of the joint and Cartesian rows are replaced by that evaluation too -- then the cable tensions from
+// Robot::dynCSPR3DOF (a2 = -cart'', a3 = 0, a4 = (0,0,g)), Robot::setA and the 3x3 LU solve.  src -> dst (all 9 rows).
+__global__ void k_out_trq(OutParams P, const OutPath *__restrict__ paths, int K, const double *__restrict__ src, const double *__restrict__ sol1,
+                          double *__restrict__ dst, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   const OutPath op = paths[out_find_path(paths, K, g, 1)];
+   const int i = (int)(g - op.off1), n1 = op.n1;
+   if (i >= n1) return;
+   const int seg = i == 0 ? 0 : i - 1;
+   const double tau = i == 0 ? 0.0 : 1.0;
+   const double tau2 = tau * tau, tau3 = tau2 * tau;
+   double val[6], d2c[3];
+#pragma unroll
+   for (int r = 0; r < 6; ++r)
+   {
+      const int64_t at = op.off1 * P.R + (int64_t)r * n1 + seg;
+      const Coef4 k = coeffs_from_sol(sol1[at], sol1[at + 1], src[at], src[at + 1]);
+      val[r] = k.c3 * tau3 + k.c2 * tau2 + k.c1 * tau + k.c0;
+      if (r >= 3) d2c[r - 3] = (6 * k.c3 * tau + 2 * k.c2) * P.afactT;
+   }
+   double b[3], A[9], xs[3];
+#pragma unroll
+   for (int j = 0; j < 3; ++j)
+   {
+      const double a2 = -d2c[j], a3 = 0.0, a4 = (j == 2) ? 9.81 : 0.0;
+      b[j] = a2 + a3 + a4;
+   }
+   cspr_setA(P.pmat, val, val + 3, A);
+   lu3_solve(A, b, xs);
+   double *__restrict__ o = dst + op.off1 * P.R + i;
+#pragma unroll
+   for (int r = 0; r < 6; ++r) o[(int64_t)r * n1] = val[r];
+#pragma unroll
+   for (int j = 0; j < 3; ++j) o[(int64_t)(6 + j) * n1] = xs[j];
 }
 
 // smooth() (util.cpp:263-290) at one index: centred moving average of width w = 2*half + 1, shrinking windows
@@ -198,7 +267,7 @@ __device__ __forceinline__ double smooth_at(const double *__restrict__ x, int n,
    return acc / w;
 }
 
-// moving average + linear down-sampling by the smoothing factor (ba.cpp:1838-1871): th2[nJ][n2] per path
+// moving average + linear down-sampling by the smoothing factor (ba.cpp:1838-1871): th2[R][n2] per path
 __global__ void k_out_down(OutParams P, const OutPath *__restrict__ paths, int K, const double *__restrict__ th1, double *__restrict__ th2,
                            int64_t total)
 {
@@ -214,11 +283,11 @@ __global__ void k_out_down(OutParams P, const OutPath *__restrict__ paths, int K
    const int cur = seg_uniform(site, 1.0, nIn);
    const double width = (double)(cur + 1) - (double)cur;
    const double t = (site - (double)cur) / width;
-   for (int c = 0; c < P.nJ; ++c)
+   for (int c = 0; c < P.R; ++c)
    {
-      const double *__restrict__ x = th1 + op.off1 * P.nJ + (int64_t)c * nIn;
+      const double *__restrict__ x = th1 + op.off1 * P.R + (int64_t)c * nIn;
       const double b0 = smooth_at(x, nIn, half, w, cur), b1 = smooth_at(x, nIn, half, w, cur + 1);
-      th2[op.off2 * P.nJ + (int64_t)c * nDown + i] = b0 + (b1 - b0) * t; // Spline::interp1linear, spline.cpp:108-120
+      th2[op.off2 * P.R + (int64_t)c * nDown + i] = b0 + (b1 - b0) * t; // Spline::interp1linear, spline.cpp:108-120
    }
 }
 
@@ -238,11 +307,11 @@ __global__ void k_out_user(OutParams P, const OutPath *__restrict__ paths, int K
    const double g0 = c1 * (double)seg, g1 = c1 * (double)(seg + 1);
    const double tau = (site - g0) / (g1 - g0);
    const double tau2 = tau * tau, tau3 = tau2 * tau;
-   for (int c = 0; c < P.nJ; ++c)
+   for (int c = 0; c < P.R; ++c)
    {
-      const int64_t at = op.off2 * P.nJ + (int64_t)c * n + seg;
+      const int64_t at = op.off2 * P.R + (int64_t)c * n + seg;
       const Coef4 k = coeffs_from_sol(sol2[at], sol2[at + 1], th2[at], th2[at + 1]);
-      thF[op.offF * P.nJ + (int64_t)c * nUser + i] = k.c3 * tau3 + k.c2 * tau2 + k.c1 * tau + k.c0;
+      thF[op.offF * P.R + (int64_t)c * nUser + i] = k.c3 * tau3 + k.c2 * tau2 + k.c1 * tau + k.c0;
    }
 }
 

@@ -181,13 +181,15 @@ int BA::exportOutputParams(void *out) const
    batotp_output_params &O = *static_cast<batotp_output_params *>(out);
    std::memset(&O, 0, sizeof(O));
    O.n_joints = (int32_t)_nJoints;
+   O.path_type = (_pathType == JOINT) ? BATOTP_PATH_JOINT : (_pathType == CART ? BATOTP_PATH_CART : 0);
    O.integ_res = _integRes;
    O.out_res = _outRes;
    O.out_smooth_fact = _outSmoothFact;
-   if (_isInterpOnly || _isTrqConOn) return -1;
-   if (!(_pathType == JOINT && _robotType == GENJNT)) return -1;
+   if (_isInterpOnly) return -1;
    if (!(_outRes > 0) || !(_integRes > 0) || !(_outSmoothFact >= 1)) return -1;
-   return 0;
+   const bool joint = _pathType == JOINT && _robotType == GENJNT && !_isTrqConOn;
+   const bool cable = _pathType == CART && _robotType == CSPR3DOF && _nJoints == 3 && _nCart == 3 && _isTrqConOn && _isParallelMechOrig && !_isSVD;
+   return (joint || cable) ? 0 : -1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -710,11 +712,25 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
             if ((r.status_rev | r.status_fwd) & BATOTP_ST_MAX_INTEG_TIME) setErrorOptimization(MAX_INTEGRATION_TIME);
             const int64_t n = nPtsOut[q];
             if (n == 0) { ok[live[k]] = 0; continue; }
-            flatTh.resize((size_t)n * _nJoints);
+            int32_t nTh = 0, nCa = 0, nTq = 0;
+            batotp_hip_output_channels(og.o, &nTh, &nCa, &nTq);
+            const size_t rows = (size_t)(nTh + nCa + nTq);
+            flatTh.resize((size_t)n * rows);
             rc = batotp_hip_output_download(og.o, (int32_t)q, flatTh.data());
             if (rc) return fail("output_download", rc);
             t.theta.assign(_nJoints, std::vector<double>());
             for (unsigned int j = 0; j < _nJoints; ++j) t.theta[j].assign(flatTh.begin() + (size_t)j * n, flatTh.begin() + (size_t)(j + 1) * n);
+            t.trq.clear();
+            if (nCa > 0)
+            {
+               // cable robot: Cartesian rows and recomputed cable tensions come with the joints
+               t.cart.assign(_nCart, std::vector<double>());
+               for (int j = 0; j < nCa; ++j) t.cart[j].assign(flatTh.begin() + (size_t)(nTh + j) * n, flatTh.begin() + (size_t)(nTh + j + 1) * n);
+               t.trq.assign(_nJoints, std::vector<double>());
+               for (int j = 0; j < nTq; ++j)
+                  t.trq[j].assign(flatTh.begin() + (size_t)(nTh + nCa + j) * n, flatTh.begin() + (size_t)(nTh + nCa + j + 1) * n);
+            }
+            else
             {
                // no kinematic model: the Cartesian rows are zeros that interpOutputData sizes (ba.cpp:1829-1836),
                // smooths and down-samples with the joints (ba.cpp:1861-1869) but does not re-interpolate
@@ -727,7 +743,6 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
                if (smoothEff > 1.5) nCartPts = std::max((int)((nCartPts - 1) / smoothEff) + 1, 4);
                t.cart.assign(_nCart, std::vector<double>((size_t)nCartPts, 0.0));
             }
-            t.trq.clear();
             t.nPts = (unsigned int)n;
             t.sres = sresOut[q];
             t.tTotalTraj = r.t_total;

@@ -263,15 +263,18 @@ int  batotp_hip_resampled_download(batotp_resampled *r, int32_t path, double *y)
 int  batotp_hip_resampled_ms(batotp_resampled *r, float *ms);
 
 /* ---- output stage behind the hot path ------------------------------------ */
-/* Replaces BA::interpOutputData (batotp/ba.cpp:1661-1931) for JOINT paths of a robot without kinematic
- * model and without torque constraints: the forward curve s(t) of every path is re-sampled at constant
- * time steps, the joint splines are evaluated there, the result is smoothed and down-sampled by
- * _outSmoothFact (smooth, batotp/util.cpp:263-290; Spline::interp1linear, spline.cpp:108-120) and, when
- * out_res is finer than the integration step, re-interpolated (ba.cpp:1873-1919).  The batch must have
- * completed the forward sweep.  Anything else returns BATOTP_ERR_ARG (the caller keeps its host code). */
+/* Replaces BA::interpOutputData (batotp/ba.cpp:1661-1931): the forward curve s(t) of every path is
+ * re-sampled at constant time steps, the path splines are evaluated there, the result is smoothed and
+ * down-sampled by _outSmoothFact (smooth, batotp/util.cpp:263-290; Spline::interp1linear,
+ * spline.cpp:108-120) and, when out_res is finer than the integration step, re-interpolated
+ * (ba.cpp:1873-1919).  Covered: JOINT paths of a robot without kinematic model and without torque
+ * constraints (joint rows), and CART paths of the 3-cable robot with torque constraints (Cartesian rows,
+ * cable lengths by Robot::invKinCSPR3DOF, cable tensions recomputed as in ba.cpp:1744-1790 with
+ * Robot::dynCSPR3DOF / setA / solveLinSys).  The batch must have completed the forward sweep.
+ * Anything else returns BATOTP_ERR_ARG (the caller keeps its host code). */
 typedef struct batotp_output_params {
     int32_t  n_joints;               /* joint channels to produce (the batch's n_joints)       */
-    int32_t  reserved;
+    int32_t  path_type;              /* BATOTP_PATH_JOINT (also 0) or BATOTP_PATH_CART         */
     double   integ_res;              /* _integRes                                              */
     double   out_res;                /* _outRes                                                */
     double   out_smooth_fact;        /* _outSmoothFact                                         */
@@ -285,9 +288,11 @@ int  batotp_hip_output(batotp_batch *batch, const batotp_output_params *prm, int
 int  batotp_hip_output_destroy(batotp_output *o);
 /* points per path (0 for a path whose sweep ended with an error status) and traj.sres of the output */
 int  batotp_hip_output_info(batotp_output *o, int64_t *n_pts /* [n_paths] */, double *sres /* [n_paths] */);
-/* joint positions of path path0 + k: theta[n_joints][n_pts[k]] */
-int  batotp_hip_output_download(batotp_output *o, int32_t k, double *theta);
-/* device pointer of all trajectories, path after path, each [n_joints][n_pts] */
+/* rows per point: n_theta joint rows, then n_cart Cartesian rows and n_trq torque rows (0 and 0 for JOINT paths) */
+int  batotp_hip_output_channels(batotp_output *o, int32_t *n_theta, int32_t *n_cart, int32_t *n_trq);
+/* trajectory of path path0 + k: rows[n_theta + n_cart + n_trq][n_pts[k]] */
+int  batotp_hip_output_download(batotp_output *o, int32_t k, double *rows);
+/* device pointer of all trajectories, path after path, each [n_theta + n_cart + n_trq][n_pts] */
 int  batotp_hip_output_device(batotp_output *o, const double **theta_dev, int64_t *n_doubles);
 /* milliseconds of the stage's kernels (HIP events on the context's stream) */
 int  batotp_hip_output_ms(batotp_output *o, float *ms);

@@ -439,7 +439,8 @@ int batotp_hip_resampled_ms(batotp_resampled *r, float *ms)
 /* ---- output stage over bo_output ----------------------------------------------- */
 struct batotp_output {
     int32_t n_paths;
-    int nJ;
+    int nJ;      /* rows per point: theta + cart + trq */
+    int nTheta, nCart, nTrq;
     int64_t *n, *off;
     double *sres;
     double *theta; /* path after path, [nJ][n] each */
@@ -463,11 +464,17 @@ int batotp_hip_output(batotp_batch *b, const batotp_output_params *prm, int32_t 
     struct timespec t0, t1;
     if (!b || !prm || !out || path0 < 0 || n_paths < 1 || path0 + n_paths > b->n_paths) return BATOTP_ERR_ARG;
     *out = NULL;
-    if ((b->prob.flags & BATOTP_F_TRQ_ON) || prm->n_joints != b->prob.n_joints || !(prm->out_res > 0) || !(prm->integ_res > 0) ||
-        !(prm->out_smooth_fact >= 1))
+    if (prm->n_joints != b->prob.n_joints || !(prm->out_res > 0) || !(prm->integ_res > 0) || !(prm->out_smooth_fact >= 1))
         return BATOTP_ERR_ARG;
-    o = (batotp_output *)calloc(1, sizeof(*o));
-    o->n_paths = n_paths; o->nJ = prm->n_joints;
+    {
+        const int cable = prm->path_type == BATOTP_PATH_CART && b->prob.robot_type == BATOTP_ROBOT_CSPR3DOF && prm->n_joints == 3 &&
+                          b->prob.n_cart == 3 && (b->prob.flags & BATOTP_F_TRQ_ON) && (b->prob.flags & BATOTP_F_PARALLEL);
+        const int joint = (prm->path_type == BATOTP_PATH_JOINT || prm->path_type == 0) && !(b->prob.flags & BATOTP_F_TRQ_ON);
+        if (!cable && !joint) return BATOTP_ERR_ARG;
+        o = (batotp_output *)calloc(1, sizeof(*o));
+        o->nTheta = prm->n_joints; o->nCart = cable ? 3 : 0; o->nTrq = cable ? 3 : 0;
+    }
+    o->n_paths = n_paths; o->nJ = o->nTheta + o->nCart + o->nTrq;
     o->n = (int64_t *)calloc((size_t)n_paths, sizeof(int64_t));
     o->off = (int64_t *)calloc((size_t)n_paths, sizeof(int64_t));
     o->sres = (double *)calloc((size_t)n_paths, sizeof(double));
@@ -481,7 +488,8 @@ int batotp_hip_output(batotp_batch *b, const batotp_output_params *prm, int32_t 
         if (r->n_fwd < 4 || (st & (BATOTP_ST_MAX_INTEG_TIME | BATOTP_ST_CAPACITY | BATOTP_ST_NONFINITE))) continue;
         {
             const double t_step = (r->status_fwd & BATOTP_ST_SHORT) ? r->t_total / 3. : prm->integ_res;
-            if (bo_output(prm, b->path[p], b->fwd_s[p], r->n_fwd, t_step, &th[k], &o->n[k], &o->sres[k]) != 0) {
+            int32_t nc = 0, nt = 0;
+            if (bo_output(&b->prob, prm, b->path[p], b->fwd_s[p], r->n_fwd, t_step, &th[k], &nc, &nt, &o->n[k], &o->sres[k]) != 0) {
 #pragma omp atomic write
                 bad = 1;
             }
@@ -509,6 +517,15 @@ int batotp_hip_output_info(batotp_output *o, int64_t *n_pts, double *sres)
         if (n_pts) n_pts[k] = o->n[k];
         if (sres) sres[k] = o->sres[k];
     }
+    return BATOTP_OK;
+}
+
+int batotp_hip_output_channels(batotp_output *o, int32_t *n_theta, int32_t *n_cart, int32_t *n_trq)
+{
+    if (!o) return BATOTP_ERR_ARG;
+    if (n_theta) *n_theta = o->nTheta;
+    if (n_cart) *n_cart = o->nCart;
+    if (n_trq) *n_trq = o->nTrq;
     return BATOTP_OK;
 }
 

@@ -272,7 +272,7 @@ void bo_cspr_pmat(double pmat[9])
 }
 
 /* Robot::setA for CSPR3DOF, robot.cpp:534-558: A[i][j] = (cart[i]-pmat[i][j])/theta[j] */
-static void cspr_setA(const double *pmat, const double *theta, const double *cart, double *A)
+void bo_cspr_setA(const double *pmat, const double *theta, const double *cart, double *A)
 {
     int i, j;
     for (i = 0; i < 3; i++)
@@ -402,7 +402,7 @@ int bo_precompute_dyn(const batotp_problem *prob, bo_path *p, const double *trig
             double *ak[4];
             ak[0] = a1; ak[1] = a2; ak[2] = a3; ak[3] = a4;
             for (j = 0; j < 3; j++) { ca[j] = cs[(int64_t)j * 3 * n + i]; th[j] = p->samp[(int64_t)j * 3 * n + i]; }
-            cspr_setA(prob->pmat, th, ca, A);
+            bo_cspr_setA(prob->pmat, th, ca, A);
             for (k = 0; k < 4; k++) {
                 for (j = 0; j < 3; j++) bs[j] = ak[k][(int64_t)j * n + i];
                 bo_solve_lin_sys(3, A, bs, xs);
@@ -525,7 +525,7 @@ static void eval_spline_partials(sweep_ctx *c)
             c->a3pt[i] = k3[3 * n + seg] * tau3 + k3[2 * n + seg] * tau2 + k3[n + seg] * tau + k3[seg];
             c->a4pt[i] = k4[3 * n + seg] * tau3 + k4[2 * n + seg] * tau2 + k4[n + seg] * tau + k4[seg];
         }
-        if (p->parallel_now) cspr_setA(prob->pmat, c->thetapt, c->cartpt, c->Apt); /* ba.cpp:1407-1410 */
+        if (p->parallel_now) bo_cspr_setA(prob->pmat, c->thetapt, c->cartpt, c->Apt); /* ba.cpp:1407-1410 */
     }
 }
 

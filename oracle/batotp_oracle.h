@@ -98,9 +98,13 @@ int  bo_resample(const bo_resample_params *prm, int64_t n_in, const double *x, d
 
 /* Output stage behind the hot path: BA::interpOutputData (ba.cpp:1661-1931) for JOINT paths
  * without kinematic model and without torque constraints.  p: the path as precomputed for the sweep;
- * fwd_s[n_fwd]: s of the forward curve; t_step: its time step.  *theta_out is malloc'd [n_joints][*n_out]. */
-int  bo_output(const batotp_output_params *prm, const bo_path *p, const double *fwd_s, int64_t n_fwd, double t_step,
-               double **theta_out, int64_t *n_out, double *sres_out);
+ * fwd_s[n_fwd]: s of the forward curve; t_step: its time step.  Also CART paths of the 3-cable robot with the torque
+ * recomputation of ba.cpp:1744-1790.  *out is malloc'd: joint rows, then (cable robot) Cartesian and torque rows. */
+int  bo_output(const batotp_problem *prob, const batotp_output_params *prm, const bo_path *p, const double *fwd_s, int64_t n_fwd,
+               double t_step, double **out /* [n_theta + n_cart + n_trq][*n_out] */, int32_t *n_cart_out, int32_t *n_trq_out,
+               int64_t *n_out, double *sres_out);
+/* Robot::setA for CSPR3DOF (robot.cpp:534-558), A row-major [3][3] */
+void bo_cspr_setA(const double *pmat, const double *theta, const double *cart, double *A);
 
 #ifdef __cplusplus
 }

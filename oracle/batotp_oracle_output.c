@@ -43,11 +43,61 @@ static void out_smooth(double *x, int64_t n, int w)
     free(y);
 }
 
-int bo_output(const batotp_output_params *prm, const bo_path *p, const double *fwd_s, int64_t n_fwd, double t_step,
-              double **theta_out, int64_t *n_out, double *sres_out)
+/* resample every row of x[C][nIn]: smooth + linear down-sampling (ba.cpp:1838-1871) */
+static double *out_smooth_down(double *x, int C, int64_t nIn, double smoothFact, int64_t *nDownOut)
+{
+    int64_t nDown = (int64_t)(int)((double)(nIn - 1) / smoothFact) + 1;
+    if (nDown < 4) nDown = 4;
+    const double sc = (double)(nIn - 1) / (double)(nDown - 1);
+    const int window = (int)smoothFact;
+    double *dn = (double *)malloc(sizeof(double) * (size_t)C * (size_t)nDown);
+    for (int j = 0; j < C; ++j) {
+        double *b = x + (size_t)j * nIn;
+        out_smooth(b, nIn, window);
+        int64_t cursor = 0;
+        for (int64_t i = 0; i < nDown; ++i) { /* findInterpSegs(0..nIn-1, sc*i) + interp1linear */
+            const double site = sc * (double)i;
+            while (!(site < (double)(cursor + 1) || cursor == nIn - 2)) ++cursor;
+            const double width = (double)(cursor + 1) - (double)cursor;
+            const double t = (site - (double)cursor) / width;
+            dn[(size_t)j * nDown + i] = b[cursor] + (b[cursor + 1] - b[cursor]) * t;
+        }
+    }
+    *nDownOut = nDown;
+    return dn;
+}
+
+/* natural splines of every row of x[C][n] evaluated at nUser uniform sites of the unit interval (ba.cpp:1873-1919) */
+static double *out_reinterp(const double *x, int C, int64_t n, int64_t nUser, double tfact)
+{
+    const double c1 = 1. / (double)(n - 1), c2 = 1. / (double)(nUser - 1);
+    double *g1 = (double *)malloc(sizeof(double) * (size_t)n), *g2 = (double *)malloc(sizeof(double) * (size_t)nUser);
+    for (int64_t i = 0; i < n; ++i) g1[i] = c1 * (double)i;
+    for (int64_t i = 0; i < nUser; ++i) g2[i] = c2 * (double)i;
+    int32_t *sg = (int32_t *)malloc(sizeof(int32_t) * (size_t)nUser);
+    double *tu = (double *)malloc(sizeof(double) * (size_t)nUser);
+    double *e1 = (double *)malloc(sizeof(double) * (size_t)nUser), *e2 = (double *)malloc(sizeof(double) * (size_t)nUser);
+    bo_find_interp_segs(g1, n, g2, nUser, sg, tu);
+    double *up = (double *)malloc(sizeof(double) * (size_t)C * (size_t)nUser);
+    double *c = (double *)calloc((size_t)4 * (size_t)n, sizeof(double));
+    for (int j = 0; j < C; ++j) {
+        memset(c, 0, sizeof(double) * 4 * (size_t)n);
+        bo_spline_coeffs(x + (size_t)j * n, n, c, 0);
+        bo_interp1_spline(c, n, sg, tu, nUser, tfact, up + (size_t)j * nUser, e1, e2);
+    }
+    free(c); free(g1); free(g2); free(sg); free(tu); free(e1); free(e2);
+    return up;
+}
+
+int bo_output(const batotp_problem *prob, const batotp_output_params *prm, const bo_path *p, const double *fwd_s, int64_t n_fwd,
+              double t_step, double **out, int32_t *n_cart_out, int32_t *n_trq_out, int64_t *n_out, double *sres_out)
 {
     const int nJ = prm->n_joints;
-    if (nJ < 1 || nJ > p->n_theta || n_fwd < 4) return -1;
+    const int cable = prm->path_type == BATOTP_PATH_CART && prob->robot_type == BATOTP_ROBOT_CSPR3DOF && nJ == 3 && p->n_cart == 3 &&
+                      (prob->flags & BATOTP_F_TRQ_ON) && (prob->flags & BATOTP_F_PARALLEL);
+    const int joint = (prm->path_type == BATOTP_PATH_JOINT || prm->path_type == 0) && !(prob->flags & BATOTP_F_TRQ_ON);
+    if (nJ < 1 || nJ > p->n_theta || n_fwd < 4 || (!cable && !joint)) return -1;
+    const int nC = cable ? 3 : 0, nT = cable ? 3 : 0, C = nJ + nC + nT;
     double outRes = prm->out_res, smoothFact = prm->out_smooth_fact;
     const double outResUser = outRes;
     int reinterp = 0;
@@ -88,63 +138,79 @@ int bo_output(const batotp_output_params *prm, const bo_path *p, const double *f
     bo_interp1_spline(cS, n_fwd, seg, tau, nOut, p->sres / smoothFact, sOut, d1, d2);
     free(cS);
 
-    /* joint values at those s */
+    /* path samples at those s: joint rows (JOINT path) or Cartesian rows + cable lengths (CART path) */
     bo_find_interp_segs(p->sC, p->n, sOut, nOut, seg, tau);
     int64_t n = nOut;
-    double *th = (double *)malloc(sizeof(double) * (size_t)nJ * (size_t)n);
-    for (int j = 0; j < nJ; ++j)
-        bo_interp1_spline(p->coef + (size_t)j * 4 * (size_t)p->n, p->n, seg, tau, nOut, outRes, th + (size_t)j * n, d1, d2);
-    free(seg); free(tau); free(sOut); free(d1); free(d2); free(tOut); free(tMVC);
-
-    if (smoothFact > 1.5) { /* ba.cpp:1838-1871 */
-        const int64_t nIn = n;
-        int64_t nDown = (int64_t)(int)((double)(nIn - 1) / smoothFact) + 1;
-        if (nDown < 4) nDown = 4;
-        const double sc = (double)(nIn - 1) / (double)(nDown - 1);
-        const int window = (int)smoothFact;
-        double *dn = (double *)malloc(sizeof(double) * (size_t)nJ * (size_t)nDown);
-        for (int j = 0; j < nJ; ++j) {
-            double *b = th + (size_t)j * nIn;
-            out_smooth(b, nIn, window);
-            int64_t cursor = 0;
-            for (int64_t i = 0; i < nDown; ++i) { /* findInterpSegs(0..nIn-1, sc*i) + interp1linear */
-                const double site = sc * (double)i;
-                while (!(site < (double)(cursor + 1) || cursor == nIn - 2)) ++cursor;
-                const double width = (double)(cursor + 1) - (double)cursor;
-                const double t = (site - (double)cursor) / width;
-                dn[(size_t)j * nDown + i] = b[cursor] + (b[cursor + 1] - b[cursor]) * t;
+    double *x = (double *)calloc((size_t)C * (size_t)n, sizeof(double));
+    if (!cable) {
+        for (int j = 0; j < nJ; ++j)
+            bo_interp1_spline(p->coef + (size_t)j * 4 * (size_t)p->n, p->n, seg, tau, nOut, outRes, x + (size_t)j * n, d1, d2);
+    } else {
+        for (int j = 0; j < nC; ++j)
+            bo_interp1_spline(p->coef + (size_t)(p->n_theta + j) * 4 * (size_t)p->n, p->n, seg, tau, nOut, outRes, x + (size_t)(nJ + j) * n, d1, d2);
+        for (int64_t i = 0; i < n; ++i) /* Robot::invKinCSPR3DOF, robot.cpp:243-278 */
+            for (int k = 0; k < 3; ++k) {
+                double sumSQ = 0.0;
+                for (int r = 0; r < 3; ++r) {
+                    const double dlt = x[(size_t)(nJ + r) * n + i] - prob->pmat[r * 3 + k];
+                    sumSQ += dlt * dlt;
+                }
+                x[(size_t)k * n + i] = sqrt(sumSQ);
             }
-        }
-        free(th);
-        th = dn;
-        n = nDown;
     }
 
+    if (cable) {
+        /* torque recomputation, parallel mechanism (ba.cpp:1744-1790): every site looks at the END of the previous
+         * segment of a natural spline through the output samples themselves */
+        const double tfact = outRes / smoothFact, vfact = 1.0 / tfact, afact = vfact * vfact;
+        for (int64_t i = 0; i < n; ++i) { seg[i] = (int32_t)(i - 1); tau[i] = 1; }
+        seg[0] = 0; tau[0] = 0;
+        double *c = (double *)calloc((size_t)4 * (size_t)n, sizeof(double));
+        double *cD2 = (double *)malloc(sizeof(double) * (size_t)nC * (size_t)n);
+        for (int j = 0; j < nJ + nC; ++j) {
+            memset(c, 0, sizeof(double) * 4 * (size_t)n);
+            bo_spline_coeffs(x + (size_t)j * n, n, c, 0);
+            bo_interp1_spline(c, n, seg, tau, n, tfact, x + (size_t)j * n, d1, d2); /* the values are re-evaluated too */
+            if (j >= nJ) memcpy(cD2 + (size_t)(j - nJ) * n, d2, sizeof(double) * (size_t)n);
+        }
+        (void)vfact; (void)afact;
+        free(c);
+        for (int64_t i = 0; i < n; ++i) {
+            /* Robot::dynCSPR3DOF (robot.cpp:487-517): a2 = -cartD2, a3 = 0, a4 = (0, 0, g) */
+            double b[3], th[3], ca[3], A[9], xs[3];
+            for (int j = 0; j < 3; ++j) {
+                const double a2 = -cD2[(size_t)j * n + i], a3 = 0.0, a4 = (j == 2) ? 9.81 : 0.0;
+                b[j] = a2 + a3 + a4;
+                ca[j] = x[(size_t)(nJ + j) * n + i];
+                th[j] = x[(size_t)j * n + i];
+            }
+            bo_cspr_setA(prob->pmat, th, ca, A);
+            bo_solve_lin_sys(3, A, b, xs);
+            for (int j = 0; j < 3; ++j) x[(size_t)(nJ + nC + j) * n + i] = xs[j];
+        }
+        free(cD2);
+    }
+    free(seg); free(tau); free(sOut); free(d1); free(d2); free(tOut); free(tMVC);
+
+    if (smoothFact > 1.5) { /* ba.cpp:1838-1871: joints, torques, Cartesian rows */
+        int64_t nDown;
+        double *dn = out_smooth_down(x, C, n, smoothFact, &nDown);
+        free(x);
+        x = dn;
+        n = nDown;
+    }
     if (reinterp) { /* ba.cpp:1873-1919 */
         int64_t nUser = (int64_t)(int)ceil(tLast / outResUser);
         if (nUser < 4) nUser = 4;
-        const double c1 = 1. / (double)(n - 1), c2 = 1. / (double)(nUser - 1);
-        double *g1 = (double *)malloc(sizeof(double) * (size_t)n), *g2 = (double *)malloc(sizeof(double) * (size_t)nUser);
-        for (int64_t i = 0; i < n; ++i) g1[i] = c1 * (double)i;
-        for (int64_t i = 0; i < nUser; ++i) g2[i] = c2 * (double)i;
-        int32_t *sg = (int32_t *)malloc(sizeof(int32_t) * (size_t)nUser);
-        double *tu = (double *)malloc(sizeof(double) * (size_t)nUser);
-        double *e1 = (double *)malloc(sizeof(double) * (size_t)nUser), *e2 = (double *)malloc(sizeof(double) * (size_t)nUser);
-        bo_find_interp_segs(g1, n, g2, nUser, sg, tu);
-        double *up = (double *)malloc(sizeof(double) * (size_t)nJ * (size_t)nUser);
-        double *c = (double *)calloc((size_t)4 * (size_t)n, sizeof(double));
-        for (int j = 0; j < nJ; ++j) {
-            memset(c, 0, sizeof(double) * 4 * (size_t)n);
-            bo_spline_coeffs(th + (size_t)j * n, n, c, 0);
-            bo_interp1_spline(c, n, sg, tu, nUser, outResUser, up + (size_t)j * nUser, e1, e2);
-        }
-        free(c); free(g1); free(g2); free(sg); free(tu); free(e1); free(e2);
-        free(th);
-        th = up;
+        double *up = out_reinterp(x, C, n, nUser, outResUser);
+        free(x);
+        x = up;
         n = nUser;
         outRes = outResUser;
     }
-    *theta_out = th;
+    *out = x;
+    *n_cart_out = nC;
+    *n_trq_out = nT;
     *n_out = n;
     *sres_out = outRes;
     return 0;

@@ -97,14 +97,26 @@ class ResampleCase:
         self.sres = float(k["sres"])
 
 
-def read_traj_out(path, n_joints):
-    """traj_out.dat as BA::trajWriteBIN writes it: float32 sres; int32 nPts; int32 1; float32 theta[nJ][nPts]; ..."""
+def read_traj_out(path, n_joints, n_cart):
+    """traj_out.dat as BA::trajWriteBIN writes it: float32 sres; int32 nPts; int32 1; float32 theta[nJ][nPts];
+    int32 hasCart; [float32 cart[nC][nPts]]; int32 hasTrq; [float32 trq[nJ][nPts]]"""
     raw = open(path, "rb").read()
     sres = np.frombuffer(raw, "<f4", 1, 0)[0]
     n = int(np.frombuffer(raw, "<i4", 1, 4)[0])
     assert int(np.frombuffer(raw, "<i4", 1, 8)[0]) == 1
-    theta = np.frombuffer(raw, "<f4", n_joints * n, 12).reshape(n_joints, n)
-    return sres, n, theta
+    pos = 12
+    theta = np.frombuffer(raw, "<f4", n_joints * n, pos).reshape(n_joints, n)
+    pos += 4 * n_joints * n
+    has_cart = int(np.frombuffer(raw, "<i4", 1, pos)[0])
+    pos += 4
+    cart = None
+    if has_cart:
+        cart = np.frombuffer(raw, "<f4", n_cart * n, pos).reshape(n_cart, n)
+        pos += 4 * n_cart * n
+    has_trq = int(np.frombuffer(raw, "<i4", 1, pos)[0])
+    pos += 4
+    trq = np.frombuffer(raw, "<f4", n_joints * n, pos).reshape(n_joints, n) if has_trq else None
+    return sres, n, theta, cart, trq
 
 
 def output_params(name):
@@ -127,10 +139,16 @@ def run_to_output(ctx, cases, extra_flags=0):
 
 def assert_output_equals_reference_file(case, out, k=0):
     """the trajectory of path k rounded to float32 = the reference binary's traj_out.dat, byte for byte"""
-    sres32, n, theta32 = read_traj_out(os.path.join(case.dir, "ref_traj_out.dat"), case.problem.n_joints)
+    sres32, n, theta32, cart32, trq32 = read_traj_out(os.path.join(case.dir, "ref_traj_out.dat"), case.problem.n_joints, case.problem.n_cart)
     assert int(out.n_pts[k]) == n, (case.name, int(out.n_pts[k]), n)
     assert np.float32(out.sres[k]) == sres32
-    assert out.theta(k).astype("<f4").tobytes() == theta32.tobytes(), case.name
+    rows = out.rows(k)
+    nT, nC = out.n_theta, out.n_cart
+    assert rows[:nT].astype("<f4").tobytes() == theta32.tobytes(), case.name + ": theta"
+    if nC:
+        assert cart32 is not None and rows[nT:nT + nC].astype("<f4").tobytes() == cart32.tobytes(), case.name + ": cart"
+    if out.n_trq:
+        assert trq32 is not None and rows[nT + nC:].astype("<f4").tobytes() == trq32.tobytes(), case.name + ": torques"
 
 
 def rr_trig(theta_samples0, theta_samples1):

@@ -20,7 +20,8 @@ def test_hip_output_matches_reference_traj_out(hip_ctx, oracle_ctx, name, flags)
     oo, ob = run_to_output(oracle_ctx, [case])
     assert_output_equals_reference_file(case, ho)
     assert int(ho.n_pts[0]) == int(oo.n_pts[0]) and ho.sres[0] == oo.sres[0]
-    assert_bit_equal(ho.theta(0), oo.theta(0), f"{name}: output trajectory (fp64)")
+    assert (ho.n_theta, ho.n_cart, ho.n_trq) == (oo.n_theta, oo.n_cart, oo.n_trq)
+    assert_bit_equal(ho.rows(0), oo.rows(0), f"{name}: output trajectory (fp64; joints, Cartesian rows, torques)")
     for x in (ho, oo):
         x.close()
     hb.close(); ob.close()
@@ -31,8 +32,31 @@ def _variants(base):
     out = []
     for out_res, smooth in ((base.integ_res, 1.0), (base.integ_res, 5.0), (base.integ_res * 0.8, 1.0), (base.integ_res * 0.8, 5.0),
                             (base.integ_res * 2.5, 4.0), (base.integ_res * 0.5, 9.0), (base.integ_res, 1.6)):
-        out.append(capi.OutputParams(base.n_joints, 0, base.integ_res, out_res, smooth))
+        out.append(capi.OutputParams(base.n_joints, base.path_type, base.integ_res, out_res, smooth))
     return out
+
+
+@pytest.mark.parametrize("name", ["synth_cspr_s3", "CSPR3DOF_par"])
+def test_cable_robot_every_branch_matches_the_oracle(hip_ctx, oracle_ctx, name):
+    """CART path of the 3-cable robot: Cartesian rows, cable lengths and recomputed cable tensions, every branch"""
+    case = Case(name)
+    base = output_params(name)
+    outs = []
+    for ctx in (hip_ctx, oracle_ctx):
+        b = capi.Batch(ctx, case.problem, [case.n, case.n], case.max_steps())
+        b.upload_knots(0, [case.y, case.y], [case.sres, case.sres])
+        b.optimize()
+        outs.append(b)
+    hb, ob = outs
+    for prm in _variants(base):
+        h, o = capi.Output(hb, prm, 0, 2), capi.Output(ob, prm, 0, 2)
+        what = f"{name} out_res={prm.out_res} smooth={prm.out_smooth_fact}"
+        assert (h.n_theta, h.n_cart, h.n_trq) == (3, 3, 3)
+        assert np.array_equal(h.n_pts, o.n_pts), what
+        for k in range(2):
+            assert_bit_equal(h.rows(k), o.rows(k), f"{what}: path {k}")
+        h.close(); o.close()
+    hb.close(); ob.close()
 
 
 def test_every_branch_and_a_ragged_batch_match_the_oracle(hip_ctx, oracle_ctx):
@@ -80,7 +104,7 @@ def test_chunked_output_equals_one_chunk(hip_lib, oracle_ctx, monkeypatch):
 def test_baseline_size_path_and_failed_paths(hip_ctx, oracle_ctx):
     """a 1e5-knot path (hundreds of thousands of output points) and a path whose sweep hit the curve capacity"""
     case = Case("synth_ur_s7_100k")
-    prm = capi.OutputParams(case.problem.n_joints, 0, case.problem.integ_res, 0.008, 5.0)
+    prm = capi.OutputParams(case.problem.n_joints, capi.PATH_JOINT, case.problem.integ_res, 0.008, 5.0)
     outs = []
     for ctx in (hip_ctx, oracle_ctx):
         b = capi.Batch(ctx, case.problem, [case.n], case.max_steps())

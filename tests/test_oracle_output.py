@@ -31,11 +31,11 @@ def test_cases_cover_both_branches():
 
 
 def test_unsupported_configuration_is_refused(octx):
-    case = Case("CSPR3DOF")  # torque constraints: the output stage would have to recompute torques
+    case = Case("CSPR3DOF")  # a cable robot run as a JOINT path: torques could not be recomputed the reference's way
     b = capi.Batch(octx, case.problem, [case.n], case.max_steps())
     b.upload_knots(0, [case.y], [case.sres])
     b.optimize()
-    prm = capi.OutputParams(case.problem.n_joints, 0, 0.01, 0.008, 5.0)
+    prm = capi.OutputParams(case.problem.n_joints, capi.PATH_JOINT, 0.01, 0.008, 5.0)
     with pytest.raises(capi.BatotpError):
         capi.Output(b, prm, 0, 1)
     b.close()
