@@ -289,15 +289,18 @@ def main():
 
     # ---- SURVEY.md 8f-2 beside the hot path: the output stage (constant-time trajectories from the forward curves)
     # of the first paths of the batch on the device; untimed side measurement
-    out_prm = capi.OutputParams(prob.n_joints, 0, prob.integ_res, 0.008, 5.0)
+    wcfg = WORKLOADS[args.workload]["cfg"]
+    out_prm = capi.OutputParams(prob.n_joints, capi.PATH_JOINT if wcfg["path_type"] == "JOINT" else capi.PATH_CART, prob.integ_res, 0.008, 5.0)
     hip_out_theta0 = None
-    if rank == 0 and not args.no_output and not (prob.flags & capi.F_TRQ_ON) and WORKLOADS[args.workload]["cfg"]["robot"] == "GENJNT":
+    covered = (wcfg["robot"] == "GENJNT" and not (prob.flags & capi.F_TRQ_ON)) or \
+              (wcfg["robot"] == "CSPR3DOF" and (prob.flags & capi.F_TRQ_ON) and (prob.flags & capi.F_PARALLEL))
+    if rank == 0 and not args.no_output and covered:
         n_out_paths = min(B, 512)
         best = None
         for _ in range(2):  # the second call finds the context's workspace allocated
             o = capi.Output(batch, out_prm, 0, n_out_paths)
             ms, pts = o.ms(), int(o.n_pts.sum())
-            hip_out_theta0 = o.theta(0)
+            hip_out_theta0 = o.rows(0)
             o.close()
             best = ms if best is None else min(best, ms)
         out["output_stage"] = {"paths": n_out_paths, "points": pts, "ms": best, "points_per_s": pts / (best * 1e-3),
@@ -343,7 +346,7 @@ def main():
             th0 = None
             if hip_out_theta0 is not None:
                 oo = capi.Output(b, out_prm, 0, 1)
-                th0 = oo.theta(0)
+                th0 = oo.rows(0)
                 oo.close()
             b.close()
             return dt, sum(nk), rr, th0
