@@ -55,6 +55,9 @@ struct batotp_ctx
    uint64_t rsEpoch = 0; // resample calls so far (a batotp_resampled is valid while its epoch is the current one)
    int device = 0;
    hipStream_t stream = nullptr;
+   hipStream_t stream2 = nullptr; // the per-knot evaluation (K3) runs here when overlap is on: nothing in the sweeps depends on it
+   hipEvent_t evJoin = nullptr;
+   int overlap = 0;
    int sweepGroup = 0; // lanes per path in the sweep kernel; 0 = automatic
    int pathsPerWave = 0; // 0 = automatic
 };
@@ -69,6 +72,7 @@ struct batotp_batch
    int64_t totalKnots = 0;
    std::vector<PathInfo> pinfo; // host mirror
    bool needPar = false;        // some path may run the parallel-mechanism torque branch
+   bool k3Pending = false;      // an overlapped per-knot evaluation may still be running on ctx->stream2
    bool compact = false;        // BATOTP_F_COMPACT_SPLINES: dElim holds the second derivatives, there is no dCoef
    bool kinDone = false, dynDone = false, sitesSet = false, revDone = false, trigSet = false;
 
@@ -184,6 +188,8 @@ extern "C" int batotp_hip_ctx_create(int device, batotp_ctx **out)
    e = hipSetDevice(device);
    if (e != hipSuccess) { delete c; return hipFail(e, "hipSetDevice"); }
    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming);
    if (e != hipSuccess) { delete c; return hipFail(e, "hipStreamCreate"); }
    int rc = uploadThomasTable();
    if (rc != BATOTP_OK) { hipStreamDestroy(c->stream); delete c; return rc; }
@@ -196,6 +202,8 @@ extern "C" int batotp_hip_ctx_destroy(batotp_ctx *ctx)
    if (!ctx) return BATOTP_OK;
    hipSetDevice(ctx->device);
    if (ctx->stream) hipStreamDestroy(ctx->stream);
+   if (ctx->stream2) hipStreamDestroy(ctx->stream2);
+   if (ctx->evJoin) hipEventDestroy(ctx->evJoin);
    for (Arena &a : ctx->ws)
       if (a.p) hipFree(a.p);
    delete ctx;
@@ -223,6 +231,7 @@ extern "C" int batotp_hip_synchronize(batotp_ctx *ctx)
    int rc = bind(ctx);
    if (rc) return rc;
    HIP_TRY(hipStreamSynchronize(ctx->stream));
+   HIP_TRY(hipStreamSynchronize(ctx->stream2));
    return BATOTP_OK;
 }
 
@@ -230,6 +239,13 @@ extern "C" int batotp_hip_set_sweep_group(batotp_ctx *ctx, int32_t lanes)
 {
    if (!ctx || !(lanes == 0 || lanes == 1 || lanes == 8 || lanes == 16 || lanes == 32)) return BATOTP_ERR_ARG;
    ctx->sweepGroup = lanes;
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_set_overlap(batotp_ctx *ctx, int32_t on)
+{
+   if (!ctx) return BATOTP_ERR_ARG;
+   ctx->overlap = on ? 1 : 0;
    return BATOTP_OK;
 }
 
@@ -291,6 +307,7 @@ extern "C" int batotp_hip_batch_destroy(batotp_batch *b)
 {
    if (!b) return BATOTP_OK;
    if (b->ctx) hipSetDevice(b->ctx->device);
+   if (b->ctx && b->k3Pending) hipStreamSynchronize(b->ctx->stream2);
    void *ptrs[] = {b->dP, b->dPinfo, b->dY, b->dSC, b->dCoef, b->dSamp, b->dDyn, b->dTrig, b->dMvc, b->dRev, b->dFwd, b->dRes, b->dStage, b->dSink, b->dElim, b->dKM, b->dUp};
    for (void *p : ptrs)
       if (p) hipFree(p);
@@ -574,6 +591,16 @@ extern "C" int batotp_hip_upload_curve(batotp_batch *b, int32_t path, const doub
 // ---------------------------------------------------------------------------------------------
 // the hot path
 // ---------------------------------------------------------------------------------------------
+static int joinK3(batotp_batch *b)
+{
+   if (b->k3Pending)
+   {
+      HIP_TRY(hipStreamSynchronize(b->ctx->stream2));
+      b->k3Pending = false;
+   }
+   return BATOTP_OK;
+}
+
 static void evStart(batotp_batch *b, int which) { hipEventRecord(b->ev[which][0], b->ctx->stream); }
 static void evStop(batotp_batch *b, int which) { hipEventRecord(b->ev[which][1], b->ctx->stream); b->evValid[which] = true; }
 
@@ -597,6 +624,7 @@ extern "C" int batotp_hip_precompute(batotp_batch *b, int32_t stage)
    const unsigned gridKnots = (unsigned)((b->totalKnots + bs - 1) / bs);
    for (int p = 0; p < b->B; ++p)
       if (b->pinfo[p].n < 4 || b->pinfo[p].sres_c == 0.0) return BATOTP_ERR_STATE; // knots not uploaded
+   if ((rc = joinK3(b))) return rc; // an overlapped per-knot evaluation still reads the splines
    if (stage == 0 || stage == 1) evStart(b, 1);
    if (stage == 0 || stage == 1)
    {
@@ -674,7 +702,17 @@ extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
    const int64_t sliceKnots = (int64_t)1 << 27; // x 8 lanes = 2^30 threads per launch
    const unsigned grid = (unsigned)((b->totalKnots + knotsPerBlock - 1) / knotsPerBlock);
    const size_t ldsBytes = grouped ? 0 : sizeof(double) * (size_t)bs * (size_t)(b->P.C * 4 + 2);
-   evStart(b, 2);
+   // overlap: K3 reads what the precompute wrote and nothing reads K3's output before the caller downloads it, so it
+   // can share the GPU with the sweeps (second stream, joined by get_results / synchronize / the next precompute)
+   const bool async = b->ctx->overlap != 0;
+   hipStream_t k3s = async ? b->ctx->stream2 : b->ctx->stream;
+   if ((rc = joinK3(b))) return rc;
+   if (async)
+   {
+      HIP_TRY(hipEventRecord(b->ctx->evJoin, b->ctx->stream));
+      HIP_TRY(hipStreamWaitEvent(k3s, b->ctx->evJoin, 0));
+   }
+   hipEventRecord(b->ev[2][0], k3s);
 #define LAUNCH_K3(F)                                                                                                                     \
    do {                                                                                                                                  \
       if (grouped)                                                                                                                       \
@@ -682,10 +720,10 @@ extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
          {                                                                                                                               \
             const int64_t cnt = (b->totalKnots - first) < sliceKnots ? (b->totalKnots - first) : sliceKnots;                            \
             hipLaunchKernelGGL(k_pointwise_grp<F>, dim3((unsigned)((cnt + knotsPerBlock - 1) / knotsPerBlock)), dim3(bs), 0,           \
-                               b->ctx->stream, b->P, b->dPinfo, b->B, b->dP, b->dSC, b->dCoef, b->dKM, b->dMvc, first,         \
+                               k3s, b->P, b->dPinfo, b->B, b->dP, b->dSC, b->dCoef, b->dKM, b->dMvc, first,         \
                                first + cnt);                                                                                             \
          }                                                                                                                               \
-      else hipLaunchKernelGGL(k_pointwise<F>, dim3(grid), dim3(bs), ldsBytes, b->ctx->stream, b->P, b->dPinfo, b->B, b->dP, b->dSC,      \
+      else hipLaunchKernelGGL(k_pointwise<F>, dim3(grid), dim3(bs), ldsBytes, k3s, b->P, b->dPinfo, b->B, b->dP, b->dSC,      \
                               b->dCoef, b->dKM, b->dMvc, b->totalKnots);                                                       \
    } while (0)
    switch (featureLevel(b))
@@ -697,9 +735,11 @@ extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
    default: LAUNCH_K3(3); break;
    }
 #undef LAUNCH_K3
-   evStop(b, 2);
+   hipEventRecord(b->ev[2][1], k3s);
+   b->evValid[2] = true;
    HIP_TRY(hipGetLastError());
-   HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+   if (async) b->k3Pending = true;
+   else HIP_TRY(hipStreamSynchronize(b->ctx->stream));
    return BATOTP_OK;
 }
 
@@ -795,6 +835,7 @@ extern "C" int batotp_hip_get_results(batotp_batch *b, batotp_path_result *out)
    if (!b || !out) return BATOTP_ERR_ARG;
    int rc = bind(b->ctx);
    if (rc) return rc;
+   if ((rc = joinK3(b))) return rc;
    HIP_TRY(hipMemcpyAsync(out, b->dRes, sizeof(batotp_path_result) * b->B, hipMemcpyDeviceToHost, b->ctx->stream));
    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
    return BATOTP_OK;
@@ -874,6 +915,7 @@ extern "C" int batotp_hip_download_mvc(batotp_batch *b, int32_t path, double *sd
    if (!b || path < 0 || path >= b->B) return BATOTP_ERR_ARG;
    int rc = bind(b->ctx);
    if (rc) return rc;
+   if ((rc = joinK3(b))) return rc;
    const PathInfo &pi = b->pinfo[path];
    const double *base = b->dMvc + pi.koff * 3;
    const size_t sz = sizeof(double) * (size_t)pi.n;

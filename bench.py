@@ -148,6 +148,8 @@ def main():
     ap.add_argument("--ppw", type=int, default=0, help="paths per wavefront in the sweep kernel (0 = automatic)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", action="store_true",
+                    help="run the per-knot evaluation (K3) beside the sweeps on a second stream (measured: slower, the SIMDs are already saturated)")
     ap.add_argument("--no-resample", action="store_true", help="skip the side measurement of the device path resampler")
     ap.add_argument("--no-output", action="store_true", help="skip the side measurement of the device output stage")
     ap.add_argument("--coefficient-rows", action="store_true",
@@ -177,6 +179,7 @@ def main():
     hip = capi.Context(capi.load_hip(), local_rank)  # raises if the HIP extension or the GPU is missing
     hip.set_sweep_group(args.group)
     hip.set_paths_per_wave(args.ppw)
+    hip.set_overlap(args.overlap)
 
     # ---- synthetic inputs: K distinct host-resampled paths per GPU, tiled so that consecutive paths
     # (the 64/G paths that share a wavefront) are all different

@@ -205,6 +205,10 @@ int  batotp_hip_set_sweep_group(batotp_ctx *ctx, int32_t lanes);
 /* tuning knob: paths per 64-lane wavefront in the sweep kernel, 1 .. 64/lanes (0 = automatic:
  * few paths are spread over more wavefronts, many paths fill every lane) */
 int  batotp_hip_set_paths_per_wave(batotp_ctx *ctx, int32_t n);
+/* tuning knob: with overlap on, batotp_hip_pointwise_mvc returns at once and its kernel shares the GPU with the
+ * sweeps that follow (second HIP stream; nothing in the sweeps reads its output); batotp_hip_get_results,
+ * batotp_hip_download_mvc, batotp_hip_synchronize and the next batotp_hip_precompute wait for it.  Default off. */
+int  batotp_hip_set_overlap(batotp_ctx *ctx, int32_t on);
 
 /* ---- path resampling before the hot path -------------------------------- */
 /* Replaces, for the path kinds listed below, everything BA::interpInputData does between loading

@@ -344,6 +344,7 @@ struct batotp_resampled {
     float ms;
 };
 
+int batotp_hip_set_overlap(batotp_ctx *ctx, int32_t on) { (void)on; return ctx ? BATOTP_OK : BATOTP_ERR_ARG; }
 int batotp_hip_ctx_trim(batotp_ctx *ctx) { return ctx ? BATOTP_OK : BATOTP_ERR_ARG; }
 
 int batotp_hip_resampled_destroy(batotp_resampled *r)

@@ -177,6 +177,27 @@ def test_pointwise_kernel_slices_batches_beyond_2_to_32_lanes(hip_lib, oracle_ct
     b.close()
 
 
+def test_overlapped_pointwise_evaluation_gives_the_same_results(hip_lib, oracle_ctx):
+    """set_overlap: the per-knot evaluation runs beside the sweeps on a second stream; every output is unchanged,
+    also when a batch is stepped repeatedly (the next precompute has to wait for it)"""
+    ctx = capi.Context(hip_lib, 0)
+    ctx.set_overlap(True)
+    for name in ("synth_ur_s2", "synth_cspr_s3"):
+        case = Case(name)
+        oo = run_pipeline(oracle_ctx, [case])[0]
+        for _ in range(2):
+            ho = run_pipeline(ctx, [case, case])
+            _compare(case, ho[0], oo)
+            _compare(case, ho[1], oo)
+    case = Case("synth_ur_s2")
+    b = capi.Batch(ctx, case.problem, [case.n], case.max_steps())
+    b.upload_knots(0, [case.y], [case.sres])
+    for _ in range(3):
+        b.precompute(0); b.pointwise_mvc(); b.sweep(-1); b.sweep(+1)
+    assert_bit_equal(np.stack(b.mvc(0)), run_pipeline(oracle_ctx, [case], details=False)[0]["mvc"], "mvc after repeated overlapped steps")
+    b.close()
+
+
 def test_edge_minimum_knots_and_short_sweep(hip_ctx, oracle_ctx):
     """4 knots (the minimum) and a path crossed in fewer than 4 steps (nPts<4 re-interpolation, ba.cpp:1171-1184)"""
     prob = capi.make_problem(2, 0, flags=capi.F_JNT_ACC_ON, jnt_vel_max=[1e3, 1e3], jnt_acc_max=[1e6, 1e6], integ_res=0.05)
