@@ -184,6 +184,9 @@ public:
    // configuration.  Returns 0 when the device resampler covers this configuration and `traj`
    // (batotp_hip_resample, include/batotp_hip.h), -1 when the host resampler has to be used.
    int exportResampleParams(const Traj &traj, void *batotp_resample_params_out) const;
+   // Extension: the first step of interpInputData (ba.cpp:100-127): drop samples with a repeated timestamp and take the
+   // input resolution from the timestamps.  To be called before exportResampleParams on freshly loaded data.
+   void dropRepeatedTimestamps(Traj &traj);
    // Extension: the output-stage parameters (struct batotp_output_params).  Returns 0 when the device output
    // stage covers this configuration (batotp_hip_output, include/batotp_hip.h), -1 when interpOutputData has
    // to run on the host.

@@ -164,7 +164,7 @@ int BA::exportResampleParams(const Traj &traj, void *out) const
    }
 
    if (_isAutoIntegRes || _isInterpOnly) return -1;
-   if (traj.timestamp.size() > 0 || traj.nPts < 4) return -1;
+   if (traj.nPts < 4) return -1; // (timestamps: call dropRepeatedTimestamps first; they only set traj.sres)
    if (_inputDecimFact > 1 || _smoothWindow > 1) return -1;
    if (_sWeights[1] + _sWeights[2] < 1e-8) return -1;
    if (_nJoints > BATOTP_MAX_JOINTS || _nCart > BATOTP_MAX_CART || _nCart < 3) return -1;
@@ -518,7 +518,10 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
    bool onDevice = _deviceResample;
    batotp_resample_params rsp;
    for (size_t p = 0; p < trajs.size() && onDevice; ++p)
+   {
+      dropRepeatedTimestamps(trajs[p]); // idempotent; prepareKnots would do the same first
       if (exportResampleParams(trajs[p], &rsp) != 0) onDevice = false;
+   }
    std::vector<double> sresKnots;
    if (onDevice)
    {

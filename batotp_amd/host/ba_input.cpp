@@ -46,8 +46,9 @@ int BA::interpInputData(Traj &traj)
    return 0;
 }
 
-// everything of interpInputData up to and including "traj.sC.clear()" (reference ba.cpp:97-297)
-int BA::prepareKnots(Traj &traj)
+// reference ba.cpp:100-127: samples whose timestamp repeats the previous one are dropped, the input resolution
+// follows from the timestamps.  Idempotent (the device path of optimizeBatch calls it before the resampler).
+void BA::dropRepeatedTimestamps(Traj &traj)
 {
    if (traj.timestamp.size() > 0)
    {
@@ -70,6 +71,12 @@ int BA::prepareKnots(Traj &traj)
       traj.sres = traj.tresInput;
       traj.sC = traj.timestamp;
    }
+}
+
+// everything of interpInputData up to and including "traj.sC.clear()" (reference ba.cpp:97-297)
+int BA::prepareKnots(Traj &traj)
+{
+   dropRepeatedTimestamps(traj);
 
    if (traj.nPts == 1)
    {

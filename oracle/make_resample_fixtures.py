@@ -58,9 +58,15 @@ def main():
             n_in = int(np.frombuffer(tb, "<i8", 1, 0)[0])
             sres_in = float(np.frombuffer(tb, "<f8", 1, 24)[0])
             traj_file = [f for f in os.listdir(d) if f.endswith(".dat") and f not in ("config.dat",) and not f.startswith("ref_")]
-            assert len(traj_file) == 1, (case, traj_file)
-            np.savez(os.path.join(d, "resample.npz"), params=np.frombuffer(raw[4:], np.uint8), traj_file=traj_file[0],
-                     n_in=n_in, sres_in=sres_in)
+            if len(traj_file) == 1:
+                np.savez(os.path.join(d, "resample.npz"), params=np.frombuffer(raw[4:], np.uint8), traj_file=traj_file[0],
+                         n_in=n_in, sres_in=sres_in)
+            else:
+                # text (CSV) input: keep the few taught points themselves, as the host reader delivers them
+                nJ, nC = (int(v) for v in np.frombuffer(tb, "<i8", 2, 8))
+                x = np.frombuffer(tb, "<f8", (nJ + nC) * n_in, 32).reshape(nJ + nC, n_in)
+                np.savez(os.path.join(d, "resample.npz"), params=np.frombuffer(raw[4:], np.uint8), traj_file="", n_in=n_in,
+                         sres_in=sres_in, x=x)
             made.append(case)
             print(f"{case:28s} n_in={n_in} -> N={N}")
     print("fixtures:", ", ".join(made))

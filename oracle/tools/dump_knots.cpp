@@ -26,6 +26,7 @@ int main(int argc, char **argv)
       //   taught.bin   : int64 n, int64 nJ, int64 nCart, double sres, double x[nJ+nCart][n] (absent rows zero)
       //   resample.bin : int32 supported (1/0), raw struct batotp_resample_params
       batotp_resample_params R;
+      ba.dropRepeatedTimestamps(tr);
       const int supported = ba.exportResampleParams(tr, &R) == 0 ? 1 : 0;
       FILE *g = fopen("resample.bin", "wb");
       fwrite(&supported, 4, 1, g); fwrite(&R, sizeof(R), 1, g);

@@ -84,14 +84,17 @@ class ResampleCase:
         self.params = capi.ResampleParams.from_buffer_copy(z["params"].tobytes())
         self.sres_in = float(z["sres_in"])
         nJ, nC = self.params.n_joints, self.params.n_cart
-        tres, theta, cart = pathgen.read_traj_bin(os.path.join(d, str(z["traj_file"])), nJ, nC)
         n = int(z["n_in"])
-        assert float(tres) == self.sres_in
-        self.x = np.zeros((nJ + nC, n))
-        if theta is not None:
-            self.x[:nJ] = theta
-        if cart is not None:
-            self.x[nJ:] = cart
+        if "x" in z.files:   # text input: the taught points are stored in the fixture
+            self.x = np.ascontiguousarray(z["x"])
+        else:
+            tres, theta, cart = pathgen.read_traj_bin(os.path.join(d, str(z["traj_file"])), nJ, nC)
+            assert float(tres) == self.sres_in
+            self.x = np.zeros((nJ + nC, n))
+            if theta is not None:
+                self.x[:nJ] = theta
+            if cart is not None:
+                self.x[nJ:] = cart
         k = np.load(os.path.join(d, "knots.npz"))
         self.y = np.ascontiguousarray(k["y"])
         self.sres = float(k["sres"])
