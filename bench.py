@@ -152,6 +152,7 @@ def main():
                     help="run the per-knot evaluation (K3) beside the sweeps on a second stream (measured: slower, the SIMDs are already saturated)")
     ap.add_argument("--no-resample", action="store_true", help="skip the side measurement of the device path resampler")
     ap.add_argument("--no-output", action="store_true", help="skip the side measurement of the device output stage")
+    ap.add_argument("--no-seven-dof", action="store_true", help="skip the GEN7DOF (7-DOF) measurement reported beside the default workload")
     ap.add_argument("--coefficient-rows", action="store_true",
                     help="keep four coefficients per knot and channel instead of the compact (value, second derivative) form")
     args = ap.parse_args()
@@ -369,12 +370,25 @@ def main():
         out["traversal_time_err_s"] = float(np.max(np.abs(res["t_total"][:m] - rows["t_total"][:m])))
         out["step_count_mismatches"] = int(np.count_nonzero(res["steps_fwd"][:m] != rows["steps_fwd"][:m]))
 
+    batch.close()
+    hip.trim()
+    hip.close()
     if rank == 0:
         if resample_info is not None:
             out["resample"] = resample_info
+        # BASELINE.json's target is worded for a 7-DOF robot at N = 100k: the same measurement on the GEN7DOF workload
+        # (child process, after this one has released the GPU memory), reported beside the UR6 line
+        if world == 1 and args.workload == "ur6" and not args.no_seven_dof:
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", "gen7", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                   "--no-resample", "--no-output", "--knots", str(args.knots)]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            try:
+                g = json.loads(r.stdout.strip().splitlines()[-1])
+                out["seven_dof"] = {"value": g["value"], "unit": g["unit"], "ms_per_step": g["ms_per_step"], "config": g["config"],
+                                    "kernel_ms": g["kernel_ms"], "steps_per_knot": g["steps_per_knot"], "roofline_frac": g["roofline"]["frac"]}
+            except Exception as e:  # the main line must not depend on the side measurement
+                out["seven_dof"] = {"error": f"{type(e).__name__}: {r.stderr[-300:]}"}
         print(json.dumps(out))
-    batch.close()
-    hip.close()
     if use_dist:
         dist.destroy_process_group()
 
