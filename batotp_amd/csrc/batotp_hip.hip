@@ -755,7 +755,8 @@ static void launchSweep(batotp_batch *b, SweepArgs &a)
       // register budget of the kernel admits 2 per SIMD).  The reverse sweep runs more bisection
       // iterations, whose count differs between the paths of a wavefront, so it prefers fewer
       // paths per wavefront than the forward sweep (measured, B = 4096: rev best at 2, fwd at 4).
-      ppw = (a.dir == -1) ? b->B / 2048 : b->B / 1024;
+      // rounded up: one path too many per wavefront costs little, a second round of wavefronts on the SIMDs costs a lot
+      ppw = (a.dir == -1) ? (b->B + 2047) / 2048 : (b->B + 1023) / 1024;
    }
    if (ppw < 1) ppw = 1;
    if (ppw > maxPpw) ppw = maxPpw;
