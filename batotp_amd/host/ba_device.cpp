@@ -598,6 +598,14 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
 
    batotp_problem prob;
    fillProblem(&prob);
+   {
+      // when the output stage runs on the device nothing on the host reads knot samples or coefficient rows: joint
+      // velocity/acceleration-only problems then keep their splines as (value, second derivative) pairs (same results,
+      // less than half the memory per path)
+      batotp_output_params probe;
+      if (_deviceOutput && exportOutputParams(&probe) == 0 && !_isTrqConOn && !_isCartVelConOn && !_isCartAccConOn)
+         prob.flags |= BATOTP_F_NO_SAMPLES | BATOTP_F_COMPACT_SPLINES;
+   }
    const int nIn = (int)(_nJoints + _nCart);
    const int64_t maxIntegSteps = (int64_t)std::floor(_maxIntegTime / _integRes) + 1;
    int64_t nMax = 0;
