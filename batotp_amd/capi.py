@@ -205,6 +205,7 @@ class Library:
             "batotp_hip_output_info": [P, C.POINTER(C.c_int64), D],
             "batotp_hip_output_channels": [P, C.POINTER(I32), C.POINTER(I32), C.POINTER(I32)],
             "batotp_hip_output_download": [P, I32, D],
+            "batotp_hip_output_download_all": [P, D],
             "batotp_hip_output_device": [P, C.POINTER(P), C.POINTER(C.c_int64)],
             "batotp_hip_output_ms": [P, C.POINTER(C.c_float)],
         }
@@ -349,6 +350,17 @@ class Output:
         out = np.empty((self.n_rows, int(self.n_pts[k])), dtype=np.float64)
         if out.size:
             self.L.check(self.lib.batotp_hip_output_download(self.handle, k, _dptr(out)), "output_download")
+        return out
+
+    def all_rows(self):
+        """every path of the range from one device-to-host copy: list of [n_rows][n_pts] arrays"""
+        flat = np.empty(int(self.n_pts.sum()) * self.n_rows, dtype=np.float64)
+        if flat.size:
+            self.L.check(self.lib.batotp_hip_output_download_all(self.handle, _dptr(flat)), "output_download_all")
+        out, at = [], 0
+        for n in self.n_pts:
+            out.append(flat[at: at + int(n) * self.n_rows].reshape(self.n_rows, int(n)))
+            at += int(n) * self.n_rows
         return out
 
     def theta(self, k: int) -> np.ndarray:

@@ -700,7 +700,7 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
       const std::chrono::steady_clock::time_point tOut0 = std::chrono::steady_clock::now();
       double kernelMs = 0;
       const size_t range = 1024;
-      std::vector<double> flatTh;
+      std::vector<double> flatAll;
       std::vector<int64_t> nPtsOut;
       std::vector<double> sresOut;
       for (size_t k0 = 0; k0 < live.size(); k0 += range)
@@ -715,6 +715,15 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
          float ms = 0;
          batotp_hip_output_ms(og.o, &ms);
          kernelMs += ms;
+         int32_t nTh = 0, nCa = 0, nTq = 0;
+         batotp_hip_output_channels(og.o, &nTh, &nCa, &nTq);
+         const size_t rows = (size_t)(nTh + nCa + nTq);
+         size_t rangePts = 0;
+         for (size_t q = 0; q < cnt; ++q) rangePts += (size_t)nPtsOut[q];
+         flatAll.resize(rangePts * rows);
+         rc = batotp_hip_output_download_all(og.o, flatAll.data()); // one copy for the whole range of paths
+         if (rc) return fail("output_download_all", rc);
+         size_t at = 0;
          for (size_t q = 0; q < cnt; ++q)
          {
             const size_t k = k0 + q;
@@ -723,23 +732,19 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
             if ((r.status_rev | r.status_fwd) & BATOTP_ST_MAX_INTEG_TIME) setErrorOptimization(MAX_INTEGRATION_TIME);
             const int64_t n = nPtsOut[q];
             if (n == 0) { ok[live[k]] = 0; continue; }
-            int32_t nTh = 0, nCa = 0, nTq = 0;
-            batotp_hip_output_channels(og.o, &nTh, &nCa, &nTq);
-            const size_t rows = (size_t)(nTh + nCa + nTq);
-            flatTh.resize((size_t)n * rows);
-            rc = batotp_hip_output_download(og.o, (int32_t)q, flatTh.data());
-            if (rc) return fail("output_download", rc);
+            const std::vector<double>::const_iterator flatTh0 = flatAll.begin() + at;
+            at += (size_t)n * rows;
             t.theta.assign(_nJoints, std::vector<double>());
-            for (unsigned int j = 0; j < _nJoints; ++j) t.theta[j].assign(flatTh.begin() + (size_t)j * n, flatTh.begin() + (size_t)(j + 1) * n);
+            for (unsigned int j = 0; j < _nJoints; ++j) t.theta[j].assign(flatTh0 + (size_t)j * n, flatTh0 + (size_t)(j + 1) * n);
             t.trq.clear();
             if (nCa > 0)
             {
                // cable robot: Cartesian rows and recomputed cable tensions come with the joints
                t.cart.assign(_nCart, std::vector<double>());
-               for (int j = 0; j < nCa; ++j) t.cart[j].assign(flatTh.begin() + (size_t)(nTh + j) * n, flatTh.begin() + (size_t)(nTh + j + 1) * n);
+               for (int j = 0; j < nCa; ++j) t.cart[j].assign(flatTh0 + (size_t)(nTh + j) * n, flatTh0 + (size_t)(nTh + j + 1) * n);
                t.trq.assign(_nJoints, std::vector<double>());
                for (int j = 0; j < nTq; ++j)
-                  t.trq[j].assign(flatTh.begin() + (size_t)(nTh + nCa + j) * n, flatTh.begin() + (size_t)(nTh + nCa + j + 1) * n);
+                  t.trq[j].assign(flatTh0 + (size_t)(nTh + nCa + j) * n, flatTh0 + (size_t)(nTh + nCa + j + 1) * n);
             }
             else
             {

@@ -296,6 +296,8 @@ int  batotp_hip_output_info(batotp_output *o, int64_t *n_pts /* [n_paths] */, do
 int  batotp_hip_output_channels(batotp_output *o, int32_t *n_theta, int32_t *n_cart, int32_t *n_trq);
 /* trajectory of path path0 + k: rows[n_theta + n_cart + n_trq][n_pts[k]] */
 int  batotp_hip_output_download(batotp_output *o, int32_t k, double *rows);
+/* all trajectories of the range in one copy: path after path, each [n_theta + n_cart + n_trq][n_pts] */
+int  batotp_hip_output_download_all(batotp_output *o, double *rows);
 /* device pointer of all trajectories, path after path, each [n_theta + n_cart + n_trq][n_pts] */
 int  batotp_hip_output_device(batotp_output *o, const double **theta_dev, int64_t *n_doubles);
 /* milliseconds of the stage's kernels (HIP events on the context's stream) */

@@ -537,6 +537,15 @@ int batotp_hip_output_download(batotp_output *o, int32_t k, double *theta)
     return BATOTP_OK;
 }
 
+int batotp_hip_output_download_all(batotp_output *o, double *rows)
+{
+    int64_t total;
+    if (!o || !rows) return BATOTP_ERR_ARG;
+    total = o->off[o->n_paths - 1] + o->n[o->n_paths - 1] * o->nJ;
+    memcpy(rows, o->theta, sizeof(double) * (size_t)total);
+    return BATOTP_OK;
+}
+
 int batotp_hip_output_device(batotp_output *o, const double **theta_dev, int64_t *n_doubles)
 {
     if (!o || !theta_dev) return BATOTP_ERR_ARG;
