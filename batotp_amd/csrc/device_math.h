@@ -45,15 +45,16 @@ __device__ __forceinline__ int dpp_mov(int v)
 __device__ __forceinline__ double vmin_f64(double a, double b)
 {
    double r;
-   // the trailing s_nop supplies the 2 wait states a DPP read of the result needs: hipcc does not
-   // pad hazards of instructions inside an asm statement (cdna_hip_programming.md 5.7 item 2)
-   asm("v_min_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+   // no trailing s_nop: the wait states a DPP read of the result needs are padded by hipcc's hazard recogniser, which
+   // treats the asm statement as a VALU write of %0 (checked in the ISA of every reduction); only hazards between
+   // instructions INSIDE one asm statement are left to the author (cdna_hip_programming.md 5.7 item 2)
+   asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
    return r;
 }
 __device__ __forceinline__ double vmax_f64(double a, double b)
 {
    double r;
-   asm("v_max_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+   asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
    return r;
 }
 
@@ -79,6 +80,47 @@ __device__ __forceinline__ double grp_max(double v)
    if (G == 16) v = vmax_f64(v, dpp_mov<DPP_ROW_MIRROR>(v));
    return v;
 }
+// min over the group of h and max over the group of l in one interleaved sequence: the two chains are independent,
+// so alternating them halves the number of hazard stalls: the DPP move that reads a v_min / v_max result needs two wait
+// states after it; hipcc's hazard recogniser pads what is missing AFTER an asm statement (checked in the ISA: it
+// inserts the s_nop itself), only hazards INSIDE one asm statement are the author's business.
+__device__ __forceinline__ double vmin_f64_raw(double a, double b)
+{
+   double r;
+   asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+   return r;
+}
+__device__ __forceinline__ double vmax_f64_raw(double a, double b)
+{
+   double r;
+   asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+   return r;
+}
+template <int G>
+__device__ __forceinline__ void grp_min_max(double &h, double &l)
+{
+   if (G == 1) return;
+   double hd = dpp_mov<DPP_QUAD_XOR1>(h);
+   double ld = dpp_mov<DPP_QUAD_XOR1>(l);
+   h = vmin_f64_raw(h, hd);
+   l = vmax_f64_raw(l, ld);
+   hd = dpp_mov<DPP_QUAD_XOR2>(h);
+   ld = dpp_mov<DPP_QUAD_XOR2>(l);
+   h = vmin_f64_raw(h, hd);
+   l = vmax_f64_raw(l, ld);
+   hd = dpp_mov<DPP_ROW_HALF_MIRROR>(h);
+   ld = dpp_mov<DPP_ROW_HALF_MIRROR>(l);
+   h = vmin_f64_raw(h, hd);
+   l = vmax_f64_raw(l, ld);
+   if (G == 16)
+   {
+         hd = dpp_mov<DPP_ROW_MIRROR>(h);
+      ld = dpp_mov<DPP_ROW_MIRROR>(l);
+      h = vmin_f64_raw(h, hd);
+      l = vmax_f64_raw(l, ld);
+   }
+}
+
 template <int G>
 __device__ __forceinline__ int grp_or(int v)
 {

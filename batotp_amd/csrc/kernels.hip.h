@@ -940,8 +940,8 @@ __device__ __forceinline__ bool verify_second_order(Pt<G, FEAT, UNI> &t, int j, 
    }
    else
    {
-      Hred = grp_min<Pt<G, FEAT, UNI>::RED>(force ? -kInf : H);
-      L = grp_max<Pt<G, FEAT, UNI>::RED>(L);
+      Hred = force ? -kInf : H;
+      grp_min_max<Pt<G, FEAT, UNI>::RED>(Hred, L);
    }
    t.sddotH = Hred;
    t.sddotL = L;
