@@ -122,3 +122,23 @@ def test_chunked_resampling_equals_one_chunk(hip_lib, oracle_ctx, monkeypatch):
     o = capi.Resampled(oracle_ctx, c.params, xs, sr)
     _same(h, o, "chunked cspr batch")
     assert_bit_equal(h.knots(4), c.y, "last path of a chunked batch")
+
+
+def test_knots_of_an_older_resample_call_are_refused(hip_lib):
+    """the knots live in a workspace the context reuses: after the next resample call (or ctx_trim) the older object
+    answers BATOTP_ERR_STATE instead of handing out memory that now belongs to someone else"""
+    c = ResampleCase("synth_gen7dof_s1_vel")
+    ctx = capi.Context(hip_lib, 0)
+    first = capi.Resampled(ctx, c.params, [c.x], [c.sres_in])
+    assert_bit_equal(first.knots(0), c.y, "first call")
+    second = capi.Resampled(ctx, c.params, [c.x, c.x], [c.sres_in] * 2)
+    with pytest.raises(capi.BatotpError):
+        first.knots(0)
+    with pytest.raises(capi.BatotpError):
+        first.device_ptr()
+    assert_bit_equal(second.knots(1), c.y, "second call")
+    ctx.trim()
+    with pytest.raises(capi.BatotpError):
+        second.knots(0)
+    third = capi.Resampled(ctx, c.params, [c.x], [c.sres_in])   # the workspaces are allocated again on demand
+    assert_bit_equal(third.knots(0), c.y, "after trim")
