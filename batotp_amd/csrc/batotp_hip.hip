@@ -701,7 +701,8 @@ extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
    const int64_t knotsPerBlock = grouped ? K3G_BLOCK / 8 : K3_BLOCK;
    const int64_t sliceKnots = (int64_t)1 << 27; // x 8 lanes = 2^30 threads per launch
    const unsigned grid = (unsigned)((b->totalKnots + knotsPerBlock - 1) / knotsPerBlock);
-   const size_t ldsBytes = grouped ? 0 : sizeof(double) * (size_t)bs * (size_t)(b->P.C * 4 + 2);
+   // (compact splines read their pair rows directly: no LDS tile, which would only cap the occupancy)
+   const size_t ldsBytes = (grouped || b->compact) ? 0 : sizeof(double) * (size_t)bs * (size_t)(b->P.C * 4 + 2);
    // overlap: K3 reads what the precompute wrote and nothing reads K3's output before the caller downloads it, so it
    // can share the GPU with the sweeps (second stream, joined by get_results / synchronize / the next precompute)
    const bool async = b->ctx->overlap != 0;
