@@ -1597,7 +1597,10 @@ __global__ void __launch_bounds__(K4_BLOCK, (FEAT <= 1 && G > 1) ? BK_SWEEP_WPE 
          // reverse sweep only (descending addresses; measured: -17 % there, +5 % on the forward sweep,
          // whose ascending walk finds the next lines already on their way): consume last stage's touch,
          // issue the next one
-         if (dir == -1)
+#ifndef BK_TOUCH_DIRS
+#define BK_TOUCH_DIRS 1 /* 0: never, 1: reverse sweep only, 2: both sweeps */
+#endif
+         if (BK_TOUCH_DIRS == 2 || (BK_TOUCH_DIRS == 1 && dir == -1))
          {
             t.sink += pf;
             pf = touch_ahead(t, j);
