@@ -1,8 +1,11 @@
 // kernels.hip.h -- the gfx950 kernels of the batotp hot path (included by batotp_hip.hip).
 //
 //   k_sites / k_spline / k_samples / k_dynamics   per-knot precompute (K1, K2)
-//   k_pointwise                                    per-knot max admissible sdot (K3)
-//   k_sweep<G>                                     reverse / forward sweep, G lanes per path (K4)
+//   k_spline_pairs / k_spline_sol / k_spline_series  the same Thomas solve leaving second derivatives (compact
+//                                                  splines of the hot path; resampler; output stage)
+//   k_pointwise, k_pointwise_grp                   per-knot max admissible sdot (K3)
+//   k_sweep<G, FEAT, UNI>                          reverse / forward sweep, G lanes per path (K4)
+// (resample.hip.h and output.hip.h hold the kernels of the stages before and after the hot path)
 //
 // Reference routines restated here (file:line under /root/reference/batotp):
 //   Spline::getSplineCoeffs spline.cpp:168-211, solveTriDiagNatural spline.cpp:252-276,
@@ -24,6 +27,8 @@
 //                           dynamics row r the four channels (a1_r, a2_r, a3_r, a4_r).
 //   samp  [Cin][3][N]       value, d/ds, d2/ds2 at the output sites
 //   dyn   [4][d][N]         a1..a4 at the knots
+//   km    [N][Cin][2]       compact splines (BATOTP_F_COMPACT_SPLINES, FEAT == -1): (knot value, second derivative)
+//                           pairs, knot-major; replaces yin, coef and the Thomas scratch
 //   curve [cap] double2     (s, sdot) of a sweep; the reverse sweep fills its curve from the end so
 //                           that it is ascending in s, as the reference leaves it after std::reverse
 #pragma once
