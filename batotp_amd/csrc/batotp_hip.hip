@@ -702,7 +702,11 @@ extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
    const int64_t sliceKnots = (int64_t)1 << 27; // x 8 lanes = 2^30 threads per launch
    const unsigned grid = (unsigned)((b->totalKnots + knotsPerBlock - 1) / knotsPerBlock);
    // (compact splines read their pair rows directly: no LDS tile, which would only cap the occupancy)
-   const size_t ldsBytes = (grouped || b->compact) ? 0 : sizeof(double) * (size_t)bs * (size_t)(b->P.C * 4 + 2);
+   // LDS staging of the coefficient rows (coalesced copy, then conflict-free reads) is available but off: measured, it
+   // is the occupancy it costs that matters -- UR6 rows (C = 6) 90 ms with the tile, 60 ms reading the rows directly;
+   // cable robot (C = 18) 125 vs 53 ms.  BATOTP_K3_TILE=1 switches it on for experiments.
+   const bool useTile = !grouped && !b->compact && getenv("BATOTP_K3_TILE") != nullptr;
+   const size_t ldsBytes = useTile ? sizeof(double) * (size_t)bs * (size_t)(b->P.C * 4 + 2) : 0;
    // overlap: K3 reads what the precompute wrote and nothing reads K3's output before the caller downloads it, so it
    // can share the GPU with the sweeps (second stream, joined by get_results / synchronize / the next precompute)
    const bool async = b->ctx->overlap != 0;
@@ -725,7 +729,7 @@ extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
                                first + cnt);                                                                                             \
          }                                                                                                                               \
       else hipLaunchKernelGGL(k_pointwise<F>, dim3(grid), dim3(bs), ldsBytes, k3s, b->P, b->dPinfo, b->B, b->dP, b->dSC,      \
-                              b->dCoef, b->dKM, b->dMvc, b->totalKnots);                                                       \
+                              b->dCoef, b->dKM, b->dMvc, b->totalKnots, useTile ? 1 : 0);                                      \
    } while (0)
    switch (featureLevel(b))
    {

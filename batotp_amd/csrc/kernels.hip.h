@@ -1245,7 +1245,7 @@ __global__ void __launch_bounds__(K3_BLOCK) k_pointwise(DevProblem P, const Path
                                                         const DevProblem *__restrict__ dP,
                                                         const double *__restrict__ sC, const double *__restrict__ coef,
                                                         const double *__restrict__ km,
-                                                        double *__restrict__ mvc, int64_t total)
+                                                        double *__restrict__ mvc, int64_t total, int useTile)
 {
    __shared__ double lim[6][8];
    extern __shared__ double tile[]; // K3_BLOCK rows of C*4 doubles, padded by 2 doubles per row
@@ -1257,7 +1257,9 @@ __global__ void __launch_bounds__(K3_BLOCK) k_pointwise(DevProblem P, const Path
    const int64_t g0 = (int64_t)blockIdx.x * K3_BLOCK;
    const int rowD = P.C * 4, rowPad = rowD + 2;
    const int rowsHere = (total - g0) < K3_BLOCK ? (int)(total - g0) : K3_BLOCK;
-   if (FEAT >= 0) // (compact splines: adjacent lanes read adjacent knots of the channel-major arrays directly)
+   // (compact splines read their pair rows directly; so do wide rows -- torque problems -- whose tile would leave
+   // room for one wavefront per SIMD only: useTile is the host's choice)
+   if (FEAT >= 0 && useTile)
    {
       const Coef4 *__restrict__ srcp = reinterpret_cast<const Coef4 *>(coef + g0 * rowD);
       const int chunks = rowsHere * P.C;
@@ -1295,7 +1297,7 @@ __global__ void __launch_bounds__(K3_BLOCK) k_pointwise(DevProblem P, const Path
    else
    {
       const int rowLocal = (int)threadIdx.x - (i - t.segC); // the last knot of a path uses the previous row
-      const double *row = (rowLocal >= 0) ? (tile + rowLocal * rowPad) : (t.coef + (unsigned)(t.segC * rowD));
+      const double *row = (useTile && rowLocal >= 0) ? (tile + rowLocal * rowPad) : (t.coef + (unsigned)(t.segC * rowD));
       eval_partials_row(t, 0, row);
    }
    double sdot = t.sdotCap;

@@ -141,7 +141,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="ur6", choices=sorted(WORKLOADS))
     ap.add_argument("--paths", type=int, default=0,
-                    help="paths per GPU (0 = what fills the GPU for the workload: 16384 ur6, 11264 gen7, 1024 cspr)")
+                    help="paths per GPU (0 = what fills the GPU for the workload: 16384 ur6, 11264 gen7, 2048 cspr)")
     ap.add_argument("--knots", type=int, default=100000, help="target knots per path")
     ap.add_argument("--distinct", type=int, default=32, help="distinct seeded paths per GPU (tiled to --paths)")
     ap.add_argument("--group", type=int, default=0, help="lanes per path in the sweep kernel (0 = automatic)")
@@ -158,7 +158,7 @@ def main():
     args = ap.parse_args()
     if args.paths <= 0:
         # ur6 / gen7: 8 paths in each of ~2048 wavefronts (2 per SIMD) is where the sweep kernel peaks, memory permitting
-        args.paths = {"ur6": 16384, "gen7": 11264, "cspr": 1024}[args.workload]
+        args.paths = {"ur6": 16384, "gen7": 11264, "cspr": 2048}[args.workload]
 
     import torch
     import torch.distributed as dist
