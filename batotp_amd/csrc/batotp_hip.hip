@@ -99,7 +99,12 @@ static int devAlloc(batotp_batch *b, void **p, size_t bytes)
 {
    if (bytes == 0) bytes = 8;
    hipError_t e = hipMalloc(p, bytes);
-   if (e != hipSuccess) { hipFail(e, "hipMalloc"); return BATOTP_ERR_ALLOC; }
+   if (e != hipSuccess)
+   {
+      hipFail(e, "hipMalloc");
+      (void)hipGetLastError(); // reported; do not leave the sticky error for a later, unrelated hipGetLastError() check
+      return BATOTP_ERR_ALLOC;
+   }
    b->bytes += (int64_t)bytes;
    return BATOTP_OK;
 }

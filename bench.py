@@ -195,11 +195,23 @@ def main():
     if (prob.flags & capi.F_NO_SAMPLES) and not args.coefficient_rows:
         prob.flags |= capi.F_COMPACT_SPLINES  # same results, half the spline bytes per knot: room for more paths per GPU
     B = args.paths
-    n_knots = [base[p % K][0].shape[1] for p in range(B)]
-    total_knots = int(sum(n_knots))
     C = WORKLOADS[args.workload]["C"]
-    cap = int(max(n_knots) * {"ur6": 0.5, "gen7": 2.2, "cspr": 0.6}[args.workload]) + 1024
-    batch = capi.Batch(hip, prob, n_knots, cap)
+    while True:
+        n_knots = [base[p % K][0].shape[1] for p in range(B)]
+        total_knots = int(sum(n_knots))
+        cap = int(max(n_knots) * {"ur6": 0.5, "gen7": 2.2, "cspr": 0.6}[args.workload]) + 1024
+        try:
+            batch = capi.Batch(hip, prob, n_knots, cap)
+            break
+        except capi.BatotpError as e:
+            # the default sizes fill most of the 288 GB: on a GPU with less free memory run a smaller batch (reported in
+            # config.paths_per_gpu) rather than nothing
+            if "-5" not in str(e) and "Alloc" not in str(e) and "alloc" not in str(e) and "memory" not in str(e):
+                raise
+            if B <= 1024:
+                raise
+            B = max(1024, (B * 3 // 4) // 1024 * 1024)
+            print(f"bench: batch did not fit, retrying with {B} paths", file=sys.stderr)
     for p in range(B):
         y, sres = base[p % K][0], base[p % K][1]
         batch.upload_knots(p, [y], [sres])
