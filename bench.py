@@ -294,6 +294,17 @@ def main():
                    "regions": "K1+K2 precompute, K3 pointwise, K4 reverse+forward sweep", "parallelism": f"paths sharded x{world}"},
         "kernel_ms": {"precompute": kernel_ms[1], "pointwise_mvc": kernel_ms[2], "sweep_rev": kernel_ms[3], "sweep_fwd": kernel_ms[4]},
         "steps_per_knot": {"rev": steps_rev / total_knots, "fwd": steps_fwd / total_knots},
+        # the three timed regions with their algorithmic bytes per waypoint (compact (y, M) figures):
+        # R1 per-knot work (K1+K2+K3) 16*C + 24, R2 both sweeps 32*C + 16*(2*rho_rev + rho_fwd), R3 = R1 + R2
+        "regions": (lambda r1_ms, r2_ms, rho_r, rho_f: {
+            "R1_per_knot": {"ms": r1_ms, "waypoints_per_s": total_knots / (r1_ms * 1e-3), "bytes_per_waypoint": 16 * C + 24,
+                            "algorithmic_GBps": total_knots * (16 * C + 24) / (r1_ms * 1e-3) / 1e9},
+            "R2_sweeps": {"ms": r2_ms, "waypoints_per_s": total_knots / (r2_ms * 1e-3),
+                          "bytes_per_waypoint": 32 * C + 16 * (2 * rho_r + rho_f),
+                          "algorithmic_GBps": total_knots * (32 * C + 16 * (2 * rho_r + rho_f)) / (r2_ms * 1e-3) / 1e9},
+            "R3_total": {"ms": r1_ms + r2_ms, "waypoints_per_s": total_knots / ((r1_ms + r2_ms) * 1e-3),
+                         "bytes_per_waypoint": 48 * C + 24 + 16 * (2 * rho_r + rho_f)},
+        })(kernel_ms[1] + kernel_ms[2], kernel_ms[3] + kernel_ms[4], steps_rev / total_knots, steps_fwd / total_knots),
         "stage_evals_per_s": 7.0 * (steps_rev + steps_fwd) / ((kernel_ms[3] + kernel_ms[4]) * 1e-3),
         "hbm_bytes_resident": batch.nbytes(),
         "gathered_rows": int(gathered.shape[0]) if gathered is not None else 0,
