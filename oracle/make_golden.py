@@ -59,9 +59,23 @@ def shipped(robot_dir: str, subs=None):
     return build
 
 
-def synth_gen7dof(seed, n_coarse, **cfg):
+def with_repeats(x, every):
+    """repeat every `every`-th taught point and the last one (remClosePts has to drop them again; the repeated last
+    point takes its tail rule)"""
+    cols = []
+    for i in range(x.shape[1]):
+        cols.append(i)
+        if i % every == every - 1:
+            cols.append(i)
+    cols.append(x.shape[1] - 1)
+    return np.ascontiguousarray(x[:, cols])
+
+
+def synth_gen7dof(seed, n_coarse, repeat_every=0, **cfg):
     def build(work):
         th = pathgen.gen7dof_fine(seed, n_coarse)
+        if repeat_every:
+            th = with_repeats(th, repeat_every)
         pathgen.write_traj_bin(os.path.join(work, "path.dat"), 0.01, th, None)
         kw = dict(robot="GENJNT", is_parallel=0, n_joints=7, n_cart=3, traj_file="path.dat", is_bin=1, path_type="JOINT",
                   degrees=0, jnt_vel=[5] * 7, jnt_acc_on=1, jnt_acc=[10] * 7, integ_res=0.01, max_integ_time=200000.0,
@@ -83,9 +97,11 @@ def synth_ur(seed, n_coarse, **cfg):
     return build
 
 
-def synth_cspr(seed, n_coarse, **cfg):
+def synth_cspr(seed, n_coarse, repeat_every=0, **cfg):
     def build(work):
         ca = pathgen.cspr_fine(seed, n_coarse)
+        if repeat_every:
+            ca = with_repeats(ca, repeat_every)
         pathgen.write_traj_bin(os.path.join(work, "path.dat"), 0.005, None, ca)
         kw = dict(robot="CSPR3DOF", is_parallel=1, n_joints=3, n_cart=3, traj_file="path.dat", is_bin=1, path_type="CART",
                   degrees=0, jnt_vel=[4] * 3, jnt_acc_on=1, jnt_acc=[8] * 3, trq_on=1, trq_max=[12] * 3, trq_min=[1] * 3,
@@ -116,6 +132,9 @@ CASES = {
     "synth_ur_s2": (synth_ur(2, 80), True),
     "synth_cspr_s3": (synth_cspr(3, 20), True),
     "synth_cspr_s5": (synth_cspr(5, 60), True),
+    # taught paths with repeated points: remClosePts really removes something (also on the device resampler's path kinds)
+    "synth_gen7dof_s6_dup": (synth_gen7dof(6, 30, repeat_every=7), True),
+    "synth_cspr_s9_dup": (synth_cspr(9, 12, repeat_every=5), True),
     # BASELINE-size single paths: digest only (sha256 of the float32 curves + 1-in-64 samples)
     "synth_gen7dof_s4_50k": (synth_gen7dof(4, 871), False),
     "synth_ur_s7_100k": (synth_ur(7, 500), False),
