@@ -132,6 +132,7 @@ class ResampleParams(C.Structure):
         ("cart_norm_res", C.c_double), ("cart_norm_res2", C.c_double),
         ("jnt_thresh", C.c_double), ("cart_thresh", C.c_double),
         ("pmat", C.c_double * 9),
+        ("input_decim_fact", C.c_int32), ("smooth_window", C.c_int32),
     ]
 
 

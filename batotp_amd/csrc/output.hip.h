@@ -243,29 +243,7 @@ __global__ void k_out_trq(OutParams P, const OutPath *__restrict__ paths, int K,
    for (int j = 0; j < 3; ++j) o[(int64_t)(6 + j) * n1] = xs[j];
 }
 
-// smooth() (util.cpp:263-290) at one index: centred moving average of width w = 2*half + 1, shrinking windows
-// next to the ends, the end points themselves unchanged
-__device__ __forceinline__ double smooth_at(const double *__restrict__ x, int n, int half, int w, int i)
-{
-   if (i == 0 || i == n - 1) return x[i];
-   if (i < half)
-   {
-      const int span = 2 * i + 1;
-      double head = 0;
-      for (int j = 0; j < span; ++j) head += x[j];
-      return head / span;
-   }
-   if (i >= n - half)
-   {
-      const int r = n - 1 - i, span = 2 * r + 1;
-      double tail = 0;
-      for (int j = 0; j < span; ++j) tail += x[n - j - 1];
-      return tail / span;
-   }
-   double acc = 0;
-   for (int j = i - half; j < i + half + 1; ++j) acc += x[j];
-   return acc / w;
-}
+// (smooth_at: resample.hip.h)
 
 // moving average + linear down-sampling by the smoothing factor (ba.cpp:1838-1871): th2[R][n2] per path
 __global__ void k_out_down(OutParams P, const OutPath *__restrict__ paths, int K, const double *__restrict__ th1, double *__restrict__ th2,

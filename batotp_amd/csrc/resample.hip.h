@@ -103,6 +103,75 @@ __global__ void k_rs_remclose(RsParams P, RsPath *__restrict__ paths, int B, dou
    if (n < 4) pp.status |= RS_TOO_SHORT;
 }
 
+// smooth() (util.cpp:263-290) at one index: centred moving average of width w = 2*half + 1, shrinking windows
+// next to the ends, the end points themselves unchanged
+__device__ __forceinline__ double smooth_at(const double *__restrict__ x, int n, int half, int w, int i)
+{
+   if (i == 0 || i == n - 1) return x[i];
+   if (i < half)
+   {
+      const int span = 2 * i + 1;
+      double head = 0;
+      for (int j = 0; j < span; ++j) head += x[j];
+      return head / span;
+   }
+   if (i >= n - half)
+   {
+      const int r = n - 1 - i, span = 2 * r + 1;
+      double tail = 0;
+      for (int j = 0; j < span; ++j) tail += x[n - j - 1];
+      return tail / span;
+   }
+   double acc = 0;
+   for (int j = i - half; j < i + half + 1; ++j) acc += x[j];
+   return acc / w;
+}
+
+// input smoothing of the driving rows [c0, c0+cN) (ba.cpp:195-242 calls smooth() with window w on them); the other
+// rows are copied.  src -> dst, same layout; one lane per point
+__global__ void k_rs_smooth(RsParams P, const RsPath *__restrict__ paths, int B, const double *__restrict__ src, double *__restrict__ dst,
+                            int c0, int cN, int window, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   int lo = 0, hi = B - 1;
+   while (lo < hi)
+   {
+      const int mid = (lo + hi + 1) >> 1;
+      if (paths[mid].off <= g) lo = mid; else hi = mid - 1;
+   }
+   const RsPath pp = paths[lo];
+   const int i = (int)(g - pp.off), n = pp.n;
+   if (i >= n || pp.status) return;
+   int w = window < n ? window : n;
+   const int half = w / 2 + w % 2 - 1;
+   w = 2 * half + 1;
+   for (int c = 0; c < P.C; ++c)
+   {
+      const double *__restrict__ x = src + pp.off * P.C + (int64_t)c * n;
+      dst[pp.off * P.C + (int64_t)c * n + i] = (c >= c0 && c < c0 + cN) ? smooth_at(x, n, half, w, i) : x[i];
+   }
+}
+
+// decimate() (util.cpp:347-356) of every row: each w-th sample, always keeping the last one.  src (layout of `from`) ->
+// dst (layout of `to`, to[p].n = (from[p].n - 1)/w + 1); one lane per kept point
+__global__ void k_rs_decimate(RsParams P, const RsPath *__restrict__ from, const RsPath *__restrict__ to, int B, const double *__restrict__ src,
+                              double *__restrict__ dst, int w, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   int lo = 0, hi = B - 1;
+   while (lo < hi)
+   {
+      const int mid = (lo + hi + 1) >> 1;
+      if (to[mid].off <= g) lo = mid; else hi = mid - 1;
+   }
+   const int i = (int)(g - to[lo].off), nOut = to[lo].n, nIn = from[lo].n;
+   if (i >= nOut || to[lo].status) return;
+   const int pick = (i == nOut - 1 && w * (nOut - 1) + 1 != nIn) ? nIn - 1 : w * i;
+   for (int c = 0; c < P.C; ++c) dst[to[lo].off * P.C + (int64_t)c * nOut + i] = src[from[lo].off * P.C + (int64_t)c * nIn + pick];
+}
+
 // Robot::invKinCSPR3DOF (robot.cpp:243-278): cable lengths from the platform position; one lane per point
 __global__ void k_rs_invkin_cspr(RsParams P, const RsPath *__restrict__ paths, int B, double *__restrict__ x, int64_t total)
 {

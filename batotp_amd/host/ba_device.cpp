@@ -156,6 +156,7 @@ int BA::exportResampleParams(const Traj &traj, void *out) const
    R.theta_norm_res = _thetaNormRes; R.theta_norm_res2 = _thetaNormRes2;
    R.cart_norm_res = _cartNormRes; R.cart_norm_res2 = _cartNormRes2;
    R.jnt_thresh = _jntThresh; R.cart_thresh = _cartThresh;
+   R.input_decim_fact = (int32_t)_inputDecimFact; R.smooth_window = (int32_t)_smoothWindow;
    if (_robotType == CSPR3DOF)
    {
       const std::vector<std::vector<double>> &A = const_cast<Robot &>(myRobot).cableAnchors();
@@ -165,7 +166,6 @@ int BA::exportResampleParams(const Traj &traj, void *out) const
 
    if (_isAutoIntegRes || _isInterpOnly) return -1;
    if (traj.nPts < 4) return -1; // (timestamps: call dropRepeatedTimestamps first; they only set traj.sres)
-   if (_inputDecimFact > 1 || _smoothWindow > 1) return -1;
    if (_sWeights[1] + _sWeights[2] < 1e-8) return -1;
    if (_nJoints > BATOTP_MAX_JOINTS || _nCart > BATOTP_MAX_CART || _nCart < 3) return -1;
    const bool joint = _pathType == JOINT && _robotType == GENJNT && !_isCartVelConOn && !_isCartAccConOn;

@@ -216,9 +216,10 @@ int  batotp_hip_set_overlap(batotp_ctx *ctx, int32_t on);
  * BA::adjust_s passes (batotp/ba.cpp:412-638) with BA::interpSpecial (ba.cpp:651-781) and the
  * resampling BA::evalSplineFullTraj (ba.cpp:790-863), Robot::invKinCSPR3DOF (robot.cpp:243-278).
  * Supported: path_type JOINT on a robot without kinematic model (GENJNT) and path_type CART on the
- * cable robot (CSPR3DOF) with a joint constraint on; no timestamps, no decimation / smoothing, no
- * automatic integration resolution.  Anything else returns BATOTP_ERR_ARG: the caller keeps using
- * its host resampler for those. */
+ * cable robot (CSPR3DOF) with a joint constraint on, including the input decimation and smoothing of
+ * ba.cpp:195-242 (smooth / decimate, util.cpp:263-290,347-356); timestamps only set sres_in (the caller
+ * drops repeated ones first); no automatic integration resolution.  Anything else returns
+ * BATOTP_ERR_ARG: the caller keeps using its host resampler for those. */
 #define BATOTP_PATH_JOINT 1   /* reference batotp/ba.h pathType JOINT */
 #define BATOTP_PATH_CART  2
 
@@ -241,6 +242,8 @@ typedef struct batotp_resample_params {
     double   cart_norm_res, cart_norm_res2;   /* _cartNormRes,  _cartNormRes2                  */
     double   jnt_thresh, cart_thresh;         /* remClosePts thresholds                        */
     double   pmat[9];                /* cable exit points (CSPR3DOF), row-major 3x3            */
+    int32_t  input_decim_fact;       /* _inputDecimFact (values < 2: no decimation)            */
+    int32_t  smooth_window;          /* _smoothWindow                                          */
 } batotp_resample_params;
 
 typedef struct batotp_resampled batotp_resampled;

@@ -57,6 +57,54 @@ static void rs_rem_close(rs_traj *t, int c0, int cN, double thresh)
     }
 }
 
+/* smooth (util.cpp:263-290): centred moving average, shrinking windows at both ends */
+static void rs_smooth(double *x, int64_t n, int w)
+{
+    if (w > n) w = (int)n;
+    const int half = w / 2 + w % 2 - 1;
+    w = 2 * half + 1;
+    double *y = (double *)malloc(sizeof(double) * (size_t)n);
+    y[0] = x[0];
+    y[n - 1] = x[n - 1];
+    for (int i = 1; i < half; ++i) {
+        const int span = 2 * i + 1;
+        double head = 0, tail = 0;
+        for (int j = 0; j < span; ++j) { head += x[j]; tail += x[n - j - 1]; }
+        y[i] = head / span;
+        y[n - i - 1] = tail / span;
+    }
+    for (int64_t i = half; i < n - half; ++i) {
+        double acc = 0;
+        for (int64_t j = i - half; j < i + half + 1; ++j) acc += x[j];
+        y[i] = acc / w;
+    }
+    memcpy(x, y, sizeof(double) * (size_t)n);
+    free(y);
+}
+
+/* input decimation and smoothing (ba.cpp:195-242) of the driving rows [c0, c0+cN); the other rows only shrink (they are
+ * zero or recomputed by the kinematics).  Note: both smoothing calls of the reference pass _inputDecimFact as window. */
+static void rs_decimate_smooth(rs_traj *t, int c0, int cN, int decim, int smooth_window)
+{
+    if (decim > 1) {
+        const int64_t nIn = t->n, nOut = (nIn - 1) / decim + 1;
+        for (int j = 0; j < cN; ++j) rs_smooth(t->x + (c0 + j) * nIn, nIn, decim);
+        double *y = (double *)calloc((size_t)t->C * (size_t)nOut, sizeof(double));
+        for (int c = 0; c < t->C; ++c) { /* decimate (util.cpp:347-356): every decim-th sample, always the last one */
+            const double *src = t->x + c * nIn;
+            double *dst = y + c * nOut;
+            for (int64_t i = 0; i < nOut; ++i) dst[i] = src[decim * i];
+            if (decim * (nOut - 1) + 1 != nIn) dst[nOut - 1] = src[nIn - 1];
+        }
+        free(t->x);
+        t->x = y;
+        t->n = nOut;
+        t->sres *= decim;
+    }
+    if (smooth_window > 1)
+        for (int j = 0; j < cN; ++j) rs_smooth(t->x + (c0 + j) * t->n, t->n, decim);
+}
+
 /* Robot::invKinCSPR3DOF (robot.cpp:243-278) */
 static void rs_invkin_cspr(rs_traj *t, const double pmat[9])
 {
@@ -257,6 +305,10 @@ int bo_resample(const bo_resample_params *prm, int64_t n_in, const double *x, do
     if (cable) rs_rem_close(&t, t.nJ, t.nC, prm->cart_thresh); /* ba.cpp:166-175 */
     else rs_rem_close(&t, 0, t.nJ, prm->jnt_thresh);
     if (t.n < 4) st |= BATOTP_RS_TOO_SHORT;
+    if (!st && (prm->input_decim_fact > 1 || prm->smooth_window > 1)) {
+        rs_decimate_smooth(&t, cable ? t.nJ : 0, cable ? t.nC : t.nJ, prm->input_decim_fact > 1 ? prm->input_decim_fact : 1, prm->smooth_window);
+        if (t.n < 4) st |= BATOTP_RS_TOO_SHORT;
+    }
     if (!st && cable) rs_invkin_cspr(&t, prm->pmat);
     for (int pass = 0; pass < 2 && !st; ++pass) {
         double *sC = (double *)malloc(sizeof(double) * (size_t)t.n);

@@ -135,6 +135,9 @@ CASES = {
     # taught paths with repeated points: remClosePts really removes something (also on the device resampler's path kinds)
     "synth_gen7dof_s6_dup": (synth_gen7dof(6, 30, repeat_every=7), True),
     "synth_cspr_s9_dup": (synth_cspr(9, 12, repeat_every=5), True),
+    # input decimation + smoothing (ba.cpp:195-242)
+    "synth_gen7dof_s10_decim": (synth_gen7dof(10, 45, decim=3, smooth=3), True),
+    "synth_cspr_s11_decim": (synth_cspr(11, 14, decim=2), True),
     # BASELINE-size single paths: digest only (sha256 of the float32 curves + 1-in-64 samples)
     "synth_gen7dof_s4_50k": (synth_gen7dof(4, 871), False),
     "synth_ur_s7_100k": (synth_ur(7, 500), False),

@@ -106,7 +106,8 @@ def test_which_configurations_the_device_stages_cover():
     path runs on the device; the fixtures (written by oracle/make_resample_fixtures.py from those decisions) pin the matrix"""
     import helpers
     assert set(helpers.RESAMPLE_CASES) == {"CSPR3DOF", "CSPR3DOF_par", "GEN7DOF", "synth_cspr_s3", "synth_cspr_s5", "synth_cspr_s9_dup",
-                                           "synth_gen7dof_s0", "synth_gen7dof_s1_vel", "synth_gen7dof_s6_dup", "synth_ur_s2"}
+                                           "synth_cspr_s11_decim", "synth_gen7dof_s0", "synth_gen7dof_s1_vel", "synth_gen7dof_s6_dup",
+                                           "synth_gen7dof_s10_decim", "synth_ur_s2"}
     assert set(helpers.OUTPUT_CASES) == set(helpers.RESAMPLE_CASES)
     # robots with forward kinematics (trigonometry on every point) and serial-robot torque recomputation stay on the host
     for name in ("UR5", "UR5_nocartacc", "KUKA-LWR-IV", "KUKA_cartacc", "RR", "RR_acc"):

@@ -26,6 +26,9 @@ def test_oracle_resample_matches_golden_knots(octx, name):
 
 def test_oracle_resample_batch_and_ragged(octx):
     cs = [ResampleCase(n) for n in RESAMPLE_CASES if n.startswith("synth_cspr")]
+    ref = bytes(ResampleCase("synth_cspr_s3").params)
+    cs = [c for c in cs if bytes(c.params) == ref]   # one parameter set per call
+    assert len(cs) >= 3
     r = capi.Resampled(octx, cs[0].params, [c.x for c in cs], [c.sres_in for c in cs])
     for k, c in enumerate(cs):
         assert r.knots(k).tobytes() == c.y.tobytes() and r.sres[k] == c.sres
