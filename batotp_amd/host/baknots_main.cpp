@@ -1,9 +1,14 @@
-// dump_knots.cpp -- TEST INFRASTRUCTURE (golden-fixture generation, build container only).
-// Runs the host half of the BA pipeline (config + trajectory IO + path resampling, no device
-// call) on a config.dat in the current directory and writes
-//   knots.bin   : int64 N, int64 nJ, int64 nCart, double sres, double y[nJ+nCart][N]
-//   problem.bin : raw struct batotp_problem (include/batotp_hip.h)
-// Usage: dump_knots config.dat
+// baknots_main.cpp -- "baknots": the host half of BA::interpInputData as a command-line tool.
+// Reads config.dat and the taught path from the current directory, runs the host resampler (config + trajectory IO +
+// path resampling; no device call is made) and writes
+//   knots.bin    : int64 N, int64 nJ, int64 nCart, double sres, double y[nJ+nCart][N]   (the uniform-s knots)
+//   problem.bin  : raw struct batotp_problem (include/batotp_hip.h)
+//   taught.bin   : int64 n, int64 nJ, int64 nCart, double sres, double x[nJ+nCart][n]   (the taught points, absent rows zero)
+//   resample.bin : int32 covered by the device resampler (1/0), raw struct batotp_resample_params
+//   output.bin   : int32 covered by the device output stage (1/0), raw struct batotp_output_params
+// bench.py and the tools use it to prepare synthetic inputs; oracle/Makefile builds the same source against the oracle
+// shim (dump_knots) for the fixture generators.
+// Usage: baknots config.dat
 #include <cstdio>
 #include <vector>
 
@@ -14,7 +19,7 @@ using namespace BATOTP;
 
 int main(int argc, char **argv)
 {
-   if (argc < 2) { fprintf(stderr, "usage: dump_knots config.dat\n"); return 2; }
+   if (argc < 2) { fprintf(stderr, "usage: baknots config.dat\n"); return 2; }
    BA ba;
    Traj tr;
    ba.setHomeFolder("./"); ba.setInputFolder("./"); ba.setOutputFolder("./");
@@ -22,16 +27,13 @@ int main(int argc, char **argv)
    if (ba.readConfigData((std::string("./") + argv[1]).c_str()) == -1) return 1;
    if (ba.loadTrajectoryData(tr) == -1) return 1;
    {
-      // the taught points and the resampling parameters, for the device-resampler fixtures:
-      //   taught.bin   : int64 n, int64 nJ, int64 nCart, double sres, double x[nJ+nCart][n] (absent rows zero)
-      //   resample.bin : int32 supported (1/0), raw struct batotp_resample_params
+      // the taught points and the parameters of the device stages
       batotp_resample_params R;
       ba.dropRepeatedTimestamps(tr);
       const int supported = ba.exportResampleParams(tr, &R) == 0 ? 1 : 0;
       FILE *g = fopen("resample.bin", "wb");
       fwrite(&supported, 4, 1, g); fwrite(&R, sizeof(R), 1, g);
       fclose(g);
-      //   output.bin   : int32 supported (1/0), raw struct batotp_output_params
       batotp_output_params O;
       const int outSupported = ba.exportOutputParams(&O) == 0 ? 1 : 0;
       g = fopen("output.bin", "wb");
@@ -64,6 +66,6 @@ int main(int argc, char **argv)
    f = fopen("problem.bin", "wb");
    fwrite(&P, sizeof(P), 1, f);
    fclose(f);
-   printf("dump_knots: N=%lld nJ=%lld nCart=%lld sres=%.17g\n", N, nJ, nC, tr.sres);
+   printf("baknots: N=%lld nJ=%lld nCart=%lld sres=%.17g\n", N, nJ, nC, tr.sres);
    return 0;
 }

@@ -31,7 +31,7 @@ from batotp_amd import capi, pathgen  # noqa: E402
 from batotp_amd import dist as bdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-DUMP_KNOTS = os.path.join(ROOT, "oracle", "_build", "dump_knots")  # host resampler front end (no device code)
+DUMP_KNOTS = os.path.join(ROOT, "batotp_amd", "host", "_build", "baknots")  # the product's host resampler as a tool (no device call)
 
 WORKLOADS = {
     # name: (fine-path generator, config kwargs, coarse points per 1000 knots)
