@@ -1,0 +1,120 @@
+"""GPU (-m gpu): randomised parity sweeps -- many small random problems through the HIP library and the oracle, bit for
+bit.  Seeds are fixed; the point is breadth (limits, path shapes, lengths, lane layouts) beyond the golden cases."""
+import numpy as np
+import pytest
+
+from helpers import assert_bit_equal
+from batotp_amd import capi, pathgen
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_knots(rng, n_joints, n, scale):
+    """smooth random joint paths: a few random Fourier modes per joint, plus a straight segment and a cusp now and then"""
+    s = np.linspace(0.0, 1.0, n)
+    y = np.zeros((n_joints, n))
+    for j in range(n_joints):
+        for k in range(1, 5):
+            y[j] += rng.normal() / k * np.sin(2 * np.pi * k * s * rng.uniform(0.3, 2.0) + rng.uniform(0, 6.28))
+    if rng.random() < 0.3:
+        a = rng.integers(n // 4, n // 2)
+        y[:, a:a + n // 8] = y[:, a:a + 1] + np.linspace(0, 1, n // 8)[None, :] * rng.normal(size=(n_joints, 1)) * 0.1
+    if rng.random() < 0.3:
+        y[rng.integers(0, n_joints)] += 0.3 * np.abs(s - rng.uniform(0.2, 0.8))
+    return np.ascontiguousarray(scale * y)
+
+
+def _run(ctx, prob, ys, sres, cap):
+    b = capi.Batch(ctx, prob, [y.shape[1] for y in ys], cap)
+    for k, y in enumerate(ys):
+        b.upload_knots(k, [y], [sres[k]])
+    b.precompute(1)
+    b.pointwise_mvc()
+    b.sweep(-1)
+    b.sweep(+1)
+    res = b.results()
+    out = [(b.curve(k, -1), b.curve(k, +1), np.stack(b.mvc(k))) for k in range(len(ys))]
+    b.close()
+    return res, out
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("lanes", [0, 8])
+def test_random_velocity_acceleration_problems(hip_lib, oracle_ctx, seed, lanes):
+    rng = np.random.default_rng(1000 + seed)
+    nJ = int(rng.integers(1, 9))
+    vmax = list(rng.uniform(0.5, 8.0, nJ))
+    amax = list(rng.uniform(1.0, 40.0, nJ))
+    flags = capi.F_JNT_ACC_ON if rng.random() < 0.8 else 0
+    prob = capi.make_problem(nJ, 0, flags=flags, jnt_vel_max=vmax, jnt_acc_max=amax, integ_res=float(rng.choice([0.004, 0.01, 0.02])),
+                             max_integ_time=1e5)
+    n_paths = int(rng.integers(3, 20))
+    ys = [_random_knots(rng, nJ, int(rng.integers(8, 400)), rng.uniform(0.2, 3.0)) for _ in range(n_paths)]
+    sres = [float(rng.uniform(0.01, 0.2)) for _ in range(n_paths)]
+    ctx = capi.Context(hip_lib, 0)
+    ctx.set_sweep_group(lanes)
+    cap = 60000
+    ro, oo = _run(oracle_ctx, prob, ys, sres, cap)
+    for extra in (0, capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES):
+        p2 = capi.Problem.from_buffer_copy(bytes(prob))
+        p2.flags |= extra
+        rh, ho = _run(ctx, p2, ys, sres, cap)
+        for f in rh.dtype.names:
+            assert np.array_equal(rh[f], ro[f]), (seed, f)
+        for k in range(n_paths):
+            for which in (0, 1):
+                assert_bit_equal(ho[k][which][0], oo[k][which][0], f"seed {seed} path {k} curve {which} s")
+                assert_bit_equal(ho[k][which][1], oo[k][which][1], f"seed {seed} path {k} curve {which} sdot")
+            assert_bit_equal(ho[k][2], oo[k][2], f"seed {seed} path {k} pointwise")
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_taught_paths_through_the_resampler_and_output_stage(hip_ctx, oracle_ctx, seed):
+    rng = np.random.default_rng(5000 + seed)
+    nJ = int(rng.integers(2, 8))
+    prm = capi.ResampleParams()
+    prm.n_joints, prm.n_cart, prm.robot_type, prm.path_type, prm.scale_type = nJ, 3, capi.ROBOT_GENJNT, capi.PATH_JOINT, 1
+    prm.s_weights[0], prm.s_weights[1], prm.s_weights[2] = 0.0, 1.0, 0.0
+    res = float(rng.uniform(0.02, 0.2))
+    prm.theta_norm_res, prm.theta_norm_res2 = res, res * float(rng.choice([1.0, 0.5, 2.0]))
+    prm.cart_norm_res = prm.cart_norm_res2 = 0.02
+    prm.jnt_thresh = prm.cart_thresh = 1e-6
+    prm.input_decim_fact = int(rng.choice([1, 1, 2, 3]))
+    prm.smooth_window = int(rng.choice([1, 3]))
+    xs = []
+    for _ in range(int(rng.integers(2, 9))):
+        n = int(rng.integers(30, 1500))
+        th = _random_knots(rng, nJ, n, rng.uniform(0.5, 3.0)).astype(np.float32).astype(np.float64)
+        if rng.random() < 0.4:   # repeated taught points
+            idx = np.sort(np.concatenate([np.arange(n), rng.integers(0, n, n // 10)]))
+            th = th[:, idx]
+        xs.append(np.vstack([th, np.zeros((3, th.shape[1]))]))
+    sr = [0.01] * len(xs)
+    h = capi.Resampled(hip_ctx, prm, xs, sr)
+    o = capi.Resampled(oracle_ctx, prm, xs, sr)
+    assert np.array_equal(h.status, o.status) and np.array_equal(h.n_knots, o.n_knots) and h.sres.tobytes() == o.sres.tobytes()
+    knots = [o.knots(k) for k in range(len(xs))]
+    for k in range(len(xs)):
+        assert_bit_equal(h.knots(k), knots[k], f"seed {seed} path {k} knots")
+    good = [k for k in range(len(xs)) if int(o.status[k]) == 0]
+    if not good:
+        return
+    prob = capi.make_problem(nJ, 3, flags=capi.F_JNT_ACC_ON, jnt_vel_max=[float(rng.uniform(1, 6))] * nJ,
+                             jnt_acc_max=[float(rng.uniform(2, 30))] * nJ, integ_res=0.01, max_integ_time=1e5)
+    outs = []
+    for ctx in (hip_ctx, oracle_ctx):
+        b = capi.Batch(ctx, prob, [knots[k].shape[1] for k in good], 80000)
+        for q, k in enumerate(good):
+            b.upload_knots(q, [knots[k]], [float(o.sres[k])])
+        b.optimize()
+        per = []
+        for out_res, smooth in ((0.008, 5.0), (0.01, 1.0), (0.02, 3.0)):
+            out = capi.Output(b, capi.OutputParams(nJ, capi.PATH_JOINT, 0.01, out_res, smooth), 0, len(good))
+            per.append((out.n_pts.copy(), [out.rows(q) for q in range(len(good))]))
+            out.close()
+        outs.append(per)
+        b.close()
+    for (nh, rh), (no, ro) in zip(*outs):
+        assert np.array_equal(nh, no)
+        for q in range(len(good)):
+            assert_bit_equal(rh[q], ro[q], f"seed {seed} output of path {good[q]}")
