@@ -1305,7 +1305,13 @@ __global__ void __launch_bounds__(K3_BLOCK) k_pointwise(DevProblem P, const Path
    t.sdotCur = sdot;
    double sddot = 0;
    int nIter;
-   (void)apply_accel_bisection<1, FEAT, false, false>(t, 0, sddot, nIter);
+   if (apply_accel_bisection<1, FEAT, false, false>(t, 0, sddot, nIter) != 0)
+   {
+      // no admissible sdot at this knot (ba.cpp:1307-1319): the K3 definition publishes NaN bounds (what the reference's
+      // early loop exits last wrote is an artefact of its loop order)
+      t.sddotL = __longlong_as_double(0x7ff8000000000000LL);
+      t.sddotH = t.sddotL;
+   }
    double *__restrict__ o = mvc + pi.koff * 3;
    o[i] = t.sdotCur;
    o[N + i] = t.sddotL;
@@ -1354,7 +1360,11 @@ __global__ void __launch_bounds__(K3G_BLOCK) k_pointwise_grp(DevProblem P, const
    t.sdotCur = sdot;
    double sddot = 0;
    int nIter;
-   (void)apply_accel_bisection<8, FEAT, false, false>(t, j, sddot, nIter);
+   if (apply_accel_bisection<8, FEAT, false, false>(t, j, sddot, nIter) != 0)
+   {
+      t.sddotL = __longlong_as_double(0x7ff8000000000000LL); // see k_pointwise
+      t.sddotH = t.sddotL;
+   }
    if (j == 0)
    {
       double *__restrict__ o = mvc + pi.koff * 3;

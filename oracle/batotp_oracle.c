@@ -801,7 +801,7 @@ int bo_sweep(const batotp_problem *prob, const bo_path *p, int dir,
 
     for (i = 1;; i++) { /* ba.cpp:1053: the array grows by nChunk, the loop is unbounded */
         double s0 = c->s_cur;
-        if (i >= cap) { *status = c->status | BATOTP_ST_CAPACITY; *n_bisect_fail = c->n_fail; return -1; }
+        if (i >= cap) { *status = c->status | BATOTP_ST_CAPACITY; *n_bisect_fail = c->n_fail; *n_steps = i; return -1; }
         c->sdot_lim_type_t = 0;
         sdotT = sdotArr[0];
         sddotT = sddotArr[0];
@@ -915,7 +915,11 @@ void bo_pointwise_mvc(const batotp_problem *prob, bo_path *p)
         sdot_lim(c, &sdot);
         c->sdot_cur = sdot;
         c->sddot_l = 0; c->sddot_h = 0;
-        (void)apply_accel_bisection(c, &sddot, &nIter);
+        if (apply_accel_bisection(c, &sddot, &nIter) != 0) {
+            /* no admissible sdot at this knot (ba.cpp:1307-1319): the interval is empty.  The reference leaves whatever its
+             * early loop exits last wrote; the K3 definition publishes NaN bounds instead */
+            c->sddot_l = NAN; c->sddot_h = NAN;
+        }
         p->mvc[i] = c->sdot_cur;
         p->mvc[n + i] = c->sddot_l;
         p->mvc[2 * n + i] = c->sddot_h;

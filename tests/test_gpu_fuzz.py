@@ -118,3 +118,54 @@ def test_random_taught_paths_through_the_resampler_and_output_stage(hip_ctx, ora
         assert np.array_equal(nh, no)
         for q in range(len(good)):
             assert_bit_equal(rh[q], ro[q], f"seed {seed} output of path {good[q]}")
+
+
+@pytest.mark.parametrize("par2ser", [0, 1])
+@pytest.mark.parametrize("seed", range(3))
+def test_random_cable_robot_problems(hip_lib, oracle_ctx, seed, par2ser):
+    """3-cable robot: cable tension limits (parallel-mechanism torque branch or its serial conversion), cable velocity /
+    acceleration limits, Cartesian speed limit; random platform paths inside the workspace"""
+    import helpers
+    rng = np.random.default_rng(9000 + seed)
+    base = helpers.Case("synth_cspr_s3").problem
+    prob = capi.Problem.from_buffer_copy(bytes(base))
+    flags = capi.F_TRQ_ON | capi.F_PARALLEL | capi.F_JNT_ACC_ON
+    if par2ser:
+        flags |= capi.F_PAR2SER
+    if rng.random() < 0.7:
+        flags |= capi.F_CART_VEL_ON
+    prob.flags = flags
+    for j in range(3):
+        prob.jnt_vel_max[j] = float(rng.uniform(2, 6)); prob.jnt_acc_max[j] = float(rng.uniform(4, 12))
+        prob.jnt_trq_max[j] = float(rng.uniform(10, 16)); prob.jnt_trq_min[j] = float(rng.uniform(0.5, 1.5))
+    prob.cart_vel_max = float(rng.uniform(2, 5))
+    pm = np.array(list(prob.pmat)).reshape(3, 3)
+    ys, sres = [], []
+    for _ in range(int(rng.integers(2, 7))):
+        n = int(rng.integers(40, 500))
+        t = np.linspace(0, 1, n)
+        cart = np.stack([1.0 * np.sin(2 * np.pi * t * rng.uniform(0.3, 1.5) + rng.uniform(0, 6)),
+                         1.0 * np.cos(2 * np.pi * t * rng.uniform(0.3, 1.5) + rng.uniform(0, 6)) + 0.4,
+                         3.0 + 0.8 * np.sin(2 * np.pi * t * rng.uniform(0.2, 1.0) + rng.uniform(0, 6))])
+        theta = np.stack([np.sqrt(((cart - pm[:, k:k + 1]) ** 2).sum(axis=0)) for k in range(3)])
+        ys.append(np.ascontiguousarray(np.vstack([theta, cart])))
+        sres.append(float(rng.uniform(0.005, 0.03)))
+    for lanes in (0, 8):
+        ctx = capi.Context(hip_lib, 0)
+        ctx.set_sweep_group(lanes)
+        outs = []
+        for c in (ctx, oracle_ctx):
+            b = capi.Batch(c, prob, [y.shape[1] for y in ys], 12000)
+            for k, y in enumerate(ys):
+                b.upload_knots(k, [y], [sres[k]])
+            b.precompute(0); b.pointwise_mvc(); b.sweep(-1); b.sweep(+1)
+            outs.append((b.results(), [(b.curve(k, -1), b.curve(k, +1), np.stack(b.mvc(k))) for k in range(len(ys))]))
+            b.close()
+        (rh, ho), (ro, oo) = outs
+        for f in rh.dtype.names:
+            assert np.array_equal(rh[f], ro[f]), (seed, f, rh[f], ro[f])
+        for k in range(len(ys)):
+            for which in (0, 1):
+                assert_bit_equal(ho[k][which][0], oo[k][which][0], f"seed {seed} path {k} curve {which} s")
+                assert_bit_equal(ho[k][which][1], oo[k][which][1], f"seed {seed} path {k} curve {which} sdot")
+            assert_bit_equal(ho[k][2], oo[k][2], f"seed {seed} path {k} pointwise")
