@@ -155,7 +155,7 @@ def test_random_cable_robot_problems(hip_lib, oracle_ctx, seed, par2ser):
         ctx.set_sweep_group(lanes)
         outs = []
         for c in (ctx, oracle_ctx):
-            b = capi.Batch(c, prob, [y.shape[1] for y in ys], 12000)
+            b = capi.Batch(c, prob, [y.shape[1] for y in ys], 4000)
             for k, y in enumerate(ys):
                 b.upload_knots(k, [y], [sres[k]])
             b.precompute(0); b.pointwise_mvc(); b.sweep(-1); b.sweep(+1)
