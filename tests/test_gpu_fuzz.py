@@ -169,3 +169,37 @@ def test_random_cable_robot_problems(hip_lib, oracle_ctx, seed, par2ser):
                 assert_bit_equal(ho[k][which][0], oo[k][which][0], f"seed {seed} path {k} curve {which} s")
                 assert_bit_equal(ho[k][which][1], oo[k][which][1], f"seed {seed} path {k} curve {which} sdot")
             assert_bit_equal(ho[k][2], oo[k][2], f"seed {seed} path {k} pointwise")
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_cartesian_constraint_problems(hip_lib, oracle_ctx, seed):
+    """joint limits plus Cartesian speed and / or acceleration limits (solveQuadratic branch), random Cartesian channels"""
+    rng = np.random.default_rng(7000 + seed)
+    nJ = int(rng.integers(2, 8))
+    flags = capi.F_JNT_ACC_ON | (capi.F_CART_VEL_ON if seed % 2 == 0 else 0) | (capi.F_CART_ACC_ON if seed % 3 != 2 else 0)
+    if not (flags & (capi.F_CART_VEL_ON | capi.F_CART_ACC_ON)):
+        flags |= capi.F_CART_VEL_ON
+    prob = capi.make_problem(nJ, 3, flags=flags, jnt_vel_max=list(rng.uniform(1, 6, nJ)), jnt_acc_max=list(rng.uniform(2, 30, nJ)),
+                             cart_vel_max=float(rng.uniform(0.3, 2.0)), cart_acc_max=float(rng.uniform(0.5, 5.0)), integ_res=0.01,
+                             max_integ_time=1e5)
+    ys, sres = [], []
+    for _ in range(int(rng.integers(2, 12))):
+        n = int(rng.integers(10, 350))
+        th = _random_knots(rng, nJ, n, rng.uniform(0.3, 2.0))
+        ca = _random_knots(rng, 3, n, rng.uniform(0.1, 1.0))
+        if rng.random() < 0.25:
+            ca[:, n // 3: n // 2] = ca[:, n // 3: n // 3 + 1]   # the tool point stands still for a while (quadratic degenerates)
+        ys.append(np.ascontiguousarray(np.vstack([th, ca])))
+        sres.append(float(rng.uniform(0.01, 0.1)))
+    ro, oo = _run(oracle_ctx, prob, ys, sres, 30000)
+    for lanes in (0, 1, 8, 16):
+        ctx = capi.Context(hip_lib, 0)
+        ctx.set_sweep_group(lanes)
+        rh, ho = _run(ctx, prob, ys, sres, 30000)
+        for f in rh.dtype.names:
+            assert np.array_equal(rh[f], ro[f]), (seed, lanes, f)
+        for k in range(len(ys)):
+            for which in (0, 1):
+                assert_bit_equal(ho[k][which][0], oo[k][which][0], f"seed {seed} lanes {lanes} path {k} curve {which} s")
+                assert_bit_equal(ho[k][which][1], oo[k][which][1], f"seed {seed} lanes {lanes} path {k} curve {which} sdot")
+            assert_bit_equal(ho[k][2], oo[k][2], f"seed {seed} lanes {lanes} path {k} pointwise")
