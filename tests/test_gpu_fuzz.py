@@ -203,3 +203,47 @@ def test_random_cartesian_constraint_problems(hip_lib, oracle_ctx, seed):
                 assert_bit_equal(ho[k][which][0], oo[k][which][0], f"seed {seed} lanes {lanes} path {k} curve {which} s")
                 assert_bit_equal(ho[k][which][1], oo[k][which][1], f"seed {seed} lanes {lanes} path {k} curve {which} sdot")
             assert_bit_equal(ho[k][2], oo[k][2], f"seed {seed} lanes {lanes} path {k} pointwise")
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_two_link_arm_with_torque_limits(hip_lib, oracle_ctx, seed):
+    """RR arm: torque limits through the serial dynamics (a1..a4 splines), with and without joint acceleration limits;
+    the trigonometric terms are uploaded (BATOTP_F_HOST_TRIG), the same arrays to both implementations"""
+    import helpers
+    rng = np.random.default_rng(3000 + seed)
+    base = helpers.Case("RR").problem
+    prob = capi.Problem.from_buffer_copy(bytes(base))
+    prob.flags = capi.F_TRQ_ON | capi.F_HOST_TRIG | (capi.F_JNT_ACC_ON if seed % 2 else 0)
+    for j in range(2):
+        prob.jnt_vel_max[j] = float(rng.uniform(100, 400)); prob.jnt_acc_max[j] = float(rng.uniform(500, 2000))
+        prob.jnt_trq_max[j] = float(rng.uniform(5, 40)); prob.jnt_trq_min[j] = -float(rng.uniform(5, 40))
+    ys = [_random_knots(rng, 2, int(rng.integers(20, 400)), rng.uniform(20, 120)) for _ in range(int(rng.integers(2, 9)))]
+    ys = [np.ascontiguousarray(np.vstack([y, np.zeros((prob.n_cart, y.shape[1]))])) for y in ys]
+    sres = [float(rng.uniform(0.2, 2.0)) for _ in ys]
+    outs = []
+    for lanes, c in ((0, None), (8, None), (-1, oracle_ctx)):
+        ctx = c
+        if ctx is None:
+            ctx = capi.Context(hip_lib, 0)
+            ctx.set_sweep_group(lanes)
+        b = capi.Batch(ctx, prob, [y.shape[1] for y in ys], 30000)
+        for k, y in enumerate(ys):
+            b.upload_knots(k, [y], [sres[k]])
+        b.precompute(1)
+        for k in range(len(ys)):
+            b.upload_rr_trig(k, helpers.rr_trig(b.samples(k, 0)[0], b.samples(k, 1)[0]))
+        b.precompute(2)
+        b.pointwise_mvc(); b.sweep(-1); b.sweep(+1)
+        outs.append((b.results(), [(b.curve(k, -1), b.curve(k, +1), np.stack(b.mvc(k)),
+                                    np.stack([np.stack([b.dyn(k, kk, r) for r in range(2)]) for kk in (1, 2, 3, 4)])) for k in range(len(ys))]))
+        b.close()
+    ro, oo = outs[-1]
+    for rh, ho in outs[:-1]:
+        for f in rh.dtype.names:
+            assert np.array_equal(rh[f], ro[f]), (seed, f)
+        for k in range(len(ys)):
+            assert_bit_equal(ho[k][3], oo[k][3], f"seed {seed} path {k} dynamics coefficients")
+            for which in (0, 1):
+                assert_bit_equal(ho[k][which][0], oo[k][which][0], f"seed {seed} path {k} curve {which} s")
+                assert_bit_equal(ho[k][which][1], oo[k][which][1], f"seed {seed} path {k} curve {which} sdot")
+            assert_bit_equal(ho[k][2], oo[k][2], f"seed {seed} path {k} pointwise")
