@@ -1,5 +1,7 @@
 """GPU (-m gpu): randomised parity sweeps -- many small random problems through the HIP library and the oracle, bit for
 bit.  Seeds are fixed; the point is breadth (limits, path shapes, lengths, lane layouts) beyond the golden cases."""
+import os
+
 import numpy as np
 import pytest
 
@@ -7,6 +9,9 @@ from helpers import assert_bit_equal
 from batotp_amd import capi, pathgen
 
 pytestmark = pytest.mark.gpu
+
+# BATOTP_FUZZ_SCALE=k runs k times as many seeds (the default keeps the GPU suite short)
+_SCALE = max(1, int(os.environ.get("BATOTP_FUZZ_SCALE", "1")))
 
 
 def _random_knots(rng, n_joints, n, scale):
@@ -38,7 +43,7 @@ def _run(ctx, prob, ys, sres, cap):
     return res, out
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(6 * _SCALE))
 @pytest.mark.parametrize("lanes", [0, 8])
 def test_random_velocity_acceleration_problems(hip_lib, oracle_ctx, seed, lanes):
     rng = np.random.default_rng(1000 + seed)
@@ -68,7 +73,7 @@ def test_random_velocity_acceleration_problems(hip_lib, oracle_ctx, seed, lanes)
             assert_bit_equal(ho[k][2], oo[k][2], f"seed {seed} path {k} pointwise")
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(4 * _SCALE))
 def test_random_taught_paths_through_the_resampler_and_output_stage(hip_ctx, oracle_ctx, seed):
     rng = np.random.default_rng(5000 + seed)
     nJ = int(rng.integers(2, 8))
@@ -121,7 +126,7 @@ def test_random_taught_paths_through_the_resampler_and_output_stage(hip_ctx, ora
 
 
 @pytest.mark.parametrize("par2ser", [0, 1])
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", range(3 * _SCALE))
 def test_random_cable_robot_problems(hip_lib, oracle_ctx, seed, par2ser):
     """3-cable robot: cable tension limits (parallel-mechanism torque branch or its serial conversion), cable velocity /
     acceleration limits, Cartesian speed limit; random platform paths inside the workspace"""
@@ -171,7 +176,7 @@ def test_random_cable_robot_problems(hip_lib, oracle_ctx, seed, par2ser):
             assert_bit_equal(ho[k][2], oo[k][2], f"seed {seed} path {k} pointwise")
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(4 * _SCALE))
 def test_random_cartesian_constraint_problems(hip_lib, oracle_ctx, seed):
     """joint limits plus Cartesian speed and / or acceleration limits (solveQuadratic branch), random Cartesian channels"""
     rng = np.random.default_rng(7000 + seed)
@@ -205,7 +210,7 @@ def test_random_cartesian_constraint_problems(hip_lib, oracle_ctx, seed):
             assert_bit_equal(ho[k][2], oo[k][2], f"seed {seed} lanes {lanes} path {k} pointwise")
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", range(3 * _SCALE))
 def test_random_two_link_arm_with_torque_limits(hip_lib, oracle_ctx, seed):
     """RR arm: torque limits through the serial dynamics (a1..a4 splines), with and without joint acceleration limits;
     the trigonometric terms are uploaded (BATOTP_F_HOST_TRIG), the same arrays to both implementations"""
