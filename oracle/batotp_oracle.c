@@ -843,6 +843,7 @@ int bo_sweep(const batotp_problem *prob, const bo_path *p, int dir,
         if (i > maxIntegSteps) { /* ba.cpp:1117-1122 */
             *status = c->status | BATOTP_ST_MAX_INTEG_TIME;
             *n_bisect_fail = c->n_fail;
+            *n_steps = i;
             return -1;
         }
     }

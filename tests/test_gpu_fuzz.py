@@ -252,3 +252,43 @@ def test_random_two_link_arm_with_torque_limits(hip_lib, oracle_ctx, seed):
                 assert_bit_equal(ho[k][which][0], oo[k][which][0], f"seed {seed} path {k} curve {which} s")
                 assert_bit_equal(ho[k][which][1], oo[k][which][1], f"seed {seed} path {k} curve {which} sdot")
             assert_bit_equal(ho[k][2], oo[k][2], f"seed {seed} path {k} pointwise")
+
+
+@pytest.mark.parametrize("ppw", [1, 8])
+def test_two_link_arm_paths_that_never_finish(hip_lib, oracle_ctx, ppw):
+    """torque-limited paths that stall (the sweep runs into its step capacity with hundreds to thousands of failed
+    bisections, one path failing at every stage): failure counts, step counts and statuses equal the oracle's, with one
+    and with several such paths per wavefront.  (This is the case that exposed the schedule dependence of the
+    experimental flat stage/bisection loop, tools/experiments/.)"""
+    import helpers
+    rng = np.random.default_rng(3000)
+    base = helpers.Case("RR").problem
+    prob = capi.Problem.from_buffer_copy(bytes(base))
+    prob.flags = capi.F_TRQ_ON | capi.F_HOST_TRIG
+    for j in range(2):
+        prob.jnt_vel_max[j] = float(rng.uniform(100, 400)); prob.jnt_acc_max[j] = float(rng.uniform(500, 2000))
+        prob.jnt_trq_max[j] = float(rng.uniform(5, 40)); prob.jnt_trq_min[j] = -float(rng.uniform(5, 40))
+    ys = [_random_knots(rng, 2, int(rng.integers(20, 400)), rng.uniform(20, 120)) for _ in range(int(rng.integers(2, 9)))]
+    ys = [np.ascontiguousarray(np.vstack([y, np.zeros((prob.n_cart, y.shape[1]))])) for y in ys]
+    sres = [float(rng.uniform(0.2, 2.0)) for _ in ys]
+    res = []
+    for c in (None, oracle_ctx):
+        ctx = c
+        if ctx is None:
+            ctx = capi.Context(hip_lib, 0)
+            ctx.set_sweep_group(8)
+            ctx.set_paths_per_wave(ppw)
+        b = capi.Batch(ctx, prob, [y.shape[1] for y in ys], 12000)
+        for k, y in enumerate(ys):
+            b.upload_knots(k, [y], [sres[k]])
+        b.precompute(1)
+        for k in range(len(ys)):
+            b.upload_rr_trig(k, helpers.rr_trig(b.samples(k, 0)[0], b.samples(k, 1)[0]))
+        b.precompute(2)
+        b.sweep(-1); b.sweep(+1)
+        res.append(b.results())
+        b.close()
+    rh, ro = res
+    assert int(ro["n_bisect_fail_rev"].max()) > 1000 and int((ro["status_rev"] & capi.ST_CAPACITY != 0).sum()) >= 3
+    for f in rh.dtype.names:
+        assert np.array_equal(rh[f], ro[f]), (f, rh[f], ro[f])

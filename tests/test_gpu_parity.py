@@ -134,6 +134,13 @@ def test_capacity_and_max_time_status(hip_ctx, oracle_ctx):
     b = run_pipeline(oracle_ctx, [short], mvc=False, details=False)[0]
     assert a["result"]["status_rev"] & capi.ST_MAX_INTEG_TIME
     assert a["result"]["status_rev"] == b["result"]["status_rev"]
+    # every field of the result row, on both error exits (steps taken, failure counts, statuses of the skipped forward sweep)
+    for c, kw in ((case, dict(max_steps=100)), (short, {})):
+        a = run_pipeline(hip_ctx, [c, c, c], mvc=False, details=False, **kw)
+        b = run_pipeline(oracle_ctx, [c], mvc=False, details=False, **kw)[0]
+        for q in a:
+            for f in b["result"].dtype.names:
+                assert q["result"][f] == b["result"][f], (f, kw)
 
 
 def test_properties_at_full_size(hip_ctx):
