@@ -1,5 +1,7 @@
+"""see README.md in this directory; needs the patch applied (batotp_hip_set_sweep_hold)"""
 import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import helpers
 from batotp_amd import capi
@@ -15,7 +17,7 @@ for j in range(2):
 ys = [_random_knots(rng, 2, int(rng.integers(20, 400)), rng.uniform(20, 120)) for _ in range(int(rng.integers(2, 9)))]
 ys = [np.ascontiguousarray(np.vstack([y, np.zeros((prob.n_cart, y.shape[1]))])) for y in ys]
 sres = [float(rng.uniform(0.2, 2.0)) for _ in ys]
-hip_lib = capi.Library(sys.argv[1]); ora = capi.Context(capi.load_oracle(), 0)
+hip_lib = capi.Library(sys.argv[1])
 def run(ctx):
     b = capi.Batch(ctx, prob, [y.shape[1] for y in ys], 30000)
     for k, y in enumerate(ys):
