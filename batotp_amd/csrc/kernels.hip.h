@@ -1395,6 +1395,7 @@ struct SweepArgs
    int B;
    int dir;
    int ppw;       // paths per wavefront, 1 .. 64/G
+   int hold;      // FLAT kernels: a stage is started once hold/8 of the wavefront's live paths wait for one
 };
 
 // Butcher tableau of ba.cpp:58-63 (_B[k][j]; stage j+1 uses column j)
@@ -1457,11 +1458,28 @@ constexpr int K4_BLOCK = 256;
 #ifndef BK_SWEEP_WPE
 #define BK_SWEEP_WPE 2
 #endif
+#ifndef BK_TOUCH_DIRS
+#define BK_TOUCH_DIRS 1 /* 0: never, 1: reverse sweep only, 2: both sweeps */
+#endif
 // waves per SIMD the register allocation of the narrow (FEAT <= 1) sweep kernels is tuned for
-template <int G, int FEAT, bool UNI>
+// FLAT: the stage loop and the bisection loop are one loop in which every path of the wavefront is either
+// waiting for its next stage or inside a constraint check (see the comment at the loop).
+template <int G, int FEAT, bool UNI, bool FLAT = false>
 __global__ void __launch_bounds__(K4_BLOCK, (FEAT <= 1 && G > 1) ? BK_SWEEP_WPE : 2) k_sweep(SweepArgs a)
 {
    __shared__ double lim[6][8];
+   __shared__ double rk[7][6]; // FLAT: rk[st][k] = weight of stage value k in stage st (column st-1 of ba.cpp:58-63), 0 for k >= st
+   if (FLAT && threadIdx.x < 42)
+   {
+      const double tab[42] = {0, 0, 0, 0, 0, 0,
+                              BK_B00, 0, 0, 0, 0, 0,
+                              BK_B01, BK_B11, 0, 0, 0, 0,
+                              BK_B02, BK_B12, BK_B22, 0, 0, 0,
+                              BK_B03, BK_B13, BK_B23, BK_B33, 0, 0,
+                              BK_B04, BK_B14, BK_B24, BK_B34, BK_B44, 0,
+                              BK_B05, BK_B15, BK_B25, BK_B35, BK_B45, BK_B55};
+      (&rk[0][0])[threadIdx.x] = tab[threadIdx.x];
+   }
    stage_limits(a.dP, lim);
 
    const int lane = threadIdx.x & 63;
@@ -1538,8 +1556,130 @@ __global__ void __launch_bounds__(K4_BLOCK, (FEAT <= 1 && G > 1) ? BK_SWEEP_WPE 
 #endif
    int64_t nPts = 0, i = 1;
    unsigned endStatus = 0;
-   bool done = false;
    int pf = 0;
+   if constexpr (FLAT)
+   {
+      // One loop instead of {stages {bisection iterations}}.  In the nested form a wavefront stays in the bisection
+      // loop of a stage as long as ANY of its paths does (24 % of the path-stages of a reverse sweep bisect, for
+      // 5-15 iterations; with 8 paths per wavefront nearly every stage has such a path) while the paths whose first
+      // check passed idle.  Here a path is either waiting for its next stage or inside a check, every pass of the
+      // loop runs one check for all paths that are inside one, and the stage prologue (tableau combination, velocity
+      // limit, spline evaluation) runs when a.hold/8 of the live paths are waiting for it, so that its cost is shared.
+      // Paths of a wavefront drift apart in stage and step; nothing in a path's own arithmetic or order changes.
+      int st = (dir == 1) ? 0 : 1;
+      // state of this lane's path: one integer in a vector register on purpose (separate booleans become lane masks in
+      // scalar registers that are merged under ever-changing exec masks across this loop)
+      constexpr int PH_FIRST = 0, PH_ENDED = 1, PH_CHECK = 2, PH_DEAD = 3; // waiting for its first stage / a stage has ended / inside a check / finished
+      int phase = PH_FIRST;
+      if (i >= cap) { endStatus = BATOTP_ST_CAPACITY; phase = PH_DEAD; }
+      double sN = 0, wN = 0;
+      double lowFact = .01, sdotGood = 0, sdotL = 0, sdotH = 0, sdotTry = 0;
+      int nGood = 0; // feasible points seen by the current bisection (anyGoodIter of ba.cpp:1254 == nGood > 0)
+      int nIter = 0;
+      for (;;)
+      {
+         const unsigned long long mAlive = __ballot(phase != PH_DEAD);
+         if (mAlive == 0) break;
+         const unsigned long long mWait = __ballot(phase < PH_CHECK);
+         const bool startNow = (mWait == mAlive) || (__popcll(mWait) * 8 >= __popcll(mAlive) * a.hold);
+         if (startNow && phase < PH_CHECK)
+         {
+            if (phase == PH_ENDED)
+            {
+               // the stage that just ended: keep its values (done here, once for all paths that wait, rather than
+               // path by path at the pass in which each one's check ended)
+               phase = PH_FIRST;
+               const double vN = t.sdotCur;
+               v1 = (st == 1) ? vN : v1; w1 = (st == 1) ? wN : w1;
+               v2 = (st == 2) ? vN : v2; w2 = (st == 2) ? wN : w2;
+               v3 = (st == 3) ? vN : v3; w3 = (st == 3) ? wN : w3;
+               v4 = (st == 4) ? vN : v4; w4 = (st == 4) ? wN : w4;
+               v5 = (st == 5) ? vN : v5; w5 = (st == 5) ? wN : w5;
+               if (BK_TOUCH_DIRS == 2 || (BK_TOUCH_DIRS == 1 && dir == -1))
+               {
+                  t.sink += pf;
+                  pf = touch_ahead(t, j);
+               }
+               if (st < 6) ++st;
+               else
+               {
+                  // FSAL shift and publish, ba.cpp:1096-1100 (stage 6: position sN, values vN, wN)
+                  s0v = sN; v0 = vN; w0 = wN; w6 = wN;
+                  sPrev = sCurPt; sdPrev = sdCurPt;
+                  sCurPt = s0v; sdCurPt = v0;
+                  if (writer) out[dir == 1 ? i : cap - 1 - i] = make_double2(s0v, v0);
+                  st = (dir == 1) ? 0 : 1;
+                  if (t.sCur * dir > sLast) { nPts = i + 1; phase = PH_DEAD; } // ba.cpp:1109-1115
+                  else if (i > maxIntegSteps) { endStatus = BATOTP_ST_MAX_INTEG_TIME; phase = PH_DEAD; } // ba.cpp:1117-1122
+                  else if (++i >= cap) { endStatus = BATOTP_ST_CAPACITY; phase = PH_DEAD; }
+               }
+            }
+            if (phase != PH_DEAD)
+            {
+               if (st == 0)
+               {
+                  // forward predictor (ba.cpp:1055-1065): only the move of the reverse-curve cursor survives
+                  t.sCur = s0v + h * v0;
+                  mvc_walk(t);
+                  st = 1;
+               }
+               const double *bc = rk[st];
+               double sdotT = 0, sddotT = 0;
+               // stage st adds the terms k < st only (a stale stage value may be infinite: 0 * inf must not enter the sum)
+               sdotT += bc[0] * v0; sddotT += bc[0] * w0;
+               { const double a1 = sdotT + bc[1] * v1, b1 = sddotT + bc[1] * w1; sdotT = (st > 1) ? a1 : sdotT; sddotT = (st > 1) ? b1 : sddotT; }
+               { const double a2 = sdotT + bc[2] * v2, b2 = sddotT + bc[2] * w2; sdotT = (st > 2) ? a2 : sdotT; sddotT = (st > 2) ? b2 : sddotT; }
+               { const double a3 = sdotT + bc[3] * v3, b3 = sddotT + bc[3] * w3; sdotT = (st > 3) ? a3 : sdotT; sddotT = (st > 3) ? b3 : sddotT; }
+               { const double a4 = sdotT + bc[4] * v4, b4 = sddotT + bc[4] * w4; sdotT = (st > 4) ? a4 : sdotT; sddotT = (st > 4) ? b4 : sddotT; }
+               { const double a5 = sdotT + bc[5] * v5, b5 = sddotT + bc[5] * w5; sdotT = (st > 5) ? a5 : sdotT; sddotT = (st > 5) ? b5 : sddotT; }
+               sN = s0v + h * sdotT;
+               double vN = v0 + h * sddotT;
+               vN = dmax(vN, floorV); // ba.cpp:1085
+               t.sCur = sN;
+               sdot_lim(t, j, vN);
+               t.sdotCur = vN;
+               // sddotArr[st] keeps its previous value when the bisection fails (ba.cpp:1091 ignores the code)
+               wN = (st == 1) ? w1 : (st == 2) ? w2 : (st == 3) ? w3 : (st == 4) ? w4 : (st == 5) ? w5 : w6;
+               // applyAccelConstraintsBisectionPt, ba.cpp:1250-1265
+               lowFact = .01; sdotGood = 0; nGood = 0; sdotL = 0; sdotH = vN; sdotTry = vN; nIter = 0;
+               eval_partials(t, j);
+               phase = PH_CHECK;
+            }
+         }
+         if (phase == PH_CHECK)
+         {
+            // one pass of the loop of ba.cpp:1267-1321: the statements of apply_accel_bisection above, written as selects
+            // (no divergent branches around the few operations of the update)
+            const bool isViol = verify_second_order(t, j, sdotTry);
+            const bool first = (nIter == 0);
+            const bool good = !isViol && !first;                 // a feasible point after at least one violated one
+            const bool shrink = isViol && nGood == 0;            // ba.cpp:1281-1285: no feasible point known yet
+            const double lowFact2 = lowFact * 2.0;
+            const double sdotLShrunk = dmax(.999 * 0.0, (1.0 - lowFact2) * sdotTry);
+            // ba.cpp:1294-1303: two successive feasible points closer than 1e-3 (relative), or a negative one
+            const bool conv = good && (ratio_lt(fabs(sdotTry - sdotGood), sdotTry, .001) || sdotTry < 0.0);
+            const bool fin = (!isViol && first) || conv;
+            lowFact = shrink ? lowFact2 : lowFact;
+            sdotH = isViol ? sdotTry : sdotH;
+            sdotL = shrink ? sdotLShrunk : ((good && !conv) ? sdotTry : sdotL);
+            sdotGood = good ? sdotTry : sdotGood;
+            nGood += good ? 1 : 0;
+            t.sdotCur = conv ? sdotTry : t.sdotCur;
+            // ba.cpp:1305-1320
+            const bool collapsed = (nGood == 0) && ratio_lt(sdotH - sdotL, sdotH, 1e-20);
+            const bool failed = !fin && (nIter + 1 > 100 || sdotTry < 0.0 || collapsed);
+            nIter += fin ? 0 : 1;
+            sdotTry = (fin || failed) ? sdotTry : .5 * (sdotH + sdotL);
+            wN = fin ? ((dir == 1) ? t.sddotH : t.sddotL) : wN;
+            t.status |= failed ? (unsigned)BATOTP_ST_BISECT_FAIL : 0u;
+            t.nfail += failed ? 1 : 0;
+            phase = (fin || failed) ? PH_ENDED : phase;
+         }
+      }
+   }
+   else
+   {
+   bool done = false;
    while (!done)
    {
       if (i >= cap) { endStatus = BATOTP_ST_CAPACITY; break; }
@@ -1614,9 +1754,6 @@ __global__ void __launch_bounds__(K4_BLOCK, (FEAT <= 1 && G > 1) ? BK_SWEEP_WPE 
          // reverse sweep only (descending addresses; measured: -17 % there, +5 % on the forward sweep,
          // whose ascending walk finds the next lines already on their way): consume last stage's touch,
          // issue the next one
-#ifndef BK_TOUCH_DIRS
-#define BK_TOUCH_DIRS 1 /* 0: never, 1: reverse sweep only, 2: both sweeps */
-#endif
          if (BK_TOUCH_DIRS == 2 || (BK_TOUCH_DIRS == 1 && dir == -1))
          {
             t.sink += pf;
@@ -1633,6 +1770,7 @@ __global__ void __launch_bounds__(K4_BLOCK, (FEAT <= 1 && G > 1) ? BK_SWEEP_WPE 
       if (t.sCur * dir > sLast) { nPts = i + 1; done = true; } // ba.cpp:1109-1115
       else if (i > maxIntegSteps) { endStatus = BATOTP_ST_MAX_INTEG_TIME; break; } // ba.cpp:1117-1122
       else ++i;
+   }
    }
    if (writer) a.sink[p] = t.sink + pf;
 #ifdef BK_PROFILE_SECTIONS

@@ -152,6 +152,7 @@ def main():
                     help="run the per-knot evaluation (K3) beside the sweeps on a second stream (measured: slower, the SIMDs are already saturated)")
     ap.add_argument("--no-resample", action="store_true", help="skip the side measurement of the device path resampler")
     ap.add_argument("--no-output", action="store_true", help="skip the side measurement of the device output stage")
+    ap.add_argument("--no-flat-loop", action="store_true", help="skip the side measurement of the optional flat reverse-sweep loop")
     ap.add_argument("--no-seven-dof", action="store_true", help="skip the GEN7DOF (7-DOF) measurement reported beside the default workload")
     ap.add_argument("--coefficient-rows", action="store_true",
                     help="keep four coefficients per knot and channel instead of the compact (value, second derivative) form")
@@ -335,6 +336,25 @@ def main():
                                "what": "s(t) spline + re-sampling at constant time steps + joint spline evaluation + smoothing / "
                                        "down-sampling (+ re-interpolation when out_res < integ_res) on the device"}
 
+    # ---- optional loop form of the reverse sweep (batotp_hip_set_sweep_hold, off by default: DESIGN.md 4): the same
+    # batch once more with it, results compared byte for byte with the timed runs'; untimed side measurement
+    if rank == 0 and not args.no_flat_loop and not (prob.flags & (capi.F_TRQ_ON | capi.F_CART_VEL_ON | capi.F_CART_ACC_ON)):
+        ref_rows = batch.results().tobytes()
+        hip.set_sweep_group(8)
+        hip.set_sweep_hold(4, -1)
+        batch.sweep(-1)
+        batch.sweep(+1)
+        flat_rev, flat_fwd = batch.kernel_ms(3), batch.kernel_ms(4)
+        same = batch.results().tobytes() == ref_rows
+        hip.set_sweep_hold(-1, -1)
+        hip.set_sweep_group(args.group)
+        step_est = 1e3 * elapsed / max(args.steps, 1) - kernel_ms[3] - kernel_ms[4] + flat_rev + flat_fwd
+        out["flat_reverse_loop"] = {"hold_reverse": 4, "sweep_rev_ms": flat_rev, "sweep_fwd_ms": flat_fwd,
+                                    "ms_per_step_with_it": step_est, "waypoints_per_s_with_it": total_knots / (step_est * 1e-3),
+                                    "result_rows_identical": bool(same),
+                                    "what": "one loop for stages and bisection passes in the reverse sweep (paths of a wavefront drift apart); "
+                                            "not the default, not part of value"}
+
     # ---- the same workload as ONE trajectory (BASELINE configs[1] wording): inherently sequential,
     # reported for transparency next to the batch figure
     if rank == 0:
@@ -408,7 +428,8 @@ def main():
             try:
                 g = json.loads(r.stdout.strip().splitlines()[-1])
                 out["seven_dof"] = {"value": g["value"], "unit": g["unit"], "ms_per_step": g["ms_per_step"], "config": g["config"],
-                                    "kernel_ms": g["kernel_ms"], "steps_per_knot": g["steps_per_knot"], "roofline_frac": g["roofline"]["frac"]}
+                                    "kernel_ms": g["kernel_ms"], "steps_per_knot": g["steps_per_knot"], "roofline_frac": g["roofline"]["frac"],
+                                    "flat_reverse_loop": g.get("flat_reverse_loop")}
             except Exception as e:  # the main line must not depend on the side measurement
                 out["seven_dof"] = {"error": f"{type(e).__name__}: {r.stderr[-300:]}"}
         print(json.dumps(out))

@@ -232,3 +232,16 @@ def assert_bit_equal(a, b, what):
         idx = np.argwhere(~same)[:5]
         raise AssertionError(f"{what}: {np.count_nonzero(~same)} of {a.size} values differ, first at {idx.tolist()}: "
                              f"{[ (a[tuple(i)], b[tuple(i)]) for i in idx ]}")
+
+
+def set_layout(ctx, layout):
+    """sweep-kernel layout of a context: 0 (automatic), 1, 8, 16, 32 lanes per path, or "flatK": 8 lanes per path, 8 paths
+    per wavefront and the flat stage / bisection loop with hold K in both directions (batotp_hip_set_sweep_hold; only
+    problems with joint velocity / acceleration limits alone use it, the others run the nested loops whatever K is)"""
+    if isinstance(layout, str) and layout.startswith("flat"):
+        k = int(layout[4:])
+        ctx.set_sweep_group(8)
+        ctx.set_paths_per_wave(8)
+        ctx.set_sweep_hold(k, k)
+    else:
+        ctx.set_sweep_group(int(layout))

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import assert_bit_equal
+from helpers import assert_bit_equal, set_layout
 from batotp_amd import capi, pathgen
 
 pytestmark = pytest.mark.gpu
@@ -44,7 +44,7 @@ def _run(ctx, prob, ys, sres, cap):
 
 
 @pytest.mark.parametrize("seed", range(6 * _SCALE))
-@pytest.mark.parametrize("lanes", [0, 8])
+@pytest.mark.parametrize("lanes", [0, 8, "flat0", "flat4"])
 def test_random_velocity_acceleration_problems(hip_lib, oracle_ctx, seed, lanes):
     rng = np.random.default_rng(1000 + seed)
     nJ = int(rng.integers(1, 9))
@@ -57,7 +57,7 @@ def test_random_velocity_acceleration_problems(hip_lib, oracle_ctx, seed, lanes)
     ys = [_random_knots(rng, nJ, int(rng.integers(8, 400)), rng.uniform(0.2, 3.0)) for _ in range(n_paths)]
     sres = [float(rng.uniform(0.01, 0.2)) for _ in range(n_paths)]
     ctx = capi.Context(hip_lib, 0)
-    ctx.set_sweep_group(lanes)
+    set_layout(ctx, lanes)
     cap = 60000
     ro, oo = _run(oracle_ctx, prob, ys, sres, cap)
     for extra in (0, capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES):
@@ -254,12 +254,13 @@ def test_random_two_link_arm_with_torque_limits(hip_lib, oracle_ctx, seed):
             assert_bit_equal(ho[k][2], oo[k][2], f"seed {seed} path {k} pointwise")
 
 
-@pytest.mark.parametrize("ppw", [1, 8])
-def test_two_link_arm_paths_that_never_finish(hip_lib, oracle_ctx, ppw):
+@pytest.mark.parametrize("ppw,hold", [(1, -1), (8, -1), (8, 4)])
+def test_two_link_arm_paths_that_never_finish(hip_lib, oracle_ctx, ppw, hold):
     """torque-limited paths that stall (the sweep runs into its step capacity with hundreds to thousands of failed
     bisections, one path failing at every stage): failure counts, step counts and statuses equal the oracle's, with one
-    and with several such paths per wavefront.  (This is the case that exposed the schedule dependence of the
-    experimental flat stage/bisection loop, tools/experiments/.)"""
+    and with several such paths per wavefront.  (This is the case that exposed the hold-dependent results of the flat
+    stage / bisection loop when it was instantiated for the torque branch, tools/experiments/; a problem with torque
+    limits runs the nested loops whatever hold is set: the last parameter set checks exactly that.)"""
     import helpers
     rng = np.random.default_rng(3000)
     base = helpers.Case("RR").problem
@@ -278,6 +279,7 @@ def test_two_link_arm_paths_that_never_finish(hip_lib, oracle_ctx, ppw):
             ctx = capi.Context(hip_lib, 0)
             ctx.set_sweep_group(8)
             ctx.set_paths_per_wave(ppw)
+            ctx.set_sweep_hold(hold, hold)
         b = capi.Batch(ctx, prob, [y.shape[1] for y in ys], 12000)
         for k, y in enumerate(ys):
             b.upload_knots(k, [y], [sres[k]])
@@ -292,3 +294,39 @@ def test_two_link_arm_paths_that_never_finish(hip_lib, oracle_ctx, ppw):
     assert int(ro["n_bisect_fail_rev"].max()) > 1000 and int((ro["status_rev"] & capi.ST_CAPACITY != 0).sum()) >= 3
     for f in rh.dtype.names:
         assert np.array_equal(rh[f], ro[f]), (f, rh[f], ro[f])
+
+
+@pytest.mark.parametrize("compact", [0, 1])
+@pytest.mark.parametrize("seed", range(2 * _SCALE))
+def test_flat_sweep_loop_on_stalled_velocity_acceleration_paths(hip_lib, oracle_ctx, seed, compact):
+    """joint velocity / acceleration limits only, one joint with a NEGATIVE acceleration limit: wherever that joint moves
+    no sddot is admissible, so some paths fail at every stage and run into the step capacity, some fail now and then (the
+    joint hovers around the zero-velocity threshold), one never does -- seven such paths in one wavefront, nested loops
+    and flat loop with every hold: everything equal to the oracle"""
+    rng = np.random.default_rng(500 + seed)
+    nJ = 3
+    amax = [float(rng.uniform(5, 30)), -1.0, float(rng.uniform(5, 30))]
+    prob = capi.make_problem(nJ, 0, flags=capi.F_JNT_ACC_ON, jnt_vel_max=list(rng.uniform(1, 6, nJ)), jnt_acc_max=amax,
+                             integ_res=0.01, max_integ_time=1e5)
+    ys = [_random_knots(rng, nJ, int(rng.integers(40, 300)), rng.uniform(0.5, 2.0)) for _ in range(7)]
+    ys[3][1, :] = 0.25
+    for k, f in ((0, 3e-6), (1, 1e-5), (2, 3e-5), (4, 1e-4)):
+        ys[k][1] *= f
+    sres = [float(rng.uniform(0.02, 0.1)) for _ in ys]
+    cap = 3000
+    ro, oo = _run(oracle_ctx, prob, ys, sres, cap)
+    assert int(ro["n_bisect_fail_rev"].max()) > 10000 and int(ro["n_bisect_fail_rev"].min()) == 0
+    p2 = capi.Problem.from_buffer_copy(bytes(prob))
+    if compact:
+        p2.flags |= capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES
+    for hold in (-1, 0, 2, 3, 4, 5, 6, 8):
+        ctx = capi.Context(hip_lib, 0)
+        ctx.set_sweep_group(8); ctx.set_paths_per_wave(8); ctx.set_sweep_hold(hold, hold)
+        rh, ho = _run(ctx, p2, ys, sres, cap)
+        for f in rh.dtype.names:
+            assert np.array_equal(rh[f], ro[f]), (seed, hold, f, rh[f], ro[f])
+        for k in range(len(ys)):
+            for which in (0, 1):
+                assert_bit_equal(ho[k][which][0], oo[k][which][0], f"seed {seed} hold {hold} path {k} curve {which} s")
+                assert_bit_equal(ho[k][which][1], oo[k][which][1], f"seed {seed} hold {hold} path {k} curve {which} sdot")
+        ctx.close()

@@ -94,11 +94,11 @@ def test_hip_baseline_size_paths(hip_ctx, oracle_ctx, name):
     assert_matches_reference(case, ho)
 
 
-@pytest.mark.parametrize("lanes", [1, 8, 16, 32])
+@pytest.mark.parametrize("lanes", [1, 8, 16, 32, "flat4"])
 def test_other_lane_groupings_agree(hip_lib, oracle_ctx, lanes):
     """the sweep kernel with 1 or 16 lanes per path publishes the same bits as the default 8"""
     ctx = capi.Context(hip_lib, 0)
-    ctx.set_sweep_group(lanes)
+    helpers.set_layout(ctx, lanes)
     for name in ("GEN7DOF", "CSPR3DOF", "UR5", "CSPR3DOF_par", "RR_acc", "synth_cspr_s5", "synth_ur_s2"):
         case = Case(name)
         ho = run_pipeline(ctx, [case], mvc=False, details=False)[0]
@@ -118,6 +118,48 @@ def test_ragged_batch_equals_single_paths(hip_ctx, oracle_ctx):
     ref = {n: run_pipeline(oracle_ctx, [c], mvc=False, details=False)[0] for n, c in zip(names, cases)}
     for k, c in enumerate(cases * 5):
         _compare(c, many[k], ref[c.name])
+
+
+@pytest.mark.parametrize("hold", [(0, 0), (3, 5), (4, -1), (5, 3), (8, 8), (-1, 6)])
+@pytest.mark.parametrize("compact", [False, True])
+def test_flat_sweep_loop_with_paths_drifting_apart(hip_lib, oracle_ctx, hold, compact):
+    """batotp_hip_set_sweep_hold: 8 different paths per wavefront in the flat stage / bisection loop (each at its own
+    stage and step), every hold: every path equals its single-path oracle run"""
+    names = ["synth_gen7dof_s0", "GEN7DOF", "synth_gen7dof_s1_vel", "GEN7DOF", "synth_gen7dof_s0", "GEN7DOF", "GEN7DOF"]
+    cases = [Case(n) for n in names]
+    for c in cases:
+        c.problem = cases[0].problem
+    ctx = capi.Context(hip_lib, 0)
+    ctx.set_sweep_group(8)
+    ctx.set_paths_per_wave(8)
+    ctx.set_sweep_hold(*hold)
+    extra = (capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES) if compact else 0
+    cap = 4 * max(c.max_steps() for c in cases)
+    many = run_pipeline(ctx, cases * 3, max_steps=cap, mvc=False, details=False, extra_flags=extra)   # 21 paths: 3 wavefronts, the last one partly filled
+    ref = {}
+    for c in cases:
+        if c.name not in ref:
+            ref[c.name] = run_pipeline(oracle_ctx, [c], max_steps=cap, mvc=False, details=False)[0]
+    for k, c in enumerate(cases * 3):
+        _compare(c, many[k], ref[c.name])
+    ctx.close()
+
+
+def test_flat_sweep_loop_capacity_and_max_time_status(hip_lib, oracle_ctx):
+    import copy
+    case = Case("GEN7DOF")
+    ctx = capi.Context(hip_lib, 0)
+    helpers.set_layout(ctx, "flat5")
+    short = copy.copy(case)
+    short.problem = capi.Problem.from_buffer_copy(bytes(case.problem))
+    short.problem.max_integ_time = 1.0
+    for c, kw in ((case, dict(max_steps=100)), (short, {})):
+        a = run_pipeline(ctx, [c, c, c], mvc=False, details=False, **kw)
+        b = run_pipeline(oracle_ctx, [c], mvc=False, details=False, **kw)[0]
+        for q in a:
+            for f in b["result"].dtype.names:
+                assert q["result"][f] == b["result"][f], f
+    ctx.close()
 
 
 def test_capacity_and_max_time_status(hip_ctx, oracle_ctx):
