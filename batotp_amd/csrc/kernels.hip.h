@@ -1679,98 +1679,99 @@ __global__ void __launch_bounds__(K4_BLOCK, (FEAT <= 1 && G > 1) ? BK_SWEEP_WPE 
    }
    else
    {
-   bool done = false;
-   while (!done)
-   {
-      if (i >= cap) { endStatus = BATOTP_ST_CAPACITY; break; }
-      const double sStart = t.sCur;
-      // st == 0: Euler predictor (ba.cpp:1055-1065).  Its sdot is overwritten by stage 6; all that
-      // survives is the move of the reverse-curve cursor inside evalsdot (forward sweep only).
-      // st == 1..6: the six stages of ba.cpp:1068-1094.  A real loop (not unrolled) keeps the
-      // kernel inside the instruction cache.
-#pragma unroll 1
-      for (int st = (dir == 1 ? 0 : 1); st < 7; ++st)
+      // the nested form: stages, and inside every stage the bisection loop of accel_pt
+      bool done = false;
+      while (!done)
       {
-         double sN, vN, sdotT = 0, sddotT = 0;
-         switch (st)
+         if (i >= cap) { endStatus = BATOTP_ST_CAPACITY; break; }
+         const double sStart = t.sCur;
+         // st == 0: Euler predictor (ba.cpp:1055-1065).  Its sdot is overwritten by stage 6; all that
+         // survives is the move of the reverse-curve cursor inside evalsdot (forward sweep only).
+         // st == 1..6: the six stages of ba.cpp:1068-1094.  A real loop (not unrolled) keeps the
+         // kernel inside the instruction cache.
+#pragma unroll 1
+         for (int st = (dir == 1 ? 0 : 1); st < 7; ++st)
          {
-         case 0: break;
-         case 1: sdotT += BK_B00 * v0; sddotT += BK_B00 * w0; break;
-         case 2: sdotT += BK_B01 * v0; sdotT += BK_B11 * v1; sddotT += BK_B01 * w0; sddotT += BK_B11 * w1; break;
-         case 3:
-            sdotT += BK_B02 * v0; sdotT += BK_B12 * v1; sdotT += BK_B22 * v2;
-            sddotT += BK_B02 * w0; sddotT += BK_B12 * w1; sddotT += BK_B22 * w2;
-            break;
-         case 4:
-            sdotT += BK_B03 * v0; sdotT += BK_B13 * v1; sdotT += BK_B23 * v2; sdotT += BK_B33 * v3;
-            sddotT += BK_B03 * w0; sddotT += BK_B13 * w1; sddotT += BK_B23 * w2; sddotT += BK_B33 * w3;
-            break;
-         case 5:
-            sdotT += BK_B04 * v0; sdotT += BK_B14 * v1; sdotT += BK_B24 * v2; sdotT += BK_B34 * v3; sdotT += BK_B44 * v4;
-            sddotT += BK_B04 * w0; sddotT += BK_B14 * w1; sddotT += BK_B24 * w2; sddotT += BK_B34 * w3; sddotT += BK_B44 * w4;
-            break;
-         default:
-            sdotT += BK_B05 * v0; sdotT += BK_B15 * v1; sdotT += BK_B25 * v2; sdotT += BK_B35 * v3; sdotT += BK_B45 * v4; sdotT += BK_B55 * v5;
-            sddotT += BK_B05 * w0; sddotT += BK_B15 * w1; sddotT += BK_B25 * w2; sddotT += BK_B35 * w3; sddotT += BK_B45 * w4; sddotT += BK_B55 * w5;
-            break;
-         }
-         if (st == 0)
-         {
-            // forward predictor: evalsdot's cursor walk at s0 + h*sdot0, nothing else is kept
-            t.sCur = s0v + h * v0;
+            double sN, vN, sdotT = 0, sddotT = 0;
+            switch (st)
+            {
+            case 0: break;
+            case 1: sdotT += BK_B00 * v0; sddotT += BK_B00 * w0; break;
+            case 2: sdotT += BK_B01 * v0; sdotT += BK_B11 * v1; sddotT += BK_B01 * w0; sddotT += BK_B11 * w1; break;
+            case 3:
+               sdotT += BK_B02 * v0; sdotT += BK_B12 * v1; sdotT += BK_B22 * v2;
+               sddotT += BK_B02 * w0; sddotT += BK_B12 * w1; sddotT += BK_B22 * w2;
+               break;
+            case 4:
+               sdotT += BK_B03 * v0; sdotT += BK_B13 * v1; sdotT += BK_B23 * v2; sdotT += BK_B33 * v3;
+               sddotT += BK_B03 * w0; sddotT += BK_B13 * w1; sddotT += BK_B23 * w2; sddotT += BK_B33 * w3;
+               break;
+            case 5:
+               sdotT += BK_B04 * v0; sdotT += BK_B14 * v1; sdotT += BK_B24 * v2; sdotT += BK_B34 * v3; sdotT += BK_B44 * v4;
+               sddotT += BK_B04 * w0; sddotT += BK_B14 * w1; sddotT += BK_B24 * w2; sddotT += BK_B34 * w3; sddotT += BK_B44 * w4;
+               break;
+            default:
+               sdotT += BK_B05 * v0; sdotT += BK_B15 * v1; sdotT += BK_B25 * v2; sdotT += BK_B35 * v3; sdotT += BK_B45 * v4; sdotT += BK_B55 * v5;
+               sddotT += BK_B05 * w0; sddotT += BK_B15 * w1; sddotT += BK_B25 * w2; sddotT += BK_B35 * w3; sddotT += BK_B45 * w4; sddotT += BK_B55 * w5;
+               break;
+            }
+            if (st == 0)
+            {
+               // forward predictor: evalsdot's cursor walk at s0 + h*sdot0, nothing else is kept
+               t.sCur = s0v + h * v0;
 #ifdef BK_OLD_MVC
-            update_cur_seg<2>(t.mvc, 0.0, t.nMvc, t.sCur, t.segMVC, t.tauMVC, t.status);
+               update_cur_seg<2>(t.mvc, 0.0, t.nMvc, t.sCur, t.segMVC, t.tauMVC, t.status);
 #else
-            mvc_walk(t);
+               mvc_walk(t);
 #endif
-            t.sCur = sStart;
-            continue;
+               t.sCur = sStart;
+               continue;
+            }
+            sN = s0v + h * sdotT;
+            vN = v0 + h * sddotT;
+            vN = dmax(vN, floorV); // ba.cpp:1085
+            t.sCur = sN;
+            BK_TICK(ta0);
+            sdot_lim(t, j, vN);
+            BK_TICK(ta1);
+            BK_ACC(t.cycA, ta0, ta1);
+            t.sdotCur = vN;
+            // sddotArr[st] keeps its previous value when the bisection fails (ba.cpp:1091 ignores the code)
+            double wN = (st == 1) ? w1 : (st == 2) ? w2 : (st == 3) ? w3 : (st == 4) ? w4 : (st == 5) ? w5 : w6;
+            BK_TICK(tc0);
+            accel_pt(t, j, wN);
+            BK_TICK(tc1);
+            BK_ACC(t.cycC, tc0, tc1);
+            vN = t.sdotCur;
+            switch (st)
+            {
+            case 1: v1 = vN; w1 = wN; break;
+            case 2: v2 = vN; w2 = wN; break;
+            case 3: v3 = vN; w3 = wN; break;
+            case 4: v4 = vN; w4 = wN; break;
+            case 5: v5 = vN; w5 = wN; break;
+            default: s6v = sN; v6 = vN; w6 = wN; break;
+            }
+            // reverse sweep only (descending addresses; measured: -17 % there, +5 % on the forward sweep,
+            // whose ascending walk finds the next lines already on their way): consume last stage's touch,
+            // issue the next one
+            if (BK_TOUCH_DIRS == 2 || (BK_TOUCH_DIRS == 1 && dir == -1))
+            {
+               t.sink += pf;
+               pf = touch_ahead(t, j);
+            }
          }
-         sN = s0v + h * sdotT;
-         vN = v0 + h * sddotT;
-         vN = dmax(vN, floorV); // ba.cpp:1085
-         t.sCur = sN;
-         BK_TICK(ta0);
-         sdot_lim(t, j, vN);
-         BK_TICK(ta1);
-         BK_ACC(t.cycA, ta0, ta1);
-         t.sdotCur = vN;
-         // sddotArr[st] keeps its previous value when the bisection fails (ba.cpp:1091 ignores the code)
-         double wN = (st == 1) ? w1 : (st == 2) ? w2 : (st == 3) ? w3 : (st == 4) ? w4 : (st == 5) ? w5 : w6;
-         BK_TICK(tc0);
-         accel_pt(t, j, wN);
-         BK_TICK(tc1);
-         BK_ACC(t.cycC, tc0, tc1);
-         vN = t.sdotCur;
-         switch (st)
-         {
-         case 1: v1 = vN; w1 = wN; break;
-         case 2: v2 = vN; w2 = wN; break;
-         case 3: v3 = vN; w3 = wN; break;
-         case 4: v4 = vN; w4 = wN; break;
-         case 5: v5 = vN; w5 = wN; break;
-         default: s6v = sN; v6 = vN; w6 = wN; break;
-         }
-         // reverse sweep only (descending addresses; measured: -17 % there, +5 % on the forward sweep,
-         // whose ascending walk finds the next lines already on their way): consume last stage's touch,
-         // issue the next one
-         if (BK_TOUCH_DIRS == 2 || (BK_TOUCH_DIRS == 1 && dir == -1))
-         {
-            t.sink += pf;
-            pf = touch_ahead(t, j);
-         }
+
+         // FSAL shift and publish, ba.cpp:1096-1100
+         s0v = s6v; v0 = v6; w0 = w6;
+         sPrev = sCurPt; sdPrev = sdCurPt;
+         sCurPt = s0v; sdCurPt = v0;
+         if (writer) out[dir == 1 ? i : cap - 1 - i] = make_double2(s0v, v0);
+
+         if (t.sCur * dir > sLast) { nPts = i + 1; done = true; } // ba.cpp:1109-1115
+         else if (i > maxIntegSteps) { endStatus = BATOTP_ST_MAX_INTEG_TIME; break; } // ba.cpp:1117-1122
+         else ++i;
       }
-
-      // FSAL shift and publish, ba.cpp:1096-1100
-      s0v = s6v; v0 = v6; w0 = w6;
-      sPrev = sCurPt; sdPrev = sdCurPt;
-      sCurPt = s0v; sdCurPt = v0;
-      if (writer) out[dir == 1 ? i : cap - 1 - i] = make_double2(s0v, v0);
-
-      if (t.sCur * dir > sLast) { nPts = i + 1; done = true; } // ba.cpp:1109-1115
-      else if (i > maxIntegSteps) { endStatus = BATOTP_ST_MAX_INTEG_TIME; break; } // ba.cpp:1117-1122
-      else ++i;
-   }
    }
    if (writer) a.sink[p] = t.sink + pf;
 #ifdef BK_PROFILE_SECTIONS
