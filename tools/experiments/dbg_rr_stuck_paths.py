@@ -31,7 +31,7 @@ def run(ctx):
     cur = [(b.curve(k, -1), b.curve(k, 1)) for k in range(len(ys))]
     b.close()
     return r, cur
-for lanes, ppw, hr, hf in ((8, 8, -1, -1), (8, 8, 6, -1), (8, 8, 4, -1), (1, 64, 6, -1)):
+for lanes, ppw, hr, hf in ((8, 8, -1, -1), (8, 8, 6, -1), (8, 8, 4, -1)):
     ctx = capi.Context(hip_lib, 0)
     ctx.set_sweep_group(lanes); ctx.set_paths_per_wave(ppw); ctx.set_sweep_hold(hr, hf)
     r, c = run(ctx)
