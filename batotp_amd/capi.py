@@ -1,12 +1,9 @@
 """ctypes binding of the C-ABI in include/batotp_hip.h.
 
-The same binding serves two libraries with the same entry points:
-  * ``batotp_amd/csrc/libbatotp_hip.so`` -- the product (HIP kernels for gfx950);
-  * ``oracle/_build/libbatotp_oracle_abi.so`` -- the CPU oracle behind the same ABI, loaded ONLY
-    by tests, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg (see ``load_oracle``).
-
-Nothing in here falls back from one to the other: ``load_hip`` raises if the HIP library is
-missing or no GPU is usable.
+The product library is ``batotp_amd/csrc/libbatotp_hip.so`` (HIP kernels for gfx950); ``load_hip`` raises
+if it is missing and ``Context`` raises if no GPU is usable -- there is no fallback.  ``Library`` binds any
+shared object that exports the same entry points; the test-suite uses that to put its CPU checker behind
+the same classes (``tests/helpers.load_oracle``) -- nothing in this package knows where that checker lives.
 """
 from __future__ import annotations
 
@@ -18,8 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-HIP_LIB_PATH = os.environ.get("BATOTP_HIP_LIB", os.path.join(_HERE, "csrc", "libbatotp_hip.so"))
-ORACLE_ABI_LIB_PATH = os.path.join(_ROOT, "oracle", "_build", "libbatotp_oracle_abi.so")
+HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libbatotp_hip.so")
 
 MAX_JOINTS = 8
 MAX_CART = 8
@@ -70,6 +66,17 @@ class Problem(C.Structure):
     @property
     def n_channels(self) -> int:
         return self.n_joints + self.n_cart + 4 * self.dyn_dim
+
+
+class SerialLink(C.Structure):
+    """struct batotp_serial_link"""
+    _fields_ = [("axis", C.c_double * 3), ("off", C.c_double * 3), ("com", C.c_double * 3), ("mass", C.c_double),
+                ("inertia", C.c_double * 6), ("fv", C.c_double)]
+
+
+class SerialModel(C.Structure):
+    """struct batotp_serial_model"""
+    _fields_ = [("n_links", C.c_int32), ("degrees", C.c_int32), ("gravity", C.c_double * 3), ("link", SerialLink * 8)]
 
 
 class PathResult(C.Structure):
@@ -175,6 +182,9 @@ class Library:
             "batotp_hip_upload_knots": [P, I32, I32, D, D],
             "batotp_hip_upload_knots_device": [P, I32, I32, P, D],
             "batotp_hip_upload_rr_trig": [P, I32, D],
+            "batotp_hip_set_serial_model": [P, C.POINTER(SerialModel)],
+            "batotp_hip_upload_joint_trig": [P, I32, D],
+            "batotp_hip_builtin_serial_model": [I32, C.POINTER(SerialModel)],
             "batotp_hip_upload_path_sites": [P, I32, D, C.c_double, C.c_double, I32],
             "batotp_hip_upload_coeffs": [P, I32, I32, D],
             "batotp_hip_upload_curve": [P, I32, D, D, I64],
@@ -223,6 +233,11 @@ class Library:
         if rc != 0:
             msg = self.lib.batotp_hip_last_error()
             raise BatotpError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+    def builtin_serial_model(self, robot_type: int) -> SerialModel:
+        m = SerialModel()
+        self.check(self.lib.batotp_hip_builtin_serial_model(robot_type, C.byref(m)), "builtin_serial_model")
+        return m
 
     def device_count(self) -> int:
         n = C.c_int(0)
@@ -424,6 +439,14 @@ class Batch:
         t = np.ascontiguousarray(trig, dtype=np.float64)
         self.L.check(self.lib.batotp_hip_upload_rr_trig(self.handle, path, _dptr(t)), "upload_rr_trig")
 
+    def set_serial_model(self, model: SerialModel):
+        self.L.check(self.lib.batotp_hip_set_serial_model(self.handle, C.byref(model)), "set_serial_model")
+
+    def upload_joint_trig(self, path: int, trig: np.ndarray):
+        """trig: [2*n_joints][N] cosines, then sines, of the joint angles (radians) at the knot samples"""
+        t = np.ascontiguousarray(trig, dtype=np.float64)
+        self.L.check(self.lib.batotp_hip_upload_joint_trig(self.handle, path, _dptr(t)), "upload_joint_trig")
+
     def upload_path_sites(self, path: int, sites: np.ndarray, vfact: float, afact: float, parallel_now: int):
         s = np.ascontiguousarray(sites, dtype=np.float64)
         self.L.check(self.lib.batotp_hip_upload_path_sites(self.handle, path, _dptr(s), vfact, afact, parallel_now), "upload_path_sites")
@@ -510,8 +533,3 @@ def load_hip() -> Library:
     if _hip_library is None:
         _hip_library = Library(HIP_LIB_PATH)
     return _hip_library
-
-
-def load_oracle() -> Library:
-    """TEST INFRASTRUCTURE: the CPU oracle behind the same ABI (tests / smoke / cpu_baseline only)."""
-    return Library(ORACLE_ABI_LIB_PATH)

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "batotp_hip.h"
+#include "batotp_models.h"
 #include "kernels.hip.h"
 #include "resample.hip.h"
 #include "output.hip.h"
@@ -87,6 +88,9 @@ struct batotp_batch
    int *dSink = nullptr;     // consumer of the sweep kernel's prefetch touches
    double *dElim = nullptr;  // Thomas elimination values of k_spline, [max(Cin,4d)][N] per path
    double *dKM = nullptr;    // compact splines: [N][Cin][2] (knot value, second derivative) per path; replaces dY, dElim and dCoef
+   batotp_serial_model *dModel = nullptr; // serial-chain dynamics model (batotp_hip_set_serial_model)
+   double *dJTrig = nullptr; // [2*nJ][N] per path: host cosines / sines of the joint angles for the serial-chain dynamics
+   bool hasSerial = false, jtrigSet = false;
    double *dUp = nullptr;    // compact splines: staging of host knots on their way into dKM
    int64_t upDoubles = 0;
    int64_t maxN = 0;
@@ -322,7 +326,7 @@ extern "C" int batotp_hip_batch_destroy(batotp_batch *b)
    if (!b) return BATOTP_OK;
    if (b->ctx) hipSetDevice(b->ctx->device);
    if (b->ctx && b->k3Pending) hipStreamSynchronize(b->ctx->stream2);
-   void *ptrs[] = {b->dP, b->dPinfo, b->dY, b->dSC, b->dCoef, b->dSamp, b->dDyn, b->dTrig, b->dMvc, b->dRev, b->dFwd, b->dRes, b->dStage, b->dSink, b->dElim, b->dKM, b->dUp};
+   void *ptrs[] = {b->dP, b->dPinfo, b->dY, b->dSC, b->dCoef, b->dSamp, b->dDyn, b->dTrig, b->dMvc, b->dRev, b->dFwd, b->dRes, b->dStage, b->dSink, b->dElim, b->dKM, b->dUp, b->dModel, b->dJTrig};
    for (void *p : ptrs)
       if (p) hipFree(p);
    for (int k = 0; k < 5; ++k)
@@ -524,6 +528,60 @@ extern "C" int batotp_hip_upload_rr_trig(batotp_batch *b, int32_t path, const do
    return BATOTP_OK;
 }
 
+extern "C" int batotp_hip_builtin_serial_model(int32_t robot_type, batotp_serial_model *out)
+{
+   if (!out) return BATOTP_ERR_ARG;
+   return batotp_builtin_serial_model(robot_type, out) == 0 ? BATOTP_OK : BATOTP_ERR_ARG;
+}
+
+extern "C" int batotp_hip_set_serial_model(batotp_batch *b, const batotp_serial_model *model)
+{
+   if (!b || !model) return BATOTP_ERR_ARG;
+   if (model->n_links != b->P.nJ || model->n_links < 1 || model->n_links > BATOTP_MAX_LINKS) return BATOTP_ERR_ARG;
+   if (!(b->prob.flags & BATOTP_F_TRQ_ON) || (b->prob.flags & BATOTP_F_PARALLEL))
+   {
+      snprintf(g_err, sizeof(g_err), "a serial-chain model needs BATOTP_F_TRQ_ON on a serial robot");
+      return BATOTP_ERR_ARG;
+   }
+   for (int i = 0; i < model->n_links; ++i)
+   {
+      // unit axis: the rotation of rot_axis is a rotation only then
+      const double *a = model->link[i].axis;
+      const double nn = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+      if (!(fabs(nn - 1.0) < 1e-9)) { snprintf(g_err, sizeof(g_err), "joint axis %d is not a unit vector", i); return BATOTP_ERR_ARG; }
+   }
+   int rc = bind(b->ctx);
+   if (rc) return rc;
+   if (!b->dModel)
+   {
+      rc = devAlloc(b, (void **)&b->dModel, sizeof(batotp_serial_model));
+      if (rc) return rc;
+   }
+   HIP_TRY(hipMemcpyAsync(b->dModel, model, sizeof(*model), hipMemcpyHostToDevice, b->ctx->stream));
+   HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+   b->hasSerial = true;
+   b->dynDone = false;
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_upload_joint_trig(batotp_batch *b, int32_t path, const double *trig)
+{
+   if (!b || !trig || path < 0 || path >= b->B || !b->hasSerial) return BATOTP_ERR_ARG;
+   int rc = bind(b->ctx);
+   if (rc) return rc;
+   if (!b->dJTrig)
+   {
+      rc = devAlloc(b, (void **)&b->dJTrig, sizeof(double) * (size_t)(b->totalKnots * 2 * b->P.nJ));
+      if (rc) return rc;
+   }
+   const PathInfo &pi = b->pinfo[path];
+   HIP_TRY(hipMemcpyAsync(b->dJTrig + pi.koff * 2 * b->P.nJ, trig, sizeof(double) * 2 * (size_t)b->P.nJ * (size_t)pi.n, hipMemcpyHostToDevice,
+                          b->ctx->stream));
+   HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+   b->jtrigSet = true;
+   return BATOTP_OK;
+}
+
 // ABI channel -> device channel (device order interleaves a1..a4 per dynamics row)
 static int devChannel(const batotp_batch *b, int ch)
 {
@@ -663,12 +721,28 @@ extern "C" int batotp_hip_precompute(batotp_batch *b, int32_t stage)
    if ((stage == 0 || stage == 2) && b->P.d > 0)
    {
       if (!b->kinDone) return BATOTP_ERR_STATE;
-      if (!(b->prob.flags & BATOTP_F_PARALLEL) && b->prob.robot_type != BATOTP_ROBOT_RR) return BATOTP_ERR_ARG; // robot.cpp:349-360
+      const bool serialModel = b->hasSerial && !(b->prob.flags & BATOTP_F_PARALLEL);
+      if (!(b->prob.flags & BATOTP_F_PARALLEL) && !serialModel && b->prob.robot_type != BATOTP_ROBOT_RR)
+      {
+         // robot.cpp:349-360: "No dynamics model provided for serial robotType"
+         snprintf(g_err, sizeof(g_err), "no dynamics model for this serial robot: call batotp_hip_set_serial_model");
+         return BATOTP_ERR_ARG;
+      }
       if ((b->prob.flags & BATOTP_F_PARALLEL) && b->prob.robot_type != BATOTP_ROBOT_CSPR3DOF) return BATOTP_ERR_ARG; // robot.cpp:452-463
-      const bool hostTrig = (b->prob.flags & BATOTP_F_HOST_TRIG) && b->prob.robot_type == BATOTP_ROBOT_RR;
-      if (hostTrig && !b->trigSet) return BATOTP_ERR_STATE;
-      hipLaunchKernelGGL(k_dynamics, dim3(gridKnots), dim3(bs), 0, st, b->P, b->dP, b->dPinfo, b->B, b->dSamp,
-                         hostTrig ? b->dTrig : (const double *)nullptr, b->dDyn, b->totalKnots);
+      if (serialModel)
+      {
+         const bool hostTrig = (b->prob.flags & BATOTP_F_HOST_TRIG) != 0;
+         if (hostTrig && !b->jtrigSet) return BATOTP_ERR_STATE;
+         hipLaunchKernelGGL(k_dyn_serial, dim3((unsigned)((b->totalKnots + KDS_BLOCK - 1) / KDS_BLOCK)), dim3(KDS_BLOCK), 0, st, b->dModel,
+                            b->P.Cin, b->dPinfo, b->B, b->dSamp, hostTrig ? b->dJTrig : (const double *)nullptr, b->dDyn, b->totalKnots);
+      }
+      else
+      {
+         const bool hostTrig = (b->prob.flags & BATOTP_F_HOST_TRIG) && b->prob.robot_type == BATOTP_ROBOT_RR;
+         if (hostTrig && !b->trigSet) return BATOTP_ERR_STATE;
+         hipLaunchKernelGGL(k_dynamics, dim3(gridKnots), dim3(bs), 0, st, b->P, b->dP, b->dPinfo, b->B, b->dSamp,
+                            hostTrig ? b->dTrig : (const double *)nullptr, b->dDyn, b->totalKnots);
+      }
       HIP_TRY(hipGetLastError());
       rc = launchSpline(b, 4 * b->P.d, 1, b->dDyn, 4 * b->P.d);
       if (rc) return rc;

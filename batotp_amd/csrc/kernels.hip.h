@@ -493,6 +493,200 @@ __global__ void k_dynamics(DevProblem P, const DevProblem *__restrict__ dP, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// K2c: dynamics coefficients of a serial chain of revolute joints (BASELINE config 3: 7-DOF arm with torque
+// limits) -- one more case of Robot::dynSerial's switch (robot.cpp:349-360), table-driven (batotp_serial_model).
+// tau = a1 sddot + a2 sdot^2 + a3 sdot + a4 (robot.cpp:368-372) with q = q(s):
+//   a1 = M q' = RNEA(q, 0, q'), a2 = M q'' + C(q, q') q' = RNEA(q, q', q''), both without gravity;
+//   a3 = fv .* q';  a4 = g(q) = RNEA(q, 0, 0) with the base accelerating at -gravity.
+// Recursive Newton-Euler in link coordinates, zero-aligned frames, Rodrigues rotation about each joint's axis.
+// One lane per knot, the model staged in LDS (every lane reads the same word: broadcast), the link loops unrolled
+// so that the link forces of the outward pass stay in registers.  The expression order is the one of the oracle's
+// bo_rnea (oracle/batotp_oracle_dyn.c); there is no reference model for this robot (parity unpinned).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cross3(const double *a, const double *b, double *o)
+{
+   o[0] = a[1] * b[2] - a[2] * b[1];
+   o[1] = a[2] * b[0] - a[0] * b[2];
+   o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ void rot_axis(const double *a, double c, double s, double *R)
+{
+   const double omc = 1.0 - c;
+   R[0] = omc * a[0] * a[0] + c;
+   R[1] = omc * a[0] * a[1] - s * a[2];
+   R[2] = omc * a[0] * a[2] + s * a[1];
+   R[3] = omc * a[1] * a[0] + s * a[2];
+   R[4] = omc * a[1] * a[1] + c;
+   R[5] = omc * a[1] * a[2] - s * a[0];
+   R[6] = omc * a[2] * a[0] - s * a[1];
+   R[7] = omc * a[2] * a[1] + s * a[0];
+   R[8] = omc * a[2] * a[2] + c;
+}
+__device__ __forceinline__ void mat_v(const double *R, const double *v, double *o)
+{
+   o[0] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+   o[1] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+   o[2] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+}
+__device__ __forceinline__ void matT_v(const double *R, const double *v, double *o)
+{
+   o[0] = R[0] * v[0] + R[3] * v[1] + R[6] * v[2];
+   o[1] = R[1] * v[0] + R[4] * v[1] + R[7] * v[2];
+   o[2] = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+}
+__device__ __forceinline__ void inertia_v(const double *I, const double *v, double *o)
+{
+   o[0] = I[0] * v[0] + I[3] * v[1] + I[4] * v[2];
+   o[1] = I[3] * v[0] + I[1] * v[1] + I[5] * v[2];
+   o[2] = I[4] * v[0] + I[5] * v[1] + I[2] * v[2];
+}
+
+// one pass of the recursion at one configuration (cosines / sines of the joint angles, rates, accelerations, base
+// acceleration); tau[n_links]
+__device__ __forceinline__ void rnea_pass(const batotp_serial_model &m, const double *cq, const double *sq, const double *qd,
+                                          const double *qdd, const double *a0, double *tau)
+{
+   const int n = m.n_links;
+   double F[BATOTP_MAX_LINKS][3], Nn[BATOTP_MAX_LINKS][3];
+   double w[3] = {0, 0, 0}, wd[3] = {0, 0, 0}, a[3] = {a0[0], a0[1], a0[2]};
+#pragma unroll
+   for (int i = 0; i < BATOTP_MAX_LINKS; ++i)
+   {
+      if (i < n)
+      {
+         const batotp_serial_link &L = m.link[i];
+         const double ax[3] = {L.axis[0], L.axis[1], L.axis[2]}, off[3] = {L.off[0], L.off[1], L.off[2]};
+         const double com[3] = {L.com[0], L.com[1], L.com[2]};
+         const double In[6] = {L.inertia[0], L.inertia[1], L.inertia[2], L.inertia[3], L.inertia[4], L.inertia[5]};
+         double R[9], t1[3], t2[3], t3[3], wp[3], wdp[3], ap[3], zq[3], ac[3], Iw[3], Iwd[3];
+         rot_axis(ax, cq[i], sq[i], R);
+         cross3(wd, off, t1);
+         cross3(w, off, t2);
+         cross3(w, t2, t3);
+#pragma unroll
+         for (int k = 0; k < 3; ++k) t1[k] = a[k] + t1[k] + t3[k];
+         matT_v(R, t1, ap);
+         matT_v(R, w, wp);
+         matT_v(R, wd, wdp);
+#pragma unroll
+         for (int k = 0; k < 3; ++k) zq[k] = ax[k] * qd[i];
+         cross3(wp, zq, t2);
+#pragma unroll
+         for (int k = 0; k < 3; ++k)
+         {
+            w[k] = wp[k] + zq[k];
+            wd[k] = wdp[k] + ax[k] * qdd[i] + t2[k];
+            a[k] = ap[k];
+         }
+         cross3(wd, com, t1);
+         cross3(w, com, t2);
+         cross3(w, t2, t3);
+#pragma unroll
+         for (int k = 0; k < 3; ++k) ac[k] = a[k] + t1[k] + t3[k];
+#pragma unroll
+         for (int k = 0; k < 3; ++k) F[i][k] = L.mass * ac[k];
+         inertia_v(In, wd, Iwd);
+         inertia_v(In, w, Iw);
+         cross3(w, Iw, t1);
+#pragma unroll
+         for (int k = 0; k < 3; ++k) Nn[i][k] = Iwd[k] + t1[k];
+      }
+   }
+   double fc[3] = {0, 0, 0}, nc[3] = {0, 0, 0};
+#pragma unroll
+   for (int i = BATOTP_MAX_LINKS - 1; i >= 0; --i)
+   {
+      if (i < n)
+      {
+         const batotp_serial_link &L = m.link[i];
+         const double ax[3] = {L.axis[0], L.axis[1], L.axis[2]}, com[3] = {L.com[0], L.com[1], L.com[2]};
+         double f[3], nn[3], t1[3], t2[3] = {0, 0, 0};
+         cross3(com, F[i], t1);
+         if (i + 1 < n)
+         {
+            const batotp_serial_link &Lc = m.link[(i + 1) & (BATOTP_MAX_LINKS - 1)];
+            const double offc[3] = {Lc.off[0], Lc.off[1], Lc.off[2]};
+            cross3(offc, fc, t2);
+         }
+#pragma unroll
+         for (int k = 0; k < 3; ++k)
+         {
+            f[k] = F[i][k] + fc[k];
+            nn[k] = Nn[i][k] + nc[k] + t1[k] + t2[k];
+         }
+         tau[i] = ax[0] * nn[0] + ax[1] * nn[1] + ax[2] * nn[2];
+         double R[9];
+         rot_axis(ax, cq[i], sq[i], R);
+         mat_v(R, f, fc);
+         mat_v(R, nn, nc);
+      }
+   }
+}
+
+constexpr int KDS_BLOCK = 128;
+__global__ void __launch_bounds__(KDS_BLOCK) k_dyn_serial(const batotp_serial_model *__restrict__ model, int Cin,
+                                                          const PathInfo *__restrict__ pinfo, int B, const double *__restrict__ samp,
+                                                          const double *__restrict__ trig, double *__restrict__ dyn, int64_t total)
+{
+   __shared__ batotp_serial_model sm;
+   {
+      // cooperative copy of the table (8-byte words)
+      const double *src = reinterpret_cast<const double *>(model);
+      double *dst = reinterpret_cast<double *>(&sm);
+      for (int k = threadIdx.x; k < (int)(sizeof(batotp_serial_model) / 8); k += KDS_BLOCK) dst[k] = src[k];
+   }
+   __syncthreads();
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   int lo = 0, hi = B - 1;
+   while (lo < hi)
+   {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pinfo[mid].koff <= g) lo = mid; else hi = mid - 1;
+   }
+   const PathInfo pi = pinfo[lo];
+   const int64_t N = pi.n, i = g - pi.koff;
+   const int nl = sm.n_links;
+   const double *__restrict__ sp = samp + pi.koff * Cin * 3;
+   const double *__restrict__ tg = trig ? trig + pi.koff * 2 * nl : nullptr;
+   double *__restrict__ dy = dyn + pi.koff * 4 * nl;
+   const double kDeg2Rad = 3.14159265358979323846 / 180.0;
+   const double unit = sm.degrees ? kDeg2Rad : 1.0;
+
+   double cq[BATOTP_MAX_LINKS], sq[BATOTP_MAX_LINKS], q1[BATOTP_MAX_LINKS], q2[BATOTP_MAX_LINKS], z[BATOTP_MAX_LINKS];
+#pragma unroll
+   for (int j = 0; j < BATOTP_MAX_LINKS; ++j)
+   {
+      cq[j] = 1; sq[j] = 0; q1[j] = 0; q2[j] = 0; z[j] = 0;
+      if (j < nl)
+      {
+         const double q = unit * sp[((int64_t)j * 3 + 0) * N + i];
+         q1[j] = unit * sp[((int64_t)j * 3 + 1) * N + i];
+         q2[j] = unit * sp[((int64_t)j * 3 + 2) * N + i];
+         if (tg) { cq[j] = tg[(int64_t)j * N + i]; sq[j] = tg[(int64_t)(nl + j) * N + i]; }
+         else { cq[j] = cos(q); sq[j] = sin(q); } // device libm: not bit-identical to glibc (BATOTP_F_HOST_TRIG)
+      }
+   }
+   const double zero3[3] = {0, 0, 0};
+   const double g0[3] = {-sm.gravity[0], -sm.gravity[1], -sm.gravity[2]};
+   double t1[BATOTP_MAX_LINKS], t2[BATOTP_MAX_LINKS], t4[BATOTP_MAX_LINKS];
+   rnea_pass(sm, cq, sq, z, q1, zero3, t1);
+   rnea_pass(sm, cq, sq, q1, q2, zero3, t2);
+   rnea_pass(sm, cq, sq, z, z, g0, t4);
+#pragma unroll
+   for (int j = 0; j < BATOTP_MAX_LINKS; ++j)
+   {
+      if (j < nl)
+      {
+         dy[((int64_t)0 * nl + j) * N + i] = t1[j];
+         dy[((int64_t)1 * nl + j) * N + i] = t2[j];
+         dy[((int64_t)2 * nl + j) * N + i] = sm.link[j].fv * q1[j];
+         dy[((int64_t)3 * nl + j) * N + i] = t4[j];
+      }
+   }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Point evaluation shared by K3 and K4.  A path is handled by a group of G lanes: lane j of the
 // group owns joint (and dynamics row) j; with G == 1 one lane loops over all joints.  Everything
 // that is one value per path (cursor, sdot, bisection bracket ...) is kept redundantly in every

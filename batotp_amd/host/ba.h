@@ -191,6 +191,11 @@ public:
    // stage covers this configuration (batotp_hip_output, include/batotp_hip.h), -1 when interpOutputData has
    // to run on the host.
    int exportOutputParams(void *batotp_output_params_out) const;
+   // Extension: torque limits on a serial robot other than the two-link arm (the reference's Robot::dynSerial,
+   // robot.cpp:349-360, knows RR only; KUKA with isTrqConOn segfaults there).  model = struct batotp_serial_model of
+   // include/batotp_hip.h (link table of a chain of revolute joints).  Robot type KUKA has a built-in table
+   // (include/batotp_models.h: LWR IV+, nominal inertial parameters) that is used when none is set.
+   void setSerialModel(const void *batotp_serial_model_in);
    unsigned int getNumJoints() const { return _nJoints; }
    unsigned int getNumCart() const { return _nCart; }
 
@@ -338,6 +343,9 @@ private:
    void fillProblem(void *prob) const;     // BA configuration -> batotp_problem
    int deviceBuildKnotModel(Traj &traj);   // ba.cpp:299-305 on the GPU (B = 1)
    int deviceSweep(Traj &traj);            // ba.cpp:979-1195 on the GPU (B = 1)
+   // serial-chain dynamics on the device: set the model on the batch and upload the host cosines / sines of the
+   // joint angles of path k (samples = knot values [nJoints][N], row stride N)
+   int deviceSerialDynamicsInputs(void *batch, int pathIndex, const double *const *thetaRows, long long N);
 
    inline void setErrorOptimization(const ErrorOptimization &e) { _errorOptimization = e; }
 

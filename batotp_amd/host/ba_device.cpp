@@ -113,7 +113,8 @@ void BA::fillProblem(void *out) const
    if (_isCartAccConOn) f |= BATOTP_F_CART_ACC_ON;
    if (_isParallelMechOrig) f |= BATOTP_F_PARALLEL;
    if (_isPar2Ser) f |= BATOTP_F_PAR2SER;
-   if (_robotType == RR) f |= BATOTP_F_HOST_TRIG; // cos/sin from the host libm: bit parity with the reference
+   // cos/sin from the host libm: bit parity with the reference (RR), and with the host twin of the chain model
+   if (_robotType == RR || (_isTrqConOn && !_isParallelMechOrig)) f |= BATOTP_F_HOST_TRIG;
    P.flags = f;
    for (unsigned int j = 0; j < _nJoints && j < BATOTP_MAX_JOINTS; ++j)
    {
@@ -134,6 +135,47 @@ void BA::fillProblem(void *out) const
       for (int r = 0; r < 3; ++r)
          for (int c = 0; c < 3; ++c) P.pmat[r * 3 + c] = A[r][c];
    }
+}
+
+namespace
+{
+// cos and sin of the same angle through two separate libm calls: inlined side by side the compiler fuses them into one
+// sincos(), whose results are not bit-identical to cos() / sin() in this glibc (SURVEY.md 8c observed the same on the
+// reference's KUKA kinematics).  The trig tables of the chain model are DEFINED as libm cos() and libm sin().
+double __attribute__((noinline)) libmCos(double x) { return std::cos(x); }
+double __attribute__((noinline)) libmSin(double x) { return std::sin(x); }
+} // namespace
+
+void BA::setSerialModel(const void *model)
+{
+   if (model) myRobot.setSerialModel(*static_cast<const batotp_serial_model *>(model));
+}
+
+// Serial robots with a chain model (every serial robot but RR): hand the table to the batch once (pathIndex 0)
+// and the host cosines / sines of the joint angles of one path
+int BA::deviceSerialDynamicsInputs(void *batch, int pathIndex, const double *const *thetaRows, long long N)
+{
+   const batotp_serial_model *m = myRobot.serialModel();
+   if (!m) return -1;
+   batotp_batch *b = static_cast<batotp_batch *>(batch);
+   int rc;
+   if (pathIndex == 0)
+   {
+      rc = batotp_hip_set_serial_model(b, m);
+      if (rc) return fail("set_serial_model", rc);
+   }
+   const double unit = m->degrees ? _DEG2RAD : 1.0;
+   std::vector<double> trig(2 * (size_t)_nJoints * (size_t)N);
+   for (unsigned int j = 0; j < _nJoints; ++j)
+      for (long long i = 0; i < N; ++i)
+      {
+         const double q = unit * thetaRows[j][i];
+         trig[(size_t)j * N + i] = libmCos(q);
+         trig[(size_t)(_nJoints + j) * N + i] = libmSin(q);
+      }
+   rc = batotp_hip_upload_joint_trig(b, pathIndex, trig.data());
+   if (rc) return fail("upload_joint_trig", rc);
+   return 0;
 }
 
 // Which configurations the device resampler takes over (the rest of prepareKnots' branches --
@@ -204,7 +246,8 @@ int BA::deviceBuildKnotModel(Traj &traj)
              BATOTP_MAX_JOINTS, BATOTP_MAX_CART);
       return -1;
    }
-   if (_isTrqConOn && !(_robotType == RR || _robotType == CSPR3DOF))
+   const bool chainModel = _isTrqConOn && !_isParallelMechOrig && _robotType != RR && myRobot.serialModel() != nullptr;
+   if (_isTrqConOn && !(_robotType == RR || _robotType == CSPR3DOF || chainModel))
    {
       // the reference has no dynamics model for the other robots either (robot.cpp:349-360,452-463)
       printf("No dynamics model provided for robotType=%s.\n", _robotTypeStr.c_str());
@@ -323,6 +366,12 @@ int BA::deviceBuildKnotModel(Traj &traj)
       }
       rc = batotp_hip_upload_rr_trig(g.b, 0, trig.data());
       if (rc) return fail("upload_rr_trig", rc);
+   }
+   else if (chainModel)
+   {
+      std::vector<const double *> rows(_nJoints);
+      for (unsigned int j = 0; j < _nJoints; ++j) rows[j] = traj.theta[j].data();
+      if (deviceSerialDynamicsInputs(g.b, 0, rows.data(), (long long)N) != 0) return -1;
    }
    rc = batotp_hip_precompute(g.b, 2);
    if (rc) return fail("precompute(dynamics)", rc);
@@ -678,6 +727,28 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
             }
             rc = batotp_hip_upload_rr_trig(g.b, (int32_t)k, trig.data());
             if (rc) return fail("upload_rr_trig", rc);
+         }
+      }
+      else if (!_isParallelMechOrig)
+      {
+         if (!myRobot.serialModel())
+         {
+            printf("No dynamics model provided for robotType=%s.\n", _robotTypeStr.c_str());
+            return -1;
+         }
+         std::vector<double> samp;
+         std::vector<const double *> rows(_nJoints);
+         for (size_t k = 0; k < live.size(); ++k)
+         {
+            const int64_t N = nKnots[k];
+            samp.resize(3 * (size_t)N * _nJoints);
+            for (unsigned int j = 0; j < _nJoints; ++j)
+            {
+               rc = batotp_hip_download_samples(g.b, (int32_t)k, (int32_t)j, samp.data() + 3 * (size_t)N * j);
+               if (rc) return fail("download_samples", rc);
+               rows[j] = samp.data() + 3 * (size_t)N * j;
+            }
+            if (deviceSerialDynamicsInputs(g.b, (int)k, rows.data(), (long long)N) != 0) return -1;
          }
       }
       rc = batotp_hip_precompute(g.b, 2);

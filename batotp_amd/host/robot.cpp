@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 
+#include "batotp_models.h"
 #include "config.h"
 
 namespace BATOTP
@@ -201,9 +202,175 @@ void Robot::buildCsprAnchors()
 int Robot::call_dynSerial(Channels &a1, Channels &a2, Channels &a3, Channels &a4,
                           const Channels &theta, const Channels &thetaD, const Channels &thetaD2)
 {
-   if (_kind == RR) { planarRRDynamics(a1, a2, a3, a4, theta, thetaD, thetaD2); return 0; }
+   if (_kind == RR && !_hasSerial) { planarRRDynamics(a1, a2, a3, a4, theta, thetaD, thetaD2); return 0; }
+   if (const batotp_serial_model *m = serialModel())
+   {
+      if ((size_t)m->n_links != theta.size())
+      {
+         printf("Serial-chain model has %d links but the path has %d joints.\n", (int)m->n_links, (int)theta.size());
+         return -1;
+      }
+      serialChainDynamics(*m, a1, a2, a3, a4, theta, thetaD, thetaD2);
+      return 0;
+   }
    printf("No dynamics model provided for serial robotType=%s.\n", _kindName.c_str());
    return -1;
+}
+
+const batotp_serial_model *Robot::serialModel()
+{
+   if (!_hasSerial && !_serialProbed)
+   {
+      _serialProbed = true;
+      // the closed-form two-link arm stays the RR model (bit parity with the reference); other robot types take
+      // the table of include/batotp_models.h if there is one
+      if (_kind != RR && batotp_builtin_serial_model(_kind, &_serial) == 0) _hasSerial = true;
+   }
+   return _hasSerial ? &_serial : nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Table-driven serial chain (BASELINE config 3).  a1 = M q', a2 = M q'' + C(q, q') q', a3 = fv q',
+// a4 = g(q) by three passes of the recursive Newton-Euler algorithm in link coordinates (zero-aligned
+// frames, Rodrigues rotation about each joint axis).  Host twin of the device kernel k_dyn_serial
+// (same expression order), used by the torque recomputation of interpOutputData (reference ba.cpp:1791-1827).
+// ---------------------------------------------------------------------------------------------
+namespace
+{
+inline void crossV(const double *a, const double *b, double *o)
+{
+   o[0] = a[1] * b[2] - a[2] * b[1];
+   o[1] = a[2] * b[0] - a[0] * b[2];
+   o[2] = a[0] * b[1] - a[1] * b[0];
+}
+inline void axisRotation(const double *a, double c, double s, double *R)
+{
+   const double omc = 1.0 - c;
+   R[0] = omc * a[0] * a[0] + c;
+   R[1] = omc * a[0] * a[1] - s * a[2];
+   R[2] = omc * a[0] * a[2] + s * a[1];
+   R[3] = omc * a[1] * a[0] + s * a[2];
+   R[4] = omc * a[1] * a[1] + c;
+   R[5] = omc * a[1] * a[2] - s * a[0];
+   R[6] = omc * a[2] * a[0] - s * a[1];
+   R[7] = omc * a[2] * a[1] + s * a[0];
+   R[8] = omc * a[2] * a[2] + c;
+}
+inline void rotate(const double *R, const double *v, double *o)
+{
+   o[0] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+   o[1] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+   o[2] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+}
+inline void rotateBack(const double *R, const double *v, double *o)
+{
+   o[0] = R[0] * v[0] + R[3] * v[1] + R[6] * v[2];
+   o[1] = R[1] * v[0] + R[4] * v[1] + R[7] * v[2];
+   o[2] = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+}
+inline void inertiaTimes(const double *I, const double *v, double *o)
+{
+   o[0] = I[0] * v[0] + I[3] * v[1] + I[4] * v[2];
+   o[1] = I[3] * v[0] + I[1] * v[1] + I[5] * v[2];
+   o[2] = I[4] * v[0] + I[5] * v[1] + I[2] * v[2];
+}
+
+// separate libm calls (see ba_device.cpp: a fused sincos() is not bit-identical to cos() / sin())
+double __attribute__((noinline)) libmCos(double x) { return std::cos(x); }
+double __attribute__((noinline)) libmSin(double x) { return std::sin(x); }
+
+void newtonEulerPass(const batotp_serial_model &m, const double *cq, const double *sq, const double *qd, const double *qdd,
+                     const double *a0, double *tau)
+{
+   const int n = m.n_links;
+   double F[BATOTP_MAX_LINKS][3], Nn[BATOTP_MAX_LINKS][3];
+   double w[3] = {0, 0, 0}, wd[3] = {0, 0, 0}, a[3] = {a0[0], a0[1], a0[2]};
+   for (int i = 0; i < n; ++i)
+   {
+      const batotp_serial_link &L = m.link[i];
+      double R[9], t1[3], t2[3], t3[3], wp[3], wdp[3], ap[3], zq[3], ac[3], Iw[3], Iwd[3];
+      axisRotation(L.axis, cq[i], sq[i], R);
+      crossV(wd, L.off, t1);
+      crossV(w, L.off, t2);
+      crossV(w, t2, t3);
+      for (int k = 0; k < 3; ++k) t1[k] = a[k] + t1[k] + t3[k];
+      rotateBack(R, t1, ap);
+      rotateBack(R, w, wp);
+      rotateBack(R, wd, wdp);
+      for (int k = 0; k < 3; ++k) zq[k] = L.axis[k] * qd[i];
+      crossV(wp, zq, t2);
+      for (int k = 0; k < 3; ++k)
+      {
+         w[k] = wp[k] + zq[k];
+         wd[k] = wdp[k] + L.axis[k] * qdd[i] + t2[k];
+         a[k] = ap[k];
+      }
+      crossV(wd, L.com, t1);
+      crossV(w, L.com, t2);
+      crossV(w, t2, t3);
+      for (int k = 0; k < 3; ++k) ac[k] = a[k] + t1[k] + t3[k];
+      for (int k = 0; k < 3; ++k) F[i][k] = L.mass * ac[k];
+      inertiaTimes(L.inertia, wd, Iwd);
+      inertiaTimes(L.inertia, w, Iw);
+      crossV(w, Iw, t1);
+      for (int k = 0; k < 3; ++k) Nn[i][k] = Iwd[k] + t1[k];
+   }
+   double fc[3] = {0, 0, 0}, nc[3] = {0, 0, 0};
+   for (int i = n - 1; i >= 0; --i)
+   {
+      const batotp_serial_link &L = m.link[i];
+      double f[3], nn[3], t1[3], t2[3] = {0, 0, 0}, R[9];
+      crossV(L.com, F[i], t1);
+      if (i + 1 < n) crossV(m.link[i + 1].off, fc, t2);
+      for (int k = 0; k < 3; ++k)
+      {
+         f[k] = F[i][k] + fc[k];
+         nn[k] = Nn[i][k] + nc[k] + t1[k] + t2[k];
+      }
+      tau[i] = L.axis[0] * nn[0] + L.axis[1] * nn[1] + L.axis[2] * nn[2];
+      axisRotation(L.axis, cq[i], sq[i], R);
+      rotate(R, f, fc);
+      rotate(R, nn, nc);
+   }
+}
+} // namespace
+
+void Robot::serialChainDynamics(const batotp_serial_model &m, Channels &a1, Channels &a2, Channels &a3, Channels &a4,
+                                const Channels &theta, const Channels &thetaD, const Channels &thetaD2) const
+{
+   const int nl = m.n_links;
+   const int n = (int)theta[0].size();
+   const double unit = m.degrees ? _DEG2RAD : 1.0;
+   for (int j = 0; j < nl; ++j)
+   {
+      a1[j].resize(n); a2[j].resize(n); a3[j].resize(n); a4[j].resize(n);
+   }
+   const double zero3[3] = {0, 0, 0};
+   const double g0[3] = {-m.gravity[0], -m.gravity[1], -m.gravity[2]};
+   for (int i = 0; i < n; ++i)
+   {
+      double cq[BATOTP_MAX_LINKS], sq[BATOTP_MAX_LINKS], q1[BATOTP_MAX_LINKS], q2[BATOTP_MAX_LINKS], z[BATOTP_MAX_LINKS];
+      double t1[BATOTP_MAX_LINKS], t2[BATOTP_MAX_LINKS], t4[BATOTP_MAX_LINKS];
+      for (int j = 0; j < nl; ++j)
+      {
+         const double q = unit * theta[j][i];
+         q1[j] = unit * thetaD[j][i];
+         q2[j] = unit * thetaD2[j][i];
+         z[j] = 0.0;
+         cq[j] = libmCos(q);
+         sq[j] = libmSin(q);
+      }
+      newtonEulerPass(m, cq, sq, z, q1, zero3, t1);
+      newtonEulerPass(m, cq, sq, q1, q2, zero3, t2);
+      newtonEulerPass(m, cq, sq, z, z, g0, t4);
+      for (int j = 0; j < nl; ++j)
+      {
+         a1[j][i] = t1[j];
+         a2[j][i] = t2[j];
+         a3[j][i] = m.link[j].fv * q1[j];
+         a4[j][i] = t4[j];
+      }
+   }
 }
 
 // point-mass 2R arm, joint values in degrees (reference robot.cpp:377-431)

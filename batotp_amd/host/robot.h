@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 
+#include "batotp_hip.h" // POD batotp_serial_model only
+
 namespace BATOTP
 {
 
@@ -42,11 +44,20 @@ public:
 
    // extension: CSPR cable anchor matrix, row-major [3][3] (built on first use)
    const std::vector<std::vector<double>> &cableAnchors();
+   // extension: dynamics of a serial chain other than the two-link arm (call_dynSerial has the RR case only,
+   // reference robot.cpp:349-360).  Without a user-supplied table the built-in one of the robot type is used
+   // (include/batotp_models.h: KUKA LWR IV+).  serialModel() returns nullptr when there is neither.
+   void setSerialModel(const batotp_serial_model &m) { _serial = m; _hasSerial = true; }
+   const batotp_serial_model *serialModel();
 
 private:
    int _kind = 0;
    std::string _kindName;
    Channels _anchors;
+   batotp_serial_model _serial;
+   bool _hasSerial = false, _serialProbed = false;
+   void serialChainDynamics(const batotp_serial_model &m, Channels &a1, Channels &a2, Channels &a3, Channels &a4,
+                            const Channels &theta, const Channels &thetaD, const Channels &thetaD2) const;
 
    void kukaToolPoint(const Channels &theta, Channels &cart) const;
    void planarRRToolPoint(const Channels &theta, Channels &cart) const;

@@ -6,6 +6,7 @@ RNG (the reference uses rand()):
                  not-a-knot cubic up-sampling x20, float32 binary file, tres 0.01)
   * cspr_*     : reference input/CSPR3DOF/generatePathPointsCSPR.m:5-33
   * ur_like_*  : a 6-joint path in degrees around a UR5 home pose (cfg 2)
+  * kuka_like_*: a 7-joint path in degrees for the KUKA LWR IV+ with torque limits (cfg 3)
 File writers follow the formats of SURVEY.md Appendix A (reference ba.cpp:2257-2312 reader,
 ba.cpp:1942-2087 config parser).
 """
@@ -51,6 +52,14 @@ def gen7dof_fine(seed: int, n_coarse: int, factor: int = 20, n_joints: int = 7, 
 def ur_like_fine(seed: int, n_coarse: int, factor: int = 20) -> np.ndarray:
     centre = np.array([-47.0, -116.0, -80.0, -72.0, 87.0, -93.0])
     u = splitmix64_uniform(seed, n_coarse * 6).reshape(n_coarse, 6)
+    return _upsample(centre + 60.0 * (u - 0.5), factor).astype(np.float32)
+
+
+def kuka_like_fine(seed: int, n_coarse: int, factor: int = 20) -> np.ndarray:
+    """7 joints in degrees around a bent-elbow pose of a 7-DOF arm (BASELINE config 3: the GEN7DOF recipe in degrees,
+    SURVEY.md 8d), inside the LWR IV+ joint ranges"""
+    centre = np.array([0.0, 30.0, 0.0, -60.0, 0.0, 45.0, 0.0])
+    u = splitmix64_uniform(seed, n_coarse * 7).reshape(n_coarse, 7)
     return _upsample(centre + 60.0 * (u - 0.5), factor).astype(np.float32)
 
 

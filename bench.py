@@ -43,6 +43,14 @@ WORKLOADS = {
                  cfg=dict(robot="GENJNT", is_parallel=0, n_joints=7, n_cart=3, traj_file="path.dat", is_bin=1, path_type="JOINT",
                           degrees=0, jnt_vel=[5] * 7, jnt_acc_on=1, jnt_acc=[10] * 7, integ_res=0.01, max_integ_time=2000000.0,
                           theta_res=0.1, theta_res2=0.1)),
+    # BASELINE configs[2]: KUKA LWR IV+ 7-DOF, joint velocity / acceleration limits of the shipped example + the rated joint
+    # torques with the chain dynamics of include/batotp_models.h (the reference has no model for this robot: DESIGN.md 5)
+    "kuka7trq": dict(C=35, gen=lambda seed, n: (pathgen.kuka_like_fine(seed, n), None, 0.01), knots_per_coarse=235.0,
+                     cfg=dict(robot="KUKA", is_parallel=0, n_joints=7, n_cart=3, traj_file="path.dat", is_bin=1, path_type="JOINT",
+                              degrees=1, jnt_vel=[110, 110, 128, 128, 204, 184, 184], jnt_acc_on=1,
+                              jnt_acc=[137.5, 157.1, 213.3, 213.3, 510.0, 460.0, 613.3], trq_on=1,
+                              trq_max=[176, 176, 100, 100, 100, 38, 38], trq_min=[float("nan")] * 7, cart_vel_on=0, cart_vel=0.6,
+                              integ_res=0.005, max_integ_time=2000000.0, theta_res=0.3, theta_res2=0.3)),
     # BASELINE configs[4]: cable robot, cable velocity/acceleration/tension limits + Cartesian speed, isPar2Ser=1
     "cspr": dict(C=18, gen=lambda seed, n: (None, pathgen.cspr_fine(seed, n), 0.005), knots_per_coarse=217.0,
                  cfg=dict(robot="CSPR3DOF", is_parallel=1, n_joints=3, n_cart=3, traj_file="path.dat", is_bin=1, path_type="CART",
@@ -69,10 +77,11 @@ def make_knots(workload: str, seed: int, n_target: int):
         sres = float(np.frombuffer(kb, "<f8", 1, 24)[0])
         y = np.frombuffer(kb, "<f8", (nJ + nC) * N, 32).reshape(nJ + nC, N)
         prob = capi.Problem.from_buffer_copy(open(os.path.join(work, "problem.bin"), "rb").read())
-    if not (prob.flags & (capi.F_CART_VEL_ON | capi.F_CART_ACC_ON | capi.F_TRQ_ON)):
-        y = y[:nJ]           # vel+acc limits only: no Cartesian channels are carried
+    if not (prob.flags & (capi.F_CART_VEL_ON | capi.F_CART_ACC_ON | capi.F_PARALLEL)):
+        y = y[:nJ]           # no Cartesian limit, no cable robot: no Cartesian channels are carried (BA::deviceSweep does the same)
         prob.n_cart = 0
-        prob.flags |= capi.F_NO_SAMPLES  # knot samples (traj.theta/thetaD/thetaD2) only feed the dynamics model
+        if not (prob.flags & capi.F_TRQ_ON):
+            prob.flags |= capi.F_NO_SAMPLES  # knot samples (traj.theta/thetaD/thetaD2) only feed the dynamics model
     return np.ascontiguousarray(y), sres, prob, (theta, cart, tres)
 
 

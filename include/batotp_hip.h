@@ -111,6 +111,30 @@ typedef struct batotp_path_result {
     int32_t  n_bisect_fail_fwd;
 } batotp_path_result;
 
+/* Dynamics model of a serial chain of revolute joints (BASELINE config 3: 7-DOF arm with torque limits).
+ * The reference dispatches Robot::dynSerial on the robot type and only knows the two-link arm
+ * (batotp/robot.cpp:349-360, dynRR robot.cpp:377-431); this table is how a further `case` is supplied without a
+ * kernel per robot: tau = a1 sddot + a2 sdot^2 + a3 sdot + a4 (robot.cpp:368-372) with
+ *   a1 = M(q) q',  a2 = M(q) q'' + C(q, q') q',  a3 = fv .* q',  a4 = g(q)
+ * evaluated per knot by three passes of the recursive Newton-Euler algorithm.
+ * Frames: every link frame coincides with the base frame at q = 0 ("zero-aligned"); joint i turns link i about
+ * `axis` (unit vector, the same in link and parent coordinates) by q_i. */
+#define BATOTP_MAX_LINKS 8
+typedef struct batotp_serial_link {
+    double axis[3];     /* joint axis                                                            */
+    double off[3];      /* joint origin relative to the parent's joint origin, parent coordinates */
+    double com[3];      /* centre of mass relative to the joint origin, link coordinates         */
+    double mass;
+    double inertia[6];  /* about the centre of mass, link coordinates: Ixx Iyy Izz Ixy Ixz Iyz    */
+    double fv;          /* viscous friction coefficient (dynRR uses 10, robot.cpp:423-424)       */
+} batotp_serial_link;
+typedef struct batotp_serial_model {
+    int32_t n_links;    /* == n_joints of the problem                                            */
+    int32_t degrees;    /* joint values are degrees: scaled by _DEG2RAD first (robot.cpp:401-406) */
+    double  gravity[3]; /* gravitational acceleration in base coordinates, e.g. (0, 0, -9.81)    */
+    batotp_serial_link link[BATOTP_MAX_LINKS];
+} batotp_serial_model;
+
 typedef struct batotp_ctx   batotp_ctx;    /* one per GPU (device + stream)        */
 typedef struct batotp_batch batotp_batch;  /* B independent paths resident in HBM  */
 
@@ -150,6 +174,17 @@ int  batotp_hip_upload_knots_device(batotp_batch *batch, int32_t path0, int32_t 
 /* RR only (BATOTP_F_HOST_TRIG): trig[4][N] = cos(th1), cos(th2), cos(th1+th2), sin(th2) of the
  * knot samples of path p, evaluated with the host libm (robot.cpp:408-419). */
 int  batotp_hip_upload_rr_trig(batotp_batch *batch, int32_t path, const double *trig);
+/* Serial-chain dynamics (BATOTP_F_TRQ_ON on a serial robot): with a model set, batotp_hip_precompute stage 2
+ * evaluates a1..a4 with it instead of the built-in two-link arm -- Robot::dynSerial's switch
+ * (batotp/robot.cpp:349-360) with one more case.  Needed for every serial robot other than BATOTP_ROBOT_RR. */
+int  batotp_hip_set_serial_model(batotp_batch *batch, const batotp_serial_model *model);
+/* BATOTP_F_HOST_TRIG with a serial model: trig[2*n_joints][N] = cos(q_j) rows, then sin(q_j) rows, of the knot
+ * samples of path p (q_j in radians), evaluated with the host libm; without the flag the device libm is used
+ * (not bit-identical to glibc). */
+int  batotp_hip_upload_joint_trig(batotp_batch *batch, int32_t path, const double *trig);
+/* the built-in model table of a robot type (include/batotp_models.h: BATOTP_ROBOT_KUKA = LWR IV+ with nominal
+ * inertial parameters, BATOTP_ROBOT_RR = the point masses of Robot::dynRR as a chain); BATOTP_ERR_ARG if none */
+int  batotp_hip_builtin_serial_model(int32_t robot_type, batotp_serial_model *out);
 
 /* Marshalling entry points used by BA::sweep (single path, B = 1), which like the reference reads
  * whatever the caller left in the public Traj arrays (reference ba.h:140-152):

@@ -13,6 +13,7 @@
 #include <time.h>
 
 #include "batotp_hip.h"
+#include "batotp_models.h" /* robot parameter tables: data, shared with the product */
 #include "batotp_oracle.h"
 
 struct batotp_ctx { int device; };
@@ -27,6 +28,8 @@ struct batotp_batch {
     double **trig;
     double **rev_s, **rev_sd, **fwd_s, **fwd_sd;
     batotp_path_result *res;
+    batotp_serial_model serial;
+    int has_serial;
     int kin_done;
     float ms[5];
 };
@@ -134,6 +137,31 @@ int batotp_hip_upload_rr_trig(batotp_batch *b, int32_t path, const double *trig)
     size_t cnt;
     if (!b || path < 0 || path >= b->n_paths) return BATOTP_ERR_ARG;
     cnt = 4 * (size_t)b->path[path]->n;
+    free(b->trig[path]);
+    b->trig[path] = (double *)malloc(cnt * sizeof(double));
+    memcpy(b->trig[path], trig, cnt * sizeof(double));
+    return BATOTP_OK;
+}
+int batotp_hip_set_serial_model(batotp_batch *b, const batotp_serial_model *model)
+{
+    int32_t p;
+    if (!b || !model || model->n_links != b->prob.n_joints || model->n_links > BATOTP_MAX_LINKS) return BATOTP_ERR_ARG;
+    if (!(b->prob.flags & BATOTP_F_TRQ_ON) || (b->prob.flags & BATOTP_F_PARALLEL)) return BATOTP_ERR_ARG;
+    b->serial = *model;
+    b->has_serial = 1;
+    for (p = 0; p < b->n_paths; p++) b->path[p]->serial = &b->serial;
+    return BATOTP_OK;
+}
+int batotp_hip_builtin_serial_model(int32_t robot_type, batotp_serial_model *out)
+{
+    if (!out) return BATOTP_ERR_ARG;
+    return batotp_builtin_serial_model(robot_type, out) == 0 ? BATOTP_OK : BATOTP_ERR_ARG;
+}
+int batotp_hip_upload_joint_trig(batotp_batch *b, int32_t path, const double *trig)
+{
+    size_t cnt;
+    if (!b || !trig || path < 0 || path >= b->n_paths || !b->has_serial) return BATOTP_ERR_ARG;
+    cnt = 2 * (size_t)b->prob.n_joints * (size_t)b->path[path]->n;
     free(b->trig[path]);
     b->trig[path] = (double *)malloc(cnt * sizeof(double));
     memcpy(b->trig[path], trig, cnt * sizeof(double));

@@ -390,8 +390,13 @@ int bo_precompute_dyn(const batotp_problem *prob, bo_path *p, const double *trig
             a4[2 * n + i] = kG;
         }
     } else {
-        if (prob->robot_type != BATOTP_ROBOT_RR) return -1; /* robot.cpp:349-360 */
-        dyn_rr(p, trig, a1, a2, a3, a4);
+        if (p->serial) {
+            /* one more case of Robot::dynSerial's switch (robot.cpp:349-360): a table-driven chain */
+            if (bo_dyn_serial(p->serial, p, trig, a1, a2, a3, a4) != 0) return -1;
+        } else {
+            if (prob->robot_type != BATOTP_ROBOT_RR) return -1; /* robot.cpp:349-360 */
+            dyn_rr(p, trig, a1, a2, a3, a4);
+        }
     }
 
     if ((prob->flags & BATOTP_F_PARALLEL) && (prob->flags & BATOTP_F_PAR2SER)) {

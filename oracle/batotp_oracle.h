@@ -41,6 +41,7 @@ typedef struct bo_path {
     double *samp;       /* [n_theta+n_cart][3][n] value, d/ds, d2/ds2 at the sMVC sites   */
     double *dyn;        /* [4][dyn_dim][n] a1..a4                                         */
     double *mvc;        /* [3][n] pointwise sdot_max, sddotL, sddotH (bo_pointwise_mvc)   */
+    const batotp_serial_model *serial; /* serial-chain dynamics model (not owned; NULL: Robot::dynSerial's built-in cases) */
 } bo_path;
 
 /* allocate / free a path for problem prob with n knots */
@@ -70,6 +71,13 @@ int  bo_precompute_kin(const batotp_problem *prob, bo_path *p, const double *y, 
 /* BA::findDynModel (ba.cpp:873-949): fills dyn and the a1..a4 channels of coef.
  * trig: optional [4][n] host trig for RR (NULL -> libm). */
 int  bo_precompute_dyn(const batotp_problem *prob, bo_path *p, const double *trig);
+/* Serial-chain dynamics (BASELINE config 3; no reference model: batotp_oracle_dyn.c says what pins it).
+ * One pass of the recursive Newton-Euler algorithm, and a1..a4 [n_links][n] at the knots of p;
+ * trig: optional [2*n_links][n] host cosines, then sines, of the joint angles (radians). */
+void bo_rnea(const batotp_serial_model *m, const double *cq, const double *sq, const double *qd,
+             const double *qdd, const double *a0, double *tau);
+int  bo_dyn_serial(const batotp_serial_model *m, const bo_path *p, const double *trig,
+                   double *a1, double *a2, double *a3, double *a4);
 
 /* BA::sweep (ba.cpp:979-1195).  dir=-1 reverse / +1 forward.  For dir=+1, (mvc_s, mvc_sdot, n_mvc)
  * is the curve published by the reverse sweep.  Output arrays have capacity cap points; ascending s.

@@ -31,8 +31,8 @@ def _ensure_oracle_built():
 def oracle_lib():
     """TEST INFRASTRUCTURE: the CPU oracle behind the C-ABI."""
     _ensure_oracle_built()
-    from batotp_amd import capi
-    return capi.load_oracle()
+    import helpers
+    return helpers.load_oracle()
 
 
 @pytest.fixture(scope="session")

@@ -32,7 +32,7 @@ def _worker(rank, world, port, names, q):
         cases = [helpers.Case(n) for n in names[lo:hi]]
         for c in cases:
             c.problem = helpers.Case(names[0]).problem
-        ctx = capi.Context(capi.load_oracle(), 0)
+        ctx = capi.Context(helpers.load_oracle(), 0)
         outs = helpers.run_pipeline(ctx, cases, mvc=False, details=False) if cases else []
         local = np.array([o["result"] for o in outs], dtype=capi.RESULT_DTYPE) if outs else np.zeros(0, dtype=capi.RESULT_DTYPE)
         allres = bdist.gather_results(local)

@@ -63,6 +63,84 @@ def test_hip_matches_oracle_and_reference(hip_ctx, oracle_ctx, name):
     assert_matches_reference(case, ho)
 
 
+@pytest.mark.parametrize("name", helpers.SELF_CASES)
+def test_serial_chain_dynamics_and_torque_limited_sweep(hip_ctx, oracle_ctx, name):
+    """BASELINE config 3 (7-DOF arm with torque limits; no reference model exists: parity unpinned for the model):
+    k_dyn_serial and everything downstream of it equal the oracle bit for bit -- a1..a4 at every knot, their
+    splines, the per-knot bounds, both curves, step counts, T -- and reproduce the self-generated fixtures"""
+    case = Case(name)
+    ho = run_pipeline(hip_ctx, [case])[0]
+    oo = run_pipeline(oracle_ctx, [case])[0]
+    assert ho["dyn"].shape[1] == 7 and np.all(np.isfinite(ho["dyn"]))
+    _compare(case, ho, oo)
+    assert_matches_reference(case, ho)
+
+
+@pytest.mark.parametrize("lanes", [1, 8, 16])
+def test_serial_chain_other_lane_groupings_and_ragged_batch(hip_lib, oracle_ctx, lanes):
+    """torque-limited 7-DOF paths of different length in one batch, every lane layout of the sweep"""
+    ctx = capi.Context(hip_lib, 0)
+    ctx.set_sweep_group(lanes)
+    names = ["KUKA_trq_rated", "KUKA_trq_tight", "KUKA_trq_rated"]
+    cases = [Case(n) for n in names]
+    for c in cases:
+        c.problem = cases[1].problem          # one problem per batch: the tight limits, Cartesian speed limit on
+    cap = 12000
+    many = run_pipeline(ctx, cases * 3, max_steps=cap, mvc=False, details=False)
+    ref = [run_pipeline(oracle_ctx, [c], max_steps=cap, mvc=False, details=False)[0] for c in cases[:2]]
+    for k, c in enumerate(cases * 3):
+        _compare(c, many[k], ref[1 if c.name == "KUKA_trq_tight" else 0])
+    ctx.close()
+
+
+def test_serial_chain_without_host_trig_is_close(hip_ctx, oracle_ctx):
+    """without BATOTP_F_HOST_TRIG the device libm supplies cos / sin: a1..a4 then agree with the oracle to rounding
+    of the trigonometric functions, not bit for bit (the documented trig policy)"""
+    case = Case("KUKA_trq_rated")
+    prob = capi.Problem.from_buffer_copy(bytes(case.problem))
+    prob.flags &= ~capi.F_HOST_TRIG
+    model = hip_ctx.library.builtin_serial_model(capi.ROBOT_KUKA)
+    b = capi.Batch(hip_ctx, prob, [case.n], case.max_steps())
+    b.upload_knots(0, [case.y], [case.sres])
+    b.precompute(1)
+    b.set_serial_model(model)
+    b.precompute(2)
+    dyn = np.stack([np.stack([b.dyn(0, kk, r) for r in range(7)]) for kk in (1, 2, 3, 4)])
+    b.close()
+    oo = run_pipeline(oracle_ctx, [case], mvc=False)[0]["dyn"]
+    scale = np.abs(oo).max(axis=2, keepdims=True) + 1e-300
+    assert np.max(np.abs(dyn - oo) / scale) < 1e-12
+
+
+def test_serial_chain_needs_a_model(hip_ctx):
+    """a serial robot without a chain model: the reference prints "No dynamics model provided" (robot.cpp:355-357);
+    the device layer refuses the dynamics stage"""
+    case = Case("KUKA_trq_rated")
+    b = capi.Batch(hip_ctx, case.problem, [case.n], 64)
+    b.upload_knots(0, [case.y], [case.sres])
+    b.precompute(1)
+    with pytest.raises(capi.BatotpError):
+        b.precompute(2)
+    b.close()
+
+
+def test_kuka_torque_limits_at_baseline_size(hip_ctx, oracle_ctx):
+    """BASELINE config 3 as worded: KUKA-LWR-IV 7-DOF with torque limits, N = 100k, one trajectory: HIP == oracle"""
+    import bench
+    y, sres, prob, _ = bench.make_knots("kuka7trq", 14, 100000)
+    assert 95000 < y.shape[1] < 105000 and prob.n_joints == 7 and (prob.flags & capi.F_TRQ_ON)
+
+    class _C:
+        name = "synth_kuka_s14_trq_100k"
+    c = _C()
+    c.y, c.sres, c.problem, c.n = y, sres, prob, y.shape[1]
+    c.max_steps = lambda: int(1.5 * y.shape[1])
+    ho = run_pipeline(hip_ctx, [c], details=False)[0]
+    oo = run_pipeline(oracle_ctx, [c], details=False)[0]
+    assert ho["result"]["status_fwd"] == 0 and ho["result"]["n_fwd"] > 1000
+    _compare(c, ho, oo)
+
+
 def _vel_acc_only(name):
     f = Case(name).problem.flags if name in helpers.FULL_CASES else 0
     return name in helpers.FULL_CASES and not (f & (capi.F_TRQ_ON | capi.F_CART_VEL_ON | capi.F_CART_ACC_ON))

@@ -5,12 +5,13 @@ import numpy as np
 import pytest
 
 from batotp_amd import capi
+import helpers
 from helpers import RESAMPLE_CASES, ResampleCase
 
 
 @pytest.fixture(scope="module")
 def octx():
-    return capi.Context(capi.load_oracle(), 0)
+    return capi.Context(helpers.load_oracle(), 0)
 
 
 @pytest.mark.parametrize("name", RESAMPLE_CASES)

@@ -2,7 +2,7 @@
 """Cycle attribution inside the sweep kernel (diagnostic build of the library: -DBK_PROFILE_SECTIONS).
 
     hipcc ... -DBK_PROFILE_SECTIONS -shared -o /tmp/libdiag.so batotp_amd/csrc/batotp_hip.hip
-    BATOTP_HIP_LIB=/tmp/libdiag.so python tools/sweep_sections.py --paths 16384
+    python tools/sweep_sections.py --lib /tmp/libdiag.so --paths 16384
 
 Per path the kernel leaves 4 numbers in the first doubles of the K3 output array: cycles in the velocity limit, in the
 spline evaluation, in the bisection / constraint checks, and the total."""
@@ -13,10 +13,10 @@ import bench
 from batotp_amd import capi
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--workload", default="ur6"); ap.add_argument("--paths", type=int, default=16384)
+ap.add_argument("--lib", default=None, help="diagnostic build of the library (-DBK_PROFILE_SECTIONS)"); ap.add_argument("--workload", default="ur6"); ap.add_argument("--paths", type=int, default=16384)
 ap.add_argument("--knots", type=int, default=100000); ap.add_argument("--distinct", type=int, default=16)
 a = ap.parse_args()
-hip = capi.Context(capi.load_hip(), 0)
+hip = capi.Context(capi.Library(a.lib) if a.lib else capi.load_hip(), 0)
 base = [bench.make_knots(a.workload, 1000 + k, a.knots) for k in range(a.distinct)]
 nk = [base[p % a.distinct][0].shape[1] for p in range(a.paths)]
 cap = int(max(nk) * {"ur6": 0.5, "gen7": 2.2, "cspr": 0.6}[a.workload]) + 1024
