@@ -108,8 +108,8 @@ def test_serial_chain_without_host_trig_is_close(hip_ctx, oracle_ctx):
     dyn = np.stack([np.stack([b.dyn(0, kk, r) for r in range(7)]) for kk in (1, 2, 3, 4)])
     b.close()
     oo = run_pipeline(oracle_ctx, [case], mvc=False)[0]["dyn"]
-    scale = np.abs(oo).max(axis=2, keepdims=True) + 1e-300
-    assert np.max(np.abs(dyn - oo) / scale) < 1e-12
+    scale = np.abs(oo).max(axis=(1, 2), keepdims=True)   # per coefficient family (the gravity torque about a vertical axis is 0)
+    assert np.max(np.abs(dyn - oo) / scale) < 1e-13
 
 
 def test_serial_chain_needs_a_model(hip_ctx):
