@@ -61,7 +61,7 @@ struct batotp_ctx
    int overlap = 0;
    int sweepGroup = 0; // lanes per path in the sweep kernel; 0 = automatic
    int pathsPerWave = 0; // 0 = automatic
-   int sweepHold[2] = {-1, -1}; // reverse, forward: -1 = nested stage / bisection loops, 0..8 = flat loop with this hold (kernels.hip.h)
+   int sweepHold[2] = {-2, -2}; // reverse, forward: -2 = automatic, -1 = nested stage / bisection loops, 0..8 = flat loop with this hold (kernels.hip.h)
 };
 
 struct batotp_batch
@@ -261,7 +261,7 @@ extern "C" int batotp_hip_set_overlap(batotp_ctx *ctx, int32_t on)
 
 extern "C" int batotp_hip_set_sweep_hold(batotp_ctx *ctx, int32_t reverse, int32_t forward)
 {
-   if (!ctx || reverse < -1 || reverse > 8 || forward < -1 || forward > 8) return BATOTP_ERR_ARG;
+   if (!ctx || reverse < -2 || reverse > 8 || forward < -2 || forward > 8) return BATOTP_ERR_ARG;
    ctx->sweepHold[0] = reverse;
    ctx->sweepHold[1] = forward;
    return BATOTP_OK;
@@ -860,17 +860,19 @@ static void launchSweep(batotp_batch *b, SweepArgs &a)
    for (int p = 0; p < b->B; ++p) uni = uni && b->pinfo[p].uniform;
    hipStream_t st = b->ctx->stream;
    int hold = b->ctx->sweepHold[a.dir == -1 ? 0 : 1];
-   if (const char *env = getenv(a.dir == -1 ? "BATOTP_SWEEP_HOLD_REV" : "BATOTP_SWEEP_HOLD_FWD")) hold = atoi(env); // tuning hook
+   // automatic: the flat stage / bisection loop for the reverse sweep (measured on the bench batches: -25 % with hold 4,
+   // bit-identical results), the nested loops for the forward sweep (which does not gain)
+   if (hold == -2) hold = (a.dir == -1) ? 4 : -1;
    if (hold > 8) hold = 8;
    a.hold = hold;
-   // The flat loop exists for the 8-lane layout of the velocity / acceleration-only problems (FEAT <= 0) and nowhere
-   // else: the instantiation with the serial torque branch gave hold-dependent results on stalled paths in this
-   // toolchain (tools/experiments/), so problems with torque or Cartesian limits always run the nested loops.
-   const bool flat = (G == 8) && hold >= 0 && featureLevel(b) <= 0;
+   // The flat loop exists for the 8-lane layout of the velocity / acceleration-only problems (FEAT <= 0) on uniform knot
+   // sites and nowhere else: the instantiation with the serial torque branch gave hold-dependent results on stalled paths
+   // with this toolchain (ROCm 7.2.0 hipcc, clang 22; DESIGN.md 4, tools/experiments/), so problems with torque or
+   // Cartesian limits always run the nested loops, and so do paths with uploaded (non-uniform) sites.
+   const bool flat = (G == 8) && hold >= 0 && featureLevel(b) <= 0 && uni;
 #define LAUNCH_K4(F)                                                                           \
    do {                                                                                        \
-      if (flat && uni) hipLaunchKernelGGL((k_sweep<G, F, true, (G == 8 && F <= 0)>), dim3(grid), dim3(K4_BLOCK), 0, st, a);  \
-      else if (flat) hipLaunchKernelGGL((k_sweep<G, F, false, (G == 8 && F <= 0)>), dim3(grid), dim3(K4_BLOCK), 0, st, a);  \
+      if (flat) hipLaunchKernelGGL((k_sweep<G, F, true, (G == 8 && F <= 0)>), dim3(grid), dim3(K4_BLOCK), 0, st, a);  \
       else if (uni) hipLaunchKernelGGL((k_sweep<G, F, true>), dim3(grid), dim3(K4_BLOCK), 0, st, a);      \
       else hipLaunchKernelGGL((k_sweep<G, F, false>), dim3(grid), dim3(K4_BLOCK), 0, st, a);        \
    } while (0)

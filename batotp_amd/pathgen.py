@@ -21,17 +21,15 @@ _MASK = (1 << 64) - 1
 
 
 def splitmix64_uniform(seed: int, n: int) -> np.ndarray:
-    """n doubles in [0,1) from the splitmix64 stream started at `seed`."""
-    out = np.empty(n, dtype=np.float64)
-    x = seed & _MASK
-    for i in range(n):
-        x = (x + 0x9E3779B97F4A7C15) & _MASK
-        z = x
-        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _MASK
-        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _MASK
-        z = z ^ (z >> 31)
-        out[i] = (z >> 11) * (1.0 / 9007199254740992.0)
-    return out
+    """n doubles in [0,1) from the splitmix64 stream started at `seed` (counter-based: element i depends on seed and i only,
+    so the whole stream is one vectorised expression in 64-bit wrap-around arithmetic)."""
+    golden = np.uint64(0x9E3779B97F4A7C15)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed & _MASK) + golden * np.arange(1, n + 1, dtype=np.uint64)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
 def _upsample(way: np.ndarray, factor: int) -> np.ndarray:

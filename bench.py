@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- constraint-evaluated waypoints/sec of the batotp hot path on MI355X.
 
-One "step" = one pass of the whole hot path over one batch of synthetic paths whose knot values are
-already resident in HBM:
+One "step" = one pass of the whole hot path over one batch of synthetic paths whose knot values are already resident
+in HBM:
     per-knot precompute (spline coefficients, knot samples [, dynamics])      -> K1/K2
     per-knot max-admissible-sdot evaluation with bisection                    -> K3
     reverse sweep + forward sweep                                             -> K4
-Workload (BASELINE.json configs[1]): UR5-like 6-DOF path, joint velocity + acceleration limits only,
-N ~ 100k knots per path; the batch holds --paths such paths per GPU (north_star: "synthetic N-point,
-B-path batches"), weak scaling over GPUs, no collective in the hot path, one RCCL all_gather of the
-per-path result table at the end of every step.
+value = knots of all paths of all ranks / time (BASELINE.json: "constraint-evaluated waypoints/sec").
 
-Prints ONE JSON line on rank 0.  Launch: python bench.py [--gpus N --steps K --warmup W], or through
-torch.distributed.run for N > 1.
+Configurations (--config):
+    fill7 (default)  GEN7DOF 7-DOF vel+acc, N ~ 100k knots per path, as many paths as fill one GPU (weak scaling over
+                     GPUs) -- BASELINE.json's target is worded for "a 7-DOF robot at N=100k" on "B-path batches";
+                     the default line also carries the four BASELINE configs AS WORDED (`as_worded`: cfg2..cfg5) and the
+                     side measurements of the stages either side of the path
+    fill6            the same with the UR5-like 6-DOF workload of cfg 2 (round 1's headline)
+    cfg2             UR5 6-DOF vel+acc, N = 100k, ONE trajectory (replicas only over GPUs)
+    cfg3             KUKA-LWR-IV 7-DOF with torque limits, N = 100k, ONE trajectory (replicas only)
+    cfg4             GEN7DOF, N = 50k, B = 1024 paths in total, sharded over the GPUs (strong scaling)
+    cfg5             CSPR3DOF cable robot with tension limits, N = 200k, B = 4096 in total, sharded (strong scaling)
+Multi-GPU: one process per GPU.  `python bench.py --gpus N` starts its own N ranks (torch.distributed.run as a child
+process, before this process touches a GPU); started under torch.distributed.run it is a rank.  Paths are sharded over
+ranks, no collective inside the hot path, one RCCL all_gather of the 64-byte result rows per step.
+
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import concurrent.futures as cf
@@ -32,27 +42,28 @@ from batotp_amd import dist as bdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 DUMP_KNOTS = os.path.join(ROOT, "batotp_amd", "host", "_build", "baknots")  # the product's host resampler as a tool (no device call)
+METRIC = "constraint-evaluated waypoints/sec + traversal-time err vs CPU ref"
 
 WORKLOADS = {
-    # name: (fine-path generator, config kwargs, coarse points per 1000 knots)
-    "ur6": dict(C=6, gen=lambda seed, n: (pathgen.ur_like_fine(seed, n), None, 0.01), knots_per_coarse=210.8,
+    # name: fine-path generator, config kwargs, knots per coarse point, capacity of a curve in points per knot
+    "ur6": dict(C=6, gen=lambda seed, n: (pathgen.ur_like_fine(seed, n), None, 0.01), knots_per_coarse=210.8, cap=0.5,
                 cfg=dict(robot="GENJNT", is_parallel=0, n_joints=6, n_cart=3, traj_file="path.dat", is_bin=1, path_type="JOINT",
                          degrees=1, jnt_vel=[160] * 6, jnt_acc_on=1, jnt_acc=[573, 573, 573, 1146, 1146, 1146], integ_res=0.008,
                          max_integ_time=2000000.0, theta_res=0.3, theta_res2=0.3)),
-    "gen7": dict(C=7, gen=lambda seed, n: (pathgen.gen7dof_fine(seed, n), None, 0.01), knots_per_coarse=58.2,
+    "gen7": dict(C=7, gen=lambda seed, n: (pathgen.gen7dof_fine(seed, n), None, 0.01), knots_per_coarse=58.2, cap=2.2,
                  cfg=dict(robot="GENJNT", is_parallel=0, n_joints=7, n_cart=3, traj_file="path.dat", is_bin=1, path_type="JOINT",
                           degrees=0, jnt_vel=[5] * 7, jnt_acc_on=1, jnt_acc=[10] * 7, integ_res=0.01, max_integ_time=2000000.0,
                           theta_res=0.1, theta_res2=0.1)),
     # BASELINE configs[2]: KUKA LWR IV+ 7-DOF, joint velocity / acceleration limits of the shipped example + the rated joint
     # torques with the chain dynamics of include/batotp_models.h (the reference has no model for this robot: DESIGN.md 5)
-    "kuka7trq": dict(C=35, gen=lambda seed, n: (pathgen.kuka_like_fine(seed, n), None, 0.01), knots_per_coarse=235.0,
+    "kuka7trq": dict(C=35, gen=lambda seed, n: (pathgen.kuka_like_fine(seed, n), None, 0.01), knots_per_coarse=235.0, cap=1.2,
                      cfg=dict(robot="KUKA", is_parallel=0, n_joints=7, n_cart=3, traj_file="path.dat", is_bin=1, path_type="JOINT",
                               degrees=1, jnt_vel=[110, 110, 128, 128, 204, 184, 184], jnt_acc_on=1,
                               jnt_acc=[137.5, 157.1, 213.3, 213.3, 510.0, 460.0, 613.3], trq_on=1,
                               trq_max=[176, 176, 100, 100, 100, 38, 38], trq_min=[float("nan")] * 7, cart_vel_on=0, cart_vel=0.6,
                               integ_res=0.005, max_integ_time=2000000.0, theta_res=0.3, theta_res2=0.3)),
     # BASELINE configs[4]: cable robot, cable velocity/acceleration/tension limits + Cartesian speed, isPar2Ser=1
-    "cspr": dict(C=18, gen=lambda seed, n: (None, pathgen.cspr_fine(seed, n), 0.005), knots_per_coarse=217.0,
+    "cspr": dict(C=18, gen=lambda seed, n: (None, pathgen.cspr_fine(seed, n), 0.005), knots_per_coarse=217.0, cap=0.6,
                  cfg=dict(robot="CSPR3DOF", is_parallel=1, n_joints=3, n_cart=3, traj_file="path.dat", is_bin=1, path_type="CART",
                           degrees=0, jnt_vel=[4] * 3, jnt_acc_on=1, jnt_acc=[8] * 3, trq_on=1, trq_max=[12] * 3, trq_min=[1] * 3,
                           cart_vel_on=1, cart_vel=4.0, cart_acc_on=0, cart_acc=100.0, integ_res=0.01, max_integ_time=2000000.0,
@@ -60,9 +71,31 @@ WORKLOADS = {
                           par2ser=1)),
 }
 
+# BASELINE.json configs as worded.  paths = total over all GPUs ("strong"), or per GPU ("weak": what fills one GPU, or the
+# single trajectory every GPU replicates)
+CONFIGS = {
+    "fill7": dict(workload="gen7", knots=100000, paths=11264, scaling="weak", distinct=2048,
+                  what="GEN7DOF 7-DOF vel+acc, N~100k knots/path, batch of independent paths filling the GPU"),
+    "fill6": dict(workload="ur6", knots=100000, paths=16384, scaling="weak", distinct=2048,
+                  what="cfg2 shape: UR5-like 6-DOF vel+acc, N~100k knots/path, batch of independent paths filling the GPU"),
+    "cfg2": dict(workload="ur6", knots=100000, paths=1, scaling="weak", distinct=1,
+                 what="cfg2 as worded: UR5 6-DOF vel+acc, N=100k, single trajectory per GPU (replicas only)"),
+    "cfg3": dict(workload="kuka7trq", knots=100000, paths=1, scaling="weak", distinct=1,
+                 what="cfg3 as worded: KUKA-LWR-IV 7-DOF with torque limits (chain dynamics), N=100k, single trajectory per GPU "
+                      "(replicas only)"),
+    "cfg4": dict(workload="gen7", knots=50000, paths=1024, scaling="strong", distinct=1024,
+                 what="cfg4 as worded: GEN7DOF, N=50k, batch of 1024 randomised paths sharded across the GPUs"),
+    "cfg5": dict(workload="cspr", knots=200000, paths=4096, scaling="strong", distinct=128,
+                 what="cfg5 as worded: CSPR3DOF cable robot with cable-tension constraints, N=200k, batch of 4096 sharded "
+                      "across the GPUs"),
+}
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# synthetic inputs
+# ---------------------------------------------------------------------------------------------------------------------
 def make_knots(workload: str, seed: int, n_target: int):
-    """one synthetic path -> (y [C_in][N], sres, problem) through the host resampler of the BA library"""
+    """one synthetic path -> (y [C_in][N], sres, problem, taught points) through the host resampler of the BA library"""
     w = WORKLOADS[workload]
     n_coarse = max(8, int(round(n_target / w["knots_per_coarse"])))
     theta, cart, tres = w["gen"](seed, n_coarse)
@@ -90,7 +123,7 @@ def resample_params(workload: str, prob) -> "capi.ResampleParams":
     cfg = WORKLOADS[workload]["cfg"]
     r = capi.ResampleParams()
     r.n_joints, r.n_cart = cfg["n_joints"], cfg["n_cart"]
-    r.robot_type = {"GENJNT": capi.ROBOT_GENJNT, "CSPR3DOF": capi.ROBOT_CSPR3DOF}[cfg["robot"]]
+    r.robot_type = {"GENJNT": capi.ROBOT_GENJNT, "CSPR3DOF": capi.ROBOT_CSPR3DOF, "KUKA": capi.ROBOT_KUKA}[cfg["robot"]]
     r.path_type = capi.PATH_JOINT if cfg["path_type"] == "JOINT" else capi.PATH_CART
     r.scale_type = cfg.get("scale_type", 1)
     r.flags = (capi.F_CART_VEL_ON if cfg.get("cart_vel_on") else 0) | (capi.F_CART_ACC_ON if cfg.get("cart_acc_on") else 0)
@@ -104,345 +137,569 @@ def resample_params(workload: str, prob) -> "capi.ResampleParams":
     return r
 
 
-def measure_resampler(hip, workload, base, n_paths):
-    """SURVEY.md 8f-1 beside the hot path: the taught points of the bench paths through batotp_hip_resample;
-    its knots must be the ones the host resampler produced for the hot path (bit for bit)"""
+def device_resamplable(workload: str) -> bool:
+    """path kinds batotp_hip_resample covers (JOINT paths of GENJNT, CART paths of the cable robot)"""
+    return WORKLOADS[workload]["cfg"]["robot"] in ("GENJNT", "CSPR3DOF")
+
+
+def taught_points_f32(workload: str, seeds, n_target: int):
+    """the taught points of one path per seed as the trajectory file stores them (float32): list of (theta or None, cart or
+    None), and the file's resolution"""
+    w = WORKLOADS[workload]
+    n_coarse = max(8, int(round(n_target / w["knots_per_coarse"])))
+    with cf.ThreadPoolExecutor(max_workers=min(len(seeds), os.cpu_count() or 1, 32)) as ex:
+        got = list(ex.map(lambda s: w["gen"](s, n_coarse), seeds))
+    return [(g[0], g[1]) for g in got], float(np.float32(got[0][2]))
+
+
+def widen(workload: str, taught):
+    """[nJ + nC][n] float64 rows the device resampler takes (theta rows, then Cartesian rows; absent ones zero)"""
     cfg = WORKLOADS[workload]["cfg"]
     nJ, nC = cfg["n_joints"], cfg["n_cart"]
-    prm = resample_params(workload, base[0][2])
-    xs = []
-    for _, _, _, (theta, cart, _) in base:
-        n = (theta if theta is not None else cart).shape[1]
-        x = np.zeros((nJ + nC, n))
-        if theta is not None:
-            x[:nJ] = theta.astype(np.float32).astype(np.float64)   # the taught file stores float32
-        if cart is not None:
-            x[nJ:] = cart.astype(np.float32).astype(np.float64)
-        xs.append(x)
-    K = len(base)
-    tiled = [xs[p % K] for p in range(n_paths)]
-    sres_in = [float(np.float32(base[0][3][2]))] * n_paths
-    best = None
-    for _ in range(2):   # the second call finds the context's workspaces allocated
-        r = capi.Resampled(hip, prm, tiled, sres_in)
-        ms = r.ms()
-        same = all(np.array_equal(r.knots(k)[: base[k][0].shape[0]], base[k][0]) and r.sres[k] == base[k][1] for k in range(min(K, 4)))
-        knots = int(r.n_knots.sum())
-        r.close()
-        best = ms if best is None else min(best, ms)
-    hip.trim()
-    return {"paths": n_paths, "knots": knots, "ms": best, "knots_per_s": knots / (best * 1e-3),
-            "identical_to_host_resampler": bool(same),
-            "what": "remClosePts + adjust_s x2 + interpSpecial + uniform re-evaluation on the device (taught points resident)"}
+    theta, cart = taught
+    n = (theta if theta is not None else cart).shape[1]
+    x = np.zeros((nJ + nC, n))
+    if theta is not None:
+        x[:nJ] = theta.astype(np.float32).astype(np.float64)
+    if cart is not None:
+        x[nJ:] = cart.astype(np.float32).astype(np.float64)
+    return x
 
 
-def run_step(batch, has_dyn):
+class Inputs:
+    """K distinct synthetic paths of a workload for one rank: problem description, knot counts / spacing per distinct path
+    and a way to put the knots of distinct path k into path p of a batch"""
+
+    CHUNK = 128   # distinct paths per call of the device resampler
+
+    def __init__(self, hip, workload, knots, seeds):
+        self.hip, self.workload, self.K = hip, workload, len(seeds)
+        self.seeds, self.knots_target = list(seeds), knots
+        first = make_knots(workload, seeds[0], knots)        # the host resampler: problem description, and the check below
+        self.prob = first[2]
+        self.on_device = device_resamplable(workload) and self.K > 4
+        if self.on_device:
+            # the device resampler produces the knots (SURVEY.md 8f-1), chunk by chunk; here only sizes are kept (and the
+            # float32 taught points, so that the second pass does not regenerate them)
+            self.prm = resample_params(workload, self.prob)
+            self.nC_in = self.prm.n_joints + self.prm.n_cart
+            self.keep = first[0].shape[0]                   # channels the batch carries (Cartesian rows dropped when unused)
+            self.n_knots, self.sres = np.zeros(self.K, np.int64), np.zeros(self.K)
+            self.taught, self.sres_in = taught_points_f32(workload, self.seeds, knots)
+            self.host_check = None
+            for k0, rs in self._chunks():
+                m = rs.n_knots.shape[0]
+                if np.any(rs.status):
+                    raise RuntimeError(f"device resampler refused {int(np.count_nonzero(rs.status))} synthetic paths")
+                self.n_knots[k0:k0 + m], self.sres[k0:k0 + m] = rs.n_knots, rs.sres
+                if k0 == 0:
+                    self.host_check = bool(np.array_equal(rs.knots(0)[: self.keep], first[0]) and rs.sres[0] == first[1])
+                rs.close()
+            self.data = f"synthetic: {self.K} distinct seeded spline paths per GPU (taught points -> knots by the device resampler)"
+        else:
+            with cf.ThreadPoolExecutor(max_workers=min(self.K, os.cpu_count() or 1)) as ex:
+                rest = list(ex.map(lambda s: make_knots(workload, s, knots), seeds[1:]))
+            self.base = [first] + rest
+            self.n_knots = np.array([b[0].shape[1] for b in self.base], np.int64)
+            self.sres = np.array([b[1] for b in self.base])
+            self.data = f"synthetic: {self.K} distinct seeded spline paths per GPU resampled by the host BA library"
+
+    def _chunks(self):
+        for k0 in range(0, self.K, self.CHUNK):
+            xs = [widen(self.workload, t) for t in self.taught[k0:k0 + self.CHUNK]]
+            yield k0, capi.Resampled(self.hip, self.prm, xs, [self.sres_in] * len(xs))
+
+    def host_knots(self, k):
+        if self.on_device:
+            return make_knots(self.workload, self.seeds[k], self.knots_target)[:2]
+        return self.base[k][0], self.base[k][1]
+
+    def fill(self, batch, n_paths):
+        """path p of the batch <- distinct path p % K"""
+        K = self.K
+        if not self.on_device:
+            for p in range(n_paths):
+                batch.upload_knots(p, [self.base[p % K][0]], [self.base[p % K][1]])
+            return
+        for k0, rs in self._chunks():
+            m = rs.n_knots.shape[0]
+            ptr = rs.device_ptr()
+            off = np.concatenate([[0], np.cumsum(rs.n_knots)]) * self.nC_in
+            if self.keep == self.nC_in and n_paths <= K:
+                hi = min(k0 + m, n_paths)     # consecutive paths are contiguous in the resampler's output
+                if hi > k0:
+                    batch.upload_knots_device(k0, hi - k0, ptr, list(rs.sres[: hi - k0]))
+            else:
+                for j in range(m):
+                    # the first `keep` rows of a path are the first keep * N doubles of its block
+                    for p in range(k0 + j, n_paths, K):
+                        batch.upload_knots_device(p, 1, ptr + 8 * int(off[j]), [float(rs.sres[j])])
+            rs.close()
+        self.hip.synchronize()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one measurement
+# ---------------------------------------------------------------------------------------------------------------------
+def run_step(batch):
     batch.precompute(0)
     batch.pointwise_mvc()
     batch.sweep(-1)
     batch.sweep(+1)
 
 
+def prepare_dynamics(batch, prob, n_paths):
+    """serial robots with a chain model (cfg 3): set the table and upload the host cosines / sines of the joint angles
+    (the trig policy of DESIGN.md 2); part of the input preparation, outside the timed region like every upload"""
+    if not (prob.flags & capi.F_TRQ_ON) or (prob.flags & capi.F_PARALLEL) or prob.robot_type == capi.ROBOT_RR:
+        return None
+    import math
+    model = batch.L.builtin_serial_model(prob.robot_type)
+    batch.set_serial_model(model)
+    batch.precompute(1)
+    unit = (3.14159265358979323846 / 180.0) if model.degrees else 1.0
+    nJ = prob.n_joints
+    for p in range(n_paths):
+        trig = np.empty((2 * nJ, int(batch.n_knots[p])))
+        for j in range(nJ):
+            q = unit * batch.samples(p, j)[0]
+            trig[j] = [math.cos(v) for v in q]       # libm's cos / sin (numpy's vectorised ones are not bit-identical)
+            trig[nJ + j] = [math.sin(v) for v in q]
+        batch.upload_joint_trig(p, trig)
+    return model
+
+
+def bytes_per_path(prob, C, n_mean, cap):
+    """HBM bytes a path of n_mean knots occupies in a batch (batotp_hip_batch_create's arrays)"""
+    cin, d = prob.n_joints + prob.n_cart, prob.dyn_dim
+    if prob.flags & capi.F_COMPACT_SPLINES:
+        per_knot = 16.0 * cin + 8 + 24
+    else:
+        per_knot = 8.0 * cin + 8 + 32.0 * C + (0 if (prob.flags & capi.F_NO_SAMPLES) else 24.0 * cin) + 32.0 * d + 24 + 8.0 * max(cin, 4 * d)
+        if d and not (prob.flags & capi.F_PARALLEL):
+            per_knot += 16.0 * prob.n_joints      # joint trig tables of the chain model
+    return per_knot * n_mean + 32.0 * cap
+
+
+def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=0, knots_override=0, group=0, ppw=0,
+            coefficient_rows=False, distinct_override=0, keep=False):
+    """run one configuration on this rank's share; returns (result dict, kept objects or None)"""
+    import torch
+    c = CONFIGS[cfg_name]
+    workload = c["workload"]
+    knots = knots_override or c["knots"]
+    total_paths = paths_override or c["paths"]
+    if c["scaling"] == "strong":
+        lo, hi = bdist.shard_range(total_paths, rank, world)
+        B = hi - lo
+    else:
+        lo, B = 0, total_paths
+    K = max(1, min(distinct_override or c["distinct"], max(B, 1)))
+    seeds = [1000 + (rank * 100003 + lo) + k for k in range(K)]
+    hip.set_sweep_group(group)
+    hip.set_paths_per_wave(ppw)
+    inp = Inputs(hip, workload, knots, seeds)
+    prob = capi.Problem.from_buffer_copy(bytes(inp.prob))
+    if (prob.flags & capi.F_NO_SAMPLES) and not coefficient_rows:
+        prob.flags |= capi.F_COMPACT_SPLINES  # same results, half the spline bytes per knot: room for more paths per GPU
+    C = WORKLOADS[workload]["C"]
+    cap = int(int(inp.n_knots.max()) * WORKLOADS[workload]["cap"]) + 1024
+
+    # A batch must fit the free HBM.  A larger share is processed in chunks of whole multiples of the K distinct paths, every
+    # chunk through the same resident device batch (chunk i holds the same K distinct paths as chunk 0, so re-running the
+    # batch IS processing the next chunk: its inputs alias the same HBM).
+    free_b, _ = torch.cuda.mem_get_info()
+    fit = max(1, int(0.93 * (free_b - (8 << 30)) / bytes_per_path(prob, C, float(inp.n_knots.mean()), cap)))
+
+    def split(limit):
+        n = 1
+        while (B + n - 1) // n > limit:
+            n += 1
+        bc = (B + n - 1) // n
+        if n > 1:
+            bc = max(K, (bc // K) * K)
+        return [min(bc, B - i * bc) for i in range((B + bc - 1) // bc)] if B else []
+    chunk_sizes = split(fit)
+    batch = None
+    while B and batch is None:
+        try:
+            batch = capi.Batch(hip, prob, [int(inp.n_knots[p % K]) for p in range(chunk_sizes[0])], cap)
+        except capi.BatotpError as e:
+            if "-5" not in str(e) or chunk_sizes[0] <= K:
+                raise
+            chunk_sizes = split(max(K, chunk_sizes[0] * 3 // 4))
+            print(f"bench: batch did not fit, retrying with chunks of {chunk_sizes[0]} paths", file=sys.stderr)
+    if B:
+        inp.fill(batch, chunk_sizes[0])
+        prepare_dynamics(batch, prob, chunk_sizes[0])
+        hip.synchronize()
+    knots_of = lambda s: int(sum(int(inp.n_knots[p % K]) for p in range(s)))
+    local_knots = sum(knots_of(s) for s in chunk_sizes)
+
+    def barrier():
+        if dist_ctx is not None:
+            dist_ctx["dist"].barrier()
+        torch.cuda.synchronize()
+
+    dev = dist_ctx["dev"] if dist_ctx is not None else None
+    kernel_ms = {1: 0.0, 2: 0.0, 3: 0.0, 4: 0.0}
+    state = {"gathered": None, "rows": None}
+
+    def one_pass(timed, sizes):
+        rows = []
+        for s in sizes:
+            run_step(batch)
+            if timed:
+                for k in kernel_ms:
+                    kernel_ms[k] += batch.kernel_ms(k)   # HIP events on the stream the kernels were launched on
+            rows.append(batch.results()[:s])
+        local = np.concatenate(rows) if rows else np.zeros(0, dtype=capi.RESULT_DTYPE)
+        state["gathered"] = bdist.gather_results(local, dev) if dist_ctx is not None else local
+        state["rows"] = local
+
+    for _ in range(warmup):
+        one_pass(False, chunk_sizes[:1])       # warm-up: the first chunk
+    rows0 = state["rows"]
+    if warmup and rows0 is not None and rows0.shape[0]:
+        bad = int(np.count_nonzero((rows0["status_rev"] | rows0["status_fwd"]) & ~np.uint32(capi.ST_BISECT_FAIL)))
+        if bad:
+            worst = float(np.max(np.maximum(rows0["steps_rev"], rows0["steps_fwd"]) / inp.n_knots[np.arange(rows0.shape[0]) % K]))
+            raise RuntimeError(f"{cfg_name}: {bad} paths ended with an error status (up to {worst:.2f} steps per knot): raise the curve capacity")
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_pass(True, chunk_sizes)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist_ctx is not None:
+        dist = dist_ctx["dist"]
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tk = torch.tensor([local_knots, B], dtype=torch.int64, device=dev)
+        dist.all_reduce(tk, op=dist.ReduceOp.SUM)
+        job_knots, job_paths = int(tk[0].item()), int(tk[1].item())
+    else:
+        job_knots, job_paths = local_knots, B
+    for k in kernel_ms:
+        kernel_ms[k] /= max(steps, 1)
+
+    res = state["rows"] if state["rows"] is not None else np.zeros(0, dtype=capi.RESULT_DTYPE)
+    steps_rev, steps_fwd = int(res["steps_rev"].sum()), int(res["steps_fwd"].sum())
+    sr, sf = res["steps_rev"].astype(np.float64), res["steps_fwd"].astype(np.float64)
+
+    # roofline of the dominant kernel (algorithmic bytes of SURVEY.md 8d, compact (y, M) figure): a sweep reads the spline
+    # data of every knot once, 16*C bytes, and writes 16 bytes per integrated point; the forward sweep also reads the
+    # reverse curve, 16 bytes per point.  k_sweep is launched twice per step and chunk: per-launch averages, which is what a
+    # rocprofv3 --stats summary of this command shows for the kernel (profiles/)
+    launches = max(len(chunk_sizes), 1)
+    bytes_rev = 16.0 * C * local_knots + 16.0 * (steps_rev + B)
+    bytes_fwd = 16.0 * C * local_knots + 16.0 * (steps_fwd + B) + 16.0 * (steps_rev + B)
+    dom_bytes = 0.5 * (bytes_rev + bytes_fwd) / launches
+    dom_ms = 0.5 * (kernel_ms[3] + kernel_ms[4]) / launches
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    layout = "compact" if (prob.flags & capi.F_COMPACT_SPLINES) else "rows"
+    traffic, traffic_src = recorded_traffic(workload, chunk_sizes[0] if B else 0, layout)
+    tk_ = max(local_knots, 1)
+    r1_ms, r2_ms = max(kernel_ms[1] + kernel_ms[2], 1e-9), max(kernel_ms[3] + kernel_ms[4], 1e-9)
+    rho_r, rho_f = steps_rev / tk_, steps_fwd / tk_
+    out = {
+        "metric": METRIC,
+        "value": job_knots * steps / elapsed,
+        "unit": "waypoints/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed / max(steps, 1),
+        "higher_is_better": True,
+        "scaling": c["scaling"],
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": inp.data + (f", tiled to {B} paths" if B > K else ""),
+        "config": {"workload": c["what"], "config": cfg_name, "paths_total": job_paths, "paths_per_gpu": B,
+                   "chunks_per_step": len(chunk_sizes), "knots_per_path_mean": local_knots / max(B, 1), "channels": C,
+                   "spline_layout": layout, "lanes_per_path": group, "distinct_paths_per_gpu": K,
+                   "regions": "K1+K2 precompute, K3 pointwise, K4 reverse+forward sweep", "parallelism": f"paths sharded x{world}"},
+        "kernel_ms": {"precompute": kernel_ms[1], "pointwise_mvc": kernel_ms[2], "sweep_rev": kernel_ms[3], "sweep_fwd": kernel_ms[4]},
+        "steps_per_knot": {"rev": rho_r, "fwd": rho_f},
+        "steps_per_path": {"rev_min_median_max": [float(np.min(sr)), float(np.median(sr)), float(np.max(sr))] if B else None,
+                           "fwd_min_median_max": [float(np.min(sf)), float(np.median(sf)), float(np.max(sf))] if B else None},
+        # SURVEY.md 8d: the three timed regions with their algorithmic bytes per waypoint (compact (y, M) figures):
+        # R1 per-knot work (K1+K2+K3) 16*C + 24, R2 both sweeps 32*C + 16*(2*rho_rev + rho_fwd), R3 = R1 + R2
+        "regions": {
+            "R1_per_knot": {"ms": r1_ms, "waypoints_per_s": local_knots / (r1_ms * 1e-3), "bytes_per_waypoint": 16 * C + 24,
+                            "algorithmic_GBps": local_knots * (16 * C + 24) / (r1_ms * 1e-3) / 1e9},
+            "R2_sweeps": {"ms": r2_ms, "waypoints_per_s": local_knots / (r2_ms * 1e-3), "bytes_per_waypoint": 32 * C + 16 * (2 * rho_r + rho_f),
+                          "algorithmic_GBps": local_knots * (32 * C + 16 * (2 * rho_r + rho_f)) / (r2_ms * 1e-3) / 1e9},
+            "R3_total": {"ms": r1_ms + r2_ms, "waypoints_per_s": local_knots / ((r1_ms + r2_ms) * 1e-3),
+                         "bytes_per_waypoint": 48 * C + 24 + 16 * (2 * rho_r + rho_f)}},
+        "stage_evals_per_s": 7.0 * (steps_rev + steps_fwd) / (r2_ms * 1e-3),
+        "us_per_integration_step": (1e3 * (kernel_ms[3] + kernel_ms[4]) / max(steps_rev + steps_fwd, 1)) if B == 1 else None,
+        "hbm_bytes_resident": batch.nbytes() if batch is not None else 0,
+        "gathered_rows": int(state["gathered"].shape[0]) if state["gathered"] is not None else 0,
+        "roofline": {"bound": "hbm", "kernel": f"k_sweep ({2 * launches} launches per step: reverse, forward; per-launch averages)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
+                     "reverse": {"ms": kernel_ms[3], "algorithmic_bytes": bytes_rev}, "forward": {"ms": kernel_ms[4], "algorithmic_bytes": bytes_fwd}},
+    }
+    if inp.on_device:
+        out["inputs_identical_to_host_resampler"] = inp.host_check
+    kept = None
+    if keep:
+        kept = dict(batch=batch, inp=inp, prob=prob, cap=cap, res=res, K=K, B=B, chunk0=chunk_sizes[0] if B else 0)
+    elif batch is not None:
+        batch.close()
+    return out, kept
+
+
+def recorded_traffic(workload, paths, layout):
+    """HBM bytes per sweep launch from the PMC counters of a recorded rocprofv3 run (profiles/pmc_sweep_traffic.json) --
+    only when that run had this workload, batch size and spline layout; otherwise null"""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_sweep_traffic.json")))
+    except Exception:
+        return None, None
+    for e in rec.get("runs", []):
+        if e.get("workload") == workload and e.get("paths") == paths and e.get("layout") == layout:
+            return e.get("hbm_bytes_per_launch"), e.get("command")
+    return None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# side measurements of a run (rank 0)
+# ---------------------------------------------------------------------------------------------------------------------
+def measure_resampler(hip, workload, knots, n_paths):
+    """SURVEY.md 8f-1 beside the hot path: taught points -> knots by batotp_hip_resample (taught points resident)"""
+    seeds = [5000 + k for k in range(min(n_paths, 64))]
+    taught, sres_in = taught_points_f32(workload, seeds, knots)
+    xs = [widen(workload, t) for t in taught]
+    host = make_knots(workload, seeds[0], knots)
+    prm = resample_params(workload, host[2])
+    tiled = [xs[p % len(xs)] for p in range(n_paths)]
+    best, same, nk = None, True, 0
+    for _ in range(2):   # the second call finds the context's workspaces allocated
+        r = capi.Resampled(hip, prm, tiled, [sres_in] * n_paths)
+        ms = r.ms()
+        same = bool(np.array_equal(r.knots(0)[: host[0].shape[0]], host[0]) and r.sres[0] == host[1])
+        nk = int(r.n_knots.sum())
+        r.close()
+        best = ms if best is None else min(best, ms)
+    hip.trim()
+    return {"paths": n_paths, "knots": nk, "ms": best, "knots_per_s": nk / (best * 1e-3), "identical_to_host_resampler": same,
+            "what": "remClosePts + adjust_s x2 + interpSpecial + uniform re-evaluation on the device (taught points resident)"}
+
+
+def load_cpu_checker():
+    """TEST INFRASTRUCTURE, cpu_baseline leg only: the CPU oracle behind the product's C-ABI (never measured as the product)"""
+    return capi.Library(os.path.join(ROOT, "oracle", "_build", "libbatotp_oracle_abi.so"))
+
+
+def cpu_baseline(kept, budget_s, out_prm=None, want_output=False):
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    octx = capi.Context(load_cpu_checker(), 0)
+    cores = os.cpu_count() or 1
+    inp, prob, cap, K = kept["inp"], kept["prob"], kept["cap"], kept["K"]
+    D = min(K, 16)                                        # distinct paths of the sample (host-resampled copies)
+    with cf.ThreadPoolExecutor(max_workers=min(D, cores)) as ex:
+        hosts = list(ex.map(inp.host_knots, range(D)))
+
+    def cpu_batch(n_paths, passes=1):
+        nk = [hosts[i % D][0].shape[1] for i in range(n_paths)]
+        pr = capi.Problem.from_buffer_copy(bytes(prob))
+        pr.flags &= ~capi.F_COMPACT_SPLINES
+        b = capi.Batch(octx, pr, nk, cap)
+        for i in range(n_paths):
+            b.upload_knots(i, [hosts[i % D][0]], [hosts[i % D][1]])
+        prepare_dynamics(b, pr, n_paths)
+        dt = 0.0
+        for _ in range(passes):
+            t = time.perf_counter()
+            b.precompute(0); b.pointwise_mvc(); b.sweep(-1); b.sweep(+1)
+            dt = time.perf_counter() - t
+        rr = b.results()
+        th0 = None
+        if want_output:
+            oo = capi.Output(b, out_prm, 0, 1)
+            th0 = oo.rows(0)
+            oo.close()
+        b.close()
+        return dt, sum(nk), rr, th0
+
+    t_one, n_one, _, th0 = cpu_batch(1, passes=2)      # one path = one busy thread
+    n_sample = int(max(cores, min(2 * cores, (budget_s / max(t_one, 1e-3)) * cores)))
+    n_sample = max(cores, (n_sample // cores) * cores)
+    wall, n_wp, rows, _ = cpu_batch(n_sample, passes=2)
+    info = {"value": n_wp / wall, "unit": "waypoints/s", "cores": cores, "kind": "port", "single_thread_value": n_one / t_one,
+            "sample": f"{n_sample} paths of the same workload ({D} distinct, N~{n_one}), OpenMP one path per thread on {cores} host "
+                      f"threads, same regions (K1-K4), oracle/ C restatement at -O2 -ffp-contract=off"}
+    m = min(n_sample, kept["chunk0"], D)
+    res = kept["res"]
+    err = float(np.max(np.abs(res["t_total"][:m] - rows["t_total"][:m])))
+    mism = int(np.count_nonzero(res["steps_fwd"][:m] != rows["steps_fwd"][:m]))
+    return info, err, mism, th0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a CHILD process (this process never
+    touches a GPU) and pass its output and exit code through"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_check(args, rank, world):
+    """--launch-check: launcher, sharding and gather without any GPU work (gloo; what the CPU test-suite drives)"""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    c = CONFIGS[args.config]
+    total = args.paths or c["paths"]
+    lo, hi = bdist.shard_range(total, rank, world) if c["scaling"] == "strong" else (0, total)
+    rows = np.zeros(hi - lo, dtype=capi.RESULT_DTYPE)
+    rows["n_fwd"] = np.arange(lo, hi) if c["scaling"] == "strong" else rank
+    allrows = bdist.gather_results(rows) if world > 1 else rows
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "config": args.config, "scaling": c["scaling"],
+                          "paths_total": total if c["scaling"] == "strong" else total * world, "gathered_rows": int(allrows.shape[0]),
+                          "rows_in_rank_order": bool(np.all(np.diff(allrows["n_fwd"]) >= 0)), "max_over_ranks": float(t.item())}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="ur6", choices=sorted(WORKLOADS))
-    ap.add_argument("--paths", type=int, default=0,
-                    help="paths per GPU (0 = what fills the GPU for the workload: 16384 ur6, 11264 gen7, 2048 cspr)")
-    ap.add_argument("--knots", type=int, default=100000, help="target knots per path")
-    ap.add_argument("--distinct", type=int, default=32, help="distinct seeded paths per GPU (tiled to --paths)")
+    ap.add_argument("--config", default="fill7", choices=sorted(CONFIGS))
+    ap.add_argument("--paths", type=int, default=0, help="override the configuration's number of paths (per GPU for weak, total for strong scaling)")
+    ap.add_argument("--knots", type=int, default=0, help="override the configuration's target knots per path")
+    ap.add_argument("--distinct", type=int, default=0, help="distinct seeded paths per GPU (tiled to the batch)")
     ap.add_argument("--group", type=int, default=0, help="lanes per path in the sweep kernel (0 = automatic)")
     ap.add_argument("--ppw", type=int, default=0, help="paths per wavefront in the sweep kernel (0 = automatic)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", action="store_true",
-                    help="run the per-knot evaluation (K3) beside the sweeps on a second stream (measured: slower, the SIMDs are already saturated)")
-    ap.add_argument("--no-resample", action="store_true", help="skip the side measurement of the device path resampler")
-    ap.add_argument("--no-output", action="store_true", help="skip the side measurement of the device output stage")
-    ap.add_argument("--no-flat-loop", action="store_true", help="skip the side measurement of the optional flat reverse-sweep loop")
-    ap.add_argument("--no-seven-dof", action="store_true", help="skip the GEN7DOF (7-DOF) measurement reported beside the default workload")
+    ap.add_argument("--no-sides", action="store_true", help="skip the side measurements (resampler, output stage, nested-loop cross-check)")
+    ap.add_argument("--no-as-worded", action="store_true", help="default configuration only: skip the BASELINE configs as worded")
     ap.add_argument("--coefficient-rows", action="store_true",
                     help="keep four coefficients per knot and channel instead of the compact (value, second derivative) form")
+    ap.add_argument("--launch-check", action="store_true", help="exercise launcher, sharding and gather only (gloo, no GPU work)")
     args = ap.parse_args()
-    if args.paths <= 0:
-        # ur6 / gen7: 8 paths in each of ~2048 wavefronts (2 per SIMD) is where the sweep kernel peaks, memory permitting
-        args.paths = {"ur6": 16384, "gen7": 11264, "cspr": 2048}[args.workload]
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))   # nothing above touched a GPU
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: start it as `python bench.py --gpus {args.gpus}` or "
+                         f"through torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.launch_check:
+        return launch_check(args, rank, world)
 
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = world > 1 or os.environ.get("BATOTP_BENCH_FORCE_DIST") == "1"   # the latter: exercise RCCL on one GPU
-    if use_dist:
+    dist_ctx = None
+    if world > 1 or os.environ.get("BATOTP_BENCH_FORCE_DIST") == "1":   # the latter: exercise RCCL on one GPU
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
+        dist_ctx = {"dist": dist, "dev": torch.device("cuda", local_rank)}
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
     hip = capi.Context(capi.load_hip(), local_rank)  # raises if the HIP extension or the GPU is missing
-    hip.set_sweep_group(args.group)
-    hip.set_paths_per_wave(args.ppw)
-    hip.set_overlap(args.overlap)
 
-    # ---- synthetic inputs: K distinct host-resampled paths per GPU, tiled so that consecutive paths
-    # (the 64/G paths that share a wavefront) are all different
-    K = max(1, min(args.distinct, args.paths))
-    seeds = [1000 + rank * K + k for k in range(K)]
-    with cf.ThreadPoolExecutor(max_workers=min(K, os.cpu_count() or 1)) as ex:
-        base = list(ex.map(lambda s: make_knots(args.workload, s, args.knots), seeds))
-    prob = base[0][2]
-    resample_info = None
-    if rank == 0 and not args.no_resample:
-        resample_info = measure_resampler(hip, args.workload, base, min(args.paths, 1024))
-    if (prob.flags & capi.F_NO_SAMPLES) and not args.coefficient_rows:
-        prob.flags |= capi.F_COMPACT_SPLINES  # same results, half the spline bytes per knot: room for more paths per GPU
-    B = args.paths
-    C = WORKLOADS[args.workload]["C"]
-    while True:
-        n_knots = [base[p % K][0].shape[1] for p in range(B)]
-        total_knots = int(sum(n_knots))
-        cap = int(max(n_knots) * {"ur6": 0.5, "gen7": 2.2, "cspr": 0.6}[args.workload]) + 1024
-        try:
-            batch = capi.Batch(hip, prob, n_knots, cap)
-            break
-        except capi.BatotpError as e:
-            # the default sizes fill most of the 288 GB: on a GPU with less free memory run a smaller batch (reported in
-            # config.paths_per_gpu) rather than nothing
-            if "-5" not in str(e) and "Alloc" not in str(e) and "alloc" not in str(e) and "memory" not in str(e):
-                raise
-            if B <= 1024:
-                raise
-            B = max(1024, (B * 3 // 4) // 1024 * 1024)
-            print(f"bench: batch did not fit, retrying with {B} paths", file=sys.stderr)
-    for p in range(B):
-        y, sres = base[p % K][0], base[p % K][1]
-        batch.upload_knots(p, [y], [sres])
-    hip.synchronize()
+    default_run = args.config == "fill7" and not args.paths and not args.knots
+    out, kept = measure(hip, args.config, rank, world, args.steps, args.warmup, dist_ctx, args.paths, args.knots, args.group, args.ppw,
+                        args.coefficient_rows, args.distinct, keep=True)
+    workload = CONFIGS[args.config]["workload"]
+    prob, batch = kept["prob"], kept["batch"]
+    vel_acc_only = not (prob.flags & (capi.F_TRQ_ON | capi.F_CART_VEL_ON | capi.F_CART_ACC_ON))
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    gathered = None
-    for _ in range(args.warmup):
-        run_step(batch, False)
-        gathered = bdist.gather_results(batch.results(), dev if use_dist else None)
-    res = batch.results()
-    bad = int(np.count_nonzero((res["status_rev"] | res["status_fwd"]) & ~np.uint32(capi.ST_BISECT_FAIL))) if args.warmup else 0
-    if bad:
-        raise RuntimeError(f"{bad} paths ended with an error status: raise the curve capacity")
-
-    kernel_ms = {1: 0.0, 2: 0.0, 3: 0.0, 4: 0.0}
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step(batch, False)
-        for k in kernel_ms:
-            kernel_ms[k] += batch.kernel_ms(k)   # HIP events on the stream the kernels were launched on
-        gathered = bdist.gather_results(batch.results(), dev if use_dist else None)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        tk = torch.tensor([total_knots], dtype=torch.int64, device=dev)
-        dist.all_reduce(tk, op=dist.ReduceOp.SUM)
-        job_knots = int(tk.item())
-    else:
-        job_knots = total_knots
-    for k in kernel_ms:
-        kernel_ms[k] /= max(args.steps, 1)
-
-    res = batch.results()
-    steps_rev, steps_fwd = int(res["steps_rev"].sum()), int(res["steps_fwd"].sum())
-
-    # ---- roofline of the dominant kernel (algorithmic bytes of SURVEY.md 8d, compact (y, M) figure):
-    # a sweep reads the spline data of every knot once, 16*C bytes, and writes 16 bytes per integrated
-    # point; the forward sweep also reads the reverse curve, 16 bytes per point
-    bytes_rev = 16.0 * C * total_knots + 16.0 * (steps_rev + B)
-    bytes_fwd = 16.0 * C * total_knots + 16.0 * (steps_fwd + B) + 16.0 * (steps_rev + B)
-    # the dominant kernel is k_sweep; a step launches it twice (reverse, forward): per-launch averages, which is what
-    # a rocprofv3 --stats summary of this command shows for the kernel (profiles/)
-    dom_bytes = 0.5 * (bytes_rev + bytes_fwd)
-    dom_ms = 0.5 * (kernel_ms[3] + kernel_ms[4])
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_sweep_traffic.json")
-    if os.path.exists(pmc_path):
-        try:
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-
-    out = {
-        "metric": "constraint-evaluated waypoints/sec + traversal-time err vs CPU ref",
-        "value": job_knots * args.steps / elapsed,
-        "unit": "waypoints/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": f"synthetic: {K} distinct seeded spline paths per GPU resampled by the host BA library, tiled to {B} paths",
-        "config": {"workload": {"ur6": f"cfg2 UR5-like 6-DOF vel+acc, N~{args.knots} knots/path, batch of independent paths",
-                                "gen7": f"cfg4 GEN7DOF 7-DOF vel+acc, N~{args.knots} knots/path, batch of independent paths",
-                                "cspr": f"cfg5 CSPR3DOF cable tensions + vel/acc + Cartesian speed, N~{args.knots} knots/path"}[args.workload],
-                   "paths_per_gpu": B, "knots_per_path_mean": total_knots / B, "channels": C, "lanes_per_path": args.group,
-                   "regions": "K1+K2 precompute, K3 pointwise, K4 reverse+forward sweep", "parallelism": f"paths sharded x{world}"},
-        "kernel_ms": {"precompute": kernel_ms[1], "pointwise_mvc": kernel_ms[2], "sweep_rev": kernel_ms[3], "sweep_fwd": kernel_ms[4]},
-        "steps_per_knot": {"rev": steps_rev / total_knots, "fwd": steps_fwd / total_knots},
-        # SURVEY.md 8d: the three timed regions with their algorithmic bytes per waypoint (compact (y, M) figures):
-        # R1 per-knot work (K1+K2+K3) 16*C + 24, R2 both sweeps 32*C + 16*(2*rho_rev + rho_fwd), R3 = R1 + R2
-        "regions": (lambda r1_ms, r2_ms, rho_r, rho_f: {
-            "R1_per_knot": {"ms": r1_ms, "waypoints_per_s": total_knots / (r1_ms * 1e-3), "bytes_per_waypoint": 16 * C + 24,
-                            "algorithmic_GBps": total_knots * (16 * C + 24) / (r1_ms * 1e-3) / 1e9},
-            "R2_sweeps": {"ms": r2_ms, "waypoints_per_s": total_knots / (r2_ms * 1e-3),
-                          "bytes_per_waypoint": 32 * C + 16 * (2 * rho_r + rho_f),
-                          "algorithmic_GBps": total_knots * (32 * C + 16 * (2 * rho_r + rho_f)) / (r2_ms * 1e-3) / 1e9},
-            "R3_total": {"ms": r1_ms + r2_ms, "waypoints_per_s": total_knots / ((r1_ms + r2_ms) * 1e-3),
-                         "bytes_per_waypoint": 48 * C + 24 + 16 * (2 * rho_r + rho_f)},
-        })(kernel_ms[1] + kernel_ms[2], kernel_ms[3] + kernel_ms[4], steps_rev / total_knots, steps_fwd / total_knots),
-        "stage_evals_per_s": 7.0 * (steps_rev + steps_fwd) / ((kernel_ms[3] + kernel_ms[4]) * 1e-3),
-        "hbm_bytes_resident": batch.nbytes(),
-        "gathered_rows": int(gathered.shape[0]) if gathered is not None else 0,
-        "roofline": {"bound": "hbm", "kernel": "k_sweep (2 launches per step: reverse, forward; per-launch averages)", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
-                     "reverse": {"ms": kernel_ms[3], "algorithmic_bytes": bytes_rev}, "forward": {"ms": kernel_ms[4], "algorithmic_bytes": bytes_fwd}},
-    }
-
-    # ---- SURVEY.md 8f-2 beside the hot path: the output stage (constant-time trajectories from the forward curves)
-    # of the first paths of the batch on the device; untimed side measurement
-    wcfg = WORKLOADS[args.workload]["cfg"]
-    out_prm = capi.OutputParams(prob.n_joints, capi.PATH_JOINT if wcfg["path_type"] == "JOINT" else capi.PATH_CART, prob.integ_res, 0.008, 5.0)
-    hip_out_theta0 = None
-    covered = (wcfg["robot"] == "GENJNT" and not (prob.flags & capi.F_TRQ_ON)) or \
-              (wcfg["robot"] == "CSPR3DOF" and (prob.flags & capi.F_TRQ_ON) and (prob.flags & capi.F_PARALLEL))
-    if rank == 0 and not args.no_output and covered:
-        n_out_paths = min(B, 512)
-        best = None
-        for _ in range(2):  # the second call finds the context's workspace allocated
-            o = capi.Output(batch, out_prm, 0, n_out_paths)
-            ms, pts = o.ms(), int(o.n_pts.sum())
-            hip_out_theta0 = o.rows(0)
-            o.close()
-            best = ms if best is None else min(best, ms)
-        out["output_stage"] = {"paths": n_out_paths, "points": pts, "ms": best, "points_per_s": pts / (best * 1e-3),
-                               "out_res": out_prm.out_res, "out_smooth_fact": out_prm.out_smooth_fact,
-                               "what": "s(t) spline + re-sampling at constant time steps + joint spline evaluation + smoothing / "
-                                       "down-sampling (+ re-interpolation when out_res < integ_res) on the device"}
-
-    # ---- optional loop form of the reverse sweep (batotp_hip_set_sweep_hold, off by default: DESIGN.md 4): the same
-    # batch once more with it, results compared byte for byte with the timed runs'; untimed side measurement
-    if rank == 0 and not args.no_flat_loop and not (prob.flags & (capi.F_TRQ_ON | capi.F_CART_VEL_ON | capi.F_CART_ACC_ON)):
-        ref_rows = batch.results().tobytes()
-        hip.set_sweep_group(8)
-        hip.set_sweep_hold(4, -1)
-        batch.sweep(-1)
-        batch.sweep(+1)
-        flat_rev, flat_fwd = batch.kernel_ms(3), batch.kernel_ms(4)
-        same = batch.results().tobytes() == ref_rows
-        hip.set_sweep_hold(-1, -1)
-        hip.set_sweep_group(args.group)
-        step_est = 1e3 * elapsed / max(args.steps, 1) - kernel_ms[3] - kernel_ms[4] + flat_rev + flat_fwd
-        out["flat_reverse_loop"] = {"hold_reverse": 4, "sweep_rev_ms": flat_rev, "sweep_fwd_ms": flat_fwd,
-                                    "ms_per_step_with_it": step_est, "waypoints_per_s_with_it": total_knots / (step_est * 1e-3),
-                                    "result_rows_identical": bool(same),
-                                    "what": "one loop for stages and bisection passes in the reverse sweep (paths of a wavefront drift apart); "
-                                            "not the default, not part of value"}
-
-    # ---- the same workload as ONE trajectory (BASELINE configs[1] wording): inherently sequential,
-    # reported for transparency next to the batch figure
-    if rank == 0:
-        y1, sres1 = base[0][0], base[0][1]
-        b1 = capi.Batch(hip, prob, [y1.shape[1]], cap)
-        b1.upload_knots(0, [y1], [sres1])
-        run_step(b1, False)
-        t1 = time.perf_counter()
-        run_step(b1, False)
-        dt1 = time.perf_counter() - t1
-        out["single_trajectory"] = {"knots": int(y1.shape[1]), "ms": 1e3 * dt1, "waypoints_per_s": y1.shape[1] / dt1,
-                                    "kernel_ms": {"precompute": b1.kernel_ms(1), "pointwise_mvc": b1.kernel_ms(2),
-                                                  "sweep_rev": b1.kernel_ms(3), "sweep_fwd": b1.kernel_ms(4)}}
-        b1.close()
-
-    # ---- CPU baseline: the oracle (bit-identical port of the reference's path) on the host cores, on a
-    # bounded sample of the same workload, one path per thread
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
-        ora_lib = capi.load_oracle()
-        cores = os.cpu_count() or 1
-        octx = capi.Context(ora_lib, 0)
-
-        def cpu_batch(n_paths, passes=1):
-            """n_paths paths of the workload through the oracle, OpenMP: one path per host thread.
-            The last of `passes` passes is timed (the first one also pays the page faults of fresh memory)."""
-            nk = [base[i % K][0].shape[1] for i in range(n_paths)]
-            b = capi.Batch(octx, prob, nk, cap)
-            for i in range(n_paths):
-                b.upload_knots(i, [base[i % K][0]], [base[i % K][1]])
-            for _ in range(passes):
-                t = time.perf_counter()
-                b.precompute(0); b.pointwise_mvc(); b.sweep(-1); b.sweep(+1)
-                dt = time.perf_counter() - t
-            rr = b.results()
-            th0 = None
-            if hip_out_theta0 is not None:
-                oo = capi.Output(b, out_prm, 0, 1)
-                th0 = oo.rows(0)
-                oo.close()
-            b.close()
-            return dt, sum(nk), rr, th0
-
-        t_one, n_one, _, th0 = cpu_batch(1, passes=2)      # one path = one busy thread
-        n_sample = int(max(cores, min(2 * cores, (args.cpu_seconds / max(t_one, 1e-3)) * cores)))
-        n_sample = max(cores, (n_sample // cores) * cores)
-        wall, n_wp, rows, _ = cpu_batch(n_sample, passes=2)
-        if th0 is not None:
-            out["output_stage"]["identical_to_oracle"] = bool(th0.tobytes() == hip_out_theta0.tobytes())
-        out["cpu_baseline"] = {"value": n_wp / wall, "unit": "waypoints/s", "cores": cores, "kind": "port",
-                               "single_thread_value": n_one / t_one,
-                               "sample": f"{n_sample} paths of the same workload (N~{n_one}), OpenMP one path per thread on {cores} "
-                                         f"host threads, same regions (K1-K4), oracle/ C restatement at -O2 -ffp-contract=off"}
-        # traversal-time error vs the CPU reference on the sampled paths (T is quantised to integRes)
-        m = min(n_sample, B)
-        out["traversal_time_err_s"] = float(np.max(np.abs(res["t_total"][:m] - rows["t_total"][:m])))
-        out["step_count_mismatches"] = int(np.count_nonzero(res["steps_fwd"][:m] != rows["steps_fwd"][:m]))
-
-    batch.close()
+    if rank == 0 and not args.no_sides and batch is not None:
+        # the automatic loop form of the reverse sweep (flat stage / bisection loop) against the nested loops on the same
+        # batch: the result rows must be identical; untimed
+        if vel_acc_only and kept["chunk0"] > 2048 and args.group in (0, 8):
+            ref_rows = batch.results().tobytes()
+            hip.set_sweep_hold(-1, -1)
+            batch.sweep(-1); batch.sweep(+1)
+            nested_rev, nested_fwd = batch.kernel_ms(3), batch.kernel_ms(4)
+            same = batch.results().tobytes() == ref_rows
+            hip.set_sweep_hold(-2, -2)
+            out["nested_loop_cross_check"] = {"sweep_rev_ms": nested_rev, "sweep_fwd_ms": nested_fwd, "result_rows_identical": bool(same),
+                                              "what": "the same batch once more with the nested stage / bisection loops in both sweeps "
+                                                      "(the default runs the flat loop in the reverse sweep); untimed"}
+        # SURVEY.md 8f-2 beside the hot path: the output stage of the first paths of the batch on the device
+        wcfg = WORKLOADS[workload]["cfg"]
+        covered = (wcfg["robot"] == "GENJNT" and not (prob.flags & capi.F_TRQ_ON)) or \
+                  (wcfg["robot"] == "CSPR3DOF" and (prob.flags & capi.F_TRQ_ON) and (prob.flags & capi.F_PARALLEL))
+        out_prm, hip_out0 = None, None
+        if covered:
+            out_prm = capi.OutputParams(prob.n_joints, capi.PATH_JOINT if wcfg["path_type"] == "JOINT" else capi.PATH_CART, prob.integ_res, 0.008, 5.0)
+            n_out_paths = min(kept["chunk0"], 512)
+            best = None
+            for _ in range(2):  # the second call finds the context's workspace allocated
+                o = capi.Output(batch, out_prm, 0, n_out_paths)
+                ms, pts = o.ms(), int(o.n_pts.sum())
+                hip_out0 = o.rows(0)
+                o.close()
+                best = ms if best is None else min(best, ms)
+            out["output_stage"] = {"paths": n_out_paths, "points": pts, "ms": best, "points_per_s": pts / (best * 1e-3),
+                                   "out_res": out_prm.out_res, "out_smooth_fact": out_prm.out_smooth_fact,
+                                   "what": "s(t) spline + re-sampling at constant time steps + joint spline evaluation + smoothing / "
+                                           "down-sampling (+ re-interpolation when out_res < integ_res) on the device"}
+        # CPU baseline: the oracle (bit-identical port of the reference's path) on the host cores, bounded sample
+        if world == 1 and not args.no_cpu_baseline:
+            info, err, mism, th0 = cpu_baseline(kept, args.cpu_seconds, out_prm, hip_out0 is not None)
+            out["cpu_baseline"] = info
+            out["vs_cpu_baseline"] = out["value"] / info["value"]
+            out["traversal_time_err_s"] = err
+            out["step_count_mismatches"] = mism
+            if th0 is not None:
+                out["output_stage"]["identical_to_oracle"] = bool(th0.tobytes() == hip_out0.tobytes())
+    if batch is not None:
+        batch.close()
+    kept = None
     hip.trim()
+
+    if rank == 0 and not args.no_sides and default_run and device_resamplable(workload):
+        out["resample"] = measure_resampler(hip, workload, CONFIGS[args.config]["knots"], 1024)
+
+    # the BASELINE configs as worded, beside the headline (every rank takes part: cfg4 / cfg5 shard their batch over the ranks)
+    if default_run and not args.no_as_worded:
+        worded = {}
+        for name in ("cfg2", "cfg3", "cfg4", "cfg5"):
+            try:
+                w, _ = measure(hip, name, rank, world, 1, 1, dist_ctx)
+                worded[name] = {k: w[k] for k in ("value", "unit", "ms_per_step", "scaling", "data", "config", "kernel_ms", "steps_per_knot",
+                                                   "us_per_integration_step", "gathered_rows")}
+                worded[name]["roofline_frac"] = w["roofline"]["frac"]
+            except Exception as e:  # the main line must not depend on a side measurement
+                if world > 1:
+                    raise          # ... but ranks must not drift apart in the collectives
+                worded[name] = {"error": f"{type(e).__name__}: {str(e)[-300:]}"}
+            hip.trim()
+        out["as_worded"] = worded
     hip.close()
     if rank == 0:
-        if resample_info is not None:
-            out["resample"] = resample_info
-        # BASELINE.json's target is worded for a 7-DOF robot at N = 100k: the same measurement on the GEN7DOF workload
-        # (child process, after this one has released the GPU memory), reported beside the UR6 line
-        if world == 1 and args.workload == "ur6" and not args.no_seven_dof:
-            cmd = [sys.executable, os.path.abspath(__file__), "--workload", "gen7", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
-                   "--no-resample", "--no-output", "--knots", str(args.knots)]
-            r = subprocess.run(cmd, capture_output=True, text=True)
-            try:
-                g = json.loads(r.stdout.strip().splitlines()[-1])
-                out["seven_dof"] = {"value": g["value"], "unit": g["unit"], "ms_per_step": g["ms_per_step"], "config": g["config"],
-                                    "kernel_ms": g["kernel_ms"], "steps_per_knot": g["steps_per_knot"], "roofline_frac": g["roofline"]["frac"],
-                                    "flat_reverse_loop": g.get("flat_reverse_loop")}
-            except Exception as e:  # the main line must not depend on the side measurement
-                out["seven_dof"] = {"error": f"{type(e).__name__}: {r.stderr[-300:]}"}
         print(json.dumps(out))
-    if use_dist:
+    if dist_ctx is not None:
         dist.destroy_process_group()
 
 

@@ -240,13 +240,14 @@ int  batotp_hip_set_sweep_group(batotp_ctx *ctx, int32_t lanes);
 /* tuning knob: paths per 64-lane wavefront in the sweep kernel, 1 .. 64/lanes (0 = automatic:
  * few paths are spread over more wavefronts, many paths fill every lane) */
 int  batotp_hip_set_paths_per_wave(batotp_ctx *ctx, int32_t n);
-/* optional loop form of the 8-lane sweep kernel, per direction, for problems with joint velocity / acceleration limits
- * only (others ignore it): -1 (default) = the stage loop contains the bisection loop (a wavefront stays in a stage's
- * bisection as long as any of its paths does); 0..8 = one flat loop in which every path is either waiting for its
- * next stage or inside a constraint check, and the next stage is started as soon as hold/8 of the wavefront's live
- * paths wait for it (8 = all of them).  Same arithmetic per path, bit-identical results in every test; measured on
- * the bench batch: reverse sweep 855 ms with hold 4 against 1130 ms (the forward sweep does not gain).  Off by default:
- * DESIGN.md 4 tells why. */
+/* loop form of the 8-lane sweep kernel, per direction, for problems with joint velocity / acceleration limits only on
+ * uniform knot sites (everything else always runs the nested loops): -1 = the stage loop contains the bisection loop (a
+ * wavefront stays in a stage's bisection as long as any of its paths does); 0..8 = one flat loop in which every path is
+ * either waiting for its next stage or inside a constraint check, and the next stage is started as soon as hold/8 of the
+ * wavefront's live paths wait for it (8 = all of them); -2 (default) = automatic: hold 4 for the reverse sweep (measured on
+ * the bench batch: 855 ms against 1130 ms), nested loops for the forward sweep (which does not gain).  Same arithmetic per
+ * path: results are bit-identical in every test (tests/test_gpu_parity.py, test_gpu_fuzz.py) and bench.py re-checks the
+ * result rows of every run against the nested loops.  DESIGN.md 4 has the history. */
 int  batotp_hip_set_sweep_hold(batotp_ctx *ctx, int32_t reverse, int32_t forward);
 /* tuning knob: with overlap on, batotp_hip_pointwise_mvc returns at once and its kernel shares the GPU with the
  * sweeps that follow (second HIP stream; nothing in the sweeps reads its output); batotp_hip_get_results,

@@ -76,3 +76,31 @@ def test_two_ranks_gather_matches_single_rank(oracle_ctx):
     for k, o in enumerate(single):
         for f in capi.RESULT_DTYPE.names:
             assert gathered[k][f] == o["result"][f], (k, f)
+
+
+def _bench_line(args, env_extra=None):
+    import json, subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_launches_its_own_ranks_and_shards_as_worded():
+    """`python bench.py --gpus 2` starts two ranks itself (torch.distributed.run as a child process) -- here on CPU with
+    --launch-check (gloo, no GPU work): strong sharding of cfg 4's 1024 paths, gather in rank order, max over ranks"""
+    r, line = _bench_line(["--gpus", "2", "--launch-check", "--config", "cfg4"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["paths_total"] == 1024
+    assert line["gathered_rows"] == 1024 and line["rows_in_rank_order"] and line["max_over_ranks"] == 2.0
+    # weak configurations keep their per-GPU batch
+    r, line = _bench_line(["--gpus", "2", "--launch-check", "--config", "cfg2"])
+    assert r.returncode == 0 and line["n_gpus"] == 2 and line["paths_total"] == 2 and line["gathered_rows"] == 2
+
+
+def test_bench_refuses_a_rank_count_that_is_not_the_one_asked_for():
+    """--gpus N with a different WORLD_SIZE (the silent single-rank run of round 1) is an error"""
+    r, line = _bench_line(["--gpus", "4", "--launch-check"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and line is None and "WORLD_SIZE is 1" in (r.stderr + r.stdout)

@@ -198,7 +198,7 @@ def test_ragged_batch_equals_single_paths(hip_ctx, oracle_ctx):
         _compare(c, many[k], ref[c.name])
 
 
-@pytest.mark.parametrize("hold", [(0, 0), (3, 5), (4, -1), (5, 3), (8, 8), (-1, 6)])
+@pytest.mark.parametrize("hold", [(0, 0), (3, 5), (4, -1), (5, 3), (8, 8), (-1, 6), (-1, -1), (-2, -2)])
 @pytest.mark.parametrize("compact", [False, True])
 def test_flat_sweep_loop_with_paths_drifting_apart(hip_lib, oracle_ctx, hold, compact):
     """batotp_hip_set_sweep_hold: 8 different paths per wavefront in the flat stage / bisection loop (each at its own

@@ -12,6 +12,7 @@ ap.add_argument("--knots", type=int, default=100000); ap.add_argument("--distinc
 ap.add_argument("--reps", type=int, default=1); ap.add_argument("--group", type=int, default=0)
 ap.add_argument("--ppw", type=int, default=0)
 ap.add_argument("--coefficient-rows", action="store_true")
+ap.add_argument("--hold", type=int, nargs=2, default=None, help="sweep loop form, reverse forward (batotp_hip_set_sweep_hold)")
 a = ap.parse_args()
 hip = capi.Context(capi.load_hip(), 0)
 hip.set_sweep_group(a.group)
@@ -19,13 +20,16 @@ if a.ppw and hasattr(hip, "set_paths_per_wave"):
     hip.set_paths_per_wave(a.ppw)
 base = [bench.make_knots(a.workload, 1000 + k, a.knots) for k in range(a.distinct)]
 nk = [base[p % a.distinct][0].shape[1] for p in range(a.paths)]
-cap = int(max(nk) * {"ur6": 0.5, "gen7": 2.2, "cspr": 0.6}[a.workload]) + 1024
+cap = int(max(nk) * bench.WORKLOADS[a.workload]["cap"]) + 1024
 prob = base[0][2]
 if (prob.flags & capi.F_NO_SAMPLES) and not a.coefficient_rows:
     prob.flags |= capi.F_COMPACT_SPLINES
 b = capi.Batch(hip, prob, nk, cap)
 for p in range(a.paths):
     b.upload_knots(p, [base[p % a.distinct][0]], [base[p % a.distinct][1]])
+bench.prepare_dynamics(b, prob, a.paths)
+if a.hold:
+    hip.set_sweep_hold(*a.hold)
 for _ in range(a.reps):
     t = time.perf_counter(); b.precompute(0); b.pointwise_mvc(); b.sweep(-1); b.sweep(1); dt = time.perf_counter() - t
     r = b.results()

@@ -19,7 +19,7 @@ a = ap.parse_args()
 hip = capi.Context(capi.Library(a.lib) if a.lib else capi.load_hip(), 0)
 base = [bench.make_knots(a.workload, 1000 + k, a.knots) for k in range(a.distinct)]
 nk = [base[p % a.distinct][0].shape[1] for p in range(a.paths)]
-cap = int(max(nk) * {"ur6": 0.5, "gen7": 2.2, "cspr": 0.6}[a.workload]) + 1024
+cap = int(max(nk) * bench.WORKLOADS[a.workload]["cap"]) + 1024
 prob = base[0][2]
 if prob.flags & capi.F_NO_SAMPLES:
     prob.flags |= capi.F_COMPACT_SPLINES
