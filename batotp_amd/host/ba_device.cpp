@@ -595,7 +595,8 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
       std::vector<int64_t> nK(trajs.size());
       std::vector<double> sr(trajs.size());
       std::vector<uint32_t> st(trajs.size());
-      batotp_hip_resampled_info(rs.r, nK.data(), sr.data(), st.data());
+      rcR = batotp_hip_resampled_info(rs.r, nK.data(), sr.data(), st.data());
+      if (rcR) return fail("resampled_info", rcR);
       for (size_t p = 0; p < trajs.size(); ++p)
          if (st[p] & (BATOTP_RS_TOO_SHORT | BATOTP_RS_CAPACITY)) onDevice = false; // rare branches: let the host resampler take them
       if (onDevice)
@@ -659,109 +660,145 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
    const int64_t maxIntegSteps = (int64_t)std::floor(_maxIntegTime / _integRes) + 1;
    int64_t nMax = 0;
    for (size_t k = 0; k < nKnots.size(); ++k) nMax = std::max(nMax, nKnots[k]);
-   const int64_t cap = std::min<int64_t>(maxIntegSteps + 2, 8 * nMax + 4096);
-
+   // Capacity of a curve in points.  The single-path API allows maxIntegSteps + 2 like the reference's unbounded arrays
+   // (ba.cpp:1053); a batch starts with what paths usually need (a few integration steps per knot) and, should a path run
+   // out of room (BATOTP_ST_CAPACITY without BATOTP_ST_MAX_INTEG_TIME), the batch is run again with four times the room
+   // -- up to maxIntegSteps + 2, where the path ends with the reference's MAX_INTEGRATION_TIME error instead.
+   int64_t cap = std::min<int64_t>(maxIntegSteps + 2, 8 * nMax + 4096);
    BatchGuard g;
-   int rc = batotp_hip_batch_create(_gpu->ctx, &prob, (int32_t)live.size(), nKnots.data(), cap, &g.b);
-   if (rc) return fail("batch_create", rc);
-
+   std::vector<batotp_path_result> res(live.size());
+   int rc = 0;
+   const double *yDev = nullptr;
+   std::vector<int64_t> offAll(trajs.size(), 0);
    if (onDevice)
    {
-      // runs of consecutive surviving paths are contiguous in the resampler's output
-      const double *yDev = nullptr;
-      batotp_hip_resampled_knots_device(rs.r, &yDev, nullptr);
+      rc = batotp_hip_resampled_knots_device(rs.r, &yDev, nullptr);
+      if (rc) return fail("resampled_knots_device", rc);
       std::vector<int64_t> nAll(trajs.size());
-      batotp_hip_resampled_info(rs.r, nAll.data(), nullptr, nullptr);
-      std::vector<int64_t> offAll(trajs.size(), 0);
+      rc = batotp_hip_resampled_info(rs.r, nAll.data(), nullptr, nullptr);
+      if (rc) return fail("resampled_info", rc);
       for (size_t p = 1; p < trajs.size(); ++p) offAll[p] = offAll[p - 1] + nAll[p - 1];
-      size_t k = 0;
-      while (k < live.size())
+   }
+   for (;;)
+   {
+      if (g.b) { batotp_hip_batch_destroy(g.b); g.b = nullptr; }
+      rc = batotp_hip_batch_create(_gpu->ctx, &prob, (int32_t)live.size(), nKnots.data(), cap, &g.b);
+      if (rc) return fail("batch_create", rc);
+
+      if (onDevice)
       {
-         size_t e = k + 1;
-         while (e < live.size() && live[e] == live[e - 1] + 1) ++e;
-         rc = batotp_hip_upload_knots_device(g.b, (int32_t)k, (int32_t)(e - k), yDev + offAll[live[k]] * nIn, sresKnots.data() + k);
-         if (rc) return fail("upload_knots_device", rc);
-         k = e;
+         // runs of consecutive surviving paths are contiguous in the resampler's output
+         size_t k = 0;
+         while (k < live.size())
+         {
+            size_t e = k + 1;
+            while (e < live.size() && live[e] == live[e - 1] + 1) ++e;
+            rc = batotp_hip_upload_knots_device(g.b, (int32_t)k, (int32_t)(e - k), yDev + offAll[live[k]] * nIn, sresKnots.data() + k);
+            if (rc) return fail("upload_knots_device", rc);
+            k = e;
+         }
       }
+      else
+      {
+         std::vector<double> y;
+         for (size_t k = 0; k < live.size(); ++k)
+         {
+            Traj &t = trajs[live[k]];
+            const int64_t N = nKnots[k];
+            y.assign((size_t)nIn * N, 0.0);
+            for (unsigned int j = 0; j < _nJoints; ++j) std::copy(t.theta[j].begin(), t.theta[j].begin() + N, y.begin() + (size_t)j * N);
+            for (unsigned int j = 0; j < _nCart && j < t.cart.size(); ++j)
+               if (t.cart[j].size() >= (size_t)N) std::copy(t.cart[j].begin(), t.cart[j].begin() + N, y.begin() + (size_t)(_nJoints + j) * N);
+            const double sres = t.sres;
+            rc = batotp_hip_upload_knots(g.b, (int32_t)k, 1, y.data(), &sres);
+            if (rc) return fail("upload_knots", rc);
+         }
+      }
+      rc = batotp_hip_precompute(g.b, 1);
+      if (rc) return fail("precompute(kinematics)", rc);
+      if (_isTrqConOn)
+      {
+         if (_robotType == RR)
+         {
+            std::vector<double> samp, trig;
+            for (size_t k = 0; k < live.size(); ++k)
+            {
+               const int64_t N = nKnots[k];
+               samp.resize(6 * (size_t)N);
+               trig.resize(4 * (size_t)N);
+               rc = batotp_hip_download_samples(g.b, (int32_t)k, 0, samp.data());
+               if (rc) return fail("download_samples", rc);
+               rc = batotp_hip_download_samples(g.b, (int32_t)k, 1, samp.data() + 3 * N);
+               if (rc) return fail("download_samples", rc);
+               for (int64_t i = 0; i < N; ++i)
+               {
+                  const double th1 = _DEG2RAD * samp[i];
+                  const double th2 = _DEG2RAD * samp[3 * N + i];
+                  trig[i] = std::cos(th1);
+                  trig[N + i] = std::cos(th2);
+                  trig[2 * N + i] = std::cos(th1 + th2);
+                  trig[3 * N + i] = sin(th2);
+               }
+               rc = batotp_hip_upload_rr_trig(g.b, (int32_t)k, trig.data());
+               if (rc) return fail("upload_rr_trig", rc);
+            }
+         }
+         else if (!_isParallelMechOrig)
+         {
+            if (!myRobot.serialModel())
+            {
+               printf("No dynamics model provided for robotType=%s.\n", _robotTypeStr.c_str());
+               return -1;
+            }
+            std::vector<double> samp;
+            std::vector<const double *> rows(_nJoints);
+            for (size_t k = 0; k < live.size(); ++k)
+            {
+               const int64_t N = nKnots[k];
+               samp.resize(3 * (size_t)N * _nJoints);
+               for (unsigned int j = 0; j < _nJoints; ++j)
+               {
+                  rc = batotp_hip_download_samples(g.b, (int32_t)k, (int32_t)j, samp.data() + 3 * (size_t)N * j);
+                  if (rc) return fail("download_samples", rc);
+                  rows[j] = samp.data() + 3 * (size_t)N * j;
+               }
+               if (deviceSerialDynamicsInputs(g.b, (int)k, rows.data(), (long long)N) != 0) return -1;
+            }
+         }
+         rc = batotp_hip_precompute(g.b, 2);
+         if (rc) return fail("precompute(dynamics)", rc);
+      }
+      rc = batotp_hip_sweep(g.b, -1);
+      if (rc) return fail("sweep(-1)", rc);
+      rc = batotp_hip_sweep(g.b, +1);
+      if (rc) return fail("sweep(+1)", rc);
+
+      rc = batotp_hip_get_results(g.b, res.data());
+      if (rc) return fail("get_results", rc);
+
+      size_t outOfRoom = 0, firstOut = 0;
+      for (size_t k = 0; k < res.size(); ++k)
+      {
+         const uint32_t st = res[k].status_rev | res[k].status_fwd;
+         if ((st & BATOTP_ST_CAPACITY) && !(st & BATOTP_ST_MAX_INTEG_TIME) && !(res[k].status_rev & BATOTP_ST_NONFINITE) &&
+             (res[k].n_rev == 0 || res[k].n_fwd == 0) && (res[k].steps_rev + 1 >= cap || res[k].steps_fwd + 1 >= cap))
+         {
+            if (outOfRoom == 0) firstOut = k;
+            ++outOfRoom;
+         }
+      }
+      if (outOfRoom == 0 || cap >= maxIntegSteps + 2) break;
+      const int64_t capNext = std::min<int64_t>(maxIntegSteps + 2, 4 * cap);
+      printf("optimizeBatch(): %d path(s) (first: path %d) need more than %lld integration steps (%.1f per knot): running the batch "
+             "again with room for %lld.\n", (int)outOfRoom, (int)live[firstOut], (long long)cap, (double)cap / (double)nKnots[firstOut],
+             (long long)capNext);
+      cap = capNext;
+   }
+   if (rs.r)
+   {
       batotp_hip_resampled_destroy(rs.r);
       rs.r = nullptr;
    }
-   else
-   {
-      std::vector<double> y;
-      for (size_t k = 0; k < live.size(); ++k)
-      {
-         Traj &t = trajs[live[k]];
-         const int64_t N = nKnots[k];
-         y.assign((size_t)nIn * N, 0.0);
-         for (unsigned int j = 0; j < _nJoints; ++j) std::copy(t.theta[j].begin(), t.theta[j].begin() + N, y.begin() + (size_t)j * N);
-         for (unsigned int j = 0; j < _nCart && j < t.cart.size(); ++j)
-            if (t.cart[j].size() >= (size_t)N) std::copy(t.cart[j].begin(), t.cart[j].begin() + N, y.begin() + (size_t)(_nJoints + j) * N);
-         const double sres = t.sres;
-         rc = batotp_hip_upload_knots(g.b, (int32_t)k, 1, y.data(), &sres);
-         if (rc) return fail("upload_knots", rc);
-      }
-   }
-   rc = batotp_hip_precompute(g.b, 1);
-   if (rc) return fail("precompute(kinematics)", rc);
-   if (_isTrqConOn)
-   {
-      if (_robotType == RR)
-      {
-         std::vector<double> samp, trig;
-         for (size_t k = 0; k < live.size(); ++k)
-         {
-            const int64_t N = nKnots[k];
-            samp.resize(6 * (size_t)N);
-            trig.resize(4 * (size_t)N);
-            batotp_hip_download_samples(g.b, (int32_t)k, 0, samp.data());
-            batotp_hip_download_samples(g.b, (int32_t)k, 1, samp.data() + 3 * N);
-            for (int64_t i = 0; i < N; ++i)
-            {
-               const double th1 = _DEG2RAD * samp[i];
-               const double th2 = _DEG2RAD * samp[3 * N + i];
-               trig[i] = std::cos(th1);
-               trig[N + i] = std::cos(th2);
-               trig[2 * N + i] = std::cos(th1 + th2);
-               trig[3 * N + i] = sin(th2);
-            }
-            rc = batotp_hip_upload_rr_trig(g.b, (int32_t)k, trig.data());
-            if (rc) return fail("upload_rr_trig", rc);
-         }
-      }
-      else if (!_isParallelMechOrig)
-      {
-         if (!myRobot.serialModel())
-         {
-            printf("No dynamics model provided for robotType=%s.\n", _robotTypeStr.c_str());
-            return -1;
-         }
-         std::vector<double> samp;
-         std::vector<const double *> rows(_nJoints);
-         for (size_t k = 0; k < live.size(); ++k)
-         {
-            const int64_t N = nKnots[k];
-            samp.resize(3 * (size_t)N * _nJoints);
-            for (unsigned int j = 0; j < _nJoints; ++j)
-            {
-               rc = batotp_hip_download_samples(g.b, (int32_t)k, (int32_t)j, samp.data() + 3 * (size_t)N * j);
-               if (rc) return fail("download_samples", rc);
-               rows[j] = samp.data() + 3 * (size_t)N * j;
-            }
-            if (deviceSerialDynamicsInputs(g.b, (int)k, rows.data(), (long long)N) != 0) return -1;
-         }
-      }
-      rc = batotp_hip_precompute(g.b, 2);
-      if (rc) return fail("precompute(dynamics)", rc);
-   }
-   rc = batotp_hip_sweep(g.b, -1);
-   if (rc) return fail("sweep(-1)", rc);
-   rc = batotp_hip_sweep(g.b, +1);
-   if (rc) return fail("sweep(+1)", rc);
-
-   std::vector<batotp_path_result> res(live.size());
-   rc = batotp_hip_get_results(g.b, res.data());
-   if (rc) return fail("get_results", rc);
 
    // 3) output stage.  On the device when the configuration allows it (batotp_hip_output): only the finished
    //    trajectories come back, in ranges of paths so that their device copy stays small.
@@ -782,12 +819,14 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
          if (rc) return fail("output", rc);
          nPtsOut.assign(cnt, 0);
          sresOut.assign(cnt, 0.0);
-         batotp_hip_output_info(og.o, nPtsOut.data(), sresOut.data());
+         rc = batotp_hip_output_info(og.o, nPtsOut.data(), sresOut.data());
+         if (rc) return fail("output_info", rc);
          float ms = 0;
-         batotp_hip_output_ms(og.o, &ms);
+         batotp_hip_output_ms(og.o, &ms); // timing only
          kernelMs += ms;
          int32_t nTh = 0, nCa = 0, nTq = 0;
-         batotp_hip_output_channels(og.o, &nTh, &nCa, &nTq);
+         rc = batotp_hip_output_channels(og.o, &nTh, &nCa, &nTq);
+         if (rc) return fail("output_channels", rc);
          const size_t rows = (size_t)(nTh + nCa + nTq);
          size_t rangePts = 0;
          for (size_t q = 0; q < cnt; ++q) rangePts += (size_t)nPtsOut[q];
@@ -840,8 +879,10 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
                t.myMVChist.sdot.assign(4, std::vector<double>());
                t.myMVChist.s[0].resize((size_t)r.n_rev); t.myMVChist.sdot[0].resize((size_t)r.n_rev);
                t.myMVChist.s[1].resize((size_t)r.n_fwd); t.myMVChist.sdot[1].resize((size_t)r.n_fwd);
-               batotp_hip_download_curve(g.b, (int32_t)k, -1, t.myMVChist.s[0].data(), t.myMVChist.sdot[0].data(), r.n_rev, &got);
-               batotp_hip_download_curve(g.b, (int32_t)k, +1, t.myMVChist.s[1].data(), t.myMVChist.sdot[1].data(), r.n_fwd, &got);
+               rc = batotp_hip_download_curve(g.b, (int32_t)k, -1, t.myMVChist.s[0].data(), t.myMVChist.sdot[0].data(), r.n_rev, &got);
+               if (rc || got != r.n_rev) return fail("download_curve(rev)", rc);
+               rc = batotp_hip_download_curve(g.b, (int32_t)k, +1, t.myMVChist.s[1].data(), t.myMVChist.sdot[1].data(), r.n_fwd, &got);
+               if (rc || got != r.n_fwd) return fail("download_curve(fwd)", rc);
             }
          }
       }
@@ -881,8 +922,10 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
       flat.resize(4 * (size_t)N); samp.resize(3 * (size_t)N);
       for (int ch = 0; ch < nIn; ++ch)
       {
-         batotp_hip_download_coeffs(g.b, (int32_t)k, ch, flat.data());
-         batotp_hip_download_samples(g.b, (int32_t)k, ch, samp.data());
+         rc = batotp_hip_download_coeffs(g.b, (int32_t)k, ch, flat.data());
+         if (rc) return fail("download_coeffs", rc);
+         rc = batotp_hip_download_samples(g.b, (int32_t)k, ch, samp.data());
+         if (rc) return fail("download_samples", rc);
          const bool isTheta = ch < (int)_nJoints;
          const int j = isTheta ? ch : ch - (int)_nJoints;
          vectorToCoeffs(flat, (size_t)N, isTheta ? t.thetaC[j] : t.cartC[j]);
@@ -903,7 +946,8 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
       t.sMVC.resize((size_t)r.n_fwd);
       t.sdot.resize((size_t)r.n_fwd);
       int64_t got = 0;
-      batotp_hip_download_curve(g.b, (int32_t)k, +1, t.sMVC.data(), t.sdot.data(), r.n_fwd, &got);
+      rc = batotp_hip_download_curve(g.b, (int32_t)k, +1, t.sMVC.data(), t.sdot.data(), r.n_fwd, &got);
+      if (rc || got != r.n_fwd) return fail("download_curve(fwd)", rc);
       t.nPts = (unsigned int)r.n_fwd;
       t.tTotalTraj = r.t_total;
       t.tMVC.resize((size_t)r.n_fwd);
@@ -915,7 +959,8 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
          t.myMVChist.sdot.assign(4, std::vector<double>());
          t.myMVChist.s[0].resize((size_t)r.n_rev);
          t.myMVChist.sdot[0].resize((size_t)r.n_rev);
-         batotp_hip_download_curve(g.b, (int32_t)k, -1, t.myMVChist.s[0].data(), t.myMVChist.sdot[0].data(), r.n_rev, &got);
+         rc = batotp_hip_download_curve(g.b, (int32_t)k, -1, t.myMVChist.s[0].data(), t.myMVChist.sdot[0].data(), r.n_rev, &got);
+         if (rc || got != r.n_rev) return fail("download_curve(rev)", rc);
          t.myMVChist.s[1] = t.sMVC;
          t.myMVChist.sdot[1] = t.sdot;
       }

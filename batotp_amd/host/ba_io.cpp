@@ -130,6 +130,13 @@ int BA::readConfigData(const char *filename)
    _isSVD = readBool(fid, got);
    _isPar2Ser = readBool(fid, got);
    fclose(fid);
+   if (_isSVD && _isParallelMech && _isTrqConOn)
+   {
+      // reference util.cpp:421-438 solves the wrench system with Eigen's JacobiSVD when isSVD = 1; only the LU solve
+      // (isSVD = 0, every shipped configuration) exists here -- refuse rather than answer with a different solver
+      printf("Error in readInputData(): isSVD = 1 (Jacobi-SVD solve of the cable wrench system) is not implemented; use isSVD = 0 (LU).\n");
+      return -1;
+   }
 
    const double wSum = _sWeights[0] + _sWeights[1] + _sWeights[2];
    if (wSum <= 0)
@@ -208,6 +215,13 @@ int BA::loadConfigData(const Config &conf)
    _outSmoothFact = conf.outSmoothFact;
    _isSVD = conf.isSVD;
    _isPar2Ser = conf.isPar2Ser;
+   if (_isSVD && _isParallelMech && _isTrqConOn)
+   {
+      // reference util.cpp:421-438 solves the wrench system with Eigen's JacobiSVD when isSVD = 1; only the LU solve
+      // (isSVD = 0, every shipped configuration) exists here -- refuse rather than answer with a different solver
+      printf("Error in readInputData(): isSVD = 1 (Jacobi-SVD solve of the cable wrench system) is not implemented; use isSVD = 0 (LU).\n");
+      return -1;
+   }
 
    const double wSum = _sWeights[0] + _sWeights[1] + _sWeights[2];
    if (wSum <= 0)

@@ -228,7 +228,13 @@ double findMedian(std::vector<double> &x)
 bool solveLinSys(const std::vector<std::vector<double>> &Av, const std::vector<double> &bv,
                  std::vector<double> &xv, const bool isSVD)
 {
-   (void)isSVD; // TODO(svd): Jacobi-SVD branch; every shipped config.dat has isSVD = 0
+   if (isSVD)
+   {
+      // reference util.cpp:421-438 (Eigen JacobiSVD): not implemented.  BA refuses such a configuration when it is
+      // loaded (ba_io.cpp); a direct caller gets the ill-conditioned answer (x untouched) instead of an LU result
+      printf("solveLinSys(): isSVD = 1 is not implemented (only the LU solve is).\n");
+      return true;
+   }
    const int dim = (int)bv.size();
    std::vector<double> lu((size_t)dim * dim);
    std::vector<double> rhs(bv);

@@ -63,7 +63,7 @@ WORKLOADS = {
                               trq_max=[176, 176, 100, 100, 100, 38, 38], trq_min=[float("nan")] * 7, cart_vel_on=0, cart_vel=0.6,
                               integ_res=0.005, max_integ_time=2000000.0, theta_res=0.3, theta_res2=0.3)),
     # BASELINE configs[4]: cable robot, cable velocity/acceleration/tension limits + Cartesian speed, isPar2Ser=1
-    "cspr": dict(C=18, gen=lambda seed, n: (None, pathgen.cspr_fine(seed, n), 0.005), knots_per_coarse=217.0, cap=0.6,
+    "cspr": dict(C=18, gen=lambda seed, n: (None, pathgen.cspr_fine(seed, n), 0.005), knots_per_coarse=217.0, cap=0.8,
                  cfg=dict(robot="CSPR3DOF", is_parallel=1, n_joints=3, n_cart=3, traj_file="path.dat", is_bin=1, path_type="CART",
                           degrees=0, jnt_vel=[4] * 3, jnt_acc_on=1, jnt_acc=[8] * 3, trq_on=1, trq_max=[12] * 3, trq_min=[1] * 3,
                           cart_vel_on=1, cart_vel=4.0, cart_acc_on=0, cart_acc=100.0, integ_res=0.01, max_integ_time=2000000.0,

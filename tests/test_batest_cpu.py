@@ -45,3 +45,46 @@ def test_batch_driver_files_equal_reference(tmp_path, oracle_lib, name, mode):
     for d in ("out_first", "out_last"):
         assert filecmp.cmp(tmp_path / d / "s-sdot.dat", os.path.join(src, "ref_s-sdot.dat"), shallow=False)
         assert filecmp.cmp(tmp_path / d / "traj_out.dat", os.path.join(src, "ref_traj_out.dat"), shallow=False)
+
+
+def _edit_config(path, subs):
+    import re
+    out = []
+    for line in open(path):
+        for key, val in subs.items():
+            if re.search(r"//\s*" + re.escape(key) + r"\b", line):
+                line = f"{val} // {key} (edited)\n"
+        out.append(line)
+    open(path, "w").write("".join(out))
+
+
+def test_batch_driver_grows_the_curve_capacity_like_the_single_path_api(tmp_path, oracle_lib):
+    """a path that needs more integration steps than the batch's first guess (8 per knot + 4096): BA::optimizeBatch runs the
+    batch again with more room instead of failing the path -- same files as BA::optimize on the same input"""
+    src = os.path.join(helpers.GOLD, "GEN7DOF")
+    one, many = tmp_path / "one", tmp_path / "many"
+    for d in (one, many):
+        d.mkdir()
+        _stage(src, d)
+        _edit_config(d / "config.dat", {"integRes": "0.0004", "outRes": "0.004"})
+    r1 = subprocess.run([os.path.join(helpers.BUILD, "batest_oracle"), "config.dat"], cwd=one, capture_output=True, text=True)
+    assert r1.returncode == 0, r1.stdout[-2000:]
+    import re
+    steps = int(re.search(r"fwd\. integ\.:\s*(\d+) steps", r1.stdout).group(1))
+    assert steps > 8 * 231 + 4096, steps          # beyond the first guess
+    r = subprocess.run([os.path.join(helpers.BUILD, "batest_batch_oracle"), "config.dat", "2"], cwd=many, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "running the batch again" in r.stdout
+    for d in ("out_first", "out_last"):
+        assert filecmp.cmp(many / d / "s-sdot.dat", one / "s-sdot.dat", shallow=False)
+        assert filecmp.cmp(many / d / "traj_out.dat", one / "traj_out.dat", shallow=False)
+
+
+def test_svd_solver_is_refused_not_silently_replaced(tmp_path, oracle_lib):
+    """isSVD = 1 on the cable robot asks for the Jacobi-SVD solve (reference util.cpp:421-438), which does not exist here:
+    the configuration is refused with a message instead of being answered by the LU solve"""
+    src = os.path.join(helpers.GOLD, "CSPR3DOF")
+    _stage(src, tmp_path)
+    _edit_config(tmp_path / "config.dat", {"isSVD": "1"})
+    r = subprocess.run([os.path.join(helpers.BUILD, "batest_oracle"), "config.dat"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode != 0 and "isSVD = 1" in r.stdout and not os.path.exists(tmp_path / "traj_out.dat")
