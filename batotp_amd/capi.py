@@ -200,6 +200,7 @@ class Library:
             "batotp_hip_download_dyn": [P, I32, I32, I32, D],
             "batotp_hip_download_mvc": [P, I32, D, D, D],
             "batotp_hip_results_device_ptr": [P, C.POINTER(P), C.POINTER(C.c_int64)],
+            "batotp_hip_pack_curves": [P, I32, I32, I32, P, I64, C.POINTER(C.c_int64)],
             "batotp_hip_last_kernel_ms": [P, I32, C.POINTER(C.c_float)],
             "batotp_hip_batch_bytes": [P, C.POINTER(C.c_int64)],
             "batotp_hip_set_sweep_group": [P, I32],
@@ -507,6 +508,14 @@ class Batch:
         a, b, c = np.empty(n), np.empty(n), np.empty(n)
         self.L.check(self.lib.batotp_hip_download_mvc(self.handle, path, _dptr(a), _dptr(b), _dptr(c)), "download_mvc")
         return a, b, c
+
+    def pack_curves(self, which: int, path0: int, n_paths: int, dst_ptr: int, dst_points: int) -> int:
+        """curves of paths [path0, path0 + n_paths) packed as (s, sdot) pairs into memory of the library's device at dst_ptr;
+        returns the number of pairs (call with dst_ptr = 0, dst_points = 0 to size the buffer when no curve is empty ...
+        sizes also follow from results()['n_fwd' / 'n_rev'])"""
+        total = C.c_int64(0)
+        self.L.check(self.lib.batotp_hip_pack_curves(self.handle, which, path0, n_paths, C.c_void_p(dst_ptr), dst_points, C.byref(total)), "pack_curves")
+        return int(total.value)
 
     def results_device_ptr(self):
         ptr, nbytes = C.c_void_p(), C.c_int64(0)

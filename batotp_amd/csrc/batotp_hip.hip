@@ -53,6 +53,7 @@ struct Arena
 struct batotp_ctx
 {
    Arena ws[3]; // resampler: stage-0 arrays, per-chunk scratch, resampled knots
+   Arena xfer;  // staging of curve uploads / downloads (packed double2 <-> separate s / sdot arrays)
    uint64_t rsEpoch = 0; // resample calls so far (a batotp_resampled is valid while its epoch is the current one)
    int device = 0;
    hipStream_t stream = nullptr;
@@ -216,6 +217,7 @@ extern "C" int batotp_hip_ctx_destroy(batotp_ctx *ctx)
    if (ctx->evJoin) hipEventDestroy(ctx->evJoin);
    for (Arena &a : ctx->ws)
       if (a.p) hipFree(a.p);
+   if (ctx->xfer.p) hipFree(ctx->xfer.p);
    delete ctx;
    return BATOTP_OK;
 }
@@ -231,6 +233,7 @@ extern "C" int batotp_hip_ctx_trim(batotp_ctx *ctx)
       if (a.p) hipFree(a.p);
       a.p = nullptr; a.cap = 0;
    }
+   if (ctx->xfer.p) { hipFree(ctx->xfer.p); ctx->xfer.p = nullptr; ctx->xfer.cap = 0; }
    ++ctx->rsEpoch;
    return BATOTP_OK;
 }
@@ -309,6 +312,21 @@ extern "C" int batotp_hip_div6_kat(batotp_ctx *ctx, int64_t n, const double *a, 
    hipError_t e = hipStreamSynchronize(ctx->stream);
    hipFree(d);
    if (e != hipSuccess) return hipFail(e, "div6_kat");
+   return BATOTP_OK;
+}
+
+// grow-only staging buffer of the context (the caller has bound the device)
+static int xferReserve(batotp_ctx *ctx, size_t bytes, double **out)
+{
+   if (ctx->xfer.cap < bytes)
+   {
+      if (ctx->xfer.p) { hipFree(ctx->xfer.p); ctx->xfer.p = nullptr; ctx->xfer.cap = 0; }
+      const size_t want = std::max(bytes, (size_t)1 << 20);
+      hipError_t e = hipMalloc(&ctx->xfer.p, want);
+      if (e != hipSuccess) { hipFail(e, "hipMalloc(staging)"); (void)hipGetLastError(); return BATOTP_ERR_ALLOC; }
+      ctx->xfer.cap = want;
+   }
+   *out = static_cast<double *>(ctx->xfer.p);
    return BATOTP_OK;
 }
 
@@ -639,7 +657,8 @@ extern "C" int batotp_hip_upload_curve(batotp_batch *b, int32_t path, const doub
    int rc = bind(b->ctx);
    if (rc) return rc;
    double *tmp = nullptr;
-   HIP_TRY(hipMalloc((void **)&tmp, sizeof(double) * 2 * (size_t)n));
+   rc = xferReserve(b->ctx, sizeof(double) * 2 * (size_t)n, &tmp);
+   if (rc) return rc;
    hipMemcpyAsync(tmp, s, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, b->ctx->stream);
    hipMemcpyAsync(tmp + n, sdot, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, b->ctx->stream);
    const int bs = 256;
@@ -654,7 +673,6 @@ extern "C" int batotp_hip_upload_curve(batotp_batch *b, int32_t path, const doub
       r.n_rev = n;
       e = hipMemcpy(b->dRes + path, &r, sizeof(r), hipMemcpyHostToDevice);
    }
-   hipFree(tmp);
    if (e != hipSuccess) return hipFail(e, "upload_curve");
    b->revDone = true;
    return BATOTP_OK;
@@ -960,13 +978,13 @@ extern "C" int batotp_hip_download_curve(batotp_batch *b, int32_t path, int32_t 
    if (m <= 0 || (!s && !sdot)) return BATOTP_OK;
    const double2 *src = which == 1 ? b->dFwd + (int64_t)path * b->cap : b->dRev + (int64_t)path * b->cap + (b->cap - avail);
    double *tmp = nullptr;
-   HIP_TRY(hipMalloc((void **)&tmp, sizeof(double) * 2 * (size_t)m));
+   rc = xferReserve(b->ctx, sizeof(double) * 2 * (size_t)m, &tmp);
+   if (rc) return rc;
    const int bs = 256;
    hipLaunchKernelGGL(k_curve_unpack, dim3((unsigned)((m + bs - 1) / bs)), dim3(bs), 0, b->ctx->stream, src, tmp, tmp + m, m);
    if (s) hipMemcpyAsync(s, tmp, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, b->ctx->stream);
    if (sdot) hipMemcpyAsync(sdot, tmp + m, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, b->ctx->stream);
    hipError_t e = hipStreamSynchronize(b->ctx->stream);
-   hipFree(tmp);
    if (e != hipSuccess) return hipFail(e, "download_curve");
    return BATOTP_OK;
 }
@@ -1037,6 +1055,43 @@ extern "C" int batotp_hip_results_device_ptr(batotp_batch *b, void **ptr, int64_
    if (!b) return BATOTP_ERR_ARG;
    if (ptr) *ptr = b->dRes;
    if (bytes) *bytes = (int64_t)sizeof(batotp_path_result) * b->B;
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_pack_curves(batotp_batch *b, int32_t which, int32_t path0, int32_t n_paths, void *dst_dev, int64_t dst_points,
+                                      int64_t *total_points)
+{
+   if (!b || (which != 1 && which != -1) || path0 < 0 || n_paths < 0 || path0 + n_paths > b->B || !total_points) return BATOTP_ERR_ARG;
+   *total_points = 0;
+   if (n_paths == 0) return BATOTP_OK;
+   int rc = bind(b->ctx);
+   if (rc) return rc;
+   std::vector<batotp_path_result> res((size_t)n_paths);
+   HIP_TRY(hipMemcpy(res.data(), b->dRes + path0, sizeof(batotp_path_result) * (size_t)n_paths, hipMemcpyDeviceToHost));
+   std::vector<int64_t> meta(2 * (size_t)n_paths + 1);   // off[n + 1], start[n]
+   int64_t total = 0;
+   for (int k = 0; k < n_paths; ++k)
+   {
+      const int64_t cnt = which == 1 ? res[k].n_fwd : res[k].n_rev;
+      meta[k] = total;
+      meta[(size_t)n_paths + 1 + k] = which == 1 ? 0 : b->cap - cnt;   // the reverse curve is stored at the end of its slot
+      total += cnt;
+   }
+   meta[n_paths] = total;
+   *total_points = total;
+   if (total == 0) return BATOTP_OK;
+   if (!dst_dev || dst_points < total) return BATOTP_ERR_ARG;
+   double *stage = nullptr;
+   rc = xferReserve(b->ctx, sizeof(int64_t) * meta.size(), &stage);
+   if (rc) return rc;
+   hipStream_t st = b->ctx->stream;
+   HIP_TRY(hipMemcpyAsync(stage, meta.data(), sizeof(int64_t) * meta.size(), hipMemcpyHostToDevice, st));
+   const int64_t *dOff = reinterpret_cast<const int64_t *>(stage), *dStart = dOff + n_paths + 1;
+   const int bs = 256;
+   hipLaunchKernelGGL(k_curves_pack, dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, st, which == 1 ? b->dFwd : b->dRev, b->cap, path0, n_paths,
+                      dOff, dStart, static_cast<double2 *>(dst_dev), total);
+   HIP_TRY(hipGetLastError());
+   HIP_TRY(hipStreamSynchronize(st));
    return BATOTP_OK;
 }
 

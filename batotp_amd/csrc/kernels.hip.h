@@ -2103,6 +2103,22 @@ __global__ void k_curve_unpack(const double2 *__restrict__ src, double *__restri
    if (i < n) { const double2 q = src[i]; s[i] = q.x; sd[i] = q.y; }
 }
 
+// curves of a range of paths packed path after path: off[k] = first output point of path k (off[n] = total),
+// start[k] = first point of path k's curve inside its slot of `cap` points
+__global__ void k_curves_pack(const double2 *__restrict__ src, int64_t cap, int path0, int n, const int64_t *__restrict__ off,
+                              const int64_t *__restrict__ start, double2 *__restrict__ dst, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   int lo = 0, hi = n - 1;
+   while (lo < hi)
+   {
+      const int mid = (lo + hi + 1) >> 1;
+      if (off[mid] <= g) lo = mid; else hi = mid - 1;
+   }
+   dst[g] = src[(int64_t)(path0 + lo) * cap + start[lo] + (g - off[lo])];
+}
+
 // fp64 known-answer test: q = a/b, r = sqrt(a), p = a*b + q (must NOT be contracted)
 __global__ void k_kat(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ q,
                       double *__restrict__ r, double *__restrict__ p)

@@ -162,6 +162,12 @@ public:
    int optimizeBatch(std::vector<Traj> &trajs);
    // Extension: select the HIP device used by this object (default 0).
    void setDevice(int device) { _deviceId = device; }
+   // Extension: optimizeBatch() over several GPUs.  The paths are independent, so the batch is cut into contiguous blocks
+   // (first devices take the remainder, as batotp_amd/dist.py shard_range), every block runs on its own device from its own
+   // host thread with its own context, and nothing is exchanged between devices.  An empty list (default)
+   // keeps the single device of setDevice(); useAllDevices() lists every visible device and returns their number.
+   void setDevices(const std::vector<int> &devices) { _devices = devices; }
+   int useAllDevices();
    // Extension: optimizeBatch() resamples the taught paths on the device when the configuration is
    // one batotp_hip_resample covers (exportResampleParams); false keeps the host resampler.
    void setDeviceResample(bool on) { _deviceResample = on; }
@@ -339,6 +345,8 @@ private:
    bool _deviceOutput = true;
    double _lastOutputMs = 0, _lastOutputKernelMs = 0;
    int _deviceId = 0;
+   std::vector<int> _devices;              // optimizeBatch over several GPUs (empty: _deviceId only)
+   int optimizeBatchOnDevice(std::vector<Traj> &trajs);
    int gpuAcquire();                       // create the context on first use; -1 + message on failure
    void fillProblem(void *prob) const;     // BA configuration -> batotp_problem
    int deviceBuildKnotModel(Traj &traj);   // ba.cpp:299-305 on the GPU (B = 1)

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 #include "ba.h"
 #include "batotp_hip.h"
@@ -543,7 +544,64 @@ int BA::deviceSweep(Traj &traj)
 // ---------------------------------------------------------------------------------------------
 // extension: many independent paths, one device batch
 // ---------------------------------------------------------------------------------------------
+int BA::useAllDevices()
+{
+   int n = 0;
+   if (batotp_hip_device_count(&n) != BATOTP_OK || n < 1) return 0;
+   _devices.resize((size_t)n);
+   std::iota(_devices.begin(), _devices.end(), 0);
+   return n;
+}
+
+// Many paths over several GPUs: contiguous blocks of paths, one host thread + one BA copy + one device context per GPU,
+// no exchange between devices (the paths are independent); the blocks come back in place.
 int BA::optimizeBatch(std::vector<Traj> &trajs)
+{
+   const size_t nDev = std::min(_devices.size(), trajs.size());
+   if (nDev <= 1)
+   {
+      if (_devices.size() == 1) _deviceId = _devices[0];
+      return optimizeBatchOnDevice(trajs);
+   }
+   const size_t base = trajs.size() / nDev, rem = trajs.size() % nDev;
+   std::vector<std::vector<Traj>> part(nDev);
+   std::vector<size_t> lo(nDev + 1, 0);
+   for (size_t d = 0; d < nDev; ++d) lo[d + 1] = lo[d] + base + (d < rem ? 1 : 0);
+   std::vector<BA> worker(nDev, *this);
+   std::vector<int> rcs(nDev, -1);
+   std::vector<std::thread> threads;
+   for (size_t d = 0; d < nDev; ++d)
+   {
+      part[d].assign(std::make_move_iterator(trajs.begin() + lo[d]), std::make_move_iterator(trajs.begin() + lo[d + 1]));
+      worker[d]._gpu.reset();            // every worker owns its context
+      worker[d]._devices.clear();
+      worker[d]._deviceId = _devices[d];
+      threads.emplace_back([&, d]() { rcs[d] = worker[d].optimizeBatchOnDevice(part[d]); });
+   }
+   for (std::thread &t : threads) t.join();
+   int failed = 0;
+   bool broken = false;
+   setErrorOptimization(NO_ERROR);
+   _lastResampleMs = _lastOutputMs = _lastOutputKernelMs = 0;
+   for (size_t d = 0; d < nDev; ++d)
+   {
+      std::move(part[d].begin(), part[d].end(), trajs.begin() + lo[d]);
+      if (rcs[d] < 0) broken = true; else failed += rcs[d];
+      if (worker[d].getErrorOptimization() == MAX_INTEGRATION_TIME) setErrorOptimization(MAX_INTEGRATION_TIME);
+      _lastResampleMs = std::max(_lastResampleMs, worker[d]._lastResampleMs);
+      _lastOutputMs = std::max(_lastOutputMs, worker[d]._lastOutputMs);
+      _lastOutputKernelMs = std::max(_lastOutputKernelMs, worker[d]._lastOutputKernelMs);
+   }
+   // what a single-device run leaves in the object (run state a later writeOutputData / interpOutputData reads)
+   _isInterpolated = worker[0]._isInterpolated;
+   _isParallelMech = worker[0]._isParallelMech;
+   _nCart = worker[0]._nCart;
+   _outRes = worker[0]._outRes;
+   _outSmoothFact = worker[0]._outSmoothFact;
+   return broken ? -1 : failed;
+}
+
+int BA::optimizeBatchOnDevice(std::vector<Traj> &trajs)
 {
    setErrorOptimization(NO_ERROR);
    if (_isAutoIntegRes)

@@ -1,6 +1,6 @@
 // batest_batch_main.cpp -- command-line driver of the many-path extension BA::optimizeBatch().
 //
-//   batest_batch config.dat nPaths [--host-resample] [--host-output]
+//   batest_batch config.dat nPaths [--host-resample] [--host-output] [--devices N | --all-devices]
 //
 // Loads the trajectory named by the configuration nPaths times, optimises all copies as one device
 // batch and writes, for the first and the last path, the same files the single-path driver writes
@@ -20,16 +20,19 @@ int main(int argc, char *argv[])
 {
    if (argc < 3)
    {
-      fprintf(stderr, "usage: batest_batch config.dat nPaths [--host-resample] [--host-output]\n");
+      fprintf(stderr, "usage: batest_batch config.dat nPaths [--host-resample] [--host-output] [--devices N | --all-devices]\n");
       return 2;
    }
    const int nPaths = atoi(argv[2]);
    if (nPaths < 1) return 2;
-   bool hostResample = false, hostOutput = false;
+   bool hostResample = false, hostOutput = false, allDevices = false;
+   int nDevices = 0;
    for (int k = 3; k < argc; ++k)
    {
       if (std::string(argv[k]) == "--host-resample") hostResample = true;
       if (std::string(argv[k]) == "--host-output") hostOutput = true;
+      if (std::string(argv[k]) == "--all-devices") allDevices = true;
+      if (std::string(argv[k]) == "--devices" && k + 1 < argc) nDevices = atoi(argv[++k]);
    }
 
    BA planner;
@@ -40,6 +43,13 @@ int main(int argc, char *argv[])
    planner.setDeviceResample(!hostResample);
    planner.setDeviceOutput(!hostOutput);
    if (planner.readConfigData((std::string("./") + argv[1]).c_str()) == -1) return 1;
+   if (allDevices) nDevices = planner.useAllDevices();
+   else if (nDevices > 0)
+   {
+      std::vector<int> devices((size_t)nDevices);
+      for (int d = 0; d < nDevices; ++d) devices[d] = d;
+      planner.setDevices(devices);
+   }
 
    std::vector<Traj> paths(nPaths);
    if (planner.loadTrajectoryData(paths[0]) == -1) return 1;
@@ -48,6 +58,7 @@ int main(int argc, char *argv[])
    const Time t0 = getTime();
    const int failed = planner.optimizeBatch(paths);
    const Time t1 = getTime();
+   if (nDevices > 1) printf("\noptimizeBatch: paths sharded over %d devices\n", nDevices);
    printf("\noptimizeBatch: %d paths, %d failed, %.3f s (resampling %s: %.3f ms; output stage %s: %.3f ms, kernels %.3f ms)\n", nPaths, failed,
           diffTime(t1, t0), hostResample ? "host" : "device", planner.getLastResampleMs(), hostOutput ? "host" : "device (where covered)",
           planner.getLastOutputMs(), planner.getLastOutputKernelMs());

@@ -384,6 +384,22 @@ def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=
     for k in kernel_ms:
         kernel_ms[k] /= max(steps, 1)
 
+    # the variable-length part of the gather: the forward curves of every path to rank 0, device to device
+    # (size exchange + grouped send/recv); untimed side measurement of the sharded configurations
+    curve_gather = None
+    if dist_ctx is not None and c["scaling"] == "strong" and batch is not None:
+        barrier()
+        tg = time.perf_counter()
+        got = bdist.gather_curves(batch, +1, dev, on_device=True)
+        barrier()
+        tg = time.perf_counter() - tg
+        if rank == 0:
+            pts = int(sum(int(t.shape[0]) for t in got[0]))
+            curve_gather = {"ms": 1e3 * tg, "points": pts, "GB": 16e-9 * pts, "GBps": 16e-9 * pts / tg,
+                            "what": "forward curves (s, sdot) of all paths of all ranks to rank 0: all_gather of the point counts + one "
+                                    "grouped send/recv of packed double2 buffers"}
+        got = None
+
     res = state["rows"] if state["rows"] is not None else np.zeros(0, dtype=capi.RESULT_DTYPE)
     steps_rev, steps_fwd = int(res["steps_rev"].sum()), int(res["steps_fwd"].sum())
     sr, sf = res["steps_rev"].astype(np.float64), res["steps_fwd"].astype(np.float64)
@@ -444,6 +460,8 @@ def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=
     }
     if inp.on_device:
         out["inputs_identical_to_host_resampler"] = inp.host_check
+    if curve_gather is not None:
+        out["curve_gather"] = curve_gather
     kept = None
     if keep:
         kept = dict(batch=batch, inp=inp, prob=prob, cap=cap, res=res, K=K, B=B, chunk0=chunk_sizes[0] if B else 0)
@@ -687,8 +705,8 @@ def main():
         for name in ("cfg2", "cfg3", "cfg4", "cfg5"):
             try:
                 w, _ = measure(hip, name, rank, world, 1, 1, dist_ctx)
-                worded[name] = {k: w[k] for k in ("value", "unit", "ms_per_step", "scaling", "data", "config", "kernel_ms", "steps_per_knot",
-                                                   "us_per_integration_step", "gathered_rows")}
+                worded[name] = {k: w.get(k) for k in ("value", "unit", "ms_per_step", "scaling", "data", "config", "kernel_ms", "steps_per_knot",
+                                                       "us_per_integration_step", "gathered_rows", "curve_gather")}
                 worded[name]["roofline_frac"] = w["roofline"]["frac"]
             except Exception as e:  # the main line must not depend on a side measurement
                 if world > 1:

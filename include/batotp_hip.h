@@ -221,11 +221,22 @@ int  batotp_hip_download_coeffs(batotp_batch *batch, int32_t path, int32_t chann
 int  batotp_hip_download_samples(batotp_batch *batch, int32_t path, int32_t channel, double *out);
 /* dynamics coefficients a_k (k=1..4) row r at the knots: out[N] */
 int  batotp_hip_download_dyn(batotp_batch *batch, int32_t path, int32_t k, int32_t row, double *out);
-/* K3 outputs of one path: sdot_max[N], sddot_l[N], sddot_h[N] (any pointer may be NULL) */
+/* K3 outputs of one path: sdot_max[N], sddot_l[N], sddot_h[N] (any pointer may be NULL).
+ * Deviation from the reference, stated here on purpose: at a knot where the bisection finds no admissible sdot
+ * (ba.cpp:1307-1319 returns -1) sddot_l / sddot_h are published as NaN.  The reference has no per-knot output at all (K3
+ * is this implementation's own product); what its early loop exits last wrote into traj.sddotL/H at such a
+ * point is an artefact of the loop order and differed between correct implementations, so the K3 definition replaces it
+ * by NaN (the sweep itself keeps the reference's stale-value behaviour: that IS observable in its curves). */
 int  batotp_hip_download_mvc(batotp_batch *batch, int32_t path, double *sdot_max,
                              double *sddot_l, double *sddot_h);
 
 /* ---- plumbing for the Python / torch.distributed layer ---------------------------------- */
+/* The integrated curves of paths [path0, path0 + n_paths) -- which = -1 reverse, +1 forward -- packed path after path
+ * into dst_dev (DEVICE memory with room for dst_points (s, sdot) pairs of doubles); *total_points = pairs written.  This
+ * is the send buffer of the multi-GPU curve gather (traj.sMVC / traj.sdot after sweep, reference ba.cpp:1154-1190): the
+ * curves have different lengths, so a size exchange + grouped send/recv moves them (batotp_amd/dist.py). */
+int  batotp_hip_pack_curves(batotp_batch *batch, int32_t which, int32_t path0, int32_t n_paths, void *dst_dev,
+                            int64_t dst_points, int64_t *total_points);
 /* device pointer + element count of the per-path result table (batotp_path_result[n_paths]) */
 int  batotp_hip_results_device_ptr(batotp_batch *batch, void **ptr, int64_t *bytes);
 /* Duration of the most recent launch of a kernel family, measured with HIP events on the

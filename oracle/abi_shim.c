@@ -354,6 +354,24 @@ int batotp_hip_results_device_ptr(batotp_batch *b, void **ptr, int64_t *bytes)
     if (bytes) *bytes = (int64_t)sizeof(batotp_path_result) * b->n_paths;
     return BATOTP_OK;
 }
+int batotp_hip_pack_curves(batotp_batch *b, int32_t which, int32_t path0, int32_t n_paths, void *dst, int64_t dst_points, int64_t *total_points)
+{
+    int32_t k;
+    int64_t total = 0, i;
+    double *o = (double *)dst;
+    if (!b || (which != 1 && which != -1) || path0 < 0 || n_paths < 0 || path0 + n_paths > b->n_paths || !total_points) return BATOTP_ERR_ARG;
+    for (k = 0; k < n_paths; k++) total += which == 1 ? b->res[path0 + k].n_fwd : b->res[path0 + k].n_rev;
+    *total_points = total;
+    if (total == 0) return BATOTP_OK;
+    if (!dst || dst_points < total) return BATOTP_ERR_ARG;
+    for (k = 0; k < n_paths; k++) {
+        const int64_t cnt = which == 1 ? b->res[path0 + k].n_fwd : b->res[path0 + k].n_rev;
+        const double *s = which == 1 ? b->fwd_s[path0 + k] : b->rev_s[path0 + k];
+        const double *sd = which == 1 ? b->fwd_sd[path0 + k] : b->rev_sd[path0 + k];
+        for (i = 0; i < cnt; i++) { *o++ = s[i]; *o++ = sd[i]; }
+    }
+    return BATOTP_OK;
+}
 int batotp_hip_last_kernel_ms(batotp_batch *b, int32_t which, float *ms)
 {
     if (!b || which < 1 || which > 4 || !ms) return BATOTP_ERR_ARG;

@@ -88,3 +88,19 @@ def test_svd_solver_is_refused_not_silently_replaced(tmp_path, oracle_lib):
     _edit_config(tmp_path / "config.dat", {"isSVD": "1"})
     r = subprocess.run([os.path.join(helpers.BUILD, "batest_oracle"), "config.dat"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode != 0 and "isSVD = 1" in r.stdout and not os.path.exists(tmp_path / "traj_out.dat")
+
+
+@pytest.mark.parametrize("name,mode", [("synth_gen7dof_s1_vel", None), ("synth_cspr_s3", None), ("RR", "host-output")])
+def test_batch_driver_over_several_devices(tmp_path, oracle_lib, name, mode):
+    """BA::optimizeBatch with setDevices({0, 1, 2}): contiguous blocks of paths, one host thread and one device context per
+    block, nothing exchanged -- every path comes back in place with the single-path files (device calls served by the
+    checker library, whose contexts accept any device index)"""
+    src = os.path.join(helpers.GOLD, name)
+    _stage(src, tmp_path)
+    cmd = [os.path.join(helpers.BUILD, "batest_batch_oracle"), "config.dat", "7", "--devices", "3"] + (["--" + mode] if mode else [])
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "sharded over 3 devices" in r.stdout and "7 paths, 0 failed" in r.stdout
+    for d in ("out_first", "out_last"):
+        assert filecmp.cmp(tmp_path / d / "s-sdot.dat", os.path.join(src, "ref_s-sdot.dat"), shallow=False)
+        assert filecmp.cmp(tmp_path / d / "traj_out.dat", os.path.join(src, "ref_traj_out.dat"), shallow=False)

@@ -36,8 +36,16 @@ def _worker(rank, world, port, names, q):
         outs = helpers.run_pipeline(ctx, cases, mvc=False, details=False) if cases else []
         local = np.array([o["result"] for o in outs], dtype=capi.RESULT_DTYPE) if outs else np.zeros(0, dtype=capi.RESULT_DTYPE)
         allres = bdist.gather_results(local)
+        # the variable-length part: both curves of every path, to rank 0
+        b = capi.Batch(ctx, cases[0].problem if cases else helpers.Case(names[0]).problem, [c.n for c in cases] or [4],
+                       max([c.max_steps() for c in cases] or [8]))
+        for k, c in enumerate(cases):
+            b.upload_knots(k, [c.y], [c.sres])
+        if cases:
+            b.optimize()
+        curves = {w: bdist.gather_curves(b, w) for w in (-1, 1)}
         if rank == 0:
-            q.put(allres.tobytes())
+            q.put((allres.tobytes(), {w: [(s.tobytes(), sd.tobytes()) for s, sd in curves[w]] for w in curves}))
     finally:
         dist.destroy_process_group()
 
@@ -63,7 +71,7 @@ def test_two_ranks_gather_matches_single_rank(oracle_ctx):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, names, q)) for r in range(2)]
     for p in procs:
         p.start()
-    raw = q.get(timeout=300)
+    raw, curves = q.get(timeout=300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -76,6 +84,11 @@ def test_two_ranks_gather_matches_single_rank(oracle_ctx):
     for k, o in enumerate(single):
         for f in capi.RESULT_DTYPE.names:
             assert gathered[k][f] == o["result"][f], (k, f)
+    # curves gathered across the two ranks == the single-rank curves, bit for bit, in path order
+    for w, key in ((-1, "rev"), (1, "fwd")):
+        assert len(curves[w]) == len(names)
+        for k, o in enumerate(single):
+            assert curves[w][k][0] == o[key][0].tobytes() and curves[w][k][1] == o[key][1].tobytes(), (w, k)
 
 
 def _bench_line(args, env_extra=None):

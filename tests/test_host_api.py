@@ -20,7 +20,7 @@ def test_reference_driver_compiles_unchanged_and_runs(tmp_path, oracle_lib):
                                             "spline.cpp", "robot.cpp", "util.cpp")]
     exe = tmp_path / "batest_refmain"
     cmd = ["g++", "-std=c++11", "-O2", "-ffp-contract=off", "-DNDEBUG", f"-I{HOST}", f"-I{helpers.ROOT}/include",
-           REF_MAIN, *srcs, f"-L{helpers.BUILD}", "-lbatotp_oracle_abi", f"-Wl,-rpath,{helpers.BUILD}", "-fopenmp", "-lm", "-o", str(exe)]
+           REF_MAIN, *srcs, f"-L{helpers.BUILD}", "-lbatotp_oracle_abi", f"-Wl,-rpath,{helpers.BUILD}", "-fopenmp", "-pthread", "-lm", "-o", str(exe)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     for name in ("RR", "GEN7DOF"):
