@@ -250,7 +250,7 @@ extern "C" int batotp_hip_synchronize(batotp_ctx *ctx)
 
 extern "C" int batotp_hip_set_sweep_group(batotp_ctx *ctx, int32_t lanes)
 {
-   if (!ctx || !(lanes == 0 || lanes == 1 || lanes == 8 || lanes == 16 || lanes == 32)) return BATOTP_ERR_ARG;
+   if (!ctx || !(lanes == 0 || lanes == 1 || lanes == 2 || lanes == 4 || lanes == 8 || lanes == 16 || lanes == 32)) return BATOTP_ERR_ARG;
    ctx->sweepGroup = lanes;
    return BATOTP_OK;
 }
@@ -887,10 +887,10 @@ static void launchSweep(batotp_batch *b, SweepArgs &a)
    // sites and nowhere else: the instantiation with the serial torque branch gave hold-dependent results on stalled paths
    // with this toolchain (ROCm 7.2.0 hipcc, clang 22; DESIGN.md 4, tools/experiments/), so problems with torque or
    // Cartesian limits always run the nested loops, and so do paths with uploaded (non-uniform) sites.
-   const bool flat = (G == 8) && hold >= 0 && featureLevel(b) <= 0 && uni;
+   const bool flat = (G == 8 || G == 4 || G == 2) && hold >= 0 && featureLevel(b) <= 0 && uni;
 #define LAUNCH_K4(F)                                                                           \
    do {                                                                                        \
-      if (flat) hipLaunchKernelGGL((k_sweep<G, F, true, (G == 8 && F <= 0)>), dim3(grid), dim3(K4_BLOCK), 0, st, a);  \
+      if (flat) hipLaunchKernelGGL((k_sweep<G, F, true, ((G == 8 || G == 4 || G == 2) && F <= 0)>), dim3(grid), dim3(K4_BLOCK), 0, st, a);  \
       else if (uni) hipLaunchKernelGGL((k_sweep<G, F, true>), dim3(grid), dim3(K4_BLOCK), 0, st, a);      \
       else hipLaunchKernelGGL((k_sweep<G, F, false>), dim3(grid), dim3(K4_BLOCK), 0, st, a);        \
    } while (0)
@@ -933,6 +933,8 @@ extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
    case 32: launchSweep<32>(b, a); break;
    case 1: launchSweep<1>(b, a); break;
    case 16: launchSweep<16>(b, a); break;
+   case 4: launchSweep<4>(b, a); break;
+   case 2: launchSweep<2>(b, a); break;
    default: launchSweep<8>(b, a); break;
    }
    evStop(b, which);

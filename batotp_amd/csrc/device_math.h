@@ -58,15 +58,15 @@ __device__ __forceinline__ double vmax_f64(double a, double b)
    return r;
 }
 
-// All-reduce over the G lanes of a path group (G = 1, 8 or 16; groups are aligned to G lanes, so
+// All-reduce over the G lanes of a path group (G = 1, 2, 4, 8 or 16; groups are aligned to G lanes, so
 // every DPP source lane belongs to the same group and shares its control flow).
 template <int G>
 __device__ __forceinline__ double grp_min(double v)
 {
    if (G == 1) return v;
    v = vmin_f64(v, dpp_mov<DPP_QUAD_XOR1>(v));
-   v = vmin_f64(v, dpp_mov<DPP_QUAD_XOR2>(v));
-   v = vmin_f64(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+   if (G >= 4) v = vmin_f64(v, dpp_mov<DPP_QUAD_XOR2>(v));
+   if (G >= 8) v = vmin_f64(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
    if (G == 16) v = vmin_f64(v, dpp_mov<DPP_ROW_MIRROR>(v));
    return v;
 }
@@ -75,8 +75,8 @@ __device__ __forceinline__ double grp_max(double v)
 {
    if (G == 1) return v;
    v = vmax_f64(v, dpp_mov<DPP_QUAD_XOR1>(v));
-   v = vmax_f64(v, dpp_mov<DPP_QUAD_XOR2>(v));
-   v = vmax_f64(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+   if (G >= 4) v = vmax_f64(v, dpp_mov<DPP_QUAD_XOR2>(v));
+   if (G >= 8) v = vmax_f64(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
    if (G == 16) v = vmax_f64(v, dpp_mov<DPP_ROW_MIRROR>(v));
    return v;
 }
@@ -104,14 +104,20 @@ __device__ __forceinline__ void grp_min_max(double &h, double &l)
    double ld = dpp_mov<DPP_QUAD_XOR1>(l);
    h = vmin_f64_raw(h, hd);
    l = vmax_f64_raw(l, ld);
-   hd = dpp_mov<DPP_QUAD_XOR2>(h);
-   ld = dpp_mov<DPP_QUAD_XOR2>(l);
-   h = vmin_f64_raw(h, hd);
-   l = vmax_f64_raw(l, ld);
-   hd = dpp_mov<DPP_ROW_HALF_MIRROR>(h);
-   ld = dpp_mov<DPP_ROW_HALF_MIRROR>(l);
-   h = vmin_f64_raw(h, hd);
-   l = vmax_f64_raw(l, ld);
+   if (G >= 4)
+   {
+      hd = dpp_mov<DPP_QUAD_XOR2>(h);
+      ld = dpp_mov<DPP_QUAD_XOR2>(l);
+      h = vmin_f64_raw(h, hd);
+      l = vmax_f64_raw(l, ld);
+   }
+   if (G >= 8)
+   {
+      hd = dpp_mov<DPP_ROW_HALF_MIRROR>(h);
+      ld = dpp_mov<DPP_ROW_HALF_MIRROR>(l);
+      h = vmin_f64_raw(h, hd);
+      l = vmax_f64_raw(l, ld);
+   }
    if (G == 16)
    {
          hd = dpp_mov<DPP_ROW_MIRROR>(h);
@@ -126,8 +132,8 @@ __device__ __forceinline__ int grp_or(int v)
 {
    if (G == 1) return v;
    v |= dpp_mov<DPP_QUAD_XOR1>(v);
-   v |= dpp_mov<DPP_QUAD_XOR2>(v);
-   v |= dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+   if (G >= 4) v |= dpp_mov<DPP_QUAD_XOR2>(v);
+   if (G >= 8) v |= dpp_mov<DPP_ROW_HALF_MIRROR>(v);
    if (G == 16) v |= dpp_mov<DPP_ROW_MIRROR>(v);
    return v;
 }

@@ -701,7 +701,7 @@ __global__ void __launch_bounds__(KDS_BLOCK) k_dyn_serial(const batotp_serial_mo
 template <int G, int FEAT, bool UNI>
 struct Pt
 {
-   static constexpr int PER = (G == 1) ? BATOTP_MAX_JOINTS : 1;
+   static constexpr int PER = (G >= BATOTP_MAX_JOINTS) ? 1 : BATOTP_MAX_JOINTS / G; // joints per lane: G = 1: 8, 2: 4, 4: 2, >= 8: 1
    // G == 16 (except for the parallel-mechanism variant): the group is two halves of 8 lanes; lane j and
    // lane j+8 own the same joint, the lower half evaluates the upper bounds of the sddot interval, the
    // upper half the lower bounds: one divide per lane and one reduction per constraint check.
@@ -1659,7 +1659,7 @@ constexpr int K4_BLOCK = 256;
 // FLAT: the stage loop and the bisection loop are one loop in which every path of the wavefront is either
 // waiting for its next stage or inside a constraint check (see the comment at the loop).
 template <int G, int FEAT, bool UNI, bool FLAT = false>
-__global__ void __launch_bounds__(K4_BLOCK, (FEAT <= 1 && G > 1) ? BK_SWEEP_WPE : 2) k_sweep(SweepArgs a)
+__global__ void __launch_bounds__(K4_BLOCK, (G > 1 && G < 8) ? 1 : (FEAT <= 1 && G > 1) ? BK_SWEEP_WPE : 2) k_sweep(SweepArgs a)
 {
    __shared__ double lim[6][8];
    __shared__ double rk[7][6]; // FLAT: rk[st][k] = weight of stage value k in stage st (column st-1 of ba.cpp:58-63), 0 for k >= st

@@ -277,5 +277,11 @@ def set_layout(ctx, layout):
         ctx.set_sweep_group(8)
         ctx.set_paths_per_wave(8)
         ctx.set_sweep_hold(k, k)
+    elif isinstance(layout, str) and layout.startswith("g"):
+        # "g4flat3": 4 lanes per path (two joints per lane), every lane of the wavefront filled, flat loop with hold 3
+        g, k = layout[1:].split("flat")
+        ctx.set_sweep_group(int(g))
+        ctx.set_paths_per_wave(64 // int(g))
+        ctx.set_sweep_hold(int(k), int(k))
     else:
         ctx.set_sweep_group(int(layout))

@@ -44,7 +44,7 @@ def _run(ctx, prob, ys, sres, cap):
 
 
 @pytest.mark.parametrize("seed", range(6 * _SCALE))
-@pytest.mark.parametrize("lanes", [0, 8, "flat0", "flat4"])
+@pytest.mark.parametrize("lanes", [0, 8, "flat0", "flat4", 4, 2, "g4flat0", "g4flat8", "g2flat3"])
 def test_random_velocity_acceleration_problems(hip_lib, oracle_ctx, seed, lanes):
     rng = np.random.default_rng(1000 + seed)
     nJ = int(rng.integers(1, 9))
@@ -197,7 +197,7 @@ def test_random_cartesian_constraint_problems(hip_lib, oracle_ctx, seed):
         ys.append(np.ascontiguousarray(np.vstack([th, ca])))
         sres.append(float(rng.uniform(0.01, 0.1)))
     ro, oo = _run(oracle_ctx, prob, ys, sres, 30000)
-    for lanes in (0, 1, 8, 16):
+    for lanes in (0, 1, 2, 4, 8, 16):
         ctx = capi.Context(hip_lib, 0)
         ctx.set_sweep_group(lanes)
         rh, ho = _run(ctx, prob, ys, sres, 30000)
@@ -226,7 +226,7 @@ def test_random_two_link_arm_with_torque_limits(hip_lib, oracle_ctx, seed):
     ys = [np.ascontiguousarray(np.vstack([y, np.zeros((prob.n_cart, y.shape[1]))])) for y in ys]
     sres = [float(rng.uniform(0.2, 2.0)) for _ in ys]
     outs = []
-    for lanes, c in ((0, None), (8, None), (-1, oracle_ctx)):
+    for lanes, c in ((0, None), (8, None), (4, None), (2, None), (-1, oracle_ctx)):
         ctx = c
         if ctx is None:
             ctx = capi.Context(hip_lib, 0)

@@ -76,7 +76,7 @@ def test_serial_chain_dynamics_and_torque_limited_sweep(hip_ctx, oracle_ctx, nam
     assert_matches_reference(case, ho)
 
 
-@pytest.mark.parametrize("lanes", [1, 8, 16])
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16])
 def test_serial_chain_other_lane_groupings_and_ragged_batch(hip_lib, oracle_ctx, lanes):
     """torque-limited 7-DOF paths of different length in one batch, every lane layout of the sweep"""
     ctx = capi.Context(hip_lib, 0)
@@ -146,7 +146,7 @@ def _vel_acc_only(name):
     return name in helpers.FULL_CASES and not (f & (capi.F_TRQ_ON | capi.F_CART_VEL_ON | capi.F_CART_ACC_ON))
 
 
-@pytest.mark.parametrize("lanes", [0, 1, 8, 16, 32])
+@pytest.mark.parametrize("lanes", [0, 1, 2, 4, 8, 16, 32])
 def test_compact_splines_give_identical_results(hip_lib, oracle_ctx, lanes):
     """BATOTP_F_COMPACT_SPLINES (value + second derivative per knot instead of four coefficients): every
     published quantity is bit-identical to the oracle's, for every lane grouping of the sweep"""
@@ -172,7 +172,7 @@ def test_hip_baseline_size_paths(hip_ctx, oracle_ctx, name):
     assert_matches_reference(case, ho)
 
 
-@pytest.mark.parametrize("lanes", [1, 8, 16, 32, "flat4"])
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 32, "flat4", "g4flat4", "g2flat5"])
 def test_other_lane_groupings_agree(hip_lib, oracle_ctx, lanes):
     """the sweep kernel with 1 or 16 lanes per path publishes the same bits as the default 8"""
     ctx = capi.Context(hip_lib, 0)
