@@ -284,6 +284,7 @@ private:
    std::string _trajFileName;
    bool _isBINfile = false;
    int _pathType = 0;
+   std::string _pathTypeStr;
 
    bool _areJointAnglesDegrees = false;
    bool _isJntVelConOn = false;
@@ -368,6 +369,7 @@ private:
    int interpTrajLinear(Traj &traj, const int nPtsNew);
 
    // ---- file IO (ba_io.cpp) -------------------------------------------------------------------------
+   int finishConfig();                     // derived settings + checks shared by readConfigData / loadConfigData
    int trajReadBIN(Traj &myTraj, const char *filename);
    int trajReadCSV(Traj &myTraj, const char *filename);
    int printInputData(const Traj &myTraj);
