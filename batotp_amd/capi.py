@@ -207,6 +207,7 @@ class Library:
             "batotp_hip_set_paths_per_wave": [P, I32],
             "batotp_hip_set_overlap": [P, I32],
             "batotp_hip_set_sweep_hold": [P, I32, I32],
+            "batotp_hip_set_sweep_prefetch": [P, I32, I32],
             "batotp_hip_resample": [P, C.POINTER(ResampleParams), I32, C.POINTER(C.c_int64), D, D, C.POINTER(P)],
             "batotp_hip_resampled_destroy": [P],
             "batotp_hip_resampled_info": [P, C.POINTER(C.c_int64), D, C.POINTER(C.c_uint32)],
@@ -271,6 +272,9 @@ class Context:
 
     def set_sweep_hold(self, reverse: int, forward: int):
         self.library.check(self.library.lib.batotp_hip_set_sweep_hold(self.handle, reverse, forward), "set_sweep_hold")
+
+    def set_sweep_prefetch(self, reverse: int, forward: int):
+        self.library.check(self.library.lib.batotp_hip_set_sweep_prefetch(self.handle, reverse, forward), "set_sweep_prefetch")
 
     def set_paths_per_wave(self, n: int):
         self.library.check(self.library.lib.batotp_hip_set_paths_per_wave(self.handle, n), "set_paths_per_wave")

@@ -1590,6 +1590,7 @@ struct SweepArgs
    int dir;
    int ppw;       // paths per wavefront, 1 .. 64/G
    int hold;      // FLAT kernels: a stage is started once hold/8 of the wavefront's live paths wait for one
+   int touch;     // software prefetch: bit 0 = spline rows ahead of the cursor, bit 1 = reverse curve ahead of its cursor (forward sweep)
 };
 
 // Butcher tableau of ba.cpp:58-63 (_B[k][j]; stage j+1 uses column j)
@@ -1644,6 +1645,16 @@ __device__ __forceinline__ int touch_ahead(const Pt<G, FEAT, UNI> &t, int j)
       v = reinterpret_cast<const int *>(t.coef)[2 * (unsigned)off];
    }
    return v;
+}
+
+// the same for the reverse curve the forward sweep follows: (s, sdot) pairs, 8 points per 128-byte line, ascending walk
+template <int G, int FEAT, bool UNI>
+__device__ __forceinline__ int touch_curve_ahead(const Pt<G, FEAT, UNI> &t, int j)
+{
+   int off = t.segMVC * 2 + (1 + (j & 7)) * 16; // in doubles
+   const int hi = (t.nMvc - 1) * 2;
+   off = off > hi ? hi : off;
+   return reinterpret_cast<const int *>(t.mvc)[2 * (unsigned)off];
 }
 
 // A workgroup is 4 wavefronts (one per SIMD of a CU): with one-wavefront workgroups the dispatcher was
@@ -1750,7 +1761,7 @@ __global__ void __launch_bounds__(K4_BLOCK, (G > 1 && G < 8) ? 1 : (FEAT <= 1 &&
 #endif
    int64_t nPts = 0, i = 1;
    unsigned endStatus = 0;
-   int pf = 0;
+   int pf = 0, pf2 = 0;
    if constexpr (FLAT)
    {
       // One loop instead of {stages {bisection iterations}}.  In the nested form a wavefront stays in the bisection
@@ -1789,7 +1800,7 @@ __global__ void __launch_bounds__(K4_BLOCK, (G > 1 && G < 8) ? 1 : (FEAT <= 1 &&
                v3 = (st == 3) ? vN : v3; w3 = (st == 3) ? wN : w3;
                v4 = (st == 4) ? vN : v4; w4 = (st == 4) ? wN : w4;
                v5 = (st == 5) ? vN : v5; w5 = (st == 5) ? wN : w5;
-               if (BK_TOUCH_DIRS == 2 || (BK_TOUCH_DIRS == 1 && dir == -1))
+               if (a.touch & 1)
                {
                   t.sink += pf;
                   pf = touch_ahead(t, j);
@@ -1949,10 +1960,15 @@ __global__ void __launch_bounds__(K4_BLOCK, (G > 1 && G < 8) ? 1 : (FEAT <= 1 &&
             // reverse sweep only (descending addresses; measured: -17 % there, +5 % on the forward sweep,
             // whose ascending walk finds the next lines already on their way): consume last stage's touch,
             // issue the next one
-            if (BK_TOUCH_DIRS == 2 || (BK_TOUCH_DIRS == 1 && dir == -1))
+            if (a.touch & 1)
             {
                t.sink += pf;
                pf = touch_ahead(t, j);
+            }
+            if (dir == 1 && (a.touch & 2))
+            {
+               t.sink += pf2;
+               pf2 = touch_curve_ahead(t, j);
             }
          }
 
@@ -1967,7 +1983,7 @@ __global__ void __launch_bounds__(K4_BLOCK, (G > 1 && G < 8) ? 1 : (FEAT <= 1 &&
          else ++i;
       }
    }
-   if (writer) a.sink[p] = t.sink + pf;
+   if (writer) a.sink[p] = t.sink + pf + pf2;
 #ifdef BK_PROFILE_SECTIONS
    if (writer) { const unsigned long long tend = __builtin_readcyclecounter(); a.prof[4 * p + 0] = (double)t.cycA; a.prof[4 * p + 1] = (double)t.cycB; a.prof[4 * p + 2] = (double)(t.cycC - t.cycB); a.prof[4 * p + 3] = (double)(tend - tstart); }
 #endif

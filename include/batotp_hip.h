@@ -260,6 +260,10 @@ int  batotp_hip_set_paths_per_wave(batotp_ctx *ctx, int32_t n);
  * path: results are bit-identical in every test (tests/test_gpu_parity.py, test_gpu_fuzz.py) and bench.py re-checks the
  * result rows of every run against the nested loops.  DESIGN.md 4 has the history. */
 int  batotp_hip_set_sweep_hold(batotp_ctx *ctx, int32_t reverse, int32_t forward);
+/* tuning knob: software prefetch in the sweep kernel, per direction: bit 0 = touch the spline rows ahead of the cursor, bit 1 = touch
+ * the reverse curve ahead of its cursor (forward sweep only); -1 (default) = automatic: rows in the reverse sweep always, rows and
+ * curve in the forward sweep while every path has a wavefront to itself (latency-bound regime).  Never changes a result. */
+int  batotp_hip_set_sweep_prefetch(batotp_ctx *ctx, int32_t reverse, int32_t forward);
 /* tuning knob: with overlap on, batotp_hip_pointwise_mvc returns at once and its kernel shares the GPU with the
  * sweeps that follow (second HIP stream; nothing in the sweeps reads its output); batotp_hip_get_results,
  * batotp_hip_download_mvc, batotp_hip_synchronize and the next batotp_hip_precompute wait for it.  Default off. */

@@ -67,6 +67,7 @@ int batotp_hip_synchronize(batotp_ctx *ctx) { (void)ctx; return BATOTP_OK; }
 int batotp_hip_set_sweep_group(batotp_ctx *ctx, int32_t lanes) { (void)ctx; (void)lanes; return BATOTP_OK; }
 int batotp_hip_set_paths_per_wave(batotp_ctx *ctx, int32_t n) { (void)ctx; (void)n; return BATOTP_OK; }
 int batotp_hip_set_sweep_hold(batotp_ctx *ctx, int32_t reverse, int32_t forward) { (void)ctx; (void)reverse; (void)forward; return BATOTP_OK; }
+int batotp_hip_set_sweep_prefetch(batotp_ctx *ctx, int32_t reverse, int32_t forward) { (void)ctx; (void)reverse; (void)forward; return BATOTP_OK; }
 
 int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *prob, int32_t n_paths,
                             const int64_t *n_knots, int64_t max_steps, batotp_batch **out)
