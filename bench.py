@@ -375,7 +375,7 @@ def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=
         if attempt == 3:
             raise RuntimeError(f"{cfg_name}: {bad} paths ended with an error status (up to {worst:.2f} steps per knot)")
         # distinct random paths differ in the integration steps they need per knot: give the curves more room and start over
-        cap = int(cap * 1.5)
+        cap = int(cap * 2)
         print(f"bench: {bad} paths ran out of curve capacity, retrying with {cap} points per curve", file=sys.stderr)
         batch.close()
         batch = capi.Batch(hip, prob, [int(inp.n_knots[p % K]) for p in range(chunk_sizes[0])], cap)
