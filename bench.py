@@ -185,6 +185,16 @@ class Inputs:
             self.nC_in = self.prm.n_joints + self.prm.n_cart
             self.keep = first[0].shape[0]                   # channels the batch carries (Cartesian rows dropped when unused)
             self.n_knots, self.sres = np.zeros(self.K, np.int64), np.zeros(self.K)
+            self.skipped = 0
+            want = self.K
+            if self.prob.flags & capi.F_PARALLEL:
+                # random cable-robot paths can ask for cable tensions outside the limits even at rest: the sweep
+                # of such a path crawls at the speed floor with a failing 100-iteration bisection at every stage until it runs
+                # out of capacity (the reference grinds through it the same way and then returns -1).  The benchmark measures
+                # feasible paths: candidates with a knot at which K3 finds no admissible sdot are skipped.
+                self.seeds = self.seeds + [self.seeds[-1] + 1 + k for k in range(max(8, self.K // 4))]
+                self.K = len(self.seeds)
+            self.n_knots, self.sres = np.zeros(self.K, np.int64), np.zeros(self.K)
             self.taught, self.sres_in = taught_points_f32(workload, self.seeds, knots)
             self.host_check = None
             for k0, rs in self._chunks():
@@ -195,7 +205,23 @@ class Inputs:
                 if k0 == 0:
                     self.host_check = bool(np.array_equal(rs.knots(0)[: self.keep], first[0]) and rs.sres[0] == first[1])
                 rs.close()
-            self.data = f"synthetic: {self.K} distinct seeded spline paths per GPU (taught points -> knots by the device resampler)"
+            if self.K > want:
+                b = capi.Batch(hip, self.prob, [int(n) for n in self.n_knots], 8)
+                self.fill(b, self.K)
+                b.precompute(0)
+                b.pointwise_mvc()
+                ok = [p for p in range(self.K) if not np.isnan(b.mvc(p)[1]).any()]
+                b.close()
+                hip.trim()
+                self.skipped = self.K - len(ok)
+                if len(ok) < want:
+                    raise RuntimeError(f"only {len(ok)} of {self.K} candidate paths are feasible")
+                ok = ok[:want]
+                self.seeds = [self.seeds[p] for p in ok]
+                self.taught = [self.taught[p] for p in ok]
+                self.n_knots, self.sres, self.K = self.n_knots[ok], self.sres[ok], want
+            self.data = f"synthetic: {self.K} distinct seeded spline paths per GPU (taught points -> knots by the device resampler)" + \
+                        (f"; {self.skipped} candidate paths with statically infeasible cable tensions skipped" if self.skipped else "")
         else:
             with cf.ThreadPoolExecutor(max_workers=min(self.K, os.cpu_count() or 1)) as ex:
                 rest = list(ex.map(lambda s: make_knots(workload, s, knots), seeds[1:]))
