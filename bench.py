@@ -216,6 +216,7 @@ class Inputs:
                 self.skipped = self.K - len(ok)
                 if len(ok) < want:
                     raise RuntimeError(f"only {len(ok)} of {self.K} candidate paths are feasible")
+                self.spares = [(self.seeds[p], self.taught[p], int(self.n_knots[p]), float(self.sres[p])) for p in ok[want:]]
                 ok = ok[:want]
                 self.seeds = [self.seeds[p] for p in ok]
                 self.taught = [self.taught[p] for p in ok]
@@ -229,6 +230,21 @@ class Inputs:
             self.n_knots = np.array([b[0].shape[1] for b in self.base], np.int64)
             self.sres = np.array([b[1] for b in self.base])
             self.data = f"synthetic: {self.K} distinct seeded spline paths per GPU resampled by the host BA library"
+
+    spares = []
+
+    def replace(self, distinct):
+        """swap distinct paths whose sweep ended with an error (the constraints do not admit them) for spare candidates;
+        returns how many could be replaced"""
+        done = 0
+        for k in distinct:
+            if not self.on_device or not self.spares:
+                break
+            seed, taught, n, sres = self.spares.pop(0)
+            self.seeds[k], self.taught[k], self.n_knots[k], self.sres[k] = seed, taught, n, sres
+            self.skipped += 1
+            done += 1
+        return done
 
     def _chunks(self):
         for k0 in range(0, self.K, self.CHUNK):
@@ -360,7 +376,6 @@ def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=
         prepare_dynamics(batch, prob, chunk_sizes[0])
         hip.synchronize()
     knots_of = lambda s: int(sum(int(inp.n_knots[p % K]) for p in range(s)))
-    local_knots = sum(knots_of(s) for s in chunk_sizes)
 
     def barrier():
         if dist_ctx is not None:
@@ -394,7 +409,7 @@ def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=
         return int(np.count_nonzero(bad)), worst
 
     failed_paths = 0
-    for attempt in range(2):
+    for attempt in range(3):
         for _ in range(max(warmup, 1) if attempt else warmup):
             one_pass(False, chunk_sizes[:1])       # warm-up: the first chunk
         bad, worst = capacity_errors() if (warmup or attempt) else (0, 0.0)
@@ -404,19 +419,26 @@ def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=
             dist_ctx["dist"].all_reduce(flag, op=dist_ctx["dist"].ReduceOp.MAX)
             bad = int(flag.item())
         failed_paths = bad
-        if not bad or attempt == 1:
+        if not bad or attempt == 2:
             break
-        # distinct random paths differ in the integration steps they need per knot: give the curves more room and start over
-        # (once: a path that still fails is one the constraints do not admit -- random cable-robot paths can be
-        # infeasible, SURVEY.md 8d -- and is reported as failed, as the reference would return -1 for it)
-        cap = int(cap * 2)
+        rows0 = state["rows"]
+        if rows0 is not None and rows0.shape[0] and inp.spares:
+            # paths the constraints do not admit (they crawl at the speed floor until the capacity is exhausted): other seeds take their place
+            st0 = (rows0["status_rev"] | rows0["status_fwd"]) & ~np.uint32(capi.ST_BISECT_FAIL)
+            inp.replace(sorted(set(int(p) % K for p in np.nonzero(st0)[0])))
+        # distinct random paths differ in the integration steps they need per knot: the first retry also gives the curves
+        # twice the room; what still fails after the retries is reported as failed (the reference would return -1 for it)
+        if attempt == 0:
+            cap = int(cap * 2)
         print(f"bench: {bad} paths ended with an error status (up to {worst:.2f} steps per knot), retrying with {cap} points per curve", file=sys.stderr)
         if batch is not None:
             batch.close()
+            cap = max(cap, int(int(inp.n_knots.max()) * WORKLOADS[workload]["cap"]) + 1024)
             batch = capi.Batch(hip, prob, [int(inp.n_knots[p % K]) for p in range(chunk_sizes[0])], cap)
             inp.fill(batch, chunk_sizes[0])
             prepare_dynamics(batch, prob, chunk_sizes[0])
             hip.synchronize()
+    local_knots = sum(knots_of(s) for s in chunk_sizes)     # (after the retries: replaced paths have other knot counts)
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
