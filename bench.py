@@ -221,17 +221,21 @@ class Inputs:
                 self.seeds = [self.seeds[p] for p in ok]
                 self.taught = [self.taught[p] for p in ok]
                 self.n_knots, self.sres, self.K = self.n_knots[ok], self.sres[ok], want
-            self.data = f"synthetic: {self.K} distinct seeded spline paths per GPU (taught points -> knots by the device resampler)" + \
-                        (f"; {self.skipped} candidate paths with statically infeasible cable tensions skipped" if self.skipped else "")
+            self._data = f"synthetic: {self.K} distinct seeded spline paths per GPU (taught points -> knots by the device resampler)"
         else:
             with cf.ThreadPoolExecutor(max_workers=min(self.K, os.cpu_count() or 1)) as ex:
                 rest = list(ex.map(lambda s: make_knots(workload, s, knots), seeds[1:]))
             self.base = [first] + rest
             self.n_knots = np.array([b[0].shape[1] for b in self.base], np.int64)
             self.sres = np.array([b[1] for b in self.base])
-            self.data = f"synthetic: {self.K} distinct seeded spline paths per GPU resampled by the host BA library"
+            self._data = f"synthetic: {self.K} distinct seeded spline paths per GPU resampled by the host BA library"
 
     spares = []
+    skipped = 0
+
+    @property
+    def data(self):
+        return self._data + (f"; {self.skipped} candidate paths the cable-tension limits do not admit were replaced by other seeds" if self.skipped else "")
 
     def replace(self, distinct):
         """swap distinct paths whose sweep ended with an error (the constraints do not admit them) for spare candidates;
