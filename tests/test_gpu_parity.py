@@ -398,3 +398,57 @@ def test_product_batest_end_to_end_on_gpu(tmp_path):
         assert r.returncode == 0, (name, r.stdout[-2000:])
         assert filecmp.cmp(work / "s-sdot.dat", os.path.join(src, "ref_s-sdot.dat"), shallow=False), name
         assert filecmp.cmp(work / "traj_out.dat", os.path.join(src, "ref_traj_out.dat"), shallow=False), name
+
+
+def _batch_as_worded(hip_lib, oracle_ctx, config, n_paths, sample):
+    """a BASELINE batch configuration as bench.py builds it (distinct seeded paths, taught points -> knots by the device
+    resampler): size-independent properties for every path, bit equality with the oracle (fed by the HOST resampler) for a sample"""
+    import bench
+    ctx = capi.Context(hip_lib, 0)
+    c = bench.CONFIGS[config]
+    seeds = [7000 + k for k in range(min(c["distinct"], n_paths))]
+    inp = bench.Inputs(ctx, c["workload"], c["knots"], seeds)
+    K = inp.K
+    prob = capi.Problem.from_buffer_copy(bytes(inp.prob))
+    if prob.flags & capi.F_NO_SAMPLES:
+        prob.flags |= capi.F_COMPACT_SPLINES
+    cap = int(int(inp.n_knots.max()) * bench.WORKLOADS[c["workload"]]["cap"] * 2) + 1024
+    b = capi.Batch(ctx, prob, [int(inp.n_knots[p % K]) for p in range(n_paths)], cap)
+    inp.fill(b, n_paths)
+    b.precompute(0); b.sweep(-1); b.sweep(+1)
+    res = b.results()
+    ok = ((res["status_rev"] | res["status_fwd"]) & ~np.uint32(capi.ST_BISECT_FAIL)) == 0
+    assert ok.mean() > 0.97, f"{(~ok).sum()} of {n_paths} paths failed"
+    assert np.all(res["t_total"][ok] == prob.integ_res * res["steps_fwd"][ok])           # T is quantised to the step
+    assert np.all(res["n_fwd"][ok] == res["steps_fwd"][ok] + 1) and np.all(res["n_rev"][ok] == res["steps_rev"][ok] + 1)
+    for p in range(K, n_paths):                                                          # tiled copies give identical rows
+        assert res[p] == res[p % K]
+    for p in sample:
+        y, sres = inp.host_knots(p % K)
+        class _C:
+            name = f"{config}:{p}"
+        cs = _C()
+        cs.y, cs.sres, cs.problem, cs.n = y, sres, inp.prob, y.shape[1]
+        cs.max_steps = lambda: cap
+        oo = run_pipeline(oracle_ctx, [cs], mvc=False, details=False)[0]
+        for f in res.dtype.names:
+            assert res[p][f] == oo["result"][f], (config, p, f)
+        if ok[p]:
+            for which, key in ((-1, "rev"), (1, "fwd")):
+                s, sd = b.curve(p, which)
+                assert_bit_equal(s, oo[key][0], f"{config} path {p} {key}.s")
+                assert_bit_equal(sd, oo[key][1], f"{config} path {p} {key}.sdot")
+                assert s[0] == 0.0 and np.all(np.diff(s) > 0)
+    b.close()
+    ctx.trim()
+    ctx.close()
+
+
+def test_cfg4_batch_as_worded(hip_lib, oracle_ctx):
+    """BASELINE config 4 as worded: GEN7DOF, N = 50k, a batch of 1024 randomised (distinct) paths"""
+    _batch_as_worded(hip_lib, oracle_ctx, "cfg4", 1024, [0, 1, 511, 777, 1023])
+
+
+def test_cfg5_share_as_worded(hip_lib, oracle_ctx):
+    """BASELINE config 5 as worded, one GPU's share of the 4096-path batch at 8 GPUs: 512 cable-robot paths of 200k knots"""
+    _batch_as_worded(hip_lib, oracle_ctx, "cfg5", 512, [0, 77, 300])
