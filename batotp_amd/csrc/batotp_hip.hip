@@ -15,6 +15,7 @@
 #include "batotp_hip.h"
 #include "batotp_models.h"
 #include "kernels.hip.h"
+#include "sweep1.hip.h"
 #include "resample.hip.h"
 #include "output.hip.h"
 
@@ -251,7 +252,7 @@ extern "C" int batotp_hip_synchronize(batotp_ctx *ctx)
 
 extern "C" int batotp_hip_set_sweep_group(batotp_ctx *ctx, int32_t lanes)
 {
-   if (!ctx || !(lanes == 0 || lanes == 1 || lanes == 2 || lanes == 4 || lanes == 8 || lanes == 16 || lanes == 32)) return BATOTP_ERR_ARG;
+   if (!ctx || !(lanes == 0 || lanes == 1 || lanes == 2 || lanes == 4 || lanes == 8 || lanes == 16 || lanes == 32 || lanes == 64)) return BATOTP_ERR_ARG;
    ctx->sweepGroup = lanes;
    return BATOTP_OK;
 }
@@ -919,6 +920,32 @@ static void launchSweep(batotp_batch *b, SweepArgs &a)
 #undef LAUNCH_K4
 }
 
+// the one-path-per-wavefront kernel of sweep1.hip.h: joint velocity / acceleration limits only, uniform knot sites
+static bool sweep1Applies(const batotp_batch *b)
+{
+   if (featureLevel(b) > 0) return false;
+   for (int p = 0; p < b->B; ++p)
+      if (!b->pinfo[p].uniform) return false;
+   return true;
+}
+
+static void launchSweep1(batotp_batch *b, SweepArgs &a)
+{
+   a.ppw = 1; a.hold = -1; a.touch = 0;
+   const unsigned grid = (unsigned)((b->B + (S1_BLOCK / 64) - 1) / (S1_BLOCK / 64));
+   hipStream_t st = b->ctx->stream;
+   if (b->compact)
+   {
+      if (a.dir == 1) hipLaunchKernelGGL((k_sweep1<-1, 1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
+      else hipLaunchKernelGGL((k_sweep1<-1, -1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
+   }
+   else
+   {
+      if (a.dir == 1) hipLaunchKernelGGL((k_sweep1<0, 1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
+      else hipLaunchKernelGGL((k_sweep1<0, -1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
+   }
+}
+
 extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
 {
    if (!b || (dir != 1 && dir != -1)) return BATOTP_ERR_ARG;
@@ -941,9 +968,13 @@ extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
       // 32-lane layout (four bisection candidates per pass) wins; beyond that the 8-lane layout, which
       // packs more paths per wavefront, has the higher throughput
       lanes = (b->B <= (a.dir == -1 ? 2048 : 1024)) ? 32 : 8;
+      // ... and where every path has a wavefront to itself anyway, the kernel written for that case (sweep1.hip.h)
+      if (lanes == 32 && sweep1Applies(b)) lanes = 64;
    }
+   if (lanes == 64 && !sweep1Applies(b)) lanes = 32; // torque / Cartesian limits, uploaded sites: the general kernel
    switch (lanes)
    {
+   case 64: launchSweep1(b, a); break;
    case 32: launchSweep<32>(b, a); break;
    case 1: launchSweep<1>(b, a); break;
    case 16: launchSweep<16>(b, a); break;

@@ -1,0 +1,436 @@
+// sweep1.hip.h -- the sweep of a path that has a wavefront to itself (the latency-bound regime: BASELINE configs 2 and 4 as
+// worded -- one trajectory, or a few hundred paths per GPU), for problems with joint velocity / acceleration limits only on
+// uniform knot sites.  Same arithmetic, same order, same results as k_sweep (kernels.hip.h) -- BA::sweep and everything it
+// calls, reference batotp/ba.cpp:979-1195, 1204-1236, 1248-1332, 1341-1413, 1449-1534, 1590-1652 -- written for the fewest
+// instructions per stage instead of for generality:
+//   * a lone wavefront issues one vector instruction every 4 cycles whatever its number of active lanes
+//     (MI355X_MICROARCH.md), and the scalar instructions of divergent control flow cost as much: k_sweep's 405 VALU + 250
+//     SALU instructions per stage evaluation are the 5170 cycles measured at B = 1 (profiles/r02_c_*).  So: the six stages
+//     are straight-line code with their tableau column as literals (no selects on the stage number, no table look-ups), one
+//     joint per lane without per-lane loops, the constraint families that are off compiled out, the stage's spline row and
+//     the knot sites of its segment kept in registers, and the bisection -- a quarter of the stages need it -- evaluates four
+//     candidates of the reference's (deterministic) candidate sequence per pass, as the 32-lane layout of k_sweep does;
+//   * lanes: lane = slot * 8 + joint, 4 candidate slots x 8 joint lanes; the other 32 lanes of the wavefront exit.
+#pragma once
+#include "kernels.hip.h"
+
+namespace bk
+{
+
+constexpr int S1_BLOCK = 256;
+
+// FEAT: -1 = compact splines ((value, second derivative) pairs), 0 = coefficient rows.  DIR: -1 reverse, +1 forward.
+template <int FEAT, int DIR>
+__global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
+{
+   __shared__ double lim[6][8];
+   stage_limits(a.dP, lim);
+   const int lane = threadIdx.x & 63;
+   const int p = blockIdx.x * (S1_BLOCK / 64) + (threadIdx.x >> 6);
+   if (p >= a.B || lane >= 32) return;
+   const int j = lane & 7, cslot = lane >> 3;
+   const bool writer = (lane == 0);
+   const PathInfo pi = a.pinfo[p];
+   const int n = (int)pi.n;
+   const int64_t cap = a.cap;
+   const int nJ = a.P.nJ, nIn = a.P.Cin, C = a.P.C;
+   const bool jv = j < nJ;
+   const int jr = jv ? j : 0; // row slot this lane reads (lanes beyond the last joint read joint 0 and discard it)
+   const bool accOn = (a.P.flags & BATOTP_F_JNT_ACC_ON) != 0;
+
+   const double sres = pi.sres_c, vfact = pi.vfact, afact = pi.afact;
+   const double thrV = a.P.jnt_thresh * vfact, thrA = a.P.jnt_thresh * afact;
+   const double absh = a.P.integ_res;
+   const double h = DIR * absh;
+   const double sEnd = sres * (double)(n - 1);
+   const double sdotCap = sEnd / absh;                 // ba.cpp:1216
+   const double sddotMax = 2 * sEnd / (absh * absh);   // ba.cpp:1257
+   const double vmaxj = lim[0][j], amaxj = lim[1][j];
+   const int64_t maxIntegSteps = (int64_t)floor(a.P.max_integ_time / absh) + 1;
+
+   const double2 *__restrict__ km = (FEAT < 0) ? reinterpret_cast<const double2 *>(a.km) + pi.koff * nIn : nullptr;
+   const double *__restrict__ coef = (FEAT < 0) ? nullptr : a.coef + pi.koff * C * 4;
+   double2 *__restrict__ out = (DIR == 1 ? a.fwd : a.rev) + (int64_t)p * cap;
+   batotp_path_result *__restrict__ r = a.res + p;
+
+   // reverse curve the forward sweep follows
+   const double *__restrict__ mvc = nullptr;
+   int nMvc = 0;
+   if (DIR == 1)
+   {
+      const int64_t nRev = r->n_rev;
+      if (nRev < 2)
+      {
+         if (writer) { r->n_fwd = 0; r->steps_fwd = 0; r->t_total = 0; r->status_fwd = r->status_rev | BATOTP_ST_CAPACITY; r->n_bisect_fail_fwd = 0; }
+         return;
+      }
+      mvc = reinterpret_cast<const double *>(a.rev + (int64_t)p * cap + (cap - nRev));
+      nMvc = (int)nRev;
+   }
+
+   // ---- cursor state -------------------------------------------------------------------------------------------------
+   int segC = (DIR == 1) ? 0 : n - 2;
+   double sSeg = sres * (double)segC, sNext = sres * (double)(segC + 1); // sites of the cursor's segment (ba.cpp:800-806)
+   double tauC = (DIR == 1) ? 0.0 : 1.0;
+   int rowSeg = -1;
+   double A3 = 0, B2 = 0, A6 = 0, c1 = 0; // 3*c3, 2*c2, 6*c3, c1 of this lane's joint on segment rowSeg
+   double thD = 0, thD2 = 0;              // theta', theta'' of this lane's joint at the last evaluated position
+   int segMVC = (DIR == 1) ? 0 : n - 2, mvcSeg = -1;
+   double tauMVC = (DIR == 1) ? 0.0 : 1.0, mS0 = 0, mS1 = 0, mD0 = 0, mD1 = 0;
+   double sdotMin = 0, sdotCur = 0, sddotH = 0, sddotL = 0;
+   unsigned status = 0;
+   int nfail = 0;
+
+   // BA::updateCurSeg on the knot sites (ba.cpp:1617-1652): the literal walk, sites sres*k recomputed only when the cursor moves
+   auto walkC = [&](double sCur) {
+      const int lastSeg = n - 2;
+      for (;;)
+      {
+         if (sCur >= sSeg && sCur <= sNext) break;
+         bool moved = false;
+         if (sCur > sSeg)
+         {
+            if (segC >= lastSeg) { segC = lastSeg; break; }
+            ++segC; moved = true;
+         }
+         if (sCur < sSeg)
+         {
+            if (segC <= 0) { segC = 0; break; }
+            --segC; moved = true;
+         }
+         if (!moved) { status |= BATOTP_ST_NONFINITE; break; }
+         sSeg = sres * (double)segC;
+         sNext = sres * (double)(segC + 1);
+      }
+      tauC = (sCur - sSeg) / (sNext - sSeg);
+   };
+
+   // BA::evalSplinePartials for joint velocity / acceleration limits only (ba.cpp:1341-1366)
+   auto evalPartials = [&](double sCur) {
+      walkC(sCur);
+      if (segC != rowSeg)
+      {
+         double k3, k2, k1;
+         if (FEAT < 0)
+         {
+            const unsigned at = (unsigned)(segC * nIn + jr);
+            const double2 kl = km[at], kr = km[at + nIn]; // knots segC and segC + 1 of this joint
+            k3 = div6(kr.y - kl.y);                        // spline.cpp:203-209
+            k2 = kl.y / 2.0;
+            k1 = kr.x - kl.x - div6(kr.y + 2 * kl.y);
+         }
+         else
+         {
+            const Coef4 k = *reinterpret_cast<const Coef4 *>(coef + (unsigned)(segC * C * 4) + jr * 4);
+            k3 = k.c3; k2 = k.c2; k1 = k.c1;
+         }
+         A3 = jv ? 3 * k3 : 0.0;
+         B2 = jv ? 2 * k2 : 0.0;
+         A6 = jv ? 6 * k3 : 0.0;
+         c1 = jv ? k1 : 0.0;
+         rowSeg = segC;
+      }
+      const double tau = tauC, tau2 = tau * tau;
+      thD = (A3 * tau2 + B2 * tau + c1) * vfact; // (3*c3*tau2 + 2*c2*tau + c1)*vFact, ba.cpp:1359
+      thD2 = (A6 * tau + B2) * afact;            // (6*c3*tau + 2*c2)*aFact, ba.cpp:1360
+   };
+
+   // BA::updateCurSeg on the reverse curve with the segment's two points cached (ba.cpp:1592)
+   auto mvcWalk = [&](double sCur) {
+      if (mvcSeg == segMVC && sCur >= mS0 && sCur <= mS1)
+      {
+         tauMVC = (sCur - mS0) / (mS1 - mS0);
+         return;
+      }
+      update_cur_seg<2>(mvc, 0.0, nMvc, sCur, segMVC, tauMVC, status);
+      const double2 pa = *reinterpret_cast<const double2 *>(mvc + 2 * segMVC);
+      const double2 pb = *reinterpret_cast<const double2 *>(mvc + 2 * segMVC + 2);
+      mS0 = pa.x; mD0 = pa.y; mS1 = pb.x; mD1 = pb.y;
+      mvcSeg = segMVC;
+   };
+
+   // BA::sdotLim (ba.cpp:1204-1236); theta' is the one of the previous evalSplinePartials call, as in the reference
+   auto sdotLim = [&](double sCur, double &sdot) {
+      if (DIR == 1)
+      {
+         mvcWalk(sCur);
+         const double sdotMVC = dmax(mD0 + tauMVC * (mD1 - mD0), sdotMin); // evalsdot, ba.cpp:1590-1607
+         if (sdot > sdotMVC) sdot = sdotMVC;
+      }
+      sdot = dmin(sdot, sdotCap);
+      sdot = dmax(sdot, sdotMin);
+      double l = kInf;
+      if (jv && fabs(thD) > thrV) l = dmin(l, fabs(vmaxj / thD));
+      l = grp_min<8>(l);
+      sdot = dmin(sdot, l);
+   };
+
+   // BA::verifySecondOrderConstraints, joint acceleration family (ba.cpp:1514-1534); see verify_second_order for why the
+   // reference's early exits are the reduced predicate
+   auto verify = [&](double sdotTry) -> bool {
+      const double sdotSQ = sdotTry * sdotTry;
+      double H = sddotMax, L = -sddotMax;
+      bool force = false;
+      if (accOn && jv)
+      {
+         const double vpt = thD;
+         if (fabs(vpt) < thrV)
+         {
+            if (!(fabs(thD2) < thrA))
+            {
+               if (sdotSQ > amaxj / fabs(thD2)) force = true;
+            }
+         }
+         else
+         {
+            const int svpt = sgn(vpt);
+            const double vTerm = thD2 * sdotSQ;
+            H = dmin(H, (svpt * amaxj - vTerm) / vpt);
+            L = dmax(L, (-svpt * amaxj - vTerm) / vpt);
+         }
+      }
+      double Hred = force ? -kInf : H;
+      grp_min_max<8>(Hred, L);
+      sddotH = Hred;
+      sddotL = L;
+      return L > Hred;
+   };
+
+   // BA::applyAccelConstraintsBisectionPt (ba.cpp:1248-1332) with four candidates per pass: the reference's loop is replayed
+   // literally; a speculated candidate is used only if it is bit-identical to the value the replay asks for (see
+   // apply_accel_bisection_spec).  Returns 0, or -1 on the failure exits (sddot untouched).
+   auto accelPt = [&](double sCur, double &sddot) {
+      const double sdotErrThresh = .001;
+      double lowFact = .01;
+      double sdotGood = 0, sdotGoodLast;
+      bool anyGoodIter = false;
+      double sdotL = 0;
+      double sdotH = sdotCur;
+      double sdotTry = sdotH;
+      int nIter = 0;
+      evalPartials(sCur); // ba.cpp:1265
+
+      // the common case first: the speed the velocity limits left is admissible (three quarters of the stages)
+      if (!verify(sdotTry))
+      {
+         sddot = (DIR == 1) ? sddotH : sddotL;
+         return;
+      }
+      // first check violated: replay of ba.cpp:1276-1321 from its first iteration, four candidates per pass.  The check of
+      // the first candidate has just been done: it is folded into the first pass below (slot 0 re-evaluates it, same bits).
+      int rc = 0, lastSlot = 0;
+      bool finished = false;
+      while (!finished)
+      {
+         const double c0 = sdotTry;
+         double cand1, cand2, cand3;
+         if (!anyGoodIter)
+         {
+            double lf = lowFact * 2.0;
+            cand1 = .5 * (c0 + dmax(.999 * 0.0, (1.0 - lf) * c0));
+            lf *= 2.0;
+            cand2 = .5 * (cand1 + dmax(.999 * 0.0, (1.0 - lf) * cand1));
+            lf *= 2.0;
+            cand3 = .5 * (cand2 + dmax(.999 * 0.0, (1.0 - lf) * cand2));
+         }
+         else
+         {
+            cand1 = .5 * (c0 + sdotL); // next midpoint if c0 is violated
+            cand2 = .5 * (sdotH + c0); // next midpoint if c0 is feasible
+            cand3 = c0;
+         }
+         const double mine = (cslot == 0) ? c0 : (cslot == 1) ? cand1 : (cslot == 2) ? cand2 : cand3;
+         const bool violMine = verify(mine); // this slot's sddotL / sddotH stay in its lanes
+         const unsigned long long ballot = __ballot(violMine);
+
+         int k = 0;
+         for (int consumed = 0; consumed < 4; ++consumed)
+         {
+            const bool isViol = (ballot >> (8 * k)) & 1ull;
+            lastSlot = k;
+            if (isViol)
+            {
+               sdotH = sdotTry;
+               if (!anyGoodIter)
+               {
+                  lowFact *= 2.0;
+                  sdotL = dmax(.999 * 0.0, (1.0 - lowFact) * sdotH);
+               }
+            }
+            else
+            {
+               if (nIter == 0) { finished = true; break; }
+               anyGoodIter = true;
+               sdotGoodLast = sdotGood;
+               sdotGood = sdotTry;
+               if (ratio_lt(fabs(sdotGood - sdotGoodLast), sdotGood, sdotErrThresh) || sdotTry < 0.0)
+               {
+                  sdotCur = sdotTry;
+                  finished = true;
+                  break;
+               }
+               sdotL = sdotTry;
+            }
+            nIter++;
+            if (nIter > 100) { rc = -1; finished = true; break; }
+            if (sdotTry < 0) { rc = -1; finished = true; break; }
+            if (!anyGoodIter)
+            {
+               if (ratio_lt(sdotH - sdotL, sdotH, 1e-20)) { rc = -1; finished = true; break; }
+            }
+            sdotTry = .5 * (sdotH + sdotL);
+            if (sdotTry == cand1) k = 1;
+            else if (sdotTry == cand2) k = 2;
+            else if (sdotTry == cand3 && !anyGoodIter) k = 3;
+            else break;
+         }
+      }
+      if (rc != 0)
+      {
+         status |= BATOTP_ST_BISECT_FAIL;
+         nfail++;
+         return;
+      }
+      const int src = 8 * lastSlot;
+      sddotH = __shfl(sddotH, src);
+      sddotL = __shfl(sddotL, src);
+      sddot = (DIR == 1) ? sddotH : sddotL;
+   };
+
+   // ---- bootstrap, ba.cpp:1021-1041 ------------------------------------------------------------------------------------
+   const double sLast = (DIR == 1) ? sEnd : 0.0;
+   double s0v = (DIR == 1) ? 0.0 : sEnd, s6v = 0;
+   double v0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0;
+   double w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, w6 = 0;
+   double sCur = s0v;
+   sdotCur = 0;
+   accelPt(sCur, w0);
+   v0 = .1 * h * w0;
+   sdotMin = v0;
+   sdotLim(sCur, v0);
+   sdotMin = v0;
+   sdotCur = v0;
+   accelPt(sCur, w0);
+   v0 = sdotCur;
+   sdotLim(sCur, v0);
+
+   double sPrev = s0v, sdPrev = v0;
+   double sCurPt = s0v, sdCurPt = v0;
+   if (writer) out[DIR == 1 ? 0 : cap - 1] = make_double2(s0v, v0);
+   const double floorV = 0.0 / absh; // ba.cpp:1050-1051: dsMinV == 0
+
+   // one stage of ba.cpp:1068-1094 with its tableau column written out (ba.cpp:58-63); SDOT / SDDOT are the partial sums
+#define S1_STAGE(SDOT, SDDOT, VST, WST)                                   \
+   {                                                                      \
+      const double sN = s0v + h * (SDOT);                                 \
+      double vN = v0 + h * (SDDOT);                                       \
+      vN = dmax(vN, floorV);                                              \
+      sCur = sN;                                                          \
+      sdotLim(sN, vN);                                                    \
+      sdotCur = vN;                                                       \
+      double wN = WST; /* kept when the bisection fails, ba.cpp:1091 */   \
+      accelPt(sN, wN);                                                    \
+      VST = sdotCur;                                                      \
+      WST = wN;                                                           \
+   }
+
+   int64_t nPts = 0, i = 1;
+   unsigned endStatus = 0;
+   bool done = false;
+   while (!done)
+   {
+      if (i >= cap) { endStatus = BATOTP_ST_CAPACITY; break; }
+      if (DIR == 1) mvcWalk(s0v + h * v0); // Euler predictor, ba.cpp:1055-1065: only the move of the reverse-curve cursor survives
+
+      S1_STAGE(BK_B00 * v0, BK_B00 * w0, v1, w1)
+      S1_STAGE(BK_B01 * v0 + BK_B11 * v1, BK_B01 * w0 + BK_B11 * w1, v2, w2)
+      S1_STAGE(BK_B02 * v0 + BK_B12 * v1 + BK_B22 * v2, BK_B02 * w0 + BK_B12 * w1 + BK_B22 * w2, v3, w3)
+      S1_STAGE(BK_B03 * v0 + BK_B13 * v1 + BK_B23 * v2 + BK_B33 * v3, BK_B03 * w0 + BK_B13 * w1 + BK_B23 * w2 + BK_B33 * w3, v4, w4)
+      S1_STAGE(BK_B04 * v0 + BK_B14 * v1 + BK_B24 * v2 + BK_B34 * v3 + BK_B44 * v4,
+               BK_B04 * w0 + BK_B14 * w1 + BK_B24 * w2 + BK_B34 * w3 + BK_B44 * w4, v5, w5)
+      S1_STAGE(BK_B05 * v0 + BK_B15 * v1 + BK_B25 * v2 + BK_B35 * v3 + BK_B45 * v4 + BK_B55 * v5,
+               BK_B05 * w0 + BK_B15 * w1 + BK_B25 * w2 + BK_B35 * w3 + BK_B45 * w4 + BK_B55 * w5, v6, w6)
+      s6v = sCur;
+
+      // FSAL shift and publish, ba.cpp:1096-1100
+      s0v = s6v; v0 = v6; w0 = w6;
+      sPrev = sCurPt; sdPrev = sdCurPt;
+      sCurPt = s0v; sdCurPt = v0;
+      if (writer) out[DIR == 1 ? i : cap - 1 - i] = make_double2(s0v, v0);
+
+      if (sCur * DIR > sLast) { nPts = i + 1; done = true; }                                // ba.cpp:1109-1115
+      else if (i > maxIntegSteps) { endStatus = BATOTP_ST_MAX_INTEG_TIME; break; }            // ba.cpp:1117-1122
+      else ++i;
+   }
+#undef S1_STAGE
+
+   status |= endStatus;
+   if (endStatus != 0)
+   {
+      if (writer)
+      {
+         if (DIR == 1) { r->n_fwd = 0; r->steps_fwd = i; r->t_total = 0; r->status_fwd = status; r->n_bisect_fail_fwd = nfail; }
+         else { r->n_rev = 0; r->steps_rev = i; r->t_rev = 0; r->status_rev = (r->status_rev & BATOTP_ST_SEG_ERROR) | status; r->n_bisect_fail_rev = nfail; }
+      }
+      return;
+   }
+
+   // end snap onto sLast, ba.cpp:1132-1134; forward: last sdot <- reverse curve's last sdot, ba.cpp:1140
+   {
+      const double sRat = (sLast - sPrev) / (sCurPt - sPrev);
+      sdCurPt = sdPrev + sRat * (sdCurPt - sdPrev);
+      sCurPt = sLast;
+      if (DIR == 1) sdCurPt = mvc[(nMvc - 1) * 2 + 1];
+      if (writer) out[DIR == 1 ? nPts - 1 : cap - nPts] = make_double2(sCurPt, sdCurPt);
+   }
+   const double tElapsed = absh * (double)(nPts - 1); // ba.cpp:1112
+   int64_t nOut = nPts;
+
+   if (nPts < 4 && writer)
+   {
+      // ba.cpp:1171-1184: re-interpolate linearly in time to four points
+      double ps[3], pd[3], tIn[3];
+      for (int k = 0; k < (int)nPts; ++k)
+      {
+         const double2 q = (k == (int)nPts - 1) ? make_double2(sCurPt, sdCurPt) : out[DIR == 1 ? k : cap - 1 - k];
+         ps[k] = q.x; pd[k] = q.y;
+         tIn[k] = absh * (double)k;
+      }
+      if (DIR != 1)
+      {
+         for (int k = 0; k < (int)nPts / 2; ++k)
+         {
+            swap_d(ps[k], ps[nPts - 1 - k]);
+            swap_d(pd[k], pd[nPts - 1 - k]);
+         }
+      }
+      const double tResNew = tIn[nPts - 1] / 3.;
+      double ns[4], nd[4];
+      int cur = 0;
+      for (int k = 0; k < 4; ++k)
+      {
+         const double tn = tResNew * (double)k;
+         while (!(tn < tIn[cur + 1] || cur == (int)nPts - 2)) ++cur;
+         const double tau = (tn - tIn[cur]) / (tIn[cur + 1] - tIn[cur]);
+         ns[k] = ps[cur] + (ps[cur + 1] - ps[cur]) * tau;
+         nd[k] = pd[cur] + (pd[cur + 1] - pd[cur]) * tau;
+      }
+      for (int k = 0; k < 4; ++k) out[DIR == 1 ? k : cap - 4 + k] = make_double2(ns[k], nd[k]);
+   }
+   if (nPts < 4) { status |= BATOTP_ST_SHORT; nOut = 4; }
+
+   if (writer)
+   {
+      if (DIR == 1)
+      {
+         r->n_fwd = nOut; r->steps_fwd = nPts - 1; r->t_total = tElapsed; r->status_fwd = status; r->n_bisect_fail_fwd = nfail;
+      }
+      else
+      {
+         r->n_rev = nOut; r->steps_rev = nPts - 1; r->t_rev = tElapsed;
+         r->status_rev = (r->status_rev & BATOTP_ST_SEG_ERROR) | status; r->n_bisect_fail_rev = nfail;
+      }
+   }
+}
+
+} // namespace bk

@@ -44,7 +44,7 @@ def _run(ctx, prob, ys, sres, cap):
 
 
 @pytest.mark.parametrize("seed", range(6 * _SCALE))
-@pytest.mark.parametrize("lanes", [0, 8, "flat0", "flat4", 4, 2, "g4flat0", "g4flat8", "g2flat3"])
+@pytest.mark.parametrize("lanes", [0, 8, "flat0", "flat4", 4, 2, "g4flat0", "g4flat8", "g2flat3", 64])
 def test_random_velocity_acceleration_problems(hip_lib, oracle_ctx, seed, lanes):
     rng = np.random.default_rng(1000 + seed)
     nJ = int(rng.integers(1, 9))

@@ -146,7 +146,7 @@ def _vel_acc_only(name):
     return name in helpers.FULL_CASES and not (f & (capi.F_TRQ_ON | capi.F_CART_VEL_ON | capi.F_CART_ACC_ON))
 
 
-@pytest.mark.parametrize("lanes", [0, 1, 2, 4, 8, 16, 32])
+@pytest.mark.parametrize("lanes", [0, 1, 2, 4, 8, 16, 32, 64])
 def test_compact_splines_give_identical_results(hip_lib, oracle_ctx, lanes):
     """BATOTP_F_COMPACT_SPLINES (value + second derivative per knot instead of four coefficients): every
     published quantity is bit-identical to the oracle's, for every lane grouping of the sweep"""
@@ -172,7 +172,7 @@ def test_hip_baseline_size_paths(hip_ctx, oracle_ctx, name):
     assert_matches_reference(case, ho)
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 32, "flat4", "g4flat4", "g2flat5"])
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 32, 64, "flat4", "g4flat4", "g2flat5"])
 def test_other_lane_groupings_agree(hip_lib, oracle_ctx, lanes):
     """the sweep kernel with 1 or 16 lanes per path publishes the same bits as the default 8"""
     ctx = capi.Context(hip_lib, 0)
