@@ -18,12 +18,21 @@ namespace bk
 {
 
 constexpr int S1_BLOCK = 256;
+constexpr int S1_WK = 64;   // knots per spline window (compact splines: 64 x nJ x 16 B <= 8 KB per path)
+constexpr int S1_WM = 256;  // points per reverse-curve window (4 KB per path)
 
 // FEAT: -1 = compact splines ((value, second derivative) pairs), 0 = coefficient rows.  DIR: -1 reverse, +1 forward.
 template <int FEAT, int DIR>
 __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
 {
    __shared__ double lim[6][8];
+   // Sliding windows in LDS, one per wavefront (= per path): the (value, second derivative) pairs of S1_WK consecutive knots
+   // and, for the forward sweep, S1_WM consecutive points of the reverse curve.  Both cursors move monotonically (up to the
+   // small back-steps of the predictor), so a window is refilled once per ~S1_WK knots by one coalesced copy -- one memory
+   // round trip -- and a segment change reads LDS instead of waiting for a dependent HBM / L2 access (a third of the cycles
+   // of a lone wavefront were s_waitcnt: profiles/r02_c_*).
+   __shared__ double2 winKAll[S1_BLOCK / 64][S1_WK * BATOTP_MAX_JOINTS];
+   __shared__ double2 winMAll[(DIR == 1) ? S1_BLOCK / 64 : 1][(DIR == 1) ? S1_WM : 1];
    stage_limits(a.dP, lim);
    const int lane = threadIdx.x & 63;
    const int p = blockIdx.x * (S1_BLOCK / 64) + (threadIdx.x >> 6);
@@ -81,6 +90,67 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    unsigned status = 0;
    int nfail = 0;
 
+   double2 *winK = winKAll[threadIdx.x >> 6];
+   double2 *winM = winMAll[(DIR == 1) ? (threadIdx.x >> 6) : 0];
+   int wK0 = 0, wKn = 0; // knots [wK0, wK0 + wKn) are in winK
+   int wM0 = 0, wMn = 0; // curve points [wM0, wM0 + wMn) are in winM
+
+   // make knots seg and seg + 1 available in winK: a coalesced copy of the window that extends from seg in the direction of travel
+   auto needK = [&](int seg) {
+      if (seg >= wK0 && seg + 1 < wK0 + wKn) return;
+      int w = (DIR == 1) ? seg : seg + 2 - S1_WK;
+      const int wmax = n - S1_WK;
+      w = w > wmax ? wmax : w;
+      w = w < 0 ? 0 : w;
+      const int cntK = (n - w) < S1_WK ? (n - w) : S1_WK;
+      const int cnt = cntK * nIn;
+      const double2 *__restrict__ src = km + (unsigned)(w * nIn);
+      double2 tmp[S1_WK * BATOTP_MAX_JOINTS / 32];
+#pragma unroll
+      for (int t = 0; t < S1_WK * BATOTP_MAX_JOINTS / 32; ++t)
+      {
+         const int e = lane + 32 * t;
+         if (e < cnt) tmp[t] = src[e];
+      }
+#pragma unroll
+      for (int t = 0; t < S1_WK * BATOTP_MAX_JOINTS / 32; ++t)
+      {
+         const int e = lane + 32 * t;
+         if (e < cnt) winK[e] = tmp[t];
+      }
+      wK0 = w; wKn = cntK;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+   };
+   // the same for points k and k + 1 of the reverse curve (a few points behind k stay in the window for the back-steps)
+   auto needM = [&](int k) {
+      if (k >= wM0 && k + 1 < wM0 + wMn) return;
+      int w = k - 16;
+      const int wmax = nMvc - S1_WM;
+      w = w > wmax ? wmax : w;
+      w = w < 0 ? 0 : w;
+      const int cnt = (nMvc - w) < S1_WM ? (nMvc - w) : S1_WM;
+      const double2 *__restrict__ src = reinterpret_cast<const double2 *>(mvc) + w;
+      double2 tmp[S1_WM / 32];
+#pragma unroll
+      for (int t = 0; t < S1_WM / 32; ++t)
+      {
+         const int e = lane + 32 * t;
+         if (e < cnt) tmp[t] = src[e];
+      }
+#pragma unroll
+      for (int t = 0; t < S1_WM / 32; ++t)
+      {
+         const int e = lane + 32 * t;
+         if (e < cnt) winM[e] = tmp[t];
+      }
+      wM0 = w; wMn = cnt;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+   };
+
    // BA::updateCurSeg on the knot sites (ba.cpp:1617-1652): the literal walk, sites sres*k recomputed only when the cursor moves
    auto walkC = [&](double sCur) {
       const int lastSeg = n - 2;
@@ -113,8 +183,9 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
          double k3, k2, k1;
          if (FEAT < 0)
          {
-            const unsigned at = (unsigned)(segC * nIn + jr);
-            const double2 kl = km[at], kr = km[at + nIn]; // knots segC and segC + 1 of this joint
+            needK(segC);
+            const int at = (segC - wK0) * nIn + jr;
+            const double2 kl = winK[at], kr = winK[at + nIn]; // knots segC and segC + 1 of this joint
             k3 = div6(kr.y - kl.y);                        // spline.cpp:203-209
             k2 = kl.y / 2.0;
             k1 = kr.x - kl.x - div6(kr.y + 2 * kl.y);
@@ -135,16 +206,36 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       thD2 = (A6 * tau + B2) * afact;            // (6*c3*tau + 2*c2)*aFact, ba.cpp:1360
    };
 
-   // BA::updateCurSeg on the reverse curve with the segment's two points cached (ba.cpp:1592)
+   // BA::updateCurSeg on the reverse curve (ba.cpp:1592, 1617-1652) with the segment's two points cached in registers and
+   // the sites read from the LDS window: the literal walk of update_cur_seg<2>
    auto mvcWalk = [&](double sCur) {
       if (mvcSeg == segMVC && sCur >= mS0 && sCur <= mS1)
       {
          tauMVC = (sCur - mS0) / (mS1 - mS0);
          return;
       }
-      update_cur_seg<2>(mvc, 0.0, nMvc, sCur, segMVC, tauMVC, status);
-      const double2 pa = *reinterpret_cast<const double2 *>(mvc + 2 * segMVC);
-      const double2 pb = *reinterpret_cast<const double2 *>(mvc + 2 * segMVC + 2);
+      const int lastSeg = nMvc - 2;
+      double2 pa, pb;
+      for (;;)
+      {
+         needM(segMVC);
+         pa = winM[segMVC - wM0];
+         pb = winM[segMVC + 1 - wM0];
+         if (sCur >= pa.x && sCur <= pb.x) break;
+         bool moved = false;
+         if (sCur > pa.x)
+         {
+            if (segMVC >= lastSeg) { segMVC = lastSeg; break; }
+            ++segMVC; moved = true;
+         }
+         if (sCur < pa.x)
+         {
+            if (segMVC <= 0) { segMVC = 0; break; }
+            --segMVC; moved = true;
+         }
+         if (!moved) { status |= BATOTP_ST_NONFINITE; break; }
+      }
+      tauMVC = (sCur - pa.x) / (pb.x - pa.x);
       mS0 = pa.x; mD0 = pa.y; mS1 = pb.x; mD1 = pb.y;
       mvcSeg = segMVC;
    };
