@@ -89,6 +89,10 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    double sdotMin = 0, sdotCur = 0, sddotH = 0, sddotL = 0;
    unsigned status = 0;
    int nfail = 0;
+#ifdef BK_PROFILE_SECTIONS
+   // diagnostic build: cycles in velocity limit / spline evaluation / first check / bisection passes, stages that bisect, passes
+   unsigned long long cyA = 0, cyB = 0, cyC = 0, cyD = 0, nBis = 0, nPass = 0, nStage = 0;
+#endif
 
    double2 *winK = winKAll[threadIdx.x >> 6];
    double2 *winM = winMAll[(DIR == 1) ? (threadIdx.x >> 6) : 0];
@@ -293,29 +297,46 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    auto accelPt = [&](double sCur, double &sddot) {
       const double sdotErrThresh = .001;
       double lowFact = .01;
-      double sdotGood = 0, sdotGoodLast;
-      bool anyGoodIter = false;
+      double sdotGood = 0;
       double sdotL = 0;
       double sdotH = sdotCur;
       double sdotTry = sdotH;
       int nIter = 0;
+      BK_TICK(tp0);
       evalPartials(sCur); // ba.cpp:1265
+      BK_TICK(tp1);
+      BK_ACC(cyB, tp0, tp1);
 
       // the common case first: the speed the velocity limits left is admissible (three quarters of the stages)
-      if (!verify(sdotTry))
+      const bool firstViol = verify(sdotTry);
+      BK_TICK(tp2);
+      BK_ACC(cyC, tp1, tp2);
+#ifdef BK_PROFILE_SECTIONS
+      ++nStage;
+#endif
+      if (!firstViol)
       {
          sddot = (DIR == 1) ? sddotH : sddotL;
          return;
       }
+#ifdef BK_PROFILE_SECTIONS
+      ++nBis;
+#endif
       // first check violated: replay of ba.cpp:1276-1321 from its first iteration, four candidates per pass.  The check of
       // the first candidate has just been done: it is folded into the first pass below (slot 0 re-evaluates it, same bits).
-      int rc = 0, lastSlot = 0;
-      bool finished = false;
-      while (!finished)
+      // One replayed iteration is written as selects (the form of the flat loop in k_sweep: no divergent branches around the few
+      // operations of the update); the loop conditions are wavefront-uniform and made scalar with readfirstlane.
+      int lastSlot = 0;
+      int nGood = 0; // feasible points seen (anyGoodIter of ba.cpp:1254 == nGood > 0)
+      bool fin = false, failed = false;
+      while (!(fin || failed))
       {
+#ifdef BK_PROFILE_SECTIONS
+         ++nPass;
+#endif
          const double c0 = sdotTry;
          double cand1, cand2, cand3;
-         if (!anyGoodIter)
+         if (nGood == 0)
          {
             double lf = lowFact * 2.0;
             cand1 = .5 * (c0 + dmax(.999 * 0.0, (1.0 - lf) * c0));
@@ -332,51 +353,44 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
          }
          const double mine = (cslot == 0) ? c0 : (cslot == 1) ? cand1 : (cslot == 2) ? cand2 : cand3;
          const bool violMine = verify(mine); // this slot's sddotL / sddotH stay in its lanes
-         const unsigned long long ballot = __ballot(violMine);
+         const unsigned ballot = (unsigned)__ballot(violMine);
 
          int k = 0;
+#pragma unroll 1
          for (int consumed = 0; consumed < 4; ++consumed)
          {
-            const bool isViol = (ballot >> (8 * k)) & 1ull;
+            const bool isViol = (ballot >> (8 * k)) & 1u;
             lastSlot = k;
-            if (isViol)
-            {
-               sdotH = sdotTry;
-               if (!anyGoodIter)
-               {
-                  lowFact *= 2.0;
-                  sdotL = dmax(.999 * 0.0, (1.0 - lowFact) * sdotH);
-               }
-            }
-            else
-            {
-               if (nIter == 0) { finished = true; break; }
-               anyGoodIter = true;
-               sdotGoodLast = sdotGood;
-               sdotGood = sdotTry;
-               if (ratio_lt(fabs(sdotGood - sdotGoodLast), sdotGood, sdotErrThresh) || sdotTry < 0.0)
-               {
-                  sdotCur = sdotTry;
-                  finished = true;
-                  break;
-               }
-               sdotL = sdotTry;
-            }
-            nIter++;
-            if (nIter > 100) { rc = -1; finished = true; break; }
-            if (sdotTry < 0) { rc = -1; finished = true; break; }
-            if (!anyGoodIter)
-            {
-               if (ratio_lt(sdotH - sdotL, sdotH, 1e-20)) { rc = -1; finished = true; break; }
-            }
-            sdotTry = .5 * (sdotH + sdotL);
-            if (sdotTry == cand1) k = 1;
-            else if (sdotTry == cand2) k = 2;
-            else if (sdotTry == cand3 && !anyGoodIter) k = 3;
-            else break;
+            const bool first = (nIter == 0);
+            const bool good = !isViol && !first;      // a feasible point after at least one violated one
+            const bool shrink = isViol && nGood == 0; // ba.cpp:1281-1285: no feasible point known yet
+            const double lowFact2 = lowFact * 2.0;
+            const double sdotLShrunk = dmax(.999 * 0.0, (1.0 - lowFact2) * sdotTry);
+            // ba.cpp:1294-1303: two successive feasible points closer than 1e-3 (relative), or a negative one
+            const bool conv = good && (ratio_lt(fabs(sdotTry - sdotGood), sdotTry, sdotErrThresh) || sdotTry < 0.0);
+            fin = (!isViol && first) || conv;
+            lowFact = shrink ? lowFact2 : lowFact;
+            sdotH = isViol ? sdotTry : sdotH;
+            sdotL = shrink ? sdotLShrunk : ((good && !conv) ? sdotTry : sdotL);
+            sdotGood = good ? sdotTry : sdotGood;
+            nGood += good ? 1 : 0;
+            sdotCur = conv ? sdotTry : sdotCur;
+            // ba.cpp:1305-1320
+            const bool collapsed = (nGood == 0) && ratio_lt(sdotH - sdotL, sdotH, 1e-20);
+            failed = !fin && (nIter + 1 > 100 || sdotTry < 0.0 || collapsed);
+            nIter += fin ? 0 : 1;
+            const bool stop = fin || failed;
+            sdotTry = stop ? sdotTry : .5 * (sdotH + sdotL);
+            // was the next value evaluated in this pass?
+            k = (sdotTry == cand1) ? 1 : (sdotTry == cand2) ? 2 : (sdotTry == cand3 && nGood == 0) ? 3 : -1;
+            if (__builtin_amdgcn_readfirstlane((int)(stop || k < 0))) break;
          }
+         fin = __builtin_amdgcn_readfirstlane((int)fin) != 0;
+         failed = __builtin_amdgcn_readfirstlane((int)failed) != 0;
       }
-      if (rc != 0)
+      BK_TICK(tp3);
+      BK_ACC(cyD, tp2, tp3);
+      if (failed)
       {
          status |= BATOTP_ST_BISECT_FAIL;
          nfail++;
@@ -417,7 +431,10 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       double vN = v0 + h * (SDDOT);                                       \
       vN = dmax(vN, floorV);                                              \
       sCur = sN;                                                          \
+      BK_TICK(ta0);                                                       \
       sdotLim(sN, vN);                                                    \
+      BK_TICK(ta1);                                                       \
+      BK_ACC(cyA, ta0, ta1);                                              \
       sdotCur = vN;                                                       \
       double wN = WST; /* kept when the bisection fails, ba.cpp:1091 */   \
       accelPt(sN, wN);                                                    \
@@ -428,11 +445,15 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    int64_t nPts = 0, i = 1;
    unsigned endStatus = 0;
    bool done = false;
+#ifdef BK_PROFILE_SECTIONS
+   const unsigned long long tstart = __builtin_readcyclecounter();
+#endif
    while (!done)
    {
       if (i >= cap) { endStatus = BATOTP_ST_CAPACITY; break; }
       if (DIR == 1) mvcWalk(s0v + h * v0); // Euler predictor, ba.cpp:1055-1065: only the move of the reverse-curve cursor survives
 
+#ifndef S1_ROLLED
       S1_STAGE(BK_B00 * v0, BK_B00 * w0, v1, w1)
       S1_STAGE(BK_B01 * v0 + BK_B11 * v1, BK_B01 * w0 + BK_B11 * w1, v2, w2)
       S1_STAGE(BK_B02 * v0 + BK_B12 * v1 + BK_B22 * v2, BK_B02 * w0 + BK_B12 * w1 + BK_B22 * w2, v3, w3)
@@ -441,6 +462,36 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
                BK_B04 * w0 + BK_B14 * w1 + BK_B24 * w2 + BK_B34 * w3 + BK_B44 * w4, v5, w5)
       S1_STAGE(BK_B05 * v0 + BK_B15 * v1 + BK_B25 * v2 + BK_B35 * v3 + BK_B45 * v4 + BK_B55 * v5,
                BK_B05 * w0 + BK_B15 * w1 + BK_B25 * w2 + BK_B35 * w3 + BK_B45 * w4 + BK_B55 * w5, v6, w6)
+#else
+      // experiment: one copy of the stage body (code size / instruction cache)
+#pragma unroll 1
+      for (int st = 1; st < 7; ++st)
+      {
+         double sdotT, sddotT, wS;
+         switch (st)
+         {
+         case 1: sdotT = BK_B00 * v0; sddotT = BK_B00 * w0; wS = w1; break;
+         case 2: sdotT = BK_B01 * v0 + BK_B11 * v1; sddotT = BK_B01 * w0 + BK_B11 * w1; wS = w2; break;
+         case 3: sdotT = BK_B02 * v0 + BK_B12 * v1 + BK_B22 * v2; sddotT = BK_B02 * w0 + BK_B12 * w1 + BK_B22 * w2; wS = w3; break;
+         case 4: sdotT = BK_B03 * v0 + BK_B13 * v1 + BK_B23 * v2 + BK_B33 * v3; sddotT = BK_B03 * w0 + BK_B13 * w1 + BK_B23 * w2 + BK_B33 * w3; wS = w4; break;
+         case 5: sdotT = BK_B04 * v0 + BK_B14 * v1 + BK_B24 * v2 + BK_B34 * v3 + BK_B44 * v4;
+                 sddotT = BK_B04 * w0 + BK_B14 * w1 + BK_B24 * w2 + BK_B34 * w3 + BK_B44 * w4; wS = w5; break;
+         default: sdotT = BK_B05 * v0 + BK_B15 * v1 + BK_B25 * v2 + BK_B35 * v3 + BK_B45 * v4 + BK_B55 * v5;
+                  sddotT = BK_B05 * w0 + BK_B15 * w1 + BK_B25 * w2 + BK_B35 * w3 + BK_B45 * w4 + BK_B55 * w5; wS = w6; break;
+         }
+         double vS = 0;
+         S1_STAGE(sdotT, sddotT, vS, wS)
+         switch (st)
+         {
+         case 1: v1 = vS; w1 = wS; break;
+         case 2: v2 = vS; w2 = wS; break;
+         case 3: v3 = vS; w3 = wS; break;
+         case 4: v4 = vS; w4 = wS; break;
+         case 5: v5 = vS; w5 = wS; break;
+         default: v6 = vS; w6 = wS; break;
+         }
+      }
+#endif
       s6v = sCur;
 
       // FSAL shift and publish, ba.cpp:1096-1100
@@ -454,6 +505,15 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       else ++i;
    }
 #undef S1_STAGE
+#ifdef BK_PROFILE_SECTIONS
+   if (writer)
+   {
+      const unsigned long long tend = __builtin_readcyclecounter();
+      double *q = a.prof + 8 * p;
+      q[0] = (double)cyA; q[1] = (double)cyB; q[2] = (double)cyC; q[3] = (double)cyD; q[4] = (double)(tend - tstart);
+      q[5] = (double)nStage; q[6] = (double)nBis; q[7] = (double)nPass;
+   }
+#endif
 
    status |= endStatus;
    if (endStatus != 0)

@@ -12,9 +12,10 @@ ap.add_argument("--knots", type=int, default=100000); ap.add_argument("--distinc
 ap.add_argument("--reps", type=int, default=1); ap.add_argument("--group", type=int, default=0)
 ap.add_argument("--ppw", type=int, default=0)
 ap.add_argument("--coefficient-rows", action="store_true")
+ap.add_argument("--lib", default=None, help="alternative build of the library (experiments)")
 ap.add_argument("--hold", type=int, nargs=2, default=None, help="sweep loop form, reverse forward (batotp_hip_set_sweep_hold)")
 a = ap.parse_args()
-hip = capi.Context(capi.load_hip(), 0)
+hip = capi.Context(capi.Library(a.lib) if a.lib else capi.load_hip(), 0)
 hip.set_sweep_group(a.group)
 if a.ppw and hasattr(hip, "set_paths_per_wave"):
     hip.set_paths_per_wave(a.ppw)
