@@ -17,6 +17,20 @@
 namespace bk
 {
 
+// ratio_lt (kernels.hip.h) for values that are the same in every lane of the wavefront: (num / den) < thr decided exactly as
+// the correctly rounded division would decide it; the division itself is only performed -- behind a scalar branch -- when
+// num / den lies within 1e-14 (relative) of the threshold or the shortcut's preconditions do not hold
+__device__ __forceinline__ bool ratio_lt_uniform(double num, double den, double thr)
+{
+   const double p = thr * den;
+   const bool pre = den > 0.0 && num >= 0.0 && p > 1e-290 && p < 1e290;
+   const bool sureLess = pre && num < p * (1.0 - 1e-14);
+   const bool sureNotLess = pre && num > p * (1.0 + 1e-14);
+   bool res = sureLess;
+   if (__builtin_amdgcn_readfirstlane((int)!(sureLess || sureNotLess))) res = num / den < thr;
+   return res;
+}
+
 constexpr int S1_BLOCK = 256;
 constexpr int S1_WK = 64;   // knots per spline window (compact splines: 64 x nJ x 16 B <= 8 KB per path)
 constexpr int S1_WM = 256;  // points per reverse-curve window (4 KB per path)
@@ -329,7 +343,34 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       int lastSlot = 0;
       int nGood = 0; // feasible points seen (anyGoodIter of ba.cpp:1254 == nGood > 0)
       bool fin = false, failed = false;
-      while (!(fin || failed))
+      // one iteration of the loop of ba.cpp:1267-1321 given the outcome of the check of sdotTry; leaves the next value to check
+      // in sdotTry; returns true when the loop has ended (fin or failed)
+      auto iterate = [&](bool isViol) -> bool {
+         const bool first = (nIter == 0);
+         const bool good = !isViol && !first;      // a feasible point after at least one violated one
+         const bool shrink = isViol && nGood == 0; // ba.cpp:1281-1285: no feasible point known yet
+         const double lowFact2 = lowFact * 2.0;
+         const double sdotLShrunk = dmax(.999 * 0.0, (1.0 - lowFact2) * sdotTry);
+         // ba.cpp:1294-1303: two successive feasible points closer than 1e-3 (relative), or a negative one
+         const bool conv = good && (ratio_lt_uniform(fabs(sdotTry - sdotGood), sdotTry, sdotErrThresh) || sdotTry < 0.0);
+         fin = (!isViol && first) || conv;
+         lowFact = shrink ? lowFact2 : lowFact;
+         sdotH = isViol ? sdotTry : sdotH;
+         sdotL = shrink ? sdotLShrunk : ((good && !conv) ? sdotTry : sdotL);
+         sdotGood = good ? sdotTry : sdotGood;
+         nGood += good ? 1 : 0;
+         sdotCur = conv ? sdotTry : sdotCur;
+         // ba.cpp:1305-1320
+         const bool collapsed = (nGood == 0) && ratio_lt_uniform(sdotH - sdotL, sdotH, 1e-20);
+         failed = !fin && (nIter + 1 > 100 || sdotTry < 0.0 || collapsed);
+         nIter += fin ? 0 : 1;
+         const bool stop = fin || failed;
+         sdotTry = stop ? sdotTry : .5 * (sdotH + sdotL);
+         return stop;
+      };
+      // the first check (violated) is the loop's first iteration; the passes below start with its successor
+      bool over = __builtin_amdgcn_readfirstlane((int)iterate(true)) != 0;
+      while (!over)
       {
 #ifdef BK_PROFILE_SECTIONS
          ++nPass;
@@ -359,35 +400,16 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
 #pragma unroll 1
          for (int consumed = 0; consumed < 4; ++consumed)
          {
-            const bool isViol = (ballot >> (8 * k)) & 1u;
             lastSlot = k;
-            const bool first = (nIter == 0);
-            const bool good = !isViol && !first;      // a feasible point after at least one violated one
-            const bool shrink = isViol && nGood == 0; // ba.cpp:1281-1285: no feasible point known yet
-            const double lowFact2 = lowFact * 2.0;
-            const double sdotLShrunk = dmax(.999 * 0.0, (1.0 - lowFact2) * sdotTry);
-            // ba.cpp:1294-1303: two successive feasible points closer than 1e-3 (relative), or a negative one
-            const bool conv = good && (ratio_lt(fabs(sdotTry - sdotGood), sdotTry, sdotErrThresh) || sdotTry < 0.0);
-            fin = (!isViol && first) || conv;
-            lowFact = shrink ? lowFact2 : lowFact;
-            sdotH = isViol ? sdotTry : sdotH;
-            sdotL = shrink ? sdotLShrunk : ((good && !conv) ? sdotTry : sdotL);
-            sdotGood = good ? sdotTry : sdotGood;
-            nGood += good ? 1 : 0;
-            sdotCur = conv ? sdotTry : sdotCur;
-            // ba.cpp:1305-1320
-            const bool collapsed = (nGood == 0) && ratio_lt(sdotH - sdotL, sdotH, 1e-20);
-            failed = !fin && (nIter + 1 > 100 || sdotTry < 0.0 || collapsed);
-            nIter += fin ? 0 : 1;
-            const bool stop = fin || failed;
-            sdotTry = stop ? sdotTry : .5 * (sdotH + sdotL);
+            const bool stop = iterate((ballot >> (8 * k)) & 1u);
             // was the next value evaluated in this pass?
             k = (sdotTry == cand1) ? 1 : (sdotTry == cand2) ? 2 : (sdotTry == cand3 && nGood == 0) ? 3 : -1;
-            if (__builtin_amdgcn_readfirstlane((int)(stop || k < 0))) break;
+            over = __builtin_amdgcn_readfirstlane((int)stop) != 0;
+            if (over || __builtin_amdgcn_readfirstlane((int)(k < 0))) break;
          }
-         fin = __builtin_amdgcn_readfirstlane((int)fin) != 0;
-         failed = __builtin_amdgcn_readfirstlane((int)failed) != 0;
       }
+      fin = __builtin_amdgcn_readfirstlane((int)fin) != 0;
+      failed = !fin;
       BK_TICK(tp3);
       BK_ACC(cyD, tp2, tp3);
       if (failed)
