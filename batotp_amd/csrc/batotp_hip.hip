@@ -923,7 +923,10 @@ static void launchSweep(batotp_batch *b, SweepArgs &a)
 // the one-path-per-wavefront kernel of sweep1.hip.h: joint velocity / acceleration limits only, uniform knot sites
 static bool sweep1Applies(const batotp_batch *b)
 {
-   if (featureLevel(b) > 0) return false;
+   const int f = featureLevel(b);
+   // joint velocity / acceleration limits, and the torque limits of a serial robot (no Cartesian family, no cable robot)
+   const bool serialTorque = f == 2 && !(b->prob.flags & (BATOTP_F_CART_VEL_ON | BATOTP_F_CART_ACC_ON | BATOTP_F_PARALLEL));
+   if (f > 0 && !serialTorque) return false;
    for (int p = 0; p < b->B; ++p)
       if (!b->pinfo[p].uniform) return false;
    return true;
@@ -934,7 +937,12 @@ static void launchSweep1(batotp_batch *b, SweepArgs &a)
    a.ppw = 1; a.hold = -1; a.touch = 0;
    const unsigned grid = (unsigned)((b->B + (S1_BLOCK / 64) - 1) / (S1_BLOCK / 64));
    hipStream_t st = b->ctx->stream;
-   if (b->compact)
+   if (featureLevel(b) == 2)
+   {
+      if (a.dir == 1) hipLaunchKernelGGL((k_sweep1<2, 1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
+      else hipLaunchKernelGGL((k_sweep1<2, -1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
+   }
+   else if (b->compact)
    {
       if (a.dir == 1) hipLaunchKernelGGL((k_sweep1<-1, 1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
       else hipLaunchKernelGGL((k_sweep1<-1, -1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);

@@ -35,7 +35,8 @@ constexpr int S1_BLOCK = 256;
 constexpr int S1_WK = 64;   // knots per spline window (compact splines: 64 x nJ x 16 B <= 8 KB per path)
 constexpr int S1_WM = 256;  // points per reverse-curve window (4 KB per path)
 
-// FEAT: -1 = compact splines ((value, second derivative) pairs), 0 = coefficient rows.  DIR: -1 reverse, +1 forward.
+// FEAT: -1 = compact splines ((value, second derivative) pairs), 0 = coefficient rows, 2 = coefficient rows + torque limits of a
+// serial robot (a1..a4 splines, ba.cpp:1387-1405, 1495-1509; BASELINE config 3).  DIR: -1 reverse, +1 forward.
 template <int FEAT, int DIR>
 __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
 {
@@ -69,6 +70,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    const double sdotCap = sEnd / absh;                 // ba.cpp:1216
    const double sddotMax = 2 * sEnd / (absh * absh);   // ba.cpp:1257
    const double vmaxj = lim[0][j], amaxj = lim[1][j];
+   const double tmaxj = lim[2][j], tminj = lim[3][j];
    const int64_t maxIntegSteps = (int64_t)floor(a.P.max_integ_time / absh) + 1;
 
    const double2 *__restrict__ km = (FEAT < 0) ? reinterpret_cast<const double2 *>(a.km) + pi.koff * nIn : nullptr;
@@ -98,6 +100,8 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    int rowSeg = -1;
    double A3 = 0, B2 = 0, A6 = 0, c1 = 0; // 3*c3, 2*c2, 6*c3, c1 of this lane's joint on segment rowSeg
    double thD = 0, thD2 = 0;              // theta', theta'' of this lane's joint at the last evaluated position
+   Coef4 dynK[(FEAT == 2) ? 4 : 1];       // FEAT == 2: coefficient rows of a1..a4 of this lane's dynamics row on segment rowSeg
+   double a1pt = 0, a2pt = 0, a3pt = 0, a4pt = 0;
    int segMVC = (DIR == 1) ? 0 : n - 2, mvcSeg = -1;
    double tauMVC = (DIR == 1) ? 0.0 : 1.0, mS0 = 0, mS1 = 0, mD0 = 0, mD1 = 0;
    double sdotMin = 0, sdotCur = 0, sddotH = 0, sddotL = 0;
@@ -210,8 +214,16 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
          }
          else
          {
-            const Coef4 k = *reinterpret_cast<const Coef4 *>(coef + (unsigned)(segC * C * 4) + jr * 4);
+            const double *__restrict__ row = coef + (unsigned)(segC * C * 4);
+            const Coef4 k = *reinterpret_cast<const Coef4 *>(row + jr * 4);
             k3 = k.c3; k2 = k.c2; k1 = k.c1;
+            if (FEAT == 2)
+            {
+               // device channel order: theta[nJ], cart[nC], then per dynamics row r the four channels (a1_r, a2_r, a3_r, a4_r)
+               const Coef4 *kd = reinterpret_cast<const Coef4 *>(row + (nIn + jr * 4) * 4);
+#pragma unroll
+               for (int q = 0; q < 4; ++q) dynK[(FEAT == 2) ? q : 0] = kd[q];
+            }
          }
          A3 = jv ? 3 * k3 : 0.0;
          B2 = jv ? 2 * k2 : 0.0;
@@ -222,6 +234,16 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       const double tau = tauC, tau2 = tau * tau;
       thD = (A3 * tau2 + B2 * tau + c1) * vfact; // (3*c3*tau2 + 2*c2*tau + c1)*vFact, ba.cpp:1359
       thD2 = (A6 * tau + B2) * afact;            // (6*c3*tau + 2*c2)*aFact, ba.cpp:1360
+      if (FEAT == 2)
+      {
+         // a1..a4 at the cursor, ba.cpp:1387-1405
+         const double tau3 = tau2 * tau;
+         const Coef4 q1 = dynK[0], q2 = dynK[(FEAT == 2) ? 1 : 0], q3 = dynK[(FEAT == 2) ? 2 : 0], q4 = dynK[(FEAT == 2) ? 3 : 0];
+         a1pt = q1.c3 * tau3 + q1.c2 * tau2 + q1.c1 * tau + q1.c0;
+         a2pt = q2.c3 * tau3 + q2.c2 * tau2 + q2.c1 * tau + q2.c0;
+         a3pt = q3.c3 * tau3 + q3.c2 * tau2 + q3.c1 * tau + q3.c0;
+         a4pt = q4.c3 * tau3 + q4.c2 * tau2 + q4.c1 * tau + q4.c0;
+      }
    };
 
    // BA::updateCurSeg on the reverse curve (ba.cpp:1592, 1617-1652) with the segment's two points cached in registers and
@@ -280,6 +302,19 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       const double sdotSQ = sdotTry * sdotTry;
       double H = sddotMax, L = -sddotMax;
       bool force = false;
+      if (FEAT == 2 && jv)
+      {
+         // torque limits of a serial robot, ba.cpp:1495-1509
+         const double tmp1 = a3pt * sdotTry + a4pt;
+         if (!(fabs(a1pt) < thrV))
+         {
+            const double tmp2 = a2pt * sdotSQ + tmp1;
+            const double s0 = (tmaxj - tmp2) / a1pt;
+            const double s1 = (tminj - tmp2) / a1pt;
+            H = dmin(H, dmax(s0, s1));
+            L = dmax(L, dmin(s0, s1));
+         }
+      }
       if (accOn && jv)
       {
          const double vpt = thD;
