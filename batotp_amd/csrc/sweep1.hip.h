@@ -32,8 +32,6 @@ __device__ __forceinline__ bool ratio_lt_uniform(double num, double den, double 
 }
 
 constexpr int S1_BLOCK = 256;
-constexpr int S1_WK = 64;   // knots per spline window (compact splines: 64 x nJ x 16 B <= 8 KB per path)
-constexpr int S1_WM = 256;  // points per reverse-curve window (4 KB per path)
 
 // FEAT: -1 = compact splines ((value, second derivative) pairs), 0 = coefficient rows, 2 = coefficient rows + torque limits of a
 // serial robot (a1..a4 splines, ba.cpp:1387-1405, 1495-1509; BASELINE config 3).  DIR: -1 reverse, +1 forward.
@@ -41,13 +39,6 @@ template <int FEAT, int DIR>
 __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
 {
    __shared__ double lim[6][8];
-   // Sliding windows in LDS, one per wavefront (= per path): the (value, second derivative) pairs of S1_WK consecutive knots
-   // and, for the forward sweep, S1_WM consecutive points of the reverse curve.  Both cursors move monotonically (up to the
-   // small back-steps of the predictor), so a window is refilled once per ~S1_WK knots by one coalesced copy -- one memory
-   // round trip -- and a segment change reads LDS instead of waiting for a dependent HBM / L2 access (a third of the cycles
-   // of a lone wavefront were s_waitcnt: profiles/r02_c_*).
-   __shared__ double2 winKAll[S1_BLOCK / 64][S1_WK * BATOTP_MAX_JOINTS];
-   __shared__ double2 winMAll[(DIR == 1) ? S1_BLOCK / 64 : 1][(DIR == 1) ? S1_WM : 1];
    stage_limits(a.dP, lim);
    const int lane = threadIdx.x & 63;
    const int p = blockIdx.x * (S1_BLOCK / 64) + (threadIdx.x >> 6);
@@ -112,67 +103,6 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    unsigned long long cyA = 0, cyB = 0, cyC = 0, cyD = 0, nBis = 0, nPass = 0, nStage = 0;
 #endif
 
-   double2 *winK = winKAll[threadIdx.x >> 6];
-   double2 *winM = winMAll[(DIR == 1) ? (threadIdx.x >> 6) : 0];
-   int wK0 = 0, wKn = 0; // knots [wK0, wK0 + wKn) are in winK
-   int wM0 = 0, wMn = 0; // curve points [wM0, wM0 + wMn) are in winM
-
-   // make knots seg and seg + 1 available in winK: a coalesced copy of the window that extends from seg in the direction of travel
-   auto needK = [&](int seg) {
-      if (seg >= wK0 && seg + 1 < wK0 + wKn) return;
-      int w = (DIR == 1) ? seg : seg + 2 - S1_WK;
-      const int wmax = n - S1_WK;
-      w = w > wmax ? wmax : w;
-      w = w < 0 ? 0 : w;
-      const int cntK = (n - w) < S1_WK ? (n - w) : S1_WK;
-      const int cnt = cntK * nIn;
-      const double2 *__restrict__ src = km + (unsigned)(w * nIn);
-      double2 tmp[S1_WK * BATOTP_MAX_JOINTS / 32];
-#pragma unroll
-      for (int t = 0; t < S1_WK * BATOTP_MAX_JOINTS / 32; ++t)
-      {
-         const int e = lane + 32 * t;
-         if (e < cnt) tmp[t] = src[e];
-      }
-#pragma unroll
-      for (int t = 0; t < S1_WK * BATOTP_MAX_JOINTS / 32; ++t)
-      {
-         const int e = lane + 32 * t;
-         if (e < cnt) winK[e] = tmp[t];
-      }
-      wK0 = w; wKn = cntK;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-   };
-   // the same for points k and k + 1 of the reverse curve (a few points behind k stay in the window for the back-steps)
-   auto needM = [&](int k) {
-      if (k >= wM0 && k + 1 < wM0 + wMn) return;
-      int w = k - 16;
-      const int wmax = nMvc - S1_WM;
-      w = w > wmax ? wmax : w;
-      w = w < 0 ? 0 : w;
-      const int cnt = (nMvc - w) < S1_WM ? (nMvc - w) : S1_WM;
-      const double2 *__restrict__ src = reinterpret_cast<const double2 *>(mvc) + w;
-      double2 tmp[S1_WM / 32];
-#pragma unroll
-      for (int t = 0; t < S1_WM / 32; ++t)
-      {
-         const int e = lane + 32 * t;
-         if (e < cnt) tmp[t] = src[e];
-      }
-#pragma unroll
-      for (int t = 0; t < S1_WM / 32; ++t)
-      {
-         const int e = lane + 32 * t;
-         if (e < cnt) winM[e] = tmp[t];
-      }
-      wM0 = w; wMn = cnt;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-   };
-
    // BA::updateCurSeg on the knot sites (ba.cpp:1617-1652): the literal walk, sites sres*k recomputed only when the cursor moves
    auto walkC = [&](double sCur) {
       const int lastSeg = n - 2;
@@ -205,9 +135,8 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
          double k3, k2, k1;
          if (FEAT < 0)
          {
-            needK(segC);
-            const int at = (segC - wK0) * nIn + jr;
-            const double2 kl = winK[at], kr = winK[at + nIn]; // knots segC and segC + 1 of this joint
+            const unsigned at = (unsigned)(segC * nIn + jr);
+            const double2 kl = km[at], kr = km[at + nIn]; // knots segC and segC + 1 of this joint
             k3 = div6(kr.y - kl.y);                        // spline.cpp:203-209
             k2 = kl.y / 2.0;
             k1 = kr.x - kl.x - div6(kr.y + 2 * kl.y);
@@ -246,8 +175,8 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       }
    };
 
-   // BA::updateCurSeg on the reverse curve (ba.cpp:1592, 1617-1652) with the segment's two points cached in registers and
-   // the sites read from the LDS window: the literal walk of update_cur_seg<2>
+   // BA::updateCurSeg on the reverse curve (ba.cpp:1592, 1617-1652) with the segment's two points cached in registers:
+   // the literal walk of update_cur_seg<2>
    auto mvcWalk = [&](double sCur) {
       if (mvcSeg == segMVC && sCur >= mS0 && sCur <= mS1)
       {
@@ -258,9 +187,9 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       double2 pa, pb;
       for (;;)
       {
-         needM(segMVC);
-         pa = winM[segMVC - wM0];
-         pb = winM[segMVC + 1 - wM0];
+         const double2 *__restrict__ pm = reinterpret_cast<const double2 *>(mvc) + segMVC;
+         pa = pm[0];
+         pb = pm[1];
          if (sCur >= pa.x && sCur <= pb.x) break;
          bool moved = false;
          if (sCur > pa.x)
@@ -510,7 +439,6 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       if (i >= cap) { endStatus = BATOTP_ST_CAPACITY; break; }
       if (DIR == 1) mvcWalk(s0v + h * v0); // Euler predictor, ba.cpp:1055-1065: only the move of the reverse-curve cursor survives
 
-#ifndef S1_ROLLED
       S1_STAGE(BK_B00 * v0, BK_B00 * w0, v1, w1)
       S1_STAGE(BK_B01 * v0 + BK_B11 * v1, BK_B01 * w0 + BK_B11 * w1, v2, w2)
       S1_STAGE(BK_B02 * v0 + BK_B12 * v1 + BK_B22 * v2, BK_B02 * w0 + BK_B12 * w1 + BK_B22 * w2, v3, w3)
@@ -519,36 +447,6 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
                BK_B04 * w0 + BK_B14 * w1 + BK_B24 * w2 + BK_B34 * w3 + BK_B44 * w4, v5, w5)
       S1_STAGE(BK_B05 * v0 + BK_B15 * v1 + BK_B25 * v2 + BK_B35 * v3 + BK_B45 * v4 + BK_B55 * v5,
                BK_B05 * w0 + BK_B15 * w1 + BK_B25 * w2 + BK_B35 * w3 + BK_B45 * w4 + BK_B55 * w5, v6, w6)
-#else
-      // experiment: one copy of the stage body (code size / instruction cache)
-#pragma unroll 1
-      for (int st = 1; st < 7; ++st)
-      {
-         double sdotT, sddotT, wS;
-         switch (st)
-         {
-         case 1: sdotT = BK_B00 * v0; sddotT = BK_B00 * w0; wS = w1; break;
-         case 2: sdotT = BK_B01 * v0 + BK_B11 * v1; sddotT = BK_B01 * w0 + BK_B11 * w1; wS = w2; break;
-         case 3: sdotT = BK_B02 * v0 + BK_B12 * v1 + BK_B22 * v2; sddotT = BK_B02 * w0 + BK_B12 * w1 + BK_B22 * w2; wS = w3; break;
-         case 4: sdotT = BK_B03 * v0 + BK_B13 * v1 + BK_B23 * v2 + BK_B33 * v3; sddotT = BK_B03 * w0 + BK_B13 * w1 + BK_B23 * w2 + BK_B33 * w3; wS = w4; break;
-         case 5: sdotT = BK_B04 * v0 + BK_B14 * v1 + BK_B24 * v2 + BK_B34 * v3 + BK_B44 * v4;
-                 sddotT = BK_B04 * w0 + BK_B14 * w1 + BK_B24 * w2 + BK_B34 * w3 + BK_B44 * w4; wS = w5; break;
-         default: sdotT = BK_B05 * v0 + BK_B15 * v1 + BK_B25 * v2 + BK_B35 * v3 + BK_B45 * v4 + BK_B55 * v5;
-                  sddotT = BK_B05 * w0 + BK_B15 * w1 + BK_B25 * w2 + BK_B35 * w3 + BK_B45 * w4 + BK_B55 * w5; wS = w6; break;
-         }
-         double vS = 0;
-         S1_STAGE(sdotT, sddotT, vS, wS)
-         switch (st)
-         {
-         case 1: v1 = vS; w1 = wS; break;
-         case 2: v2 = vS; w2 = wS; break;
-         case 3: v3 = vS; w3 = wS; break;
-         case 4: v4 = vS; w4 = wS; break;
-         case 5: v5 = vS; w5 = wS; break;
-         default: v6 = vS; w6 = wS; break;
-         }
-      }
-#endif
       s6v = sCur;
 
       // FSAL shift and publish, ba.cpp:1096-1100
