@@ -32,6 +32,8 @@ __device__ __forceinline__ bool ratio_lt_uniform(double num, double den, double 
 }
 
 constexpr int S1_BLOCK = 256;
+constexpr int S1_WK = 64;   // knots per spline window (compact splines: 64 knots x 8 joint slots x 16 B = 8 KB per path)
+constexpr int S1_WM = 256;  // points per reverse-curve window (4 KB per path)
 
 // FEAT: -1 = compact splines ((value, second derivative) pairs), 0 = coefficient rows, 2 = coefficient rows + torque limits of a
 // serial robot (a1..a4 splines, ba.cpp:1387-1405, 1495-1509; BASELINE config 3).  DIR: -1 reverse, +1 forward.
@@ -39,6 +41,13 @@ template <int FEAT, int DIR>
 __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
 {
    __shared__ double lim[6][8];
+   // Sliding windows in LDS, one per wavefront (= per path): the (value, second derivative) pairs of S1_WK consecutive knots
+   // and, for the forward sweep, S1_WM consecutive points of the reverse curve.  Both cursors move monotonically (up to small
+   // back-steps), so a window is refilled once per ~S1_WK knots by one coalesced copy -- one memory round trip -- and a
+   // segment change reads LDS instead of waiting ~1500 cycles for a dependent HBM access (39 % of the cycles of the lone
+   // wavefront were s_waitcnt without the windows: profiles/r02_e_*).
+   __shared__ double2 winKAll[(FEAT < 0) ? S1_BLOCK / 64 : 1][(FEAT < 0) ? S1_WK * BATOTP_MAX_JOINTS : 1];
+   __shared__ double2 winMAll[(DIR == 1) ? S1_BLOCK / 64 : 1][(DIR == 1) ? S1_WM : 1];
    stage_limits(a.dP, lim);
    const int lane = threadIdx.x & 63;
    const int p = blockIdx.x * (S1_BLOCK / 64) + (threadIdx.x >> 6);
@@ -103,6 +112,73 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    unsigned long long cyA = 0, cyB = 0, cyC = 0, cyD = 0, nBis = 0, nPass = 0, nStage = 0;
 #endif
 
+   double2 *winK = winKAll[(FEAT < 0) ? (threadIdx.x >> 6) : 0];
+   double2 *winM = winMAll[(DIR == 1) ? (threadIdx.x >> 6) : 0];
+   int wK0 = 0, wKn = 0; // knots [wK0, wK0 + wKn) are in winK, layout [knot][8 joint slots]
+   int wM0 = 0, wMn = 0; // curve points [wM0, wM0 + wMn) are in winM
+
+   // make knots seg and seg + 1 available in winK: a coalesced copy of the window that extends from seg in the direction of
+   // travel (two knots of slack behind it).  Fixed stride of 8 slots per knot: Cartesian channels the batch may carry are not
+   // copied; slots beyond the last joint hold a copy of joint 0.
+   auto needK = [&](int seg) {
+      if (seg >= wK0 && seg + 1 < wK0 + wKn) return;
+      int w = (DIR == 1) ? seg - 2 : seg + 4 - S1_WK;
+      const int wmax = n - S1_WK;
+      w = w > wmax ? wmax : w;
+      w = w < 0 ? 0 : w;
+      const int cntK = (n - w) < S1_WK ? (n - w) : S1_WK;
+      const int groups = (cntK + 3) >> 2;  // 4 knots (32 lanes) per group
+      const int kLane = lane >> 3;         // knot offset of this lane inside a group
+      const double2 *__restrict__ src = km + jr;
+      // Eight loads in flight per lane and round trip, then eight unconditional LDS writes (slots past the last knot of
+      // the window receive a copy of the path's last knot and are never read).  Written with named temporaries and
+      // unconditional stores: with a temporary array the compiler kept it in scratch memory, and with stores under a
+      // condition it sank every load into its store's block -- load / s_waitcnt vmcnt(0) / ds_write per group, one
+      // memory round trip per 4 knots.
+#define S1_LD(T, I) { int ki = w + 4 * (g0 + I) + kLane; ki = ki < n ? ki : n - 1; T = src[(unsigned)(ki * nIn)]; }
+#define S1_ST(T, I) winK[lane + 32 * (g0 + I)] = T;
+#pragma unroll 1
+      for (int g0 = 0; g0 < groups; g0 += 8)
+      {
+         double2 t0, t1, t2, t3, t4, t5, t6, t7;
+         S1_LD(t0, 0) S1_LD(t1, 1) S1_LD(t2, 2) S1_LD(t3, 3) S1_LD(t4, 4) S1_LD(t5, 5) S1_LD(t6, 6) S1_LD(t7, 7)
+         __builtin_amdgcn_sched_barrier(0);
+         S1_ST(t0, 0) S1_ST(t1, 1) S1_ST(t2, 2) S1_ST(t3, 3) S1_ST(t4, 4) S1_ST(t5, 5) S1_ST(t6, 6) S1_ST(t7, 7)
+      }
+#undef S1_LD
+#undef S1_ST
+      wK0 = w; wKn = cntK;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+   };
+   // the same for points k and k + 1 of the reverse curve (a few points behind k stay in the window for the back-steps)
+   auto needM = [&](int k) {
+      if (k >= wM0 && k + 1 < wM0 + wMn) return;
+      int w = k - 16;
+      const int wmax = nMvc - S1_WM;
+      w = w > wmax ? wmax : w;
+      w = w < 0 ? 0 : w;
+      const int cnt = (nMvc - w) < S1_WM ? (nMvc - w) : S1_WM;
+      const double2 *__restrict__ src = reinterpret_cast<const double2 *>(mvc) + w;
+      {
+         // the whole window in one round trip: 8 loads in flight per lane (indices clamped to the last point), 8 LDS writes
+         static_assert(S1_WM == 256, "needM moves 8 groups of 32 points");
+#define S1_LD(T, I) { const int e = lane + 32 * I; T = src[e < cnt ? e : cnt - 1]; }
+#define S1_ST(T, I) winM[lane + 32 * I] = T;
+         double2 t0, t1, t2, t3, t4, t5, t6, t7;
+         S1_LD(t0, 0) S1_LD(t1, 1) S1_LD(t2, 2) S1_LD(t3, 3) S1_LD(t4, 4) S1_LD(t5, 5) S1_LD(t6, 6) S1_LD(t7, 7)
+         __builtin_amdgcn_sched_barrier(0);
+         S1_ST(t0, 0) S1_ST(t1, 1) S1_ST(t2, 2) S1_ST(t3, 3) S1_ST(t4, 4) S1_ST(t5, 5) S1_ST(t6, 6) S1_ST(t7, 7)
+#undef S1_LD
+#undef S1_ST
+      }
+      wM0 = w; wMn = cnt;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+   };
+
    // BA::updateCurSeg on the knot sites (ba.cpp:1617-1652): the literal walk, sites sres*k recomputed only when the cursor moves
    auto walkC = [&](double sCur) {
       const int lastSeg = n - 2;
@@ -135,8 +211,9 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
          double k3, k2, k1;
          if (FEAT < 0)
          {
-            const unsigned at = (unsigned)(segC * nIn + jr);
-            const double2 kl = km[at], kr = km[at + nIn]; // knots segC and segC + 1 of this joint
+            needK(segC);
+            const int at = (segC - wK0) * BATOTP_MAX_JOINTS + j;
+            const double2 kl = winK[at], kr = winK[at + BATOTP_MAX_JOINTS]; // knots segC and segC + 1 of this joint
             k3 = div6(kr.y - kl.y);                        // spline.cpp:203-209
             k2 = kl.y / 2.0;
             k1 = kr.x - kl.x - div6(kr.y + 2 * kl.y);
@@ -187,9 +264,9 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       double2 pa, pb;
       for (;;)
       {
-         const double2 *__restrict__ pm = reinterpret_cast<const double2 *>(mvc) + segMVC;
-         pa = pm[0];
-         pb = pm[1];
+         needM(segMVC);
+         pa = winM[segMVC - wM0];
+         pb = winM[segMVC + 1 - wM0];
          if (sCur >= pa.x && sCur <= pb.x) break;
          bool moved = false;
          if (sCur > pa.x)
