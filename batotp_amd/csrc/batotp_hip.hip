@@ -80,6 +80,8 @@ struct batotp_batch
    bool k3Pending = false;      // an overlapped per-knot evaluation may still be running on ctx->stream2
    bool compact = false;        // BATOTP_F_COMPACT_SPLINES: dElim holds the second derivatives, there is no dCoef
    bool kinDone = false, dynDone = false, sitesSet = false, revDone = false, trigSet = false;
+   bool inPlace = false;   // BATOTP_F_CURVES_IN_PLACE: dFwd aliases dRev
+   bool revGone = false;   // ... and the forward sweep has overwritten the reverse curve
 
    // device memory
    DevProblem *dP = nullptr;
@@ -354,6 +356,7 @@ extern "C" int batotp_hip_batch_destroy(batotp_batch *b)
    if (!b) return BATOTP_OK;
    if (b->ctx) hipSetDevice(b->ctx->device);
    if (b->ctx && b->k3Pending) hipStreamSynchronize(b->ctx->stream2);
+   if (b->dFwd == b->dRev) b->dFwd = nullptr; // BATOTP_F_CURVES_IN_PLACE: one buffer
    void *ptrs[] = {b->dP, b->dPinfo, b->dY, b->dSC, b->dCoef, b->dSamp, b->dDyn, b->dTrig, b->dMvc, b->dRev, b->dFwd, b->dRes, b->dStage, b->dSink, b->dElim, b->dKM, b->dUp, b->dModel, b->dJTrig};
    for (void *p : ptrs)
       if (p) hipFree(p);
@@ -443,7 +446,9 @@ extern "C" int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *pr
    ALLOC(b->dTrig, (prob->robot_type == BATOTP_ROBOT_RR && d) ? off * 4 : 0, double)
    ALLOC(b->dMvc, off * 3, double)
    ALLOC(b->dRev, (int64_t)n_paths * max_steps, double2)
-   ALLOC(b->dFwd, (int64_t)n_paths * max_steps, double2)
+   b->inPlace = (prob->flags & BATOTP_F_CURVES_IN_PLACE) != 0;
+   if (b->inPlace) b->dFwd = b->dRev; // one curve buffer: the forward sweep overwrites the reverse points behind its cursor
+   else { ALLOC(b->dFwd, (int64_t)n_paths * max_steps, double2) }
    ALLOC(b->dRes, n_paths, batotp_path_result)
    ALLOC(b->dStage, 4 * b->maxN, double)
    ALLOC(b->dSink, n_paths, int)
@@ -685,6 +690,7 @@ extern "C" int batotp_hip_upload_curve(batotp_batch *b, int32_t path, const doub
    }
    if (e != hipSuccess) return hipFail(e, "upload_curve");
    b->revDone = true;
+   b->revGone = false;
    return BATOTP_OK;
 }
 
@@ -878,6 +884,10 @@ static void launchSweep(batotp_batch *b, SweepArgs &a)
       // paths per wavefront than the forward sweep (measured, B = 4096: rev best at 2, fwd at 4).
       // rounded up: one path too many per wavefront costs little, a second round of wavefronts on the SIMDs costs a lot
       ppw = (a.dir == -1) ? (b->B + 2047) / 2048 : (b->B + 1023) / 1024;
+      // forward, more than 4096 paths: two wavefronts per SIMD as well, but never fewer than the 4 paths per wavefront that
+      // were best at 4096 (11 264 GEN7DOF paths: 2600 ms with 6 paths per wavefront / 1878 wavefronts, 2762 ms with 8 / 1408 --
+      // 1.4 wavefronts per SIMD leaves the SIMDs with one wavefront idle while those with two finish)
+      if (a.dir == 1 && ppw > 4) ppw = std::max(4, (b->B + 2047) / 2048);
    }
    if (ppw < 1) ppw = 1;
    if (ppw > maxPpw) ppw = maxPpw;
@@ -923,10 +933,9 @@ static void launchSweep(batotp_batch *b, SweepArgs &a)
 // the one-path-per-wavefront kernel of sweep1.hip.h: joint velocity / acceleration limits only, uniform knot sites
 static bool sweep1Applies(const batotp_batch *b)
 {
-   const int f = featureLevel(b);
-   // joint velocity / acceleration limits, and the torque limits of a serial robot (no Cartesian family, no cable robot)
-   const bool serialTorque = f == 2 && !(b->prob.flags & (BATOTP_F_CART_VEL_ON | BATOTP_F_CART_ACC_ON | BATOTP_F_PARALLEL));
-   if (f > 0 && !serialTorque) return false;
+   // every constraint family except the torque limits of a parallel mechanism that is still parallel (the cable robot without
+   // isPar2Ser: an LU solve per joint and limit); uniform knot sites
+   if (featureLevel(b) > 2) return false;
    for (int p = 0; p < b->B; ++p)
       if (!b->pinfo[p].uniform) return false;
    return true;
@@ -941,6 +950,11 @@ static void launchSweep1(batotp_batch *b, SweepArgs &a)
    {
       if (a.dir == 1) hipLaunchKernelGGL((k_sweep1<2, 1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
       else hipLaunchKernelGGL((k_sweep1<2, -1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
+   }
+   else if (featureLevel(b) == 1)
+   {
+      if (a.dir == 1) hipLaunchKernelGGL((k_sweep1<1, 1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
+      else hipLaunchKernelGGL((k_sweep1<1, -1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
    }
    else if (b->compact)
    {
@@ -959,7 +973,7 @@ extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
    if (!b || (dir != 1 && dir != -1)) return BATOTP_ERR_ARG;
    int rc = readyForSweep(b);
    if (rc) return rc;
-   if (dir == 1 && !b->revDone) return BATOTP_ERR_STATE;
+   if (dir == 1 && (!b->revDone || b->revGone)) return BATOTP_ERR_STATE; // in-place curves: the reverse curve is consumed by one forward sweep
    rc = bind(b->ctx);
    if (rc) return rc;
    SweepArgs a;
@@ -979,7 +993,7 @@ extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
       // ... and where every path has a wavefront to itself anyway, the kernel written for that case (sweep1.hip.h)
       if (lanes == 32 && sweep1Applies(b)) lanes = 64;
    }
-   if (lanes == 64 && !sweep1Applies(b)) lanes = 32; // torque / Cartesian limits, uploaded sites: the general kernel
+   if (lanes == 64 && !sweep1Applies(b)) lanes = 32; // a parallel mechanism's torque limits, uploaded sites: the general kernel
    switch (lanes)
    {
    case 64: launchSweep1(b, a); break;
@@ -993,7 +1007,8 @@ extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
    evStop(b, which);
    HIP_TRY(hipGetLastError());
    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
-   if (dir == -1) b->revDone = true;
+   if (dir == -1) { b->revDone = true; b->revGone = false; }
+   else if (b->inPlace) b->revGone = true;
    return BATOTP_OK;
 }
 
@@ -1023,6 +1038,7 @@ extern "C" int batotp_hip_get_results(batotp_batch *b, batotp_path_result *out)
 extern "C" int batotp_hip_download_curve(batotp_batch *b, int32_t path, int32_t which, double *s, double *sdot, int64_t cap, int64_t *n)
 {
    if (!b || path < 0 || path >= b->B || (which != 1 && which != -1)) return BATOTP_ERR_ARG;
+   if (which == -1 && b->revGone) return BATOTP_ERR_STATE; // BATOTP_F_CURVES_IN_PLACE: overwritten by the forward sweep
    int rc = bind(b->ctx);
    if (rc) return rc;
    batotp_path_result r;
@@ -1118,6 +1134,7 @@ extern "C" int batotp_hip_pack_curves(batotp_batch *b, int32_t which, int32_t pa
 {
    if (!b || (which != 1 && which != -1) || path0 < 0 || n_paths < 0 || path0 + n_paths > b->B || !total_points) return BATOTP_ERR_ARG;
    *total_points = 0;
+   if (which == -1 && b->revGone) return BATOTP_ERR_STATE; // BATOTP_F_CURVES_IN_PLACE: overwritten by the forward sweep
    if (n_paths == 0) return BATOTP_OK;
    int rc = bind(b->ctx);
    if (rc) return rc;

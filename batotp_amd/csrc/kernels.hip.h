@@ -1721,6 +1721,12 @@ __global__ void __launch_bounds__(K4_BLOCK, (G > 1 && G < 8) ? 1 : (FEAT <= 1 &&
       t.mvc = reinterpret_cast<const double *>(a.rev + (int64_t)p * cap + (cap - nRev));
       t.nMvc = (int)nRev;
    }
+   // BATOTP_F_CURVES_IN_PLACE (forward sweep, a.fwd == a.rev): point i of the forward curve goes to slot i, reverse point m sits in
+   // slot cap - nRev + m.  The forward curve has at least as many points up to any s as the reverse curve, so slot i has been
+   // left behind by the reverse-curve cursor -- checked every step with 64 points of margin (the cursor's back-steps, the
+   // prefetch and the windows of k_sweep1 stay within 32); a path that would run into live reverse points ends as if out of capacity.
+   const int64_t revStart = (dir == 1 && a.fwd == a.rev) ? cap - (int64_t)t.nMvc : ((int64_t)1 << 62);
+#define BK_CURVE_FULL(i) ((i) >= cap || (i) + 64 >= revStart + (int64_t)t.segMVC)
 
    const double absh = a.P.integ_res;
    const double h = dir * absh;
@@ -1776,7 +1782,7 @@ __global__ void __launch_bounds__(K4_BLOCK, (G > 1 && G < 8) ? 1 : (FEAT <= 1 &&
       // scalar registers that are merged under ever-changing exec masks across this loop)
       constexpr int PH_FIRST = 0, PH_ENDED = 1, PH_CHECK = 2, PH_DEAD = 3; // waiting for its first stage / a stage has ended / inside a check / finished
       int phase = PH_FIRST;
-      if (i >= cap) { endStatus = BATOTP_ST_CAPACITY; phase = PH_DEAD; }
+      if (BK_CURVE_FULL(i)) { endStatus = BATOTP_ST_CAPACITY; phase = PH_DEAD; }
       double sN = 0, wN = 0;
       double lowFact = .01, sdotGood = 0, sdotL = 0, sdotH = 0, sdotTry = 0;
       int nGood = 0; // feasible points seen by the current bisection (anyGoodIter of ba.cpp:1254 == nGood > 0)
@@ -1816,7 +1822,7 @@ __global__ void __launch_bounds__(K4_BLOCK, (G > 1 && G < 8) ? 1 : (FEAT <= 1 &&
                   st = (dir == 1) ? 0 : 1;
                   if (t.sCur * dir > sLast) { nPts = i + 1; phase = PH_DEAD; } // ba.cpp:1109-1115
                   else if (i > maxIntegSteps) { endStatus = BATOTP_ST_MAX_INTEG_TIME; phase = PH_DEAD; } // ba.cpp:1117-1122
-                  else if (++i >= cap) { endStatus = BATOTP_ST_CAPACITY; phase = PH_DEAD; }
+                  else if (++i, BK_CURVE_FULL(i)) { endStatus = BATOTP_ST_CAPACITY; phase = PH_DEAD; }
                }
             }
             if (phase != PH_DEAD)
@@ -1888,7 +1894,7 @@ __global__ void __launch_bounds__(K4_BLOCK, (G > 1 && G < 8) ? 1 : (FEAT <= 1 &&
       bool done = false;
       while (!done)
       {
-         if (i >= cap) { endStatus = BATOTP_ST_CAPACITY; break; }
+         if (BK_CURVE_FULL(i)) { endStatus = BATOTP_ST_CAPACITY; break; }
          const double sStart = t.sCur;
          // st == 0: Euler predictor (ba.cpp:1055-1065).  Its sdot is overwritten by stage 6; all that
          // survives is the move of the reverse-curve cursor inside evalsdot (forward sweep only).
@@ -2058,6 +2064,7 @@ __global__ void __launch_bounds__(K4_BLOCK, (G > 1 && G < 8) ? 1 : (FEAT <= 1 &&
       }
    }
 }
+#undef BK_CURVE_FULL
 
 // ---------------------------------------------------------------------------------------------
 // marshalling helpers: one channel between [4][N] (C-ABI) and the interleaved device layout

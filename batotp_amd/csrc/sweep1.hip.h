@@ -35,7 +35,8 @@ constexpr int S1_BLOCK = 256;
 constexpr int S1_WK = 64;   // knots per spline window (compact splines: 64 knots x 8 joint slots x 16 B = 8 KB per path)
 constexpr int S1_WM = 256;  // points per reverse-curve window (4 KB per path)
 
-// FEAT: -1 = compact splines ((value, second derivative) pairs), 0 = coefficient rows, 2 = coefficient rows + torque limits of a
+// FEAT: -1 = compact splines ((value, second derivative) pairs), 0 = coefficient rows, 1 = coefficient rows + the Cartesian
+// speed / acceleration limits (ba.cpp:1225-1229, 1423-1439, 1535-1579), 2 = those + torque limits of a
 // serial robot (a1..a4 splines, ba.cpp:1387-1405, 1495-1509; BASELINE config 3).  DIR: -1 reverse, +1 forward.
 template <int FEAT, int DIR>
 __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
@@ -100,6 +101,17 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    int rowSeg = -1;
    double A3 = 0, B2 = 0, A6 = 0, c1 = 0; // 3*c3, 2*c2, 6*c3, c1 of this lane's joint on segment rowSeg
    double thD = 0, thD2 = 0;              // theta', theta'' of this lane's joint at the last evaluated position
+   // FEAT >= 1: the three Cartesian channels on segment rowSeg (3*c3, 2*c2, 6*c3, c1 each; the same in every lane) and the
+   // quadratic's coefficients at the last evaluated position (BA::evalCartQuadCoeffs, ba.cpp:1423-1439)
+   const bool cartVelOn = FEAT >= 1 && (a.P.flags & BATOTP_F_CART_VEL_ON) != 0;
+   const bool cartAccOn = FEAT >= 1 && (a.P.flags & BATOTP_F_CART_ACC_ON) != 0;
+   const bool cartAny = cartVelOn || cartAccOn;
+   double cA3[(FEAT >= 1) ? 3 : 1], cB2[(FEAT >= 1) ? 3 : 1], cA6[(FEAT >= 1) ? 3 : 1], cC1[(FEAT >= 1) ? 3 : 1];
+#pragma unroll
+   for (int q = 0; q < ((FEAT >= 1) ? 3 : 1); ++q) { cA3[q] = 0; cB2[q] = 0; cA6[q] = 0; cC1[q] = 0; }
+   double cq0 = 0, cq1 = 0, cq2 = 0;
+   const double quadA = a.P.quad_thresh * afact, quadA2 = a.P.quad_thresh * a.P.quad_thresh * afact * afact;
+   const double cartAccMaxSQ = a.P.cart_acc_max * a.P.cart_acc_max, cartVelMax = a.P.cart_vel_max;
    Coef4 dynK[(FEAT == 2) ? 4 : 1];       // FEAT == 2: coefficient rows of a1..a4 of this lane's dynamics row on segment rowSeg
    double a1pt = 0, a2pt = 0, a3pt = 0, a4pt = 0;
    int segMVC = (DIR == 1) ? 0 : n - 2, mvcSeg = -1;
@@ -223,6 +235,15 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
             const double *__restrict__ row = coef + (unsigned)(segC * C * 4);
             const Coef4 k = *reinterpret_cast<const Coef4 *>(row + jr * 4);
             k3 = k.c3; k2 = k.c2; k1 = k.c1;
+            if (FEAT >= 1 && cartAny)
+            {
+#pragma unroll
+               for (int q = 0; q < ((FEAT >= 1) ? 3 : 1); ++q)
+               {
+                  const Coef4 kc = *reinterpret_cast<const Coef4 *>(row + (nJ + q) * 4);
+                  cA3[q] = 3 * kc.c3; cB2[q] = 2 * kc.c2; cA6[q] = 6 * kc.c3; cC1[q] = kc.c1;
+               }
+            }
             if (FEAT == 2)
             {
                // device channel order: theta[nJ], cart[nC], then per dynamics row r the four channels (a1_r, a2_r, a3_r, a4_r)
@@ -240,6 +261,20 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       const double tau = tauC, tau2 = tau * tau;
       thD = (A3 * tau2 + B2 * tau + c1) * vfact; // (3*c3*tau2 + 2*c2*tau + c1)*vFact, ba.cpp:1359
       thD2 = (A6 * tau + B2) * afact;            // (6*c3*tau + 2*c2)*aFact, ba.cpp:1360
+      if (FEAT >= 1 && cartAny)
+      {
+         // Cartesian velocity / acceleration along s and the quadratic's coefficients, ba.cpp:1368-1385, 1423-1439
+         double v[3], ac[3];
+#pragma unroll
+         for (int q = 0; q < 3; ++q)
+         {
+            v[q] = (cA3[(FEAT >= 1) ? q : 0] * tau2 + cB2[(FEAT >= 1) ? q : 0] * tau + cC1[(FEAT >= 1) ? q : 0]) * vfact;
+            ac[q] = (cA6[(FEAT >= 1) ? q : 0] * tau + cB2[(FEAT >= 1) ? q : 0]) * afact;
+         }
+         cq0 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+         cq1 = 2 * (v[0] * ac[0] + v[1] * ac[1] + v[2] * ac[2]);
+         cq2 = ac[0] * ac[0] + ac[1] * ac[1] + ac[2] * ac[2];
+      }
       if (FEAT == 2)
       {
          // a1..a4 at the cursor, ba.cpp:1387-1405
@@ -300,6 +335,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       if (jv && fabs(thD) > thrV) l = dmin(l, fabs(vmaxj / thD));
       l = grp_min<8>(l);
       sdot = dmin(sdot, l);
+      if (FEAT >= 1 && cartVelOn && cq0 > quadA) sdot = dmin(sdot, cartVelMax / sqrt(cq0)); // ba.cpp:1225-1229
    };
 
    // BA::verifySecondOrderConstraints, joint acceleration family (ba.cpp:1514-1534); see verify_second_order for why the
@@ -343,7 +379,30 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       grp_min_max<8>(Hred, L);
       sddotH = Hred;
       sddotL = L;
-      return L > Hred;
+      if (L > Hred) return true;
+      if (FEAT >= 1 && cartAccOn)
+      {
+         // ba.cpp:1535-1579 (the values are the same in the 8 lanes of a candidate slot)
+         if (cq0 > quadA)
+         {
+            const double Bq = cq1 * sdotSQ;
+            const double Cq = cq2 * sdotSQ * sdotSQ - cartAccMaxSQ;
+            double sol1 = 0, sol2 = 0;
+            const int ef = solve_quadratic(cq0, Bq, Cq, sol1, sol2);
+            if (ef == -1) return true;
+            const double cmax = dmax(sol1, sol2), cmin = dmin(sol1, sol2);
+            sddotH = dmin(sddotH, cmax);
+            sddotL = dmax(sddotL, cmin);
+            if (sddotL > sddotH) return true;
+         }
+         else
+         {
+            if (cq2 < quadA2) return false;
+            if (sdotSQ * sdotSQ > cartAccMaxSQ / cq2) return true;
+            return false;
+         }
+      }
+      return false;
    };
 
    // BA::applyAccelConstraintsBisectionPt (ba.cpp:1248-1332) with four candidates per pass: the reference's loop is replayed
@@ -506,6 +565,8 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    }
 
    int64_t nPts = 0, i = 1;
+   // BATOTP_F_CURVES_IN_PLACE: see k_sweep (the forward curve overwrites reverse points its cursor has left behind)
+   const int64_t revStart = (DIR == 1 && a.fwd == a.rev) ? cap - (int64_t)nMvc : ((int64_t)1 << 62);
    unsigned endStatus = 0;
    bool done = false;
 #ifdef BK_PROFILE_SECTIONS
@@ -513,7 +574,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
 #endif
    while (!done)
    {
-      if (i >= cap) { endStatus = BATOTP_ST_CAPACITY; break; }
+      if (i >= cap || i + 64 >= revStart + (int64_t)segMVC) { endStatus = BATOTP_ST_CAPACITY; break; }
       if (DIR == 1) mvcWalk(s0v + h * v0); // Euler predictor, ba.cpp:1055-1065: only the move of the reverse-curve cursor survives
 
       S1_STAGE(BK_B00 * v0, BK_B00 * w0, v1, w1)

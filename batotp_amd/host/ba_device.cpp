@@ -714,6 +714,9 @@ int BA::optimizeBatchOnDevice(std::vector<Traj> &trajs)
       if (_deviceOutput && exportOutputParams(&probe) == 0 && !_isTrqConOn && !_isCartVelConOn && !_isCartAccConOn)
          prob.flags |= BATOTP_F_NO_SAMPLES | BATOTP_F_COMPACT_SPLINES;
    }
+   // the reverse curves are only read back for s-sdot.dat: without it one curve buffer per path is enough (the forward curve
+   // replaces the reverse curve, as traj.sMVC / traj.sdot do in the reference)
+   if (!is_sdotOut) prob.flags |= BATOTP_F_CURVES_IN_PLACE;
    const int nIn = (int)(_nJoints + _nCart);
    const int64_t maxIntegSteps = (int64_t)std::floor(_maxIntegTime / _integRes) + 1;
    int64_t nMax = 0;

@@ -74,7 +74,9 @@ WORKLOADS = {
 # BASELINE.json configs as worded.  paths = total over all GPUs ("strong"), or per GPU ("weak": what fills one GPU, or the
 # single trajectory every GPU replicates)
 CONFIGS = {
-    "fill7": dict(workload="gen7", knots=100000, paths=11264, scaling="weak", distinct=2048,
+    # in_place: BATOTP_F_CURVES_IN_PLACE (one curve buffer per path, the forward curve overwrites the reverse curve as in the
+    # reference's Traj): 17.8 instead of 21.3 MB per path -> 13 312 instead of 11 264 paths, 7 instead of 6 per wavefront
+    "fill7": dict(workload="gen7", knots=100000, paths=13312, scaling="weak", distinct=2048, in_place=True,
                   what="GEN7DOF 7-DOF vel+acc, N~100k knots/path, batch of independent paths filling the GPU"),
     "fill6": dict(workload="ur6", knots=100000, paths=16384, scaling="weak", distinct=2048,
                   what="cfg2 shape: UR5-like 6-DOF vel+acc, N~100k knots/path, batch of independent paths filling the GPU"),
@@ -324,7 +326,7 @@ def bytes_per_path(prob, C, n_mean, cap):
         per_knot = 8.0 * cin + 8 + 32.0 * C + (0 if (prob.flags & capi.F_NO_SAMPLES) else 24.0 * cin) + 32.0 * d + 24 + 8.0 * max(cin, 4 * d)
         if d and not (prob.flags & capi.F_PARALLEL):
             per_knot += 16.0 * prob.n_joints      # joint trig tables of the chain model
-    return per_knot * n_mean + 32.0 * cap
+    return per_knot * n_mean + (16.0 if prob.flags & capi.F_CURVES_IN_PLACE else 32.0) * cap
 
 
 def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=0, knots_override=0, group=0, ppw=0,
@@ -348,6 +350,8 @@ def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=
     prob = capi.Problem.from_buffer_copy(bytes(inp.prob))
     if (prob.flags & capi.F_NO_SAMPLES) and not coefficient_rows:
         prob.flags |= capi.F_COMPACT_SPLINES  # same results, half the spline bytes per knot: room for more paths per GPU
+    if c.get("in_place"):
+        prob.flags |= capi.F_CURVES_IN_PLACE   # same results, one curve buffer per path
     C = WORKLOADS[workload]["C"]
     cap = int(int(inp.n_knots.max()) * WORKLOADS[workload]["cap"]) + 1024
 

@@ -68,6 +68,15 @@ extern "C" {
                                             coefficients are formed where they are used (same arithmetic, same results).
                                             Joint velocity/acceleration-only problems with BATOTP_F_NO_SAMPLES;
                                             upload_coeffs then fails, download_coeffs still works */
+#define BATOTP_F_CURVES_IN_PLACE (1u<<9) /* the forward sweep writes its curve over the reverse curve, as the reference does
+                                            with traj.sMVC / traj.sdot (ba.cpp:1143-1160): one curve buffer of max_steps points
+                                            per path instead of two.  The forward curve has at least as many points up to any
+                                            s as the reverse curve (its speed is capped by it), so it only ever overwrites
+                                            reverse points its cursor has left behind; a path whose forward curve comes within
+                                            64 points of the reverse points still to be read ends with BATOTP_ST_CAPACITY
+                                            (max_steps >= forward points + 72 suffices).  After batotp_hip_sweep(b, +1)
+                                            the reverse curve is gone: download / pack of curve -1 and a second forward sweep
+                                            return BATOTP_ERR_STATE until the reverse sweep has run again.  Same results. */
 
 /* per-path status bits written by the sweep kernel (the reference only printf()s these) */
 #define BATOTP_ST_MAX_INTEG_TIME (1u<<0) /* ba.cpp:1117-1122 (MAX_INTEGRATION_TIME)        */

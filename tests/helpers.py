@@ -196,7 +196,7 @@ def run_pipeline(ctx, cases, max_steps=None, mvc=True, details=True, extra_flags
     if extra_flags:
         prob = capi.Problem.from_buffer_copy(bytes(prob))
         prob.flags |= extra_flags
-    cap = max_steps or max(c.max_steps() for c in cases)
+    cap = max_steps or max(c.max_steps() for c in cases) + (16 if prob.flags & capi.F_CURVES_IN_PLACE else 0)  # in place: 72 points of margin
     b = capi.Batch(ctx, prob, [c.n for c in cases], cap)
     for k, c in enumerate(cases):
         b.upload_knots(k, [c.y], [c.sres])
@@ -216,12 +216,15 @@ def run_pipeline(ctx, cases, max_steps=None, mvc=True, details=True, extra_flags
     if mvc:
         b.pointwise_mvc()
     b.sweep(-1)
+    # BATOTP_F_CURVES_IN_PLACE: the forward sweep overwrites the reverse curve, so it is fetched between the sweeps
+    in_place = bool(prob.flags & capi.F_CURVES_IN_PLACE)
+    rev_early = [b.curve(k, -1) for k in range(len(cases))] if in_place else None
     b.sweep(+1)
     res = b.results()
     out = []
     for k, c in enumerate(cases):
         d = {"result": res[k]}
-        d["rev"] = b.curve(k, -1)
+        d["rev"] = rev_early[k] if in_place else b.curve(k, -1)
         d["fwd"] = b.curve(k, +1)
         if details:
             nch = prob.n_channels

@@ -240,6 +240,62 @@ def test_flat_sweep_loop_capacity_and_max_time_status(hip_lib, oracle_ctx):
     ctx.close()
 
 
+@pytest.mark.parametrize("lanes", [0, 1, 8, 16, 32, 64, "flat4"])
+def test_curves_in_place_give_identical_results(hip_lib, oracle_ctx, lanes):
+    """BATOTP_F_CURVES_IN_PLACE: one curve buffer per path, the forward curve written over the reverse points its cursor has left
+    behind -- result rows and both curves (the reverse one fetched between the sweeps) equal the oracle's"""
+    ctx = capi.Context(hip_lib, 0)
+    helpers.set_layout(ctx, lanes)
+    for name in ("GEN7DOF", "synth_gen7dof_s0", "UR5", "CSPR3DOF", "RR_acc", "synth_cspr_s5", "synth_ur_s2", "KUKA_trq"):
+        case = Case(name)
+        variants = [capi.F_CURVES_IN_PLACE]
+        if _vel_acc_only(name):
+            variants.append(capi.F_CURVES_IN_PLACE | capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES)
+        oo = run_pipeline(oracle_ctx, [case], mvc=False, details=False)[0]
+        for flags in variants:
+            ho = run_pipeline(ctx, [case], mvc=False, details=False, extra_flags=flags)[0]
+            _compare(case, ho, oo)
+    ctx.close()
+
+
+def test_curves_in_place_state_and_capacity(hip_ctx, oracle_ctx):
+    """after the forward sweep the reverse curve is gone (state errors until the reverse sweep has run again); a curve buffer
+    with room for the forward curve + 72 points is enough, one that is too short ends with the capacity status"""
+    case = Case("synth_gen7dof_s0")
+    ref = run_pipeline(oracle_ctx, [case], mvc=False, details=False)[0]
+    n_fwd = int(ref["result"]["n_fwd"])
+    prob = capi.Problem.from_buffer_copy(bytes(case.problem))
+    prob.flags |= capi.F_CURVES_IN_PLACE
+    b = capi.Batch(hip_ctx, prob, [case.n, case.n], n_fwd + 72)
+    b.upload_knots(0, [case.y, case.y], [case.sres, case.sres])
+    b.precompute(0)
+    b.sweep(-1)
+    b.sweep(+1)
+    for k in range(2):
+        r = b.results()[k]
+        for f in ref["result"].dtype.names:
+            assert r[f] == ref["result"][f], f
+        s, sd = b.curve(k, +1)
+        helpers.assert_bit_equal(s, ref["fwd"][0], "fwd.s"); helpers.assert_bit_equal(sd, ref["fwd"][1], "fwd.sdot")
+    with pytest.raises(capi.BatotpError):
+        b.curve(0, -1)
+    with pytest.raises(capi.BatotpError):
+        b.sweep(+1)
+    with pytest.raises(capi.BatotpError):
+        b.pack_curves(-1, 0, 2, 0, 0)
+    b.sweep(-1)                       # the reverse curve is back
+    helpers.assert_bit_equal(b.curve(1, -1)[1], ref["rev"][1], "rev.sdot after re-running the reverse sweep")
+    b.sweep(+1)
+    assert int(b.results()[1]["n_fwd"]) == n_fwd
+    b.close()
+    b = capi.Batch(hip_ctx, prob, [case.n], n_fwd + 8)   # fits both curves one after the other, not the margin
+    b.upload_knots(0, [case.y], [case.sres])
+    b.optimize()
+    r = b.results()[0]
+    assert int(r["n_rev"]) == int(ref["result"]["n_rev"]) and int(r["n_fwd"]) == 0 and (int(r["status_fwd"]) & capi.ST_CAPACITY)
+    b.close()
+
+
 def test_capacity_and_max_time_status(hip_ctx, oracle_ctx):
     case = Case("GEN7DOF")
     for ctx in (hip_ctx, oracle_ctx):
