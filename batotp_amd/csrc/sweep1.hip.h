@@ -1,8 +1,9 @@
-// sweep1.hip.h -- the sweep of a path that has a wavefront to itself (the latency-bound regime: BASELINE configs 2 and 4 as
-// worded -- one trajectory, or a few hundred paths per GPU), for problems with joint velocity / acceleration limits only on
-// uniform knot sites.  Same arithmetic, same order, same results as k_sweep (kernels.hip.h) -- BA::sweep and everything it
-// calls, reference batotp/ba.cpp:979-1195, 1204-1236, 1248-1332, 1341-1413, 1449-1534, 1590-1652 -- written for the fewest
-// instructions per stage instead of for generality:
+// sweep1.hip.h -- the sweep of a path that has a wavefront to itself (the latency-bound regime: BASELINE configs 2, 3 and 4
+// as worded -- one trajectory, or up to ~2 k paths per GPU, which is also one GPU's share of config 5), on uniform knot sites,
+// for every constraint family except the torque limits of a parallel mechanism that was not converted (isPar2Ser = 0).
+// Same arithmetic, same order, same results as k_sweep (kernels.hip.h) -- BA::sweep and everything it calls, reference
+// batotp/ba.cpp:979-1195, 1204-1236, 1248-1332, 1341-1439, 1449-1581, 1590-1652 -- written for the fewest instructions per
+// stage instead of for generality:
 //   * a lone wavefront issues one vector instruction every 4 cycles whatever its number of active lanes
 //     (MI355X_MICROARCH.md), and the scalar instructions of divergent control flow cost as much: k_sweep's 405 VALU + 250
 //     SALU instructions per stage evaluation are the 5170 cycles measured at B = 1 (profiles/r02_c_*).  So: the six stages
