@@ -31,6 +31,7 @@ struct batotp_batch {
     batotp_serial_model serial;
     int has_serial;
     int kin_done;
+    int rev_gone;        /* BATOTP_F_CURVES_IN_PLACE: the forward sweep has consumed the reverse curve (state rules of the product) */
     float ms[5];
 };
 
@@ -200,6 +201,7 @@ int batotp_hip_upload_curve(batotp_batch *b, int32_t path, const double *s, cons
     if (!b || path < 0 || path >= b->n_paths || n < 2) return BATOTP_ERR_ARG;
     set_curve(b->rev_s, b->rev_sd, path, s, sdot, n);
     b->res[path].n_rev = n;
+    b->rev_gone = 0;
     return BATOTP_OK;
 }
 
@@ -243,6 +245,7 @@ int batotp_hip_sweep(batotp_batch *b, int32_t dir)
     int32_t p;
     double t0 = now_ms();
     if (!b || !b->kin_done || (dir != 1 && dir != -1)) return BATOTP_ERR_STATE;
+    if (dir == 1 && b->rev_gone) return BATOTP_ERR_STATE;
     for (p = 0; p < b->n_paths; p++)
         if (dir == 1 && !b->rev_s[p]) return BATOTP_ERR_STATE;
     #pragma omp parallel for schedule(dynamic, 1)
@@ -274,6 +277,8 @@ int batotp_hip_sweep(batotp_batch *b, int32_t dir)
         }
     }
     b->ms[dir == -1 ? 3 : 4] = (float)(now_ms() - t0);
+    if (dir == -1) b->rev_gone = 0;
+    else if (b->prob.flags & BATOTP_F_CURVES_IN_PLACE) b->rev_gone = 1; /* the checker keeps both curves; only the state rule is mirrored */
     return BATOTP_OK;
 }
 
@@ -298,6 +303,7 @@ int batotp_hip_download_curve(batotp_batch *b, int32_t path, int32_t which, doub
     int64_t m, avail;
     const double *ss, *sd;
     if (!b || path < 0 || path >= b->n_paths) return BATOTP_ERR_ARG;
+    if (which == -1 && b->rev_gone) return BATOTP_ERR_STATE;
     ss = which == 1 ? b->fwd_s[path] : b->rev_s[path];
     sd = which == 1 ? b->fwd_sd[path] : b->rev_sd[path];
     avail = which == 1 ? b->res[path].n_fwd : b->res[path].n_rev;
@@ -361,6 +367,7 @@ int batotp_hip_pack_curves(batotp_batch *b, int32_t which, int32_t path0, int32_
     int64_t total = 0, i;
     double *o = (double *)dst;
     if (!b || (which != 1 && which != -1) || path0 < 0 || n_paths < 0 || path0 + n_paths > b->n_paths || !total_points) return BATOTP_ERR_ARG;
+    if (which == -1 && b->rev_gone) { *total_points = 0; return BATOTP_ERR_STATE; }
     for (k = 0; k < n_paths; k++) total += which == 1 ? b->res[path0 + k].n_fwd : b->res[path0 + k].n_rev;
     *total_points = total;
     if (total == 0) return BATOTP_OK;

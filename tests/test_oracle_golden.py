@@ -41,3 +41,28 @@ def test_bisection_failure_branch_is_pinned():
     import json, os
     e = json.load(open(os.path.join(helpers.GOLD, "synth_cspr_s8_40k", "expected.json")))
     assert e["ref_bisect_fail_msgs"] >= 1
+
+
+def test_checker_mirrors_the_state_rules_of_in_place_curves(oracle_ctx):
+    """BATOTP_F_CURVES_IN_PLACE through the checker library: same results (it keeps both curves), and the product's state rules
+    -- after the forward sweep the reverse curve cannot be fetched and the forward sweep cannot be repeated"""
+    from batotp_amd import capi
+    case = Case("GEN7DOF")
+    plain = run_pipeline(oracle_ctx, [case], mvc=False, details=False)[0]
+    flagged = run_pipeline(oracle_ctx, [case], mvc=False, details=False, extra_flags=capi.F_CURVES_IN_PLACE)[0]
+    for f in plain["result"].dtype.names:
+        assert plain["result"][f] == flagged["result"][f], f
+    for which in ("rev", "fwd"):
+        assert np.array_equal(plain[which][0], flagged[which][0]) and np.array_equal(plain[which][1], flagged[which][1])
+    prob = capi.Problem.from_buffer_copy(bytes(case.problem))
+    prob.flags |= capi.F_CURVES_IN_PLACE
+    b = capi.Batch(oracle_ctx, prob, [case.n], case.max_steps() + 16)
+    b.upload_knots(0, [case.y], [case.sres])
+    b.optimize()
+    with pytest.raises(capi.BatotpError):
+        b.curve(0, -1)
+    with pytest.raises(capi.BatotpError):
+        b.sweep(+1)
+    b.sweep(-1)
+    assert len(b.curve(0, -1)[0]) == int(plain["result"]["n_rev"])
+    b.close()
