@@ -82,6 +82,7 @@ struct batotp_batch
    bool kinDone = false, dynDone = false, sitesSet = false, revDone = false, trigSet = false;
    bool inPlace = false;   // BATOTP_F_CURVES_IN_PLACE: dFwd aliases dRev
    bool revGone = false;   // ... and the forward sweep has overwritten the reverse curve
+   bool mvcInCurves = false, mvcValid = false; // BATOTP_F_MVC_IN_CURVES: K3's values live in the curve slots until a sweep starts
 
    // device memory
    DevProblem *dP = nullptr;
@@ -438,13 +439,22 @@ extern "C" int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *pr
    ALLOC(b->dP, 1, DevProblem)
    ALLOC(b->dPinfo, n_paths, PathInfo)
    ALLOC(b->dY, b->compact ? 0 : off * P.Cin, double)
-   ALLOC(b->dSC, off, double)
+   // knot sites: kept for the row layouts (K2 reads them); compact batches compute uniform sites where they are needed and get
+   // the array only when a path's sites are uploaded (batotp_hip_upload_path_sites)
+   if (!b->compact) { ALLOC(b->dSC, off, double) }   // (devAlloc turns a zero-size request into 8 bytes: the pointer must stay null here)
    ALLOC(b->dCoef, b->compact ? 0 : off * P.C * 4, double)
    if ((prob->flags & BATOTP_F_NO_SAMPLES) && d != 0) { batotp_hip_batch_destroy(b); return BATOTP_ERR_ARG; }
    ALLOC(b->dSamp, (prob->flags & BATOTP_F_NO_SAMPLES) ? 0 : off * P.Cin * 3, double)
    ALLOC(b->dDyn, off * 4 * (d ? d : 0), double)
    ALLOC(b->dTrig, (prob->robot_type == BATOTP_ROBOT_RR && d) ? off * 4 : 0, double)
-   ALLOC(b->dMvc, off * 3, double)
+   b->mvcInCurves = (prob->flags & BATOTP_F_MVC_IN_CURVES) != 0;
+   if (b->mvcInCurves && 2 * max_steps < 3 * b->maxN)
+   {
+      snprintf(g_err, sizeof(g_err), "BATOTP_F_MVC_IN_CURVES needs max_steps >= 1.5 x the knots of the longest path");
+      batotp_hip_batch_destroy(b);
+      return BATOTP_ERR_ARG;
+   }
+   if (!b->mvcInCurves) { ALLOC(b->dMvc, off * 3, double) }
    ALLOC(b->dRev, (int64_t)n_paths * max_steps, double2)
    b->inPlace = (prob->flags & BATOTP_F_CURVES_IN_PLACE) != 0;
    if (b->inPlace) b->dFwd = b->dRev; // one curve buffer: the forward sweep overwrites the reverse points behind its cursor
@@ -631,6 +641,14 @@ extern "C" int batotp_hip_upload_path_sites(batotp_batch *b, int32_t path, const
    int rc = bind(b->ctx);
    if (rc) return rc;
    PathInfo &pi = b->pinfo[path];
+   if (!b->dSC)
+   {
+      // compact batch: the site array exists from the first uploaded path on; the other paths keep their computed sites
+      rc = devAlloc(b, (void **)&b->dSC, sizeof(double) * (size_t)b->totalKnots);
+      if (rc) return rc;
+      const int bs = 256;
+      hipLaunchKernelGGL(k_sites, dim3((unsigned)((b->totalKnots + bs - 1) / bs)), dim3(bs), 0, b->ctx->stream, b->dPinfo, b->B, b->dSC, b->totalKnots);
+   }
    HIP_TRY(hipMemcpyAsync(b->dSC + pi.koff, sites, sizeof(double) * (size_t)pi.n, hipMemcpyHostToDevice, b->ctx->stream));
    pi.vfact = vfact; pi.afact = afact;
    pi.parallel_now = parallel_now;
@@ -691,6 +709,7 @@ extern "C" int batotp_hip_upload_curve(batotp_batch *b, int32_t path, const doub
    if (e != hipSuccess) return hipFail(e, "upload_curve");
    b->revDone = true;
    b->revGone = false;
+   b->mvcValid = false;
    return BATOTP_OK;
 }
 
@@ -734,7 +753,7 @@ extern "C" int batotp_hip_precompute(batotp_batch *b, int32_t stage)
    if (stage == 0 || stage == 1) evStart(b, 1);
    if (stage == 0 || stage == 1)
    {
-      hipLaunchKernelGGL(k_sites, dim3(gridKnots), dim3(bs), 0, st, b->dPinfo, b->B, b->dSC, b->totalKnots);
+      if (b->dSC) hipLaunchKernelGGL(k_sites, dim3(gridKnots), dim3(bs), 0, st, b->dPinfo, b->B, b->dSC, b->totalKnots);
       if (b->compact)
       {
          const int threads = b->B * b->P.Cin;
@@ -831,7 +850,9 @@ extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
    const size_t ldsBytes = useTile ? sizeof(double) * (size_t)bs * (size_t)(b->P.C * 4 + 2) : 0;
    // overlap: K3 reads what the precompute wrote and nothing reads K3's output before the caller downloads it, so it
    // can share the GPU with the sweeps (second stream, joined by get_results / synchronize / the next precompute)
-   const bool async = b->ctx->overlap != 0;
+   const bool async = b->ctx->overlap != 0 && !b->mvcInCurves; // in the curve slots the values must be complete before a sweep starts
+   double *mvcOut = b->mvcInCurves ? reinterpret_cast<double *>(b->dRev) : b->dMvc;
+   const int64_t mvcSlot = b->mvcInCurves ? 2 * b->cap : 0;
    hipStream_t k3s = async ? b->ctx->stream2 : b->ctx->stream;
    if ((rc = joinK3(b))) return rc;
    if (async)
@@ -847,11 +868,11 @@ extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
          {                                                                                                                               \
             const int64_t cnt = (b->totalKnots - first) < sliceKnots ? (b->totalKnots - first) : sliceKnots;                            \
             hipLaunchKernelGGL(k_pointwise_grp<F>, dim3((unsigned)((cnt + knotsPerBlock - 1) / knotsPerBlock)), dim3(bs), 0,           \
-                               k3s, b->P, b->dPinfo, b->B, b->dP, b->dSC, b->dCoef, b->dKM, b->dMvc, first,         \
-                               first + cnt);                                                                                             \
+                               k3s, b->P, b->dPinfo, b->B, b->dP, b->dSC, b->dCoef, b->dKM, mvcOut, first,         \
+                               first + cnt, mvcSlot);                                                                                             \
          }                                                                                                                               \
       else hipLaunchKernelGGL(k_pointwise<F>, dim3(grid), dim3(bs), ldsBytes, k3s, b->P, b->dPinfo, b->B, b->dP, b->dSC,      \
-                              b->dCoef, b->dKM, b->dMvc, b->totalKnots, useTile ? 1 : 0);                                      \
+                              b->dCoef, b->dKM, mvcOut, b->totalKnots, useTile ? 1 : 0, mvcSlot);                                      \
    } while (0)
    switch (featureLevel(b))
    {
@@ -867,6 +888,11 @@ extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
    HIP_TRY(hipGetLastError());
    if (async) b->k3Pending = true;
    else HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+   if (b->mvcInCurves)
+   {
+      b->mvcValid = true;
+      b->revDone = false; b->revGone = false; // whatever curves the slots held are overwritten
+   }
    return BATOTP_OK;
 }
 
@@ -976,6 +1002,7 @@ extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
    if (dir == 1 && (!b->revDone || b->revGone)) return BATOTP_ERR_STATE; // in-place curves: the reverse curve is consumed by one forward sweep
    rc = bind(b->ctx);
    if (rc) return rc;
+   b->mvcValid = false; // BATOTP_F_MVC_IN_CURVES: the sweep writes over the pointwise values
    SweepArgs a;
    a.P = b->P; a.dP = b->dP; a.pinfo = b->dPinfo; a.sC = b->dSC; a.coef = b->dCoef; a.km = b->dKM;
    a.rev = b->dRev; a.fwd = b->dFwd; a.res = b->dRes; a.sink = b->dSink; a.prof = b->dMvc; a.cap = b->cap; a.B = b->B; a.dir = dir; a.ppw = 1;
@@ -1111,8 +1138,9 @@ extern "C" int batotp_hip_download_mvc(batotp_batch *b, int32_t path, double *sd
    int rc = bind(b->ctx);
    if (rc) return rc;
    if ((rc = joinK3(b))) return rc;
+   if (b->mvcInCurves && !b->mvcValid) return BATOTP_ERR_STATE; // a sweep has used the curve slots since the last pointwise evaluation
    const PathInfo &pi = b->pinfo[path];
-   const double *base = b->dMvc + pi.koff * 3;
+   const double *base = b->mvcInCurves ? reinterpret_cast<const double *>(b->dRev + (int64_t)path * b->cap) : b->dMvc + pi.koff * 3;
    const size_t sz = sizeof(double) * (size_t)pi.n;
    if (sdot_max) HIP_TRY(hipMemcpyAsync(sdot_max, base, sz, hipMemcpyDeviceToHost, b->ctx->stream));
    if (sddot_l) HIP_TRY(hipMemcpyAsync(sddot_l, base + pi.n, sz, hipMemcpyDeviceToHost, b->ctx->stream));

@@ -1378,7 +1378,7 @@ __device__ __forceinline__ void pt_init(Pt<G, FEAT, UNI> &t, const DevProblem &P
    t.thrA = P.jnt_thresh * pi.afact;
    t.quadA = P.quad_thresh * pi.afact;
    t.quadA2 = P.quad_thresh * P.quad_thresh * pi.afact * pi.afact;
-   const double sLastKnot = UNI ? pi.sres_c * (double)(t.n - 1) : t.sC[t.n - 1];
+   const double sLastKnot = (UNI || pi.uniform) ? pi.sres_c * (double)(t.n - 1) : t.sC[t.n - 1]; // uniform: as k_sites computes it
    t.sdotCap = sLastKnot / P.integ_res;                      // ba.cpp:1216
    t.sddotMax = 2 * sLastKnot / (P.integ_res * P.integ_res); // ba.cpp:1257
    t.cartAccMaxSQ = P.cart_acc_max * P.cart_acc_max;
@@ -1439,7 +1439,7 @@ __global__ void __launch_bounds__(K3_BLOCK) k_pointwise(DevProblem P, const Path
                                                         const DevProblem *__restrict__ dP,
                                                         const double *__restrict__ sC, const double *__restrict__ coef,
                                                         const double *__restrict__ km,
-                                                        double *__restrict__ mvc, int64_t total, int useTile)
+                                                        double *__restrict__ mvc, int64_t total, int useTile, int64_t mvcSlot)
 {
    __shared__ double lim[6][8];
    extern __shared__ double tile[]; // K3_BLOCK rows of C*4 doubles, padded by 2 doubles per row
@@ -1481,10 +1481,12 @@ __global__ void __launch_bounds__(K3_BLOCK) k_pointwise(DevProblem P, const Path
    Pt<1, FEAT, false> t;
    pt_init(t, P, pi, sC, coef, km, lim, 0, -1);
    t.segC = (i < N - 1) ? i : N - 2;
-   t.sCur = t.sC[i];
+   // uniform sites are computed as k_sites computes them (the array is not kept for compact batches)
+   t.sCur = pi.uniform ? pi.sres_c * (double)i : t.sC[i];
    // cursor already on its segment: updateCurSeg only computes tau (0 at a knot, 1 at the last knot)
    {
-      const double sSeg = t.sC[t.segC], sNext = t.sC[t.segC + 1];
+      const double sSeg = pi.uniform ? pi.sres_c * (double)t.segC : t.sC[t.segC];
+      const double sNext = pi.uniform ? pi.sres_c * (double)(t.segC + 1) : t.sC[t.segC + 1];
       t.tauC = (t.sCur - sSeg) / (sNext - sSeg);
    }
    if (FEAT < 0) eval_partials_cached(t, 0);
@@ -1506,7 +1508,8 @@ __global__ void __launch_bounds__(K3_BLOCK) k_pointwise(DevProblem P, const Path
       t.sddotL = __longlong_as_double(0x7ff8000000000000LL);
       t.sddotH = t.sddotL;
    }
-   double *__restrict__ o = mvc + pi.koff * 3;
+   // mvcSlot != 0 (BATOTP_F_MVC_IN_CURVES): the values go to the front of the path's curve slot (mvcSlot doubles per path)
+   double *__restrict__ o = mvcSlot ? mvc + (int64_t)lo * mvcSlot : mvc + pi.koff * 3;
    o[i] = t.sdotCur;
    o[N + i] = t.sddotL;
    o[2 * (int64_t)N + i] = t.sddotH;
@@ -1522,7 +1525,7 @@ template <int FEAT>
 __global__ void __launch_bounds__(K3G_BLOCK) k_pointwise_grp(DevProblem P, const PathInfo *__restrict__ pinfo, int B,
                                                              const DevProblem *__restrict__ dP, const double *__restrict__ sC,
                                                              const double *__restrict__ coef, const double *__restrict__ km,
-                                                             double *__restrict__ mvc, int64_t first, int64_t total)
+                                                             double *__restrict__ mvc, int64_t first, int64_t total, int64_t mvcSlot)
 {
    __shared__ double lim[6][8];
    stage_limits(dP, lim);
@@ -1542,9 +1545,10 @@ __global__ void __launch_bounds__(K3G_BLOCK) k_pointwise_grp(DevProblem P, const
    Pt<8, FEAT, false> t;
    pt_init(t, P, pi, sC, coef, km, lim, j, -1);
    t.segC = (i < N - 1) ? i : N - 2;
-   t.sCur = t.sC[i];
+   t.sCur = pi.uniform ? pi.sres_c * (double)i : t.sC[i];
    {
-      const double sSeg = t.sC[t.segC], sNext = t.sC[t.segC + 1];
+      const double sSeg = pi.uniform ? pi.sres_c * (double)t.segC : t.sC[t.segC];
+      const double sNext = pi.uniform ? pi.sres_c * (double)(t.segC + 1) : t.sC[t.segC + 1];
       t.tauC = (t.sCur - sSeg) / (sNext - sSeg);
    }
    if (FEAT < 0) eval_partials_cached(t, j);
@@ -1561,7 +1565,7 @@ __global__ void __launch_bounds__(K3G_BLOCK) k_pointwise_grp(DevProblem P, const
    }
    if (j == 0)
    {
-      double *__restrict__ o = mvc + pi.koff * 3;
+      double *__restrict__ o = mvcSlot ? mvc + (int64_t)lo * mvcSlot : mvc + pi.koff * 3;
       o[i] = t.sdotCur;
       o[N + i] = t.sddotL;
       o[2 * (int64_t)N + i] = t.sddotH;

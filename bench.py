@@ -74,9 +74,11 @@ WORKLOADS = {
 # BASELINE.json configs as worded.  paths = total over all GPUs ("strong"), or per GPU ("weak": what fills one GPU, or the
 # single trajectory every GPU replicates)
 CONFIGS = {
-    # in_place: BATOTP_F_CURVES_IN_PLACE (one curve buffer per path, the forward curve overwrites the reverse curve as in the
-    # reference's Traj): 17.8 instead of 21.3 MB per path -> 13 312 instead of 11 264 paths, 7 instead of 6 per wavefront
-    "fill7": dict(workload="gen7", knots=100000, paths=13312, scaling="weak", distinct=2048, in_place=True,
+    # lean: BATOTP_F_CURVES_IN_PLACE (one curve buffer per path, the forward curve overwrites the reverse curve as in the
+    # reference's Traj) + BATOTP_F_MVC_IN_CURVES (the pointwise values live in the curve slots until the sweeps start); compact
+    # batches keep no site array: 14.6 instead of 21.3 MB per path -> 16 384 instead of 11 264 paths, every lane of 2048
+    # wavefronts carries a path
+    "fill7": dict(workload="gen7", knots=100000, paths=16384, scaling="weak", distinct=2048, lean=True,
                   what="GEN7DOF 7-DOF vel+acc, N~100k knots/path, batch of independent paths filling the GPU"),
     "fill6": dict(workload="ur6", knots=100000, paths=16384, scaling="weak", distinct=2048,
                   what="cfg2 shape: UR5-like 6-DOF vel+acc, N~100k knots/path, batch of independent paths filling the GPU"),
@@ -320,10 +322,11 @@ def prepare_dynamics(batch, prob, n_paths):
 def bytes_per_path(prob, C, n_mean, cap):
     """HBM bytes a path of n_mean knots occupies in a batch (batotp_hip_batch_create's arrays)"""
     cin, d = prob.n_joints + prob.n_cart, prob.dyn_dim
+    mvc = 0 if (prob.flags & capi.F_MVC_IN_CURVES) else 24
     if prob.flags & capi.F_COMPACT_SPLINES:
-        per_knot = 16.0 * cin + 8 + 24
+        per_knot = 16.0 * cin + mvc        # no site array for compact batches
     else:
-        per_knot = 8.0 * cin + 8 + 32.0 * C + (0 if (prob.flags & capi.F_NO_SAMPLES) else 24.0 * cin) + 32.0 * d + 24 + 8.0 * max(cin, 4 * d)
+        per_knot = 8.0 * cin + 8 + 32.0 * C + (0 if (prob.flags & capi.F_NO_SAMPLES) else 24.0 * cin) + 32.0 * d + mvc + 8.0 * max(cin, 4 * d)
         if d and not (prob.flags & capi.F_PARALLEL):
             per_knot += 16.0 * prob.n_joints      # joint trig tables of the chain model
     return per_knot * n_mean + (16.0 if prob.flags & capi.F_CURVES_IN_PLACE else 32.0) * cap
@@ -350,8 +353,8 @@ def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=
     prob = capi.Problem.from_buffer_copy(bytes(inp.prob))
     if (prob.flags & capi.F_NO_SAMPLES) and not coefficient_rows:
         prob.flags |= capi.F_COMPACT_SPLINES  # same results, half the spline bytes per knot: room for more paths per GPU
-    if c.get("in_place"):
-        prob.flags |= capi.F_CURVES_IN_PLACE   # same results, one curve buffer per path
+    if c.get("lean"):
+        prob.flags |= capi.F_CURVES_IN_PLACE | capi.F_MVC_IN_CURVES   # same results, one curve buffer per path and nothing else per knot
     C = WORKLOADS[workload]["C"]
     cap = int(int(inp.n_knots.max()) * WORKLOADS[workload]["cap"]) + 1024
 
@@ -693,6 +696,7 @@ def main():
     ap.add_argument("--group", type=int, default=0, help="lanes per path in the sweep kernel (0 = automatic)")
     ap.add_argument("--ppw", type=int, default=0, help="paths per wavefront in the sweep kernel (0 = automatic)")
     ap.add_argument("--prefetch", type=int, nargs=2, default=None, help="sweep prefetch bits, reverse forward (batotp_hip_set_sweep_prefetch)")
+    ap.add_argument("--hold", type=int, nargs=2, default=None, help="sweep loop form, reverse forward (batotp_hip_set_sweep_hold; -2 automatic)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sides", action="store_true", help="skip the side measurements (resampler, output stage, nested-loop cross-check)")
@@ -728,6 +732,8 @@ def main():
     hip = capi.Context(capi.load_hip(), local_rank)  # raises if the HIP extension or the GPU is missing
     if args.prefetch:
         hip.set_sweep_prefetch(*args.prefetch)
+    if args.hold:
+        hip.set_sweep_hold(*args.hold)
 
     default_run = args.config == "fill7" and not args.paths and not args.knots
     out, kept = measure(hip, args.config, rank, world, args.steps, args.warmup, dist_ctx, args.paths, args.knots, args.group, args.ppw,

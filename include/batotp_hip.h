@@ -77,6 +77,12 @@ extern "C" {
                                             (max_steps >= forward points + 72 suffices).  After batotp_hip_sweep(b, +1)
                                             the reverse curve is gone: download / pack of curve -1 and a second forward sweep
                                             return BATOTP_ERR_STATE until the reverse sweep has run again.  Same results. */
+#define BATOTP_F_MVC_IN_CURVES   (1u<<10) /* batotp_hip_pointwise_mvc writes its three values per knot into the paths' curve
+                                            buffers instead of an array of its own (24 bytes per knot less; needs max_steps >=
+                                            1.5 * knots of every path).  They are valid until the next sweep starts: afterwards
+                                            batotp_hip_download_mvc returns BATOTP_ERR_STATE, and a pointwise evaluation after a
+                                            sweep invalidates the curves (the reverse sweep has to run again).  The overlap
+                                            mode (batotp_hip_set_overlap) is ignored for such a batch.  Same results. */
 
 /* per-path status bits written by the sweep kernel (the reference only printf()s these) */
 #define BATOTP_ST_MAX_INTEG_TIME (1u<<0) /* ba.cpp:1117-1122 (MAX_INTEGRATION_TIME)        */

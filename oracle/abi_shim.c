@@ -31,6 +31,7 @@ struct batotp_batch {
     batotp_serial_model serial;
     int has_serial;
     int kin_done;
+    int mvc_stale;       /* BATOTP_F_MVC_IN_CURVES: a sweep has run since the last pointwise evaluation (state rule of the product) */
     int rev_gone;        /* BATOTP_F_CURVES_IN_PLACE: the forward sweep has consumed the reverse curve (state rules of the product) */
     float ms[5];
 };
@@ -237,6 +238,7 @@ int batotp_hip_pointwise_mvc(batotp_batch *b)
     #pragma omp parallel for schedule(dynamic, 1)
     for (p = 0; p < b->n_paths; p++) bo_pointwise_mvc(&b->prob, b->path[p]);
     b->ms[2] = (float)(now_ms() - t0);
+    b->mvc_stale = 0;
     return BATOTP_OK;
 }
 
@@ -246,6 +248,7 @@ int batotp_hip_sweep(batotp_batch *b, int32_t dir)
     double t0 = now_ms();
     if (!b || !b->kin_done || (dir != 1 && dir != -1)) return BATOTP_ERR_STATE;
     if (dir == 1 && b->rev_gone) return BATOTP_ERR_STATE;
+    b->mvc_stale = 1;
     for (p = 0; p < b->n_paths; p++)
         if (dir == 1 && !b->rev_s[p]) return BATOTP_ERR_STATE;
     #pragma omp parallel for schedule(dynamic, 1)
@@ -348,6 +351,7 @@ int batotp_hip_download_mvc(batotp_batch *b, int32_t path, double *sdot_max, dou
     bo_path *p;
     size_t n;
     if (!b || path < 0 || path >= b->n_paths) return BATOTP_ERR_ARG;
+    if ((b->prob.flags & BATOTP_F_MVC_IN_CURVES) && b->mvc_stale) return BATOTP_ERR_STATE;
     p = b->path[path]; n = (size_t)p->n;
     if (sdot_max) memcpy(sdot_max, p->mvc, sizeof(double) * n);
     if (sddot_l) memcpy(sddot_l, p->mvc + n, sizeof(double) * n);

@@ -197,6 +197,8 @@ def run_pipeline(ctx, cases, max_steps=None, mvc=True, details=True, extra_flags
         prob = capi.Problem.from_buffer_copy(bytes(prob))
         prob.flags |= extra_flags
     cap = max_steps or max(c.max_steps() for c in cases) + (16 if prob.flags & capi.F_CURVES_IN_PLACE else 0)  # in place: 72 points of margin
+    if prob.flags & capi.F_MVC_IN_CURVES:
+        cap = max(cap, (3 * max(c.n for c in cases) + 1) // 2)   # the pointwise values of a path must fit its curve slot
     b = capi.Batch(ctx, prob, [c.n for c in cases], cap)
     for k, c in enumerate(cases):
         b.upload_knots(k, [c.y], [c.sres])
@@ -213,8 +215,11 @@ def run_pipeline(ctx, cases, max_steps=None, mvc=True, details=True, extra_flags
             for k in range(len(cases)):
                 b.upload_rr_trig(k, rr_trig(b.samples(k, 0)[0], b.samples(k, 1)[0]))
         b.precompute(2)
+    mvc_early = None
     if mvc:
         b.pointwise_mvc()
+        if prob.flags & capi.F_MVC_IN_CURVES:   # valid until a sweep starts
+            mvc_early = [np.stack(b.mvc(k)) for k in range(len(cases))]
     b.sweep(-1)
     # BATOTP_F_CURVES_IN_PLACE: the forward sweep overwrites the reverse curve, so it is fetched between the sweeps
     in_place = bool(prob.flags & capi.F_CURVES_IN_PLACE)
@@ -234,7 +239,7 @@ def run_pipeline(ctx, cases, max_steps=None, mvc=True, details=True, extra_flags
             if prob.dyn_dim:
                 d["dyn"] = np.stack([np.stack([b.dyn(k, kk, r) for r in range(prob.dyn_dim)]) for kk in (1, 2, 3, 4)])
         if mvc:
-            d["mvc"] = np.stack(b.mvc(k))
+            d["mvc"] = mvc_early[k] if mvc_early is not None else np.stack(b.mvc(k))
         out.append(d)
     b.close()
     return out

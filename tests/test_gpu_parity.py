@@ -296,6 +296,44 @@ def test_curves_in_place_state_and_capacity(hip_ctx, oracle_ctx):
     b.close()
 
 
+@pytest.mark.parametrize("lanes", [0, 8, 64])
+def test_pointwise_values_in_the_curve_slots(hip_lib, oracle_ctx, lanes):
+    """BATOTP_F_MVC_IN_CURVES (+ in-place curves, compact splines without a site array): the pointwise values, fetched before
+    the sweeps, and everything the sweeps publish equal the oracle's; afterwards the values are gone (state error)"""
+    ctx = capi.Context(hip_lib, 0)
+    helpers.set_layout(ctx, lanes)
+    for name in ("GEN7DOF", "synth_gen7dof_s0", "UR5", "CSPR3DOF", "synth_ur_s2"):
+        case = Case(name)
+        variants = [capi.F_MVC_IN_CURVES, capi.F_MVC_IN_CURVES | capi.F_CURVES_IN_PLACE]
+        if _vel_acc_only(name):
+            variants.append(capi.F_MVC_IN_CURVES | capi.F_CURVES_IN_PLACE | capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES)
+        oo = run_pipeline(oracle_ctx, [case], mvc=True, details=False)[0]
+        for flags in variants:
+            ho = run_pipeline(ctx, [case, case], mvc=True, details=False, extra_flags=flags)
+            for h in ho:
+                _compare(case, h, oo)
+    case = Case("GEN7DOF")
+    prob = capi.Problem.from_buffer_copy(bytes(case.problem))
+    prob.flags |= capi.F_MVC_IN_CURVES
+    with pytest.raises(capi.BatotpError):
+        capi.Batch(ctx, prob, [case.n], case.n)              # a slot shorter than 1.5 x the knots
+    b = capi.Batch(ctx, prob, [case.n], case.max_steps())
+    b.upload_knots(0, [case.y], [case.sres])
+    b.precompute(0); b.pointwise_mvc()
+    first = np.stack(b.mvc(0))
+    b.sweep(-1)
+    with pytest.raises(capi.BatotpError):
+        b.mvc(0)
+    b.sweep(+1)
+    b.pointwise_mvc()                                         # again: values back, curves invalid until the reverse sweep reruns
+    helpers.assert_bit_equal(np.stack(b.mvc(0)), first, "pointwise values after re-evaluation")
+    with pytest.raises(capi.BatotpError):
+        b.sweep(+1)
+    b.sweep(-1); b.sweep(+1)
+    assert int(b.results()[0]["n_fwd"]) == case.expected["n_fwd"]
+    b.close(); ctx.close()
+
+
 def test_capacity_and_max_time_status(hip_ctx, oracle_ctx):
     case = Case("GEN7DOF")
     for ctx in (hip_ctx, oracle_ctx):
@@ -435,6 +473,34 @@ def test_uploaded_sites_and_coefficients_path(hip_ctx, oracle_ctx):
         assert res[0][4] == res[1][4]
         if not stretch:
             assert_bit_equal(res[0][1], oo["rev"][1], "uploaded == precomputed")
+
+
+def test_compact_batch_gets_its_site_array_when_sites_are_uploaded(hip_ctx, oracle_ctx):
+    """compact batches keep no knot-site array (uniform sites are computed); uploading the sites of ONE path creates it for
+    all: the stretched path and its untouched neighbour both equal the oracle's"""
+    case = Case("GEN7DOF")
+    n = case.n
+    flags = capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES
+    sites = case.sres * np.arange(n, dtype=np.float64) * (1.0 + 1e-3 * np.sin(np.arange(n)))
+    sites[0] = 0.0
+    vf = 1.0 / case.sres
+    out = []
+    for ctx, fl in ((hip_ctx, flags), (oracle_ctx, 0)):
+        prob = capi.Problem.from_buffer_copy(bytes(case.problem))
+        prob.flags |= fl
+        b = capi.Batch(ctx, prob, [n, n], 4 * case.max_steps())
+        b.upload_knots(0, [case.y, case.y], [case.sres, case.sres])
+        b.precompute(0)
+        b.upload_path_sites(1, sites, vf, vf * vf, 0)
+        b.pointwise_mvc(); b.sweep(-1); b.sweep(+1)
+        out.append(([b.curve(k, w) for k in (0, 1) for w in (-1, 1)], [np.stack(b.mvc(k)) for k in (0, 1)], b.results().copy()))
+        b.close()
+    for a, c in zip(out[0][0], out[1][0]):
+        assert_bit_equal(a[0], c[0], "s"); assert_bit_equal(a[1], c[1], "sdot")
+    for a, c in zip(out[0][1], out[1][1]):
+        assert_bit_equal(a, c, "pointwise values")
+    assert out[0][2].tobytes() == out[1][2].tobytes()
+    assert out[0][2][0]["n_fwd"] == case.expected["n_fwd"] and out[0][2][1]["n_fwd"] != 0
 
 
 def test_product_batest_end_to_end_on_gpu(tmp_path):
