@@ -27,7 +27,10 @@ if prob.flags & capi.F_NO_SAMPLES:
 b = capi.Batch(hip, prob, nk, cap)
 for p in range(a.paths):
     b.upload_knots(p, [base[p % a.distinct][0]], [base[p % a.distinct][1]])
-b.precompute(0)
+b.precompute(1)
+bench.prepare_dynamics(b, prob, a.paths)   # serial robots with a chain model: cos / sin of the joint angles from the host
+if prob.dyn_dim:
+    b.precompute(2)
 for d, name in ((-1, "reverse"), (+1, "forward")):
     b.sweep(d)
     raw = b.mvc(0)[0][: 8 * a.paths].reshape(a.paths, 8)
