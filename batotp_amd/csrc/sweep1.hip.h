@@ -497,6 +497,41 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
          const bool violMine = verify(mine); // this slot's sddotL / sddotH stay in its lanes
          const unsigned ballot = (unsigned)__ballot(violMine);
 
+         // Plain bisection (a feasible point is known, ba.cpp:1286-1303): the pass consumes c0 and then cand1 (c0 violated) or
+         // cand2 (c0 feasible).  The convergence test of a feasible candidate (ba.cpp:1294) is evaluated by its own slot beside
+         // the constraint check -- it compares with the last feasible point before it, which is sdotGood for c0 and cand1 and
+         // c0 for cand2 -- so the replay of the two iterations is a walk over ballot bits instead of two runs of iterate().
+         // Same updates, same order, same values; the generic replay below keeps the cases with a failure exit in reach
+         // (iteration count near 100, a negative candidate) and the search phase before the first feasible point.
+         if (__builtin_amdgcn_readfirstlane((int)(nGood != 0 && nIter <= 98 && !(c0 < 0.0) && !(sdotL < 0.0))))
+         {
+            const double prevGood = (cslot == 2) ? c0 : sdotGood;
+            const bool convMine = ratio_lt(fabs(mine - prevGood), mine, sdotErrThresh) || mine < 0.0;
+            const unsigned conv = (unsigned)__ballot(convMine);
+            int k2;
+            if (ballot & 1u) { sdotH = c0; k2 = 1; }                       // c0 violated: ba.cpp:1278-1280
+            else
+            {
+               sdotGood = c0; ++nGood;
+               if (conv & 1u) { sdotCur = c0; lastSlot = 0; fin = true; over = true; break; } // ba.cpp:1294-1303
+               sdotL = c0; k2 = 2;
+            }
+            ++nIter;
+            const double m = (k2 == 1) ? cand1 : cand2;                  // == .5 * (sdotH + sdotL), the value iterate() would ask for
+            const unsigned bit = 1u << (8 * k2);
+            lastSlot = k2;
+            if (ballot & bit) sdotH = m;
+            else
+            {
+               sdotGood = m; ++nGood;
+               if (conv & bit) { sdotCur = m; fin = true; over = true; break; }
+               sdotL = m;
+            }
+            ++nIter;
+            sdotTry = .5 * (sdotH + sdotL);
+            continue;
+         }
+
          int k = 0;
 #pragma unroll 1
          for (int consumed = 0; consumed < 4; ++consumed)
