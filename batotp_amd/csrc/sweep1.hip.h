@@ -497,39 +497,79 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
          const bool violMine = verify(mine); // this slot's sddotL / sddotH stay in its lanes
          const unsigned ballot = (unsigned)__ballot(violMine);
 
-         // Plain bisection (a feasible point is known, ba.cpp:1286-1303): the pass consumes c0 and then cand1 (c0 violated) or
-         // cand2 (c0 feasible).  The convergence test of a feasible candidate (ba.cpp:1294) is evaluated by its own slot beside
-         // the constraint check -- it compares with the last feasible point before it, which is sdotGood for c0 and cand1 and
-         // c0 for cand2 -- so the replay of the two iterations is a walk over ballot bits instead of two runs of iterate().
-         // Same updates, same order, same values; the generic replay below keeps the cases with a failure exit in reach
-         // (iteration count near 100, a negative candidate) and the search phase before the first feasible point.
-         if (__builtin_amdgcn_readfirstlane((int)(nGood != 0 && nIter <= 98 && !(c0 < 0.0) && !(sdotL < 0.0))))
+         // The replay of the reference's loop for this pass as a walk over ballot bits instead of runs of iterate(): whatever an
+         // iteration tests about its candidate -- the convergence test of a feasible one (ba.cpp:1294), the collapsed-bracket
+         // test of a violated one while no feasible point is known (ba.cpp:1311-1315) -- is evaluated by the candidate's own
+         // slot beside the constraint check, all four at once.  Same updates, same order, same values; the generic replay
+         // below keeps what can end in a failure exit (iteration count near 100, a negative candidate, a collapsed bracket).
+         if (__builtin_amdgcn_readfirstlane((int)(nIter <= 96 && !(c0 < 0.0) && !(sdotL < 0.0))))
          {
-            const double prevGood = (cslot == 2) ? c0 : sdotGood;
-            const bool convMine = ratio_lt(fabs(mine - prevGood), mine, sdotErrThresh) || mine < 0.0;
+            if (nGood != 0)
+            {
+               // plain bisection (ba.cpp:1286-1303): c0, then cand1 (c0 violated) or cand2 (c0 feasible); a feasible candidate is
+               // compared with the last feasible point before it: sdotGood for c0 and cand1, c0 for cand2
+               const double prevGood = (cslot == 2) ? c0 : sdotGood;
+               const bool convMine = ratio_lt(fabs(mine - prevGood), mine, sdotErrThresh) || mine < 0.0;
+               const unsigned conv = (unsigned)__ballot(convMine);
+               int k2;
+               if (ballot & 1u) { sdotH = c0; k2 = 1; }                       // c0 violated: ba.cpp:1278-1280
+               else
+               {
+                  sdotGood = c0; ++nGood;
+                  if (conv & 1u) { sdotCur = c0; lastSlot = 0; fin = true; over = true; break; } // ba.cpp:1294-1303
+                  sdotL = c0; k2 = 2;
+               }
+               ++nIter;
+               const double m = (k2 == 1) ? cand1 : cand2;                  // == .5 * (sdotH + sdotL), the value iterate() would ask for
+               const unsigned bit = 1u << (8 * k2);
+               lastSlot = k2;
+               if (ballot & bit) sdotH = m;
+               else
+               {
+                  sdotGood = m; ++nGood;
+                  if (conv & bit) { sdotCur = m; fin = true; over = true; break; }
+                  sdotL = m;
+               }
+               ++nIter;
+               sdotTry = .5 * (sdotH + sdotL);
+               continue;
+            }
+            // the search for a first feasible point (ba.cpp:1281-1285): c0, cand1, cand2, cand3 as long as they are violated,
+            // the bracket shrinking below each; the first feasible one starts the plain bisection
+            const double lfMine = lowFact * (double)(2 << cslot);
+            const double shrunkMine = dmax(.999 * 0.0, (1.0 - lfMine) * mine);
+            const bool convMine = ratio_lt(fabs(mine - sdotGood), mine, sdotErrThresh) || mine < 0.0;
+            const bool badMine = mine < 0.0 || ratio_lt(mine - shrunkMine, mine, 1e-20);  // a failure exit if this one is violated
             const unsigned conv = (unsigned)__ballot(convMine);
-            int k2;
-            if (ballot & 1u) { sdotH = c0; k2 = 1; }                       // c0 violated: ba.cpp:1278-1280
-            else
+            if ((((unsigned)__ballot(badMine)) & ballot & 0x01010101u) == 0u)
             {
-               sdotGood = c0; ++nGood;
-               if (conv & 1u) { sdotCur = c0; lastSlot = 0; fin = true; over = true; break; } // ba.cpp:1294-1303
-               sdotL = c0; k2 = 2;
+               bool ended = false;
+#pragma unroll
+               for (int d = 0; d < 4; ++d)
+               {
+                  if (ended) break;
+                  const double m = (d == 0) ? c0 : (d == 1) ? cand1 : (d == 2) ? cand2 : cand3;
+                  const unsigned bit = 1u << (8 * d);
+                  lastSlot = d;
+                  if (ballot & bit)
+                  {
+                     lowFact *= 2.0;                                   // ba.cpp:1281-1285
+                     sdotH = m;
+                     sdotL = dmax(.999 * 0.0, (1.0 - lowFact) * m);
+                     ++nIter;
+                  }
+                  else
+                  {
+                     sdotGood = m; nGood = 1;
+                     if (conv & bit) { sdotCur = m; fin = true; over = true; }
+                     else { sdotL = m; ++nIter; }
+                     ended = true;
+                  }
+               }
+               if (over) break;
+               sdotTry = .5 * (sdotH + sdotL);
+               continue;
             }
-            ++nIter;
-            const double m = (k2 == 1) ? cand1 : cand2;                  // == .5 * (sdotH + sdotL), the value iterate() would ask for
-            const unsigned bit = 1u << (8 * k2);
-            lastSlot = k2;
-            if (ballot & bit) sdotH = m;
-            else
-            {
-               sdotGood = m; ++nGood;
-               if (conv & bit) { sdotCur = m; fin = true; over = true; break; }
-               sdotL = m;
-            }
-            ++nIter;
-            sdotTry = .5 * (sdotH + sdotL);
-            continue;
          }
 
          int k = 0;
