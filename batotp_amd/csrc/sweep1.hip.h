@@ -476,6 +476,9 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
 #ifdef BK_PROFILE_SECTIONS
          ++nPass;
 #endif
+         // the loop's counters are the same in every lane: say so, and every branch on them is a scalar branch
+         nGood = __builtin_amdgcn_readfirstlane(nGood);
+         nIter = __builtin_amdgcn_readfirstlane(nIter);
          const double c0 = sdotTry;
          double cand1, cand2, cand3;
          if (nGood == 0)
