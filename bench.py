@@ -807,10 +807,17 @@ def main():
             hip.trim()
         out["as_worded"] = worded
     hip.close()
-    if rank == 0:
-        print(json.dumps(out))
     if dist_ctx is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio on rank 0: push it out first, so that the JSON line is the last line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
