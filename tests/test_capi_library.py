@@ -38,3 +38,18 @@ def test_no_gpu_means_loud_failure(hip_lib):
         pytest.skip("a GPU is present")
     with pytest.raises(capi.BatotpError):
         capi.Context(hip_lib, 0)
+
+
+def test_flag_and_status_constants_match_the_header():
+    """the Python binding's BATOTP_F_* / BATOTP_ST_* values are the header's"""
+    text = open(os.path.join(helpers.ROOT, "include", "batotp_hip.h")).read()
+    defs = {m.group(1): 1 << int(m.group(2)) for m in re.finditer(r"#define\s+BATOTP_(F_\w+|ST_\w+)\s+\(1u<<(\d+)\)", text)}
+    assert len(defs) >= 15
+    checked = 0
+    for name, value in defs.items():
+        if hasattr(capi, name):
+            assert getattr(capi, name) == value, name
+            checked += 1
+    for name in ("F_COMPACT_SPLINES", "F_CURVES_IN_PLACE", "F_MVC_IN_CURVES", "F_NO_SAMPLES", "ST_CAPACITY", "ST_MAX_INTEG_TIME"):
+        assert name in defs and hasattr(capi, name), name
+    assert checked >= 12
