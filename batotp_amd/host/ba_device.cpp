@@ -743,6 +743,8 @@ int BA::optimizeBatchOnDevice(std::vector<Traj> &trajs)
    for (;;)
    {
       if (g.b) { batotp_hip_batch_destroy(g.b); g.b = nullptr; }
+      // this call sequence never asks for the pointwise values (K3): without the flag their array would only occupy HBM
+      if (2 * cap >= 3 * nMax) prob.flags |= BATOTP_F_MVC_IN_CURVES; else prob.flags &= ~(uint32_t)BATOTP_F_MVC_IN_CURVES;
       rc = batotp_hip_batch_create(_gpu->ctx, &prob, (int32_t)live.size(), nKnots.data(), cap, &g.b);
       if (rc) return fail("batch_create", rc);
 
