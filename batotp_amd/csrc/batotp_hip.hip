@@ -1017,8 +1017,11 @@ extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
       // 32-lane layout (four bisection candidates per pass) wins; beyond that the 8-lane layout, which
       // packs more paths per wavefront, has the higher throughput
       lanes = (b->B <= (a.dir == -1 ? 2048 : 1024)) ? 32 : 8;
-      // ... and where every path has a wavefront to itself anyway, the kernel written for that case (sweep1.hip.h)
-      if (lanes == 32 && sweep1Applies(b)) lanes = 64;
+      // ... and where every path has a wavefront to itself anyway, the kernel written for that case (sweep1.hip.h).  It also
+      // wins for a while beyond that, with its wavefronts queueing for the two slots per SIMD its registers leave: the 8-lane
+      // layout at 2-4 paths per wavefront is latency-bound and slower (GEN7DOF, N = 5e4, reverse: 3072 paths 944 vs 1882 ms,
+      // 6144 paths 1784 vs 2024, 8192 paths 2328 vs 2137; forward: 3072 paths 923 vs 981, 4096 paths 1118 vs 1031; UR6 alike)
+      if (sweep1Applies(b) && b->B <= (a.dir == -1 ? 6144 : 3072)) lanes = 64;
    }
    if (lanes == 64 && !sweep1Applies(b)) lanes = 32; // a parallel mechanism's torque limits, uploaded sites: the general kernel
    switch (lanes)

@@ -745,7 +745,7 @@ def main():
     if rank == 0 and not args.no_sides and batch is not None:
         # the automatic loop form of the reverse sweep (flat stage / bisection loop) against the nested loops on the same
         # batch: the result rows must be identical; untimed
-        if vel_acc_only and kept["chunk0"] > 2048 and args.group in (0, 8):
+        if vel_acc_only and kept["chunk0"] > 6144 and args.group in (0, 8):   # up to 6144 paths the reverse sweep runs k_sweep1, not the flat loop
             ref_rows = batch.results().tobytes()
             hip.set_sweep_hold(-1, -1)
             batch.sweep(-1); batch.sweep(+1)

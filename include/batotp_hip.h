@@ -263,7 +263,8 @@ int  batotp_hip_batch_bytes(batotp_batch *batch, int64_t *bytes);
 /* tuning knob: lanes per path in the sweep kernel: 8 (a joint per lane), 16 (two halves of 8 lanes share the bounds of the
  * sddot interval), 32 (four bisection candidates per pass), 4 / 2 / 1 (two / four / all joints per lane), 64 (a wavefront
  * per path: the kernel written for the latency-bound regime; a parallel mechanism's torque limits without BATOTP_F_PAR2SER
- * and paths with uploaded sites fall back to 32) or 0 = automatic (default: 64 or 32 while every path can have a wavefront to itself, 8 beyond) */
+ * and paths with uploaded sites fall back to 32) or 0 = automatic (default: 64 up to 6144 paths in the reverse and 3072 in the forward sweep -- 32 where 64 does not apply and
+ * every path can have a wavefront to itself --, 8 beyond) */
 int  batotp_hip_set_sweep_group(batotp_ctx *ctx, int32_t lanes);
 /* tuning knob: paths per 64-lane wavefront in the sweep kernel, 1 .. 64/lanes (0 = automatic:
  * few paths are spread over more wavefronts, many paths fill every lane) */
