@@ -83,6 +83,7 @@ struct batotp_batch
    bool inPlace = false;   // BATOTP_F_CURVES_IN_PLACE: dFwd aliases dRev
    bool revGone = false;   // ... and the forward sweep has overwritten the reverse curve
    bool mvcInCurves = false, mvcValid = false; // BATOTP_F_MVC_IN_CURVES: K3's values live in the curve slots until a sweep starts
+   bool revStale = false, fwdStale = false;    // ... and a pointwise evaluation has overwritten that curve since its sweep
 
    // device memory
    DevProblem *dP = nullptr;
@@ -709,6 +710,7 @@ extern "C" int batotp_hip_upload_curve(batotp_batch *b, int32_t path, const doub
    if (e != hipSuccess) return hipFail(e, "upload_curve");
    b->revDone = true;
    b->revGone = false;
+   b->revStale = false;
    b->mvcValid = false;
    return BATOTP_OK;
 }
@@ -892,6 +894,7 @@ extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
    {
       b->mvcValid = true;
       b->revDone = false; b->revGone = false; // whatever curves the slots held are overwritten
+      b->revStale = true; b->fwdStale = true;
    }
    return BATOTP_OK;
 }
@@ -1037,8 +1040,12 @@ extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
    evStop(b, which);
    HIP_TRY(hipGetLastError());
    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
-   if (dir == -1) { b->revDone = true; b->revGone = false; }
-   else if (b->inPlace) b->revGone = true;
+   if (dir == -1) { b->revDone = true; b->revGone = false; b->revStale = false; }
+   else
+   {
+      b->fwdStale = false;
+      if (b->inPlace) b->revGone = true;
+   }
    return BATOTP_OK;
 }
 
@@ -1069,6 +1076,7 @@ extern "C" int batotp_hip_download_curve(batotp_batch *b, int32_t path, int32_t 
 {
    if (!b || path < 0 || path >= b->B || (which != 1 && which != -1)) return BATOTP_ERR_ARG;
    if (which == -1 && b->revGone) return BATOTP_ERR_STATE; // BATOTP_F_CURVES_IN_PLACE: overwritten by the forward sweep
+   if (which == -1 ? b->revStale : b->fwdStale) return BATOTP_ERR_STATE; // BATOTP_F_MVC_IN_CURVES: overwritten by a pointwise evaluation
    int rc = bind(b->ctx);
    if (rc) return rc;
    batotp_path_result r;
@@ -1166,6 +1174,7 @@ extern "C" int batotp_hip_pack_curves(batotp_batch *b, int32_t which, int32_t pa
    if (!b || (which != 1 && which != -1) || path0 < 0 || n_paths < 0 || path0 + n_paths > b->B || !total_points) return BATOTP_ERR_ARG;
    *total_points = 0;
    if (which == -1 && b->revGone) return BATOTP_ERR_STATE; // BATOTP_F_CURVES_IN_PLACE: overwritten by the forward sweep
+   if (which == -1 ? b->revStale : b->fwdStale) return BATOTP_ERR_STATE; // BATOTP_F_MVC_IN_CURVES: overwritten by a pointwise evaluation
    if (n_paths == 0) return BATOTP_OK;
    int rc = bind(b->ctx);
    if (rc) return rc;

@@ -725,7 +725,7 @@ struct Pt
    // lane constants (limits of this lane's joints)
    double vmax[PER], amax[PER], tmax[PER], tmin[PER];
    // reverse curve (forward sweep only)
-   const double *__restrict__ mvc; // (s, sdot) pairs
+   const double *mvc; // (s, sdot) pairs; no __restrict__: with BATOTP_F_CURVES_IN_PLACE it points into the buffer `out` writes
    int nMvc;
    int dir;
    // cursor state (ba.h:94-103,144-145)
@@ -1667,9 +1667,6 @@ constexpr int K4_BLOCK = 256;
 #ifndef BK_SWEEP_WPE
 #define BK_SWEEP_WPE 2
 #endif
-#ifndef BK_TOUCH_DIRS
-#define BK_TOUCH_DIRS 1 /* 0: never, 1: reverse sweep only, 2: both sweeps */
-#endif
 // waves per SIMD the register allocation of the narrow (FEAT <= 1) sweep kernels is tuned for
 // FLAT: the stage loop and the bisection loop are one loop in which every path of the wavefront is either
 // waiting for its next stage or inside a constraint check (see the comment at the loop).
@@ -1711,7 +1708,7 @@ __global__ void __launch_bounds__(K4_BLOCK, (G > 1 && G < 8) ? 1 : (FEAT <= 1 &&
    t.cslot = SPEC ? ((lane >> 3) & 3) : 0;
    t.pbase = lane & ~(G - 1);
 
-   double2 *__restrict__ out = (dir == 1 ? a.fwd : a.rev) + (int64_t)p * cap;
+   double2 *out = (dir == 1 ? a.fwd : a.rev) + (int64_t)p * cap; // may alias t.mvc (curves in place): no __restrict__
    batotp_path_result *__restrict__ r = a.res + p;
    if (dir == 1)
    {

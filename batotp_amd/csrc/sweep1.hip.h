@@ -77,11 +77,11 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
 
    const double2 *__restrict__ km = (FEAT < 0) ? reinterpret_cast<const double2 *>(a.km) + pi.koff * nIn : nullptr;
    const double *__restrict__ coef = (FEAT < 0) ? nullptr : a.coef + pi.koff * C * 4;
-   double2 *__restrict__ out = (DIR == 1 ? a.fwd : a.rev) + (int64_t)p * cap;
+   double2 *out = (DIR == 1 ? a.fwd : a.rev) + (int64_t)p * cap; // forward, curves in place: the same buffer as mvc (no __restrict__)
    batotp_path_result *__restrict__ r = a.res + p;
 
    // reverse curve the forward sweep follows
-   const double *__restrict__ mvc = nullptr;
+   const double *mvc = nullptr;
    int nMvc = 0;
    if (DIR == 1)
    {
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       w = w > wmax ? wmax : w;
       w = w < 0 ? 0 : w;
       const int cnt = (nMvc - w) < S1_WM ? (nMvc - w) : S1_WM;
-      const double2 *__restrict__ src = reinterpret_cast<const double2 *>(mvc) + w;
+      const double2 *src = reinterpret_cast<const double2 *>(mvc) + w;
       {
          // the whole window in one round trip: 8 loads in flight per lane (indices clamped to the last point), 8 LDS writes
          static_assert(S1_WM == 256, "needM moves 8 groups of 32 points");

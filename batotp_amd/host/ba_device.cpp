@@ -843,8 +843,12 @@ int BA::optimizeBatchOnDevice(std::vector<Traj> &trajs)
       for (size_t k = 0; k < res.size(); ++k)
       {
          const uint32_t st = res[k].status_rev | res[k].status_fwd;
+         // with one curve buffer per path (BATOTP_F_CURVES_IN_PLACE) the forward sweep gives up as soon as its curve comes
+         // within 64 points of the reverse points still to be read -- long before steps_fwd reaches cap
+         const bool inPlaceFull = (prob.flags & BATOTP_F_CURVES_IN_PLACE) && res[k].n_rev > 0 && (res[k].status_fwd & BATOTP_ST_CAPACITY) &&
+                                  !(res[k].status_fwd & BATOTP_ST_NONFINITE);
          if ((st & BATOTP_ST_CAPACITY) && !(st & BATOTP_ST_MAX_INTEG_TIME) && !(res[k].status_rev & BATOTP_ST_NONFINITE) &&
-             (res[k].n_rev == 0 || res[k].n_fwd == 0) && (res[k].steps_rev + 1 >= cap || res[k].steps_fwd + 1 >= cap))
+             (res[k].n_rev == 0 || res[k].n_fwd == 0) && (res[k].steps_rev + 1 >= cap || res[k].steps_fwd + 1 >= cap || inPlaceFull))
          {
             if (outOfRoom == 0) firstOut = k;
             ++outOfRoom;

@@ -32,6 +32,7 @@ struct batotp_batch {
     int has_serial;
     int kin_done;
     int mvc_stale;       /* BATOTP_F_MVC_IN_CURVES: a sweep has run since the last pointwise evaluation (state rule of the product) */
+    int rev_stale, fwd_stale; /* BATOTP_F_MVC_IN_CURVES: a pointwise evaluation has overwritten that curve since its sweep (state rule of the product) */
     int rev_gone;        /* BATOTP_F_CURVES_IN_PLACE: the forward sweep has consumed the reverse curve (state rules of the product) */
     float ms[5];
 };
@@ -203,6 +204,7 @@ int batotp_hip_upload_curve(batotp_batch *b, int32_t path, const double *s, cons
     set_curve(b->rev_s, b->rev_sd, path, s, sdot, n);
     b->res[path].n_rev = n;
     b->rev_gone = 0;
+    b->rev_stale = 0;
     return BATOTP_OK;
 }
 
@@ -239,6 +241,7 @@ int batotp_hip_pointwise_mvc(batotp_batch *b)
     for (p = 0; p < b->n_paths; p++) bo_pointwise_mvc(&b->prob, b->path[p]);
     b->ms[2] = (float)(now_ms() - t0);
     b->mvc_stale = 0;
+    if (b->prob.flags & BATOTP_F_MVC_IN_CURVES) { b->rev_stale = 1; b->fwd_stale = 1; }
     return BATOTP_OK;
 }
 
@@ -266,7 +269,8 @@ int batotp_hip_sweep(batotp_batch *b, int32_t dir)
             r->n_fwd = 0; r->steps_fwd = 0; r->t_total = 0; r->status_fwd = r->status_rev | BATOTP_ST_CAPACITY; r->n_bisect_fail_fwd = 0;
             continue;
         }
-        bo_sweep(&b->prob, b->path[p], dir, b->rev_s[p], b->rev_sd[p], r->n_rev, s, sd, b->cap, &n, &steps, &T, &st, &nf);
+        bo_sweep_ex(&b->prob, b->path[p], dir, b->rev_s[p], b->rev_sd[p], r->n_rev, s, sd, b->cap, &n, &steps, &T, &st, &nf,
+                    (b->prob.flags & BATOTP_F_CURVES_IN_PLACE) != 0);
         if (dir == -1) {
             free(b->rev_s[p]); free(b->rev_sd[p]);
             b->rev_s[p] = s; b->rev_sd[p] = sd;
@@ -280,8 +284,9 @@ int batotp_hip_sweep(batotp_batch *b, int32_t dir)
         }
     }
     b->ms[dir == -1 ? 3 : 4] = (float)(now_ms() - t0);
+    if (dir == -1) b->rev_stale = 0; else b->fwd_stale = 0;
     if (dir == -1) b->rev_gone = 0;
-    else if (b->prob.flags & BATOTP_F_CURVES_IN_PLACE) b->rev_gone = 1; /* the checker keeps both curves; only the state rule is mirrored */
+    else if (b->prob.flags & BATOTP_F_CURVES_IN_PLACE) b->rev_gone = 1; /* the checker keeps both curves; the state rule and the capacity margin (bo_sweep_ex) are mirrored */
     return BATOTP_OK;
 }
 
@@ -307,6 +312,7 @@ int batotp_hip_download_curve(batotp_batch *b, int32_t path, int32_t which, doub
     const double *ss, *sd;
     if (!b || path < 0 || path >= b->n_paths) return BATOTP_ERR_ARG;
     if (which == -1 && b->rev_gone) return BATOTP_ERR_STATE;
+    if (which == -1 ? b->rev_stale : b->fwd_stale) return BATOTP_ERR_STATE;
     ss = which == 1 ? b->fwd_s[path] : b->rev_s[path];
     sd = which == 1 ? b->fwd_sd[path] : b->rev_sd[path];
     avail = which == 1 ? b->res[path].n_fwd : b->res[path].n_rev;
@@ -372,6 +378,7 @@ int batotp_hip_pack_curves(batotp_batch *b, int32_t which, int32_t path0, int32_
     double *o = (double *)dst;
     if (!b || (which != 1 && which != -1) || path0 < 0 || n_paths < 0 || path0 + n_paths > b->n_paths || !total_points) return BATOTP_ERR_ARG;
     if (which == -1 && b->rev_gone) { *total_points = 0; return BATOTP_ERR_STATE; }
+    if (which == -1 ? b->rev_stale : b->fwd_stale) { *total_points = 0; return BATOTP_ERR_STATE; }
     for (k = 0; k < n_paths; k++) total += which == 1 ? b->res[path0 + k].n_fwd : b->res[path0 + k].n_rev;
     *total_points = total;
     if (total == 0) return BATOTP_OK;

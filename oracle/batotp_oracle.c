@@ -747,6 +747,18 @@ int bo_sweep(const batotp_problem *prob, const bo_path *p, int dir,
              double *out_s, double *out_sdot, int64_t cap,
              int64_t *n_out, int64_t *n_steps, double *t_total, uint32_t *status, int32_t *n_bisect_fail)
 {
+    return bo_sweep_ex(prob, p, dir, mvc_s, mvc_sdot, n_mvc, out_s, out_sdot, cap, n_out, n_steps, t_total, status, n_bisect_fail, 0);
+}
+
+/* in_place != 0 mirrors the PRODUCT's storage rule for BATOTP_F_CURVES_IN_PLACE (include/batotp_hip.h; no counterpart in the
+ * reference, whose arrays grow): the forward curve shares a buffer of cap points with the right-aligned reverse curve and the
+ * path ends with BATOTP_ST_CAPACITY as soon as point i would come within 64 points of the reverse points still to be read.
+ * The arithmetic of the sweep is untouched. */
+int bo_sweep_ex(const batotp_problem *prob, const bo_path *p, int dir,
+                const double *mvc_s, const double *mvc_sdot, int64_t n_mvc,
+                double *out_s, double *out_sdot, int64_t cap,
+                int64_t *n_out, int64_t *n_steps, double *t_total, uint32_t *status, int32_t *n_bisect_fail, int in_place)
+{
     sweep_ctx cx;
     sweep_ctx *c = &cx;
     const int64_t maxIntegSteps = (int64_t)floor(prob->max_integ_time / prob->integ_res) + 1;
@@ -806,7 +818,9 @@ int bo_sweep(const batotp_problem *prob, const bo_path *p, int dir,
 
     for (i = 1;; i++) { /* ba.cpp:1053: the array grows by nChunk, the loop is unbounded */
         double s0 = c->s_cur;
-        if (i >= cap) { *status = c->status | BATOTP_ST_CAPACITY; *n_bisect_fail = c->n_fail; *n_steps = i; return -1; }
+        if (i >= cap || (in_place && dir == 1 && i + 64 >= (cap - n_mvc) + c->cur_seg_mvc)) {
+            *status = c->status | BATOTP_ST_CAPACITY; *n_bisect_fail = c->n_fail; *n_steps = i; return -1;
+        }
         c->sdot_lim_type_t = 0;
         sdotT = sdotArr[0];
         sddotT = sddotArr[0];

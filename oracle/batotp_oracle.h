@@ -86,6 +86,12 @@ int  bo_sweep(const batotp_problem *prob, const bo_path *p, int dir,
               const double *mvc_s, const double *mvc_sdot, int64_t n_mvc,
               double *out_s, double *out_sdot, int64_t cap,
               int64_t *n_out, int64_t *n_steps, double *t_total, uint32_t *status, int32_t *n_bisect_fail);
+/* the same sweep under the product's storage rule for BATOTP_F_CURVES_IN_PLACE (in_place != 0, forward sweep: the path ends
+ * with BATOTP_ST_CAPACITY when its curve comes within 64 points of the reverse points still to be read) */
+int  bo_sweep_ex(const batotp_problem *prob, const bo_path *p, int dir,
+                 const double *mvc_s, const double *mvc_sdot, int64_t n_mvc,
+                 double *out_s, double *out_sdot, int64_t cap,
+                 int64_t *n_out, int64_t *n_steps, double *t_total, uint32_t *status, int32_t *n_bisect_fail, int in_place);
 
 /* sdotLim + applyAccelConstraintsBisectionPt at every knot (K3 definition) */
 void bo_pointwise_mvc(const batotp_problem *prob, bo_path *p);

@@ -80,6 +80,32 @@ def test_batch_driver_grows_the_curve_capacity_like_the_single_path_api(tmp_path
         assert filecmp.cmp(many / d / "traj_out.dat", one / "traj_out.dat", shallow=False)
 
 
+def test_batch_driver_grows_a_shared_curve_buffer_when_only_the_forward_curve_runs_out(tmp_path, oracle_lib):
+    """is_sdotOut = 0: one curve buffer per path (BATOTP_F_CURVES_IN_PLACE).  The reverse curve fits the first guess, the
+    forward curve does not: its sweep gives up 64 points before it would overwrite unread reverse points, i.e. with
+    steps_fwd well below the capacity -- BA::optimizeBatch must still read that as 'out of room' and run the batch again
+    (round-2 advisor finding; the checker library applies the same margin through bo_sweep_ex)"""
+    import re
+    src = os.path.join(helpers.GOLD, "GEN7DOF")
+    one, many = tmp_path / "one", tmp_path / "many"
+    for d, sdot_out in ((one, "1"), (many, "0")):
+        d.mkdir()
+        _stage(src, d)
+        _edit_config(d / "config.dat", {"integRes": "0.00076", "outRes": "0.004", "is_sdotOut": sdot_out})
+    r1 = subprocess.run([os.path.join(helpers.BUILD, "batest_oracle"), "config.dat"], cwd=one, capture_output=True, text=True)
+    assert r1.returncode == 0, r1.stdout[-2000:]
+    fwd = int(re.search(r"fwd\. integ\.:\s*(\d+) steps", r1.stdout).group(1))
+    rev = int(re.search(r"rev\. integ\.:\s*(\d+) steps", r1.stdout).group(1))
+    cap = 8 * 231 + 4096
+    assert rev + 1 < cap <= fwd + 66, (rev, fwd, cap)          # the window the finding is about
+    r = subprocess.run([os.path.join(helpers.BUILD, "batest_batch_oracle"), "config.dat", "2"], cwd=many, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "running the batch again" in r.stdout and "2 paths, 0 failed" in r.stdout
+    for d in ("out_first", "out_last"):
+        assert filecmp.cmp(many / d / "traj_out.dat", one / "traj_out.dat", shallow=False)
+        assert not os.path.exists(many / d / "s-sdot.dat")
+
+
 def test_svd_solver_is_refused_not_silently_replaced(tmp_path, oracle_lib):
     """isSVD = 1 on the cable robot asks for the Jacobi-SVD solve (reference util.cpp:421-438), which does not exist here:
     the configuration is refused with a message instead of being answered by the LU solve"""

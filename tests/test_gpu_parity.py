@@ -329,7 +329,14 @@ def test_pointwise_values_in_the_curve_slots(hip_lib, oracle_ctx, lanes):
     helpers.assert_bit_equal(np.stack(b.mvc(0)), first, "pointwise values after re-evaluation")
     with pytest.raises(capi.BatotpError):
         b.sweep(+1)
-    b.sweep(-1); b.sweep(+1)
+    for which in (-1, +1):                                    # the curve slots now hold pointwise values, not curves
+        with pytest.raises(capi.BatotpError):
+            b.curve(0, which)
+    b.sweep(-1)
+    assert len(b.curve(0, -1)[0]) == case.expected["n_rev"]
+    with pytest.raises(capi.BatotpError):
+        b.curve(0, +1)                                        # still the stale forward curve
+    b.sweep(+1)
     assert int(b.results()[0]["n_fwd"]) == case.expected["n_fwd"]
     b.close(); ctx.close()
 

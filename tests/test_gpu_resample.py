@@ -111,6 +111,33 @@ def test_product_batch_driver_on_gpu(tmp_path, name):
         assert filecmp.cmp(tmp_path / d / "traj_out.dat", os.path.join(src, "ref_traj_out.dat"), shallow=False), name
 
 
+def test_product_batch_driver_grows_a_shared_curve_buffer(tmp_path):
+    """is_sdotOut = 0 (one curve buffer per path, BATOTP_F_CURVES_IN_PLACE) and a forward curve that does not fit the first
+    capacity guess while the reverse curve does: the forward kernel gives up 64 points before unread reverse points, with
+    steps_fwd below the capacity; BA::optimizeBatch reads that as out of room and runs the batch again -- same trajectory as
+    the single-path driver (round-2 advisor finding)"""
+    import filecmp, os, re, shutil, subprocess
+    from test_batest_cpu import _edit_config, _stage
+    build = os.path.join(helpers.ROOT, "batotp_amd", "host", "_build")
+    src = os.path.join(helpers.GOLD, "GEN7DOF")
+    one, many = tmp_path / "one", tmp_path / "many"
+    for d, sdot_out in ((one, "1"), (many, "0")):
+        d.mkdir()
+        _stage(src, d)
+        _edit_config(d / "config.dat", {"integRes": "0.00076", "outRes": "0.004", "is_sdotOut": sdot_out})
+    r1 = subprocess.run([os.path.join(build, "batest"), "config.dat"], cwd=one, capture_output=True, text=True)
+    assert r1.returncode == 0, r1.stdout[-2000:]
+    fwd = int(re.search(r"fwd\. integ\.:\s*(\d+) steps", r1.stdout).group(1))
+    rev = int(re.search(r"rev\. integ\.:\s*(\d+) steps", r1.stdout).group(1))
+    cap = 8 * 231 + 4096
+    assert rev + 1 < cap <= fwd + 66, (rev, fwd, cap)
+    r = subprocess.run([os.path.join(build, "batest_batch"), "config.dat", "3"], cwd=many, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "running the batch again" in r.stdout and "3 paths, 0 failed" in r.stdout
+    for d in ("out_first", "out_last"):
+        assert filecmp.cmp(many / d / "traj_out.dat", one / "traj_out.dat", shallow=False)
+
+
 def test_chunked_resampling_equals_one_chunk(hip_lib, oracle_ctx, monkeypatch):
     """a tiny scratch budget forces several chunks of paths: the result must not depend on the chunking"""
     c = ResampleCase("synth_cspr_s3")

@@ -66,3 +66,42 @@ def test_checker_mirrors_the_state_rules_of_in_place_curves(oracle_ctx):
     b.sweep(-1)
     assert len(b.curve(0, -1)[0]) == int(plain["result"]["n_rev"])
     b.close()
+
+
+def test_checker_mirrors_the_state_rules_of_pointwise_values_in_the_curve_slots(oracle_ctx):
+    """BATOTP_F_MVC_IN_CURVES through the checker library: a pointwise evaluation after a sweep invalidates both curves (they
+    shared the slots with its values) until their sweeps have run again; in-place forward sweeps give up within 64 points of
+    the unread reverse points exactly as the kernels do (bo_sweep_ex)"""
+    from batotp_amd import capi
+    case = Case("GEN7DOF")
+    prob = capi.Problem.from_buffer_copy(bytes(case.problem))
+    prob.flags |= capi.F_MVC_IN_CURVES
+    b = capi.Batch(oracle_ctx, prob, [case.n], case.max_steps())
+    b.upload_knots(0, [case.y], [case.sres])
+    b.optimize()
+    n_rev, n_fwd = len(b.curve(0, -1)[0]), len(b.curve(0, +1)[0])
+    b.pointwise_mvc()
+    for which in (-1, +1):
+        with pytest.raises(capi.BatotpError):
+            b.curve(0, which)
+    b.sweep(-1)
+    assert len(b.curve(0, -1)[0]) == n_rev
+    with pytest.raises(capi.BatotpError):
+        b.curve(0, +1)
+    b.sweep(+1)
+    assert len(b.curve(0, +1)[0]) == n_fwd
+    b.close()
+    # the capacity margin of the shared buffer: room for the forward curve + 72 points is enough, + 8 is not
+    prob = capi.Problem.from_buffer_copy(bytes(case.problem))
+    prob.flags |= capi.F_CURVES_IN_PLACE
+    for extra, ok in ((72, True), (8, False)):
+        b = capi.Batch(oracle_ctx, prob, [case.n], n_fwd + extra)
+        b.upload_knots(0, [case.y], [case.sres])
+        b.optimize()
+        r = b.results()[0]
+        assert int(r["n_rev"]) == n_rev
+        if ok:
+            assert int(r["n_fwd"]) == n_fwd
+        else:
+            assert int(r["n_fwd"]) == 0 and (int(r["status_fwd"]) & capi.ST_CAPACITY) and int(r["steps_fwd"]) + 1 < n_fwd + extra
+        b.close()
