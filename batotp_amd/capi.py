@@ -210,6 +210,9 @@ class Library:
             "batotp_hip_set_overlap": [P, I32],
             "batotp_hip_set_sweep_hold": [P, I32, I32],
             "batotp_hip_set_sweep_prefetch": [P, I32, I32],
+            "batotp_hip_flat_loop_status": [P, C.POINTER(I32)],
+            "batotp_hip_toolchain": [C.c_char_p, C.c_char_p, I32],
+            "batotp_hip_last_sweep_launch": [P, I32, C.POINTER(I32), C.POINTER(I32), C.POINTER(I32)],
             "batotp_hip_resample": [P, C.POINTER(ResampleParams), I32, C.POINTER(C.c_int64), D, D, C.POINTER(P)],
             "batotp_hip_resampled_destroy": [P],
             "batotp_hip_resampled_info": [P, C.POINTER(C.c_int64), D, C.POINTER(C.c_uint32)],
@@ -242,6 +245,12 @@ class Library:
         m = SerialModel()
         self.check(self.lib.batotp_hip_builtin_serial_model(robot_type, C.byref(m)), "builtin_serial_model")
         return m
+
+    def toolchain(self):
+        """(built with, flat loop validated with)"""
+        a, b = C.create_string_buffer(256), C.create_string_buffer(256)
+        self.check(self.lib.batotp_hip_toolchain(a, b, 256), "toolchain")
+        return a.value.decode(), b.value.decode()
 
     def device_count(self) -> int:
         n = C.c_int(0)
@@ -277,6 +286,12 @@ class Context:
 
     def set_sweep_prefetch(self, reverse: int, forward: int):
         self.library.check(self.library.lib.batotp_hip_set_sweep_prefetch(self.handle, reverse, forward), "set_sweep_prefetch")
+
+    def flat_loop_status(self) -> int:
+        """1 = the automatic loop choice uses the flat loop; negative: why not (include/batotp_hip.h)"""
+        st = C.c_int32(0)
+        self.library.check(self.library.lib.batotp_hip_flat_loop_status(self.handle, C.byref(st)), "flat_loop_status")
+        return st.value
 
     def set_paths_per_wave(self, n: int):
         self.library.check(self.library.lib.batotp_hip_set_paths_per_wave(self.handle, n), "set_paths_per_wave")
@@ -479,6 +494,12 @@ class Batch:
 
     def optimize(self):
         self.L.check(self.lib.batotp_hip_optimize(self.handle), "optimize")
+
+    def last_sweep_launch(self, direction: int):
+        """(lanes per path, paths per wavefront, hold of the flat loop or -1 for the nested loops) of the last launch"""
+        lanes, ppw, hold = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self.L.check(self.lib.batotp_hip_last_sweep_launch(self.handle, direction, C.byref(lanes), C.byref(ppw), C.byref(hold)), "last_sweep_launch")
+        return lanes.value, ppw.value, hold.value
 
     # ---- results -----------------------------------------------------------------------------
     def results(self) -> np.ndarray:

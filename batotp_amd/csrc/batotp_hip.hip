@@ -41,6 +41,26 @@ static int hipFail(hipError_t e, const char *what)
 extern "C" const char *batotp_hip_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------------
+// toolchain gate of the flat sweep loop (its torque instantiation was miscompiled by the
+// toolchain below for a reason that is not understood; the instantiations that ship passed the whole
+// parity / fuzz suite with exactly this compiler, so another compiler gets the nested loops until
+// somebody has run the suite with it and updated the string)
+// ---------------------------------------------------------------------------------------------
+#define BK_STR2(x) #x
+#define BK_STR(x) BK_STR2(x)
+static const char kBuiltWith[] = "clang " __clang_version__ " / HIP " BK_STR(HIP_VERSION_MAJOR) "." BK_STR(HIP_VERSION_MINOR) "." BK_STR(HIP_VERSION_PATCH);
+static const char kFlatValidatedWith[] =
+   "clang 22.0.0git (https://github.com/RadeonOpenCompute/llvm-project roc-7.2.0 26014 7b800a19466229b8479a78de19143dc33c3ab9b5) / HIP 7.2.26015";
+
+extern "C" int batotp_hip_toolchain(char *built_with, char *validated_with, int32_t cap)
+{
+   if (cap < 1) return BATOTP_ERR_ARG;
+   if (built_with) { strncpy(built_with, kBuiltWith, (size_t)cap - 1); built_with[cap - 1] = 0; }
+   if (validated_with) { strncpy(validated_with, kFlatValidatedWith, (size_t)cap - 1); validated_with[cap - 1] = 0; }
+   return BATOTP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // objects
 // ---------------------------------------------------------------------------------------------
 // grow-only device workspace cached in the context: hipMalloc of tens of GB costs ~40 ms/GB on this
@@ -65,6 +85,11 @@ struct batotp_ctx
    int pathsPerWave = 0; // 0 = automatic
    int sweepTouch[2] = {-1, -1}; // reverse, forward: -1 = automatic, else bit 0 rows, bit 1 reverse curve (kernels.hip.h touch_*)
    int sweepHold[2] = {-2, -2}; // reverse, forward: -2 = automatic, -1 = nested stage / bisection loops, 0..8 = flat loop with this hold (kernels.hip.h)
+   // May the AUTOMATIC choice use the flat stage / bisection loop?  0 = not decided yet, 1 = yes (this library was built by the
+   // toolchain the loop was validated with and the canary of flatLoopStatus agreed with the nested loops on this device),
+   // -1 = built by another toolchain, -2 = the canary disagreed, -3 = the canary could not run
+   int flatStatus = 0;
+   char builtWith[192] = "";    // toolchain the gate compares (the real one unless BATOTP_ASSUME_TOOLCHAIN overrides it for a test)
 };
 
 struct batotp_batch
@@ -105,6 +130,7 @@ struct batotp_batch
 
    hipEvent_t ev[5][2] = {};
    bool evValid[5] = {};
+   int lastLanes[2] = {0, 0}, lastPpw[2] = {0, 0}, lastHold[2] = {-1, -1}; // reverse, forward: what the last launch used
 };
 
 static int devAlloc(batotp_batch *b, void **p, size_t bytes)
@@ -202,6 +228,12 @@ extern "C" int batotp_hip_ctx_create(int device, batotp_ctx **out)
    batotp_ctx *c = new (std::nothrow) batotp_ctx;
    if (!c) return BATOTP_ERR_ALLOC;
    c->device = device;
+   {
+      // a test can pretend the library came from another compiler (tests/test_gpu_parity.py: the automatic choice must then
+      // run the nested loops); nothing else reads the variable
+      const char *assume = getenv("BATOTP_ASSUME_TOOLCHAIN");
+      strncpy(c->builtWith, (assume && assume[0]) ? assume : kBuiltWith, sizeof(c->builtWith) - 1);
+   }
    e = hipSetDevice(device);
    if (e != hipSuccess) { delete c; return hipFail(e, "hipSetDevice"); }
    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -899,6 +931,120 @@ extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
    return BATOTP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Gate of the flat stage / bisection loop.  The AUTOMATIC loop choice uses it only when (a) this library was compiled by the
+// toolchain the loop was validated with and (b) a canary on this device agrees with the nested loops: two small batches
+// (compact pairs and coefficient rows) of 24 velocity / acceleration-only paths, 8 per wavefront, of three kinds -- ordinary
+// ones, paths that crawl under a tiny acceleration limit (long searches for a first feasible speed) and paths on which every
+// bisection fails (a negative limit: 100 iterations per stage, stale sddot) until they run out of curve capacity -- i.e. the
+// population on which the torque instantiation of the loop once went wrong.  Result rows and reverse curves
+// must be identical bit for bit.  Runs once per context, the first time the automatic choice would take the flat loop
+// (a few tens of milliseconds); an explicit batotp_hip_set_sweep_hold is honoured without it.
+// ---------------------------------------------------------------------------------------------
+static int flatCanaryOnce(batotp_ctx *ctx, bool compact, bool *same)
+{
+   *same = false;
+   const int B = 24, nJ = 6;
+   const int64_t cap = 40;
+   batotp_problem prob;
+   memset(&prob, 0, sizeof(prob));
+   prob.n_joints = nJ; prob.n_cart = 0; prob.robot_type = BATOTP_ROBOT_GENJNT;
+   prob.flags = BATOTP_F_JNT_ACC_ON | (compact ? (BATOTP_F_NO_SAMPLES | BATOTP_F_COMPACT_SPLINES) : 0u);
+   for (int j = 0; j < nJ; ++j) { prob.jnt_vel_max[j] = 5.0; prob.jnt_acc_max[j] = 10.0; }
+   prob.jnt_acc_max[4] = 1e-7; // paths on which joint 4 moves crawl
+   prob.jnt_acc_max[5] = -1.0; // paths on which joint 5 moves fail every bisection
+   prob.jnt_thresh = 1e-6; prob.quad_rad_thresh = 1e-12;
+   prob.integ_res = 0.02; prob.max_integ_time = 1e6;
+   std::vector<int64_t> nk(B);
+   for (int p = 0; p < B; ++p) nk[p] = 12 + (p * 7) % 23;
+   batotp_batch *b = nullptr;
+   int rc = batotp_hip_batch_create(ctx, &prob, B, nk.data(), cap, &b);
+   if (rc) return rc;
+   std::vector<double> y, sres(B);
+   uint64_t lcg = 0x9E3779B97F4A7C15ull;
+   auto rnd = [&]() { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (double)(lcg >> 11) * (1.0 / 9007199254740992.0); };
+   for (int p = 0; p < B; ++p)
+   {
+      const int64_t N = nk[p];
+      sres[p] = 0.05 + 0.01 * (double)(p % 5);
+      for (int j = 0; j < nJ; ++j)
+      {
+         const bool still = (j == 4 && p % 3 != 1) || (j == 5 && p % 3 != 2); // kinds: 0 ordinary, 1 crawls, 2 fails
+         const double c1 = 2.0 * rnd() - 1.0, c2 = 2.0 * rnd() - 1.0, c3 = 2.0 * rnd() - 1.0;
+         for (int64_t i = 0; i < N; ++i)
+         {
+            const double x = (double)i / (double)(N - 1);
+            y.push_back(still ? 0.25 : c1 * x + c2 * x * x * (1.0 - x) + c3 * x * x * x);
+         }
+      }
+   }
+   std::vector<batotp_path_result> rows[2];
+   std::vector<double2> curves[2];
+   const int holdSaved[2] = {ctx->sweepHold[0], ctx->sweepHold[1]}, groupSaved = ctx->sweepGroup, ppwSaved = ctx->pathsPerWave;
+   ctx->sweepGroup = 8; ctx->pathsPerWave = 8;
+   rc = batotp_hip_upload_knots(b, 0, B, y.data(), sres.data());
+   if (!rc) rc = batotp_hip_precompute(b, 0);
+   for (int form = 0; form < 2 && !rc; ++form)
+   {
+      ctx->sweepHold[0] = form == 0 ? -1 : 4; // nested, then the flat loop as the automatic choice would run it
+      rc = batotp_hip_sweep(b, -1);
+      rows[form].resize(B);
+      if (!rc) rc = batotp_hip_get_results(b, rows[form].data());
+      curves[form].resize((size_t)B * (size_t)cap);
+      if (!rc && hipMemcpy(curves[form].data(), b->dRev, sizeof(double2) * curves[form].size(), hipMemcpyDeviceToHost) != hipSuccess) rc = BATOTP_ERR_HIP;
+   }
+   ctx->sweepHold[0] = holdSaved[0]; ctx->sweepHold[1] = holdSaved[1]; ctx->sweepGroup = groupSaved; ctx->pathsPerWave = ppwSaved;
+   batotp_hip_batch_destroy(b);
+   if (rc) return rc;
+   bool eq = memcmp(rows[0].data(), rows[1].data(), sizeof(batotp_path_result) * (size_t)B) == 0;
+   int finished = 0, stalled = 0;
+   for (int p = 0; p < B && eq; ++p)
+   {
+      const int64_t n = rows[0][p].n_rev;
+      if (n > 0) ++finished; else ++stalled;
+      const size_t at = (size_t)p * (size_t)cap + (size_t)(cap - n);
+      if (n > 0 && memcmp(&curves[0][at], &curves[1][at], sizeof(double2) * (size_t)n) != 0) eq = false;
+   }
+   // the canary must contain both populations, otherwise it says nothing
+   if (eq && (finished < 4 || stalled < 4))
+   {
+      snprintf(g_err, sizeof(g_err), "flat-loop canary degenerate: %d finished, %d stalled paths", finished, stalled);
+      return BATOTP_ERR_STATE;
+   }
+   *same = eq;
+   return BATOTP_OK;
+}
+
+static int flatLoopStatus(batotp_ctx *ctx)
+{
+   if (ctx->flatStatus != 0) return ctx->flatStatus;
+   if (strcmp(ctx->builtWith, kFlatValidatedWith) != 0) return ctx->flatStatus = -1;
+   ctx->flatStatus = -3; // (the canary's own sweeps set their loop form explicitly and never ask)
+   bool sameA = false, sameB = false;
+   if (flatCanaryOnce(ctx, true, &sameA) != BATOTP_OK || flatCanaryOnce(ctx, false, &sameB) != BATOTP_OK) return ctx->flatStatus = -3;
+   return ctx->flatStatus = (sameA && sameB) ? 1 : -2;
+}
+
+extern "C" int batotp_hip_flat_loop_status(batotp_ctx *ctx, int32_t *status)
+{
+   if (!ctx || !status) return BATOTP_ERR_ARG;
+   int rc = bind(ctx);
+   if (rc) return rc;
+   *status = flatLoopStatus(ctx);
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_last_sweep_launch(batotp_batch *b, int32_t dir, int32_t *lanes, int32_t *paths_per_wave, int32_t *hold)
+{
+   if (!b || (dir != 1 && dir != -1)) return BATOTP_ERR_ARG;
+   const int k = dir == -1 ? 0 : 1;
+   if (b->lastLanes[k] == 0) return BATOTP_ERR_STATE;
+   if (lanes) *lanes = b->lastLanes[k];
+   if (paths_per_wave) *paths_per_wave = b->lastPpw[k];
+   if (hold) *hold = b->lastHold[k];
+   return BATOTP_OK;
+}
+
 template <int G>
 static void launchSweep(batotp_batch *b, SweepArgs &a)
 {
@@ -933,8 +1079,13 @@ static void launchSweep(batotp_batch *b, SweepArgs &a)
    hipStream_t st = b->ctx->stream;
    int hold = b->ctx->sweepHold[a.dir == -1 ? 0 : 1];
    // automatic: the flat stage / bisection loop for the reverse sweep (measured on the bench batches: -25 % with hold 4,
-   // bit-identical results), the nested loops for the forward sweep (which does not gain)
-   if (hold == -2) hold = (a.dir == -1) ? 4 : -1;
+   // bit-identical results) -- where it exists (below) and only behind the gate of flatLoopStatus: validated toolchain and
+   // a canary on this device --, the nested loops for the forward sweep (which does not gain)
+   if (hold == -2)
+   {
+      const bool candidate = a.dir == -1 && (G == 8 || G == 4 || G == 2) && featureLevel(b) <= 0 && uni;
+      hold = (candidate && flatLoopStatus(b->ctx) == 1) ? 4 : -1;
+   }
    if (hold > 8) hold = 8;
    a.hold = hold;
    // The flat loop exists for the 8-lane layout of the velocity / acceleration-only problems (FEAT <= 0) on uniform knot
@@ -942,6 +1093,7 @@ static void launchSweep(batotp_batch *b, SweepArgs &a)
    // with this toolchain (ROCm 7.2.0 hipcc, clang 22; DESIGN.md 4, tools/experiments/), so problems with torque or
    // Cartesian limits always run the nested loops, and so do paths with uploaded (non-uniform) sites.
    const bool flat = (G == 8 || G == 4 || G == 2) && hold >= 0 && featureLevel(b) <= 0 && uni;
+   b->lastLanes[a.dir == -1 ? 0 : 1] = G; b->lastPpw[a.dir == -1 ? 0 : 1] = ppw; b->lastHold[a.dir == -1 ? 0 : 1] = flat ? hold : -1;
 #define LAUNCH_K4(F)                                                                           \
    do {                                                                                        \
       if (flat) hipLaunchKernelGGL((k_sweep<G, F, true, ((G == 8 || G == 4 || G == 2) && F <= 0)>), dim3(grid), dim3(K4_BLOCK), 0, st, a);  \
@@ -973,6 +1125,7 @@ static bool sweep1Applies(const batotp_batch *b)
 static void launchSweep1(batotp_batch *b, SweepArgs &a)
 {
    a.ppw = 1; a.hold = -1; a.touch = 0;
+   b->lastLanes[a.dir == -1 ? 0 : 1] = 64; b->lastPpw[a.dir == -1 ? 0 : 1] = 1; b->lastHold[a.dir == -1 ? 0 : 1] = -1;
    const unsigned grid = (unsigned)((b->B + (S1_BLOCK / 64) - 1) / (S1_BLOCK / 64));
    hipStream_t st = b->ctx->stream;
    if (featureLevel(b) == 2)
@@ -1010,7 +1163,6 @@ extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
    a.P = b->P; a.dP = b->dP; a.pinfo = b->dPinfo; a.sC = b->dSC; a.coef = b->dCoef; a.km = b->dKM;
    a.rev = b->dRev; a.fwd = b->dFwd; a.res = b->dRes; a.sink = b->dSink; a.prof = b->dMvc; a.cap = b->cap; a.B = b->B; a.dir = dir; a.ppw = 1;
    const int which = dir == -1 ? 3 : 4;
-   evStart(b, which);
    int lanes = b->ctx->sweepGroup;
    if (lanes == 0)
    {
@@ -1027,6 +1179,9 @@ extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
       if (sweep1Applies(b) && b->B <= (a.dir == -1 ? 6144 : 3072)) lanes = 64;
    }
    if (lanes == 64 && !sweep1Applies(b)) lanes = 32; // a parallel mechanism's torque limits, uploaded sites: the general kernel
+   // the gate of the flat loop (its canary launches sweeps of its own) is settled before this sweep's timed region starts
+   if (dir == -1 && b->ctx->sweepHold[0] == -2 && (lanes == 8 || lanes == 4 || lanes == 2) && featureLevel(b) <= 0) (void)flatLoopStatus(b->ctx);
+   evStart(b, which);
    switch (lanes)
    {
    case 64: launchSweep1(b, a); break;

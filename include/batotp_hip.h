@@ -278,6 +278,21 @@ int  batotp_hip_set_paths_per_wave(batotp_ctx *ctx, int32_t n);
  * path: results are bit-identical in every test (tests/test_gpu_parity.py, test_gpu_fuzz.py) and bench.py re-checks the
  * result rows of every run against the nested loops.  DESIGN.md 4 has the history. */
 int  batotp_hip_set_sweep_hold(batotp_ctx *ctx, int32_t reverse, int32_t forward);
+/* The gate of that automatic choice.  The flat loop's torque instantiation gave wrong results with the toolchain named
+ * below for a reason that is not understood and is not compiled; the instantiations that ship passed the whole
+ * parity / fuzz suite with exactly that toolchain.  So the automatic choice takes the flat loop only if (a) the library was
+ * built by the validated toolchain (batotp_hip_toolchain reports both strings) and (b) a canary on this device -- two small
+ * batches with ordinary, crawling and always-failing paths, 8 per wavefront, nested against flat loop, result rows and
+ * curves compared bit for bit; run once per context on first use, tens of milliseconds -- found no difference.
+ * status: 1 = flat loop in use, -1 = library built by another toolchain (nested loops), -2 = the canary found a
+ * difference (nested loops), -3 = the canary could not run (nested loops).  An explicit batotp_hip_set_sweep_hold(>= 0)
+ * is honoured regardless: that is the developer's switch. */
+int  batotp_hip_flat_loop_status(batotp_ctx *ctx, int32_t *status);
+/* toolchain this library was built with / toolchain the flat loop was validated with (NUL-terminated, truncated to cap) */
+int  batotp_hip_toolchain(char *built_with, char *validated_with, int32_t cap);
+/* what the most recent sweep launch of this batch in direction dir used: lanes per path (64 = a wavefront per path), paths
+ * per wavefront, and the hold of the flat loop (-1 = nested loops).  Any pointer may be NULL. */
+int  batotp_hip_last_sweep_launch(batotp_batch *batch, int32_t dir, int32_t *lanes, int32_t *paths_per_wave, int32_t *hold);
 /* tuning knob: software prefetch in the sweep kernel, per direction: bit 0 = touch the spline rows ahead of the cursor, bit 1 = touch
  * the reverse curve ahead of its cursor (forward sweep only); -1 (default) = automatic: rows in the reverse sweep always, rows and
  * curve in the forward sweep while every path has a wavefront to itself (latency-bound regime).  Never changes a result. */

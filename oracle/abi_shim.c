@@ -71,6 +71,23 @@ int batotp_hip_set_sweep_group(batotp_ctx *ctx, int32_t lanes) { (void)ctx; (voi
 int batotp_hip_set_paths_per_wave(batotp_ctx *ctx, int32_t n) { (void)ctx; (void)n; return BATOTP_OK; }
 int batotp_hip_set_sweep_hold(batotp_ctx *ctx, int32_t reverse, int32_t forward) { (void)ctx; (void)reverse; (void)forward; return BATOTP_OK; }
 int batotp_hip_set_sweep_prefetch(batotp_ctx *ctx, int32_t reverse, int32_t forward) { (void)ctx; (void)reverse; (void)forward; return BATOTP_OK; }
+/* the checker has one loop form (the reference's); the introspection calls of the product answer accordingly */
+int batotp_hip_flat_loop_status(batotp_ctx *ctx, int32_t *status) { if (!ctx || !status) return BATOTP_ERR_ARG; *status = -1; return BATOTP_OK; }
+int batotp_hip_toolchain(char *built_with, char *validated_with, int32_t cap)
+{
+    if (cap < 1) return BATOTP_ERR_ARG;
+    if (built_with) { strncpy(built_with, "cpu checker", (size_t)cap - 1); built_with[cap - 1] = 0; }
+    if (validated_with) validated_with[0] = 0;
+    return BATOTP_OK;
+}
+int batotp_hip_last_sweep_launch(batotp_batch *b, int32_t dir, int32_t *lanes, int32_t *paths_per_wave, int32_t *hold)
+{
+    if (!b || (dir != 1 && dir != -1)) return BATOTP_ERR_ARG;
+    if (lanes) *lanes = 1;
+    if (paths_per_wave) *paths_per_wave = 1;
+    if (hold) *hold = -1;
+    return BATOTP_OK;
+}
 
 int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *prob, int32_t n_paths,
                             const int64_t *n_knots, int64_t max_steps, batotp_batch **out)

@@ -240,6 +240,44 @@ def test_flat_sweep_loop_capacity_and_max_time_status(hip_lib, oracle_ctx):
     ctx.close()
 
 
+def test_flat_sweep_loop_is_gated_by_toolchain_and_canary(hip_lib, oracle_ctx, monkeypatch):
+    """the AUTOMATIC loop choice takes the flat reverse loop only if the library was built by the toolchain the loop was
+    validated with and the on-device canary (nested against flat loop on ordinary, crawling and always-failing paths) found
+    no difference; a library from another toolchain -- forced here through BATOTP_ASSUME_TOOLCHAIN -- runs the nested loops.
+    Results are the oracle's either way."""
+    built, validated = hip_lib.toolchain()
+    assert built and validated
+    case = Case("synth_gen7dof_s0")
+    flags = capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES
+    oo = run_pipeline(oracle_ctx, [case], mvc=False, details=False)[0]
+    seen = {}
+    for label, assume in (("real", None), ("other", "clang 99.0 / HIP 99.0")):
+        if assume is None:
+            monkeypatch.delenv("BATOTP_ASSUME_TOOLCHAIN", raising=False)
+        else:
+            monkeypatch.setenv("BATOTP_ASSUME_TOOLCHAIN", assume)
+        ctx = capi.Context(hip_lib, 0)
+        ctx.set_sweep_group(8)                                 # the layout of large batches; the loop form stays automatic
+        ctx.set_paths_per_wave(8)
+        prob = capi.Problem.from_buffer_copy(bytes(case.problem))
+        prob.flags |= flags
+        b = capi.Batch(ctx, prob, [case.n] * 9, case.max_steps())
+        b.upload_knots(0, [case.y] * 9, [case.sres] * 9)
+        b.optimize()
+        seen[label] = (ctx.flat_loop_status(), b.last_sweep_launch(-1), b.last_sweep_launch(+1))
+        res = b.results()
+        for p in (0, 8):
+            for f in res.dtype.names:
+                assert res[p][f] == oo["result"][f], (label, p, f)
+            s, sd = b.curve(p, +1)
+            assert_bit_equal(s, oo["fwd"][0], f"{label} fwd.s"); assert_bit_equal(sd, oo["fwd"][1], f"{label} fwd.sdot")
+        b.close(); ctx.close()
+    expect_real = 1 if built == validated else -1
+    assert seen["real"][0] == expect_real, seen
+    assert seen["real"][1] == (8, 8, 4 if expect_real == 1 else -1) and seen["real"][2] == (8, 8, -1), seen
+    assert seen["other"][0] == -1 and seen["other"][1] == (8, 8, -1) and seen["other"][2] == (8, 8, -1), seen
+
+
 @pytest.mark.parametrize("lanes", [0, 1, 8, 16, 32, 64, "flat4"])
 def test_curves_in_place_give_identical_results(hip_lib, oracle_ctx, lanes):
     """BATOTP_F_CURVES_IN_PLACE: one curve buffer per path, the forward curve written over the reverse points its cursor has left
