@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "batotp_hip.h"
@@ -73,7 +74,8 @@ struct Arena
 
 struct batotp_ctx
 {
-   Arena ws[3]; // resampler: stage-0 arrays, per-chunk scratch, resampled knots
+   Arena ws[4]; // resampler: stage-0 arrays, per-chunk scratch, resampled knots, forward-kinematics scratch (packed joint rows + trig tables)
+   std::vector<double> kinTheta, kinTrig; // host side of the trig tables (BATOTP_F_HOST_TRIG)
    Arena xfer;  // staging of curve uploads / downloads (packed double2 <-> separate s / sdot arrays)
    uint64_t rsEpoch = 0; // resample calls so far (a batotp_resampled is valid while its epoch is the current one)
    int device = 0;
@@ -121,6 +123,7 @@ struct batotp_batch
    double *dElim = nullptr;  // Thomas elimination values of k_spline, [max(Cin,4d)][N] per path
    double *dKM = nullptr;    // compact splines: [N][Cin][2] (knot value, second derivative) per path; replaces dY, dElim and dCoef
    batotp_serial_model *dModel = nullptr; // serial-chain dynamics model (batotp_hip_set_serial_model)
+   batotp_serial_model hModel;            // ... its host copy (the output stage needs `degrees` for its trig tables)
    double *dJTrig = nullptr; // [2*nJ][N] per path: host cosines / sines of the joint angles for the serial-chain dynamics
    bool hasSerial = false, jtrigSet = false;
    double *dUp = nullptr;    // compact splines: staging of host knots on their way into dKM
@@ -210,6 +213,29 @@ static int uploadThomasTable()
       tab[0] = 1.0 / den;
    }
    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_ctab), tab, sizeof(tab)));
+   // the same for Spline::solveTriDiagClamped (spline.cpp:229-237): c[0] = 1/2, c[i] = 1/(4 - c[i-1])
+   double tcl[64];
+   {
+      double c0 = 1.0;
+      c0 /= 2.0;
+      tcl[0] = c0;
+   }
+   for (int i = 1; i < 64; ++i)
+   {
+      double ci = 1.0;
+      ci /= 4.0 - 1.0 * tcl[i - 1];
+      tcl[i] = ci;
+   }
+   {
+      double chk2 = 1.0;
+      chk2 /= 4.0 - 1.0 * tcl[63];
+      if (chk2 != tcl[63] || tcl[62] != tcl[63])
+      {
+         snprintf(g_err, sizeof(g_err), "clamped Thomas coefficient table is not a fixed point");
+         return BATOTP_ERR_STATE;
+      }
+   }
+   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_ctab_cl), tcl, sizeof(tcl)));
    return BATOTP_OK;
 }
 
@@ -635,6 +661,7 @@ extern "C" int batotp_hip_set_serial_model(batotp_batch *b, const batotp_serial_
    }
    HIP_TRY(hipMemcpyAsync(b->dModel, model, sizeof(*model), hipMemcpyHostToDevice, b->ctx->stream));
    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+   b->hModel = *model;
    b->hasSerial = true;
    b->dynDone = false;
    return BATOTP_OK;

@@ -243,6 +243,130 @@ __global__ void k_out_trq(OutParams P, const OutPath *__restrict__ paths, int K,
    for (int j = 0; j < 3; ++j) o[(int64_t)(6 + j) * n1] = xs[j];
 }
 
+// ---------------------------------------------------------------------------------------------
+// JOINT paths of the robots with forward kinematics and the serial-robot torque recomputation
+// (ba.cpp:1722-1725, 1744-1750, 1791-1827)
+// ---------------------------------------------------------------------------------------------
+// Cartesian rows nJ..nJ+2 of a stage array x[R][n1] from its joint rows (fwdkin_point: resample.hip.h).  The two-link
+// arm's routine leaves the third row alone (robot.cpp:192-193): it keeps what the Traj held -- the knot samples of that
+// channel (zsamp: value rows of the batch's sample array) -- cut or zero-extended to the new length.
+__global__ void k_out_fwdkin(OutParams P, int robot, const OutPath *__restrict__ paths, int K, double *__restrict__ x, const double *__restrict__ trig,
+                             int trigRows, const PathInfo *__restrict__ pinfo, const double *__restrict__ samp, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   const OutPath op = paths[out_find_path(paths, K, g, 1)];
+   const int i = (int)(g - op.off1), n1 = op.n1;
+   if (i >= n1) return;
+   double *__restrict__ xb = x + op.off1 * P.R;
+   if (robot == BATOTP_ROBOT_RR)
+   {
+      const PathInfo pi = pinfo[op.p];
+      const double *__restrict__ z = samp + pi.koff * P.Cin * 3 + (int64_t)(P.nJ + 2) * 3 * pi.n;
+      xb[(int64_t)(P.nJ + 2) * n1 + i] = i < pi.n ? z[i] : 0.0;
+   }
+   fwdkin_point(robot, xb, xb + (int64_t)P.nJ * n1, trig ? trig + op.off1 * trigRows : nullptr, n1, i);
+}
+
+// joint rows of a stage array x[R][n1], packed [nJ][n1] per path at off1*nJ (what the host needs for trig tables)
+__global__ void k_out_pack_theta(OutParams P, const OutPath *__restrict__ paths, int K, const double *__restrict__ x, double *__restrict__ out, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   const OutPath op = paths[out_find_path(paths, K, g, 1)];
+   const int i = (int)(g - op.off1), n1 = op.n1;
+   if (i >= n1) return;
+   for (int j = 0; j < P.nJ; ++j) out[op.off1 * P.nJ + (int64_t)j * n1 + i] = x[op.off1 * P.R + (int64_t)j * n1 + i];
+}
+
+// Spline::solveTriDiagClamped (spline.cpp:225-243) on the right-hand sides 6(y[i-1] - 2y[i] + y[i+1]) of
+// Spline::getSplineCoeffs (spline.cpp:186-190): series k has n[k] values y[yOff[k] + i] and leaves its second derivatives at
+// sol[solOff[k] + i].  One lane per series.  Pivots: b = 2 in the first and last row, 4 elsewhere; the super-diagonal
+// c[i] = 1/(b[i] - c[i-1]) depends on i alone and is a table (c_ctab_cl, constant from index 63 on; checked by the host).  The
+// back substitution starts at row n-3 ("for (i = n-2; i-- > 0;)", spline.cpp:240): row n-2 keeps its eliminated value.
+__constant__ double c_ctab_cl[64];
+__global__ void __launch_bounds__(64) k_spline_series_clamped(int count, const int64_t *__restrict__ yOff, const int64_t *__restrict__ solOff,
+                                                              const int *__restrict__ n, const double *__restrict__ y, double *__restrict__ sol)
+{
+   const int k = blockIdx.x * blockDim.x + threadIdx.x;
+   if (k >= count || n[k] < 4) return;
+   const int N = n[k];
+   const double *__restrict__ yy = y + yOff[k];
+   double *__restrict__ d = sol + solOff[k];
+   double dprev = 0.0 / 2.0;                       // d[0] /= b[0] with sol[0] = 0
+   d[0] = dprev;
+   double ym = yy[0], y0 = yy[1];
+   for (int i = 1; i < N; ++i)
+   {
+      const double cprev = (i - 1) < 63 ? c_ctab_cl[i - 1] : c_ctab_cl[63];
+      double rhs = 0.0, bi = 2.0;
+      if (i < N - 1)
+      {
+         const double yp = yy[i + 1];
+         rhs = 6 * (ym - 2 * y0 + yp);
+         ym = y0; y0 = yp;
+         bi = 4.0;
+      }
+      const double di = (rhs - 1.0 * dprev) / (bi - 1.0 * cprev);
+      d[i] = di;
+      dprev = di;
+   }
+   double next = d[N - 2];
+   for (int i = N - 3; i >= 0; --i)
+   {
+      const double ci = i < 63 ? c_ctab_cl[i] : c_ctab_cl[63];
+      const double v = d[i] - ci * next;
+      d[i] = v;
+      next = v;
+   }
+}
+
+// ba.cpp:1791-1800: every site evaluated at the END of the previous segment of the clamped spline through the joint samples
+// (site 0: start of segment 0): value, first and second derivative per joint -> a sample array laid out like the batch's
+// ([Cin][3][n1] per path at off1*Cin*3: what k_dynamics / k_dyn_serial read), a packed copy of the values ([nJ][n1] at
+// off1*nJ: what the host needs for the trig tables) and the joint rows of dst; the Cartesian rows are carried over.
+__global__ void k_out_serial_eval(OutParams P, const OutPath *__restrict__ paths, int K, const double *__restrict__ src, const double *__restrict__ solC,
+                                  double *__restrict__ dst, double *__restrict__ sampT, double *__restrict__ pack, int nCartRows, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   const OutPath op = paths[out_find_path(paths, K, g, 1)];
+   const int i = (int)(g - op.off1), n1 = op.n1;
+   if (i >= n1) return;
+   const int seg = i == 0 ? 0 : i - 1;
+   const double tau = i == 0 ? 0.0 : 1.0;
+   const double tau2 = tau * tau, tau3 = tau2 * tau;
+   for (int j = 0; j < P.nJ; ++j)
+   {
+      const int64_t at = op.off1 * P.R + (int64_t)j * n1 + seg;
+      const Coef4 k = coeffs_from_sol(solC[at], solC[at + 1], src[at], src[at + 1]);
+      const double v = k.c3 * tau3 + k.c2 * tau2 + k.c1 * tau + k.c0;          // spline.cpp:149-151
+      const double v1 = (3 * k.c3 * tau2 + 2 * k.c2 * tau + k.c1) * P.vfactT;
+      const double v2 = (6 * k.c3 * tau + 2 * k.c2) * P.afactT;
+      double *__restrict__ sp = sampT + op.off1 * P.Cin * 3 + (int64_t)j * 3 * n1;
+      sp[i] = v; sp[n1 + i] = v1; sp[2 * (int64_t)n1 + i] = v2;
+      pack[op.off1 * P.nJ + (int64_t)j * n1 + i] = v;
+      dst[op.off1 * P.R + (int64_t)j * n1 + i] = v;
+   }
+   for (int c = 0; c < nCartRows; ++c)
+      dst[op.off1 * P.R + (int64_t)(P.nJ + c) * n1 + i] = src[op.off1 * P.R + (int64_t)(P.nJ + c) * n1 + i];
+}
+
+// torque rows = a2 + a3 + a4 (ba.cpp:1819-1825) from the dynamics array [4][nJ][n1] per path at off1*4*nJ
+__global__ void k_out_trq_sum(OutParams P, const OutPath *__restrict__ paths, int K, const double *__restrict__ dyn, double *__restrict__ dst, int r0,
+                              int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   const OutPath op = paths[out_find_path(paths, K, g, 1)];
+   const int i = (int)(g - op.off1), n1 = op.n1;
+   if (i >= n1) return;
+   const double *__restrict__ dy = dyn + op.off1 * 4 * P.nJ;
+   for (int j = 0; j < P.nJ; ++j)
+      dst[op.off1 * P.R + (int64_t)(r0 + j) * n1 + i] =
+         dy[((int64_t)1 * P.nJ + j) * n1 + i] + dy[((int64_t)2 * P.nJ + j) * n1 + i] + dy[((int64_t)3 * P.nJ + j) * n1 + i];
+}
+
 // (smooth_at: resample.hip.h)
 
 // moving average + linear down-sampling by the smoothing factor (ba.cpp:1838-1871): th2[R][n2] per path

@@ -523,6 +523,122 @@ __global__ void k_rs_regular(RsParams P, const RsPath *__restrict__ src, const R
    }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Forward kinematics: Robot::fwdKinKuka robot.cpp:105-174, Robot::fwdKinRR robot.cpp:188-202, called
+// by the resampler after each of its passes (ba.cpp:626-628), before them when a Cartesian constraint is on (ba.cpp:247-256)
+// and by the output stage (ba.cpp:1722-1725).  One lane per point.
+//
+// The trigonometry is a table when the caller wants bit parity with the host (BATOTP_F_HOST_TRIG: glibc sincos() of
+// every joint angle, computed by the host side of the library between two kernels), else the device libm's sincos (last-bit
+// differences against glibc: the knots then differ from the reference's in the last bits and the chaotic sweep may take a
+// different number of steps -- documented tolerance mode).  Table layout per path: [rows][n] at trigBase + off*rows with
+// KUKA: cos(t_k), k = 0..6, then sin(t_k); RR: cos(th1), cos(th1+th2), sin(th1), sin(th1+th2).
+//
+// 3x3 products in the summation order of the reference binary's Eigen (host robot.cpp): rows 0 and 1 of a product left to
+// right, row 2 and the row-times-vector products a0 + (a1 + a2).
+// ---------------------------------------------------------------------------------------------
+constexpr double KIN_DEG2RAD = 3.14159265358979323846 / 180.0; // config.h:28
+
+__host__ __device__ inline int fwdkin_trig_rows(int robot, int nJ)
+{
+   if (robot == BATOTP_ROBOT_KUKA && nJ == 7) return 14;
+   if (robot == BATOTP_ROBOT_RR && nJ == 2) return 4;
+   return 0;
+}
+
+__device__ __forceinline__ double kin_sum_seq(double a0, double a1, double a2) { return (a0 + a1) + a2; }
+__device__ __forceinline__ double kin_sum_tree(double a0, double a1, double a2) { return a0 + (a1 + a2); }
+
+__device__ __forceinline__ void kin_mul3(const double (&L)[3][3], const double (&R)[3][3], double (&out)[3][3])
+{
+#pragma unroll
+   for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+      {
+         const double t0 = L[r][0] * R[0][c], t1 = L[r][1] * R[1][c], t2 = L[r][2] * R[2][c];
+         out[r][c] = (r == 2) ? kin_sum_tree(t0, t1, t2) : kin_sum_seq(t0, t1, t2);
+      }
+}
+
+// tool point of the KUKA LWR IV+ from the cosines / sines of its seven joint angles
+__device__ __forceinline__ void kuka_tool_point(const double (&c)[7], const double (&s)[7], double (&p)[3])
+{
+   const double c1 = c[0], c2 = c[1], c3 = c[2], c4 = c[3], c5 = c[4], c6 = c[5], c7 = c[6];
+   const double s1 = s[0], s2 = s[1], s3 = s[2], s4 = s[3], s5 = s[4], s6 = s[5], s7 = s[6];
+   const double Q12[3][3] = {{c1 * c2, -s1, -c1 * s2}, {c2 * s1, c1, -s1 * s2}, {s2, 0, c2}};
+   const double Q34[3][3] = {{c3 * c4, -s3, c3 * s4}, {c4 * s3, c3, s3 * s4}, {-s4, 0, c4}};
+   const double Q567[3][3] = {{c5 * c6 * c7 - s5 * s7, -c7 * s5 - c5 * c6 * s7, -c5 * s6},
+                              {c5 * s7 + c6 * c7 * s5, c5 * c7 - c6 * s5 * s7, -s5 * s6},
+                              {c7 * s6, -s6 * s7, c6}};
+   double Q1234[3][3], Q[3][3];
+   kin_mul3(Q12, Q34, Q1234);
+   kin_mul3(Q1234, Q567, Q);
+   const double tool0 = 0, tool1 = -.08, tool2 = .545;   // robot.cpp:113
+   const double a0 = .3105, a1 = .4, a2 = .39;           // robot.cpp:117
+   const double x1 = a1 * Q12[0][2], y1 = a1 * Q12[1][2], z1 = a1 * Q12[2][2] + a0;
+   const double x2 = x1 + a2 * Q1234[0][2], y2 = y1 + a2 * Q1234[1][2], z2 = z1 + a2 * Q1234[2][2];
+   p[0] = x2 + kin_sum_tree(Q[0][0] * tool0, Q[0][1] * tool1, Q[0][2] * tool2);
+   p[1] = y2 + kin_sum_tree(Q[1][0] * tool0, Q[1][1] * tool1, Q[1][2] * tool2);
+   p[2] = z2 + kin_sum_tree(Q[2][0] * tool0, Q[2][1] * tool1, Q[2][2] * tool2);
+}
+
+// Cartesian rows of point i of a path from its joint rows: th / ca point at row 0 of the joint / Cartesian rows, both with
+// row stride n; trig = this path's table (row stride n) or nullptr for the device libm
+__device__ __forceinline__ void fwdkin_point(int robot, const double *__restrict__ th, double *__restrict__ ca, const double *__restrict__ trig,
+                                             int64_t n, int64_t i)
+{
+   if (robot == BATOTP_ROBOT_RR)
+   {
+      double c1, c12, s1, s12;
+      if (trig) { c1 = trig[i]; c12 = trig[n + i]; s1 = trig[2 * n + i]; s12 = trig[3 * n + i]; }
+      else
+      {
+         const double th1 = KIN_DEG2RAD * th[i], th2 = KIN_DEG2RAD * th[n + i];
+         sincos(th1, &s1, &c1);
+         sincos(th1 + th2, &s12, &c12);
+      }
+      const double a1 = .4, a2 = .6;
+      ca[i] = a1 * c1 + a2 * c12;           // robot.cpp:198-199; the third row is only sized
+      ca[n + i] = a1 * s1 + a2 * s12;
+      return;
+   }
+   double c[7], s[7], p[3];
+#pragma unroll
+   for (int k = 0; k < 7; ++k)
+   {
+      if (trig) { c[k] = trig[k * n + i]; s[k] = trig[(7 + k) * n + i]; }
+      else sincos(KIN_DEG2RAD * th[k * n + i], &s[k], &c[k]);
+   }
+   kuka_tool_point(c, s, p);
+   ca[i] = p[0]; ca[n + i] = p[1]; ca[2 * n + i] = p[2];
+}
+
+__global__ void k_rs_fwdkin(RsParams P, const RsPath *__restrict__ paths, int B, double *__restrict__ x, const double *__restrict__ trig, int trigRows,
+                            int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   const int lo = rs_find_path(paths, B, g);
+   const RsPath pp = paths[lo];
+   const int i = (int)(g - pp.off), n = pp.n;
+   if (i >= n || pp.status) return;
+   double *__restrict__ xb = x + pp.off * P.C;
+   fwdkin_point(P.robot, xb, xb + (int64_t)P.nJ * n, trig ? trig + pp.off * trigRows : nullptr, n, i);
+}
+
+// joint rows of every path of a stage, packed [nJ][n] per path at off*nJ (what the host needs for the trig tables)
+__global__ void k_rs_pack_theta(RsParams P, const RsPath *__restrict__ paths, int B, const double *__restrict__ x, double *__restrict__ out, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   const int lo = rs_find_path(paths, B, g);
+   const RsPath pp = paths[lo];
+   const int i = (int)(g - pp.off), n = pp.n;
+   if (i >= n) return;
+   for (int j = 0; j < P.nJ; ++j) out[pp.off * P.nJ + (int64_t)j * n + i] = x[pp.off * P.C + (int64_t)j * n + i];
+}
+
 // zero the Cartesian channels of a stage (robot without kinematic model: ba.cpp:618-625)
 __global__ void k_rs_zero_cart(RsParams P, const RsPath *__restrict__ paths, int B, double *__restrict__ x, int64_t total)
 {

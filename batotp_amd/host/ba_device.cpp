@@ -115,7 +115,8 @@ void BA::fillProblem(void *out) const
    if (_isParallelMechOrig) f |= BATOTP_F_PARALLEL;
    if (_isPar2Ser) f |= BATOTP_F_PAR2SER;
    // cos/sin from the host libm: bit parity with the reference (RR), and with the host twin of the chain model
-   if (_robotType == RR || (_isTrqConOn && !_isParallelMechOrig)) f |= BATOTP_F_HOST_TRIG;
+   // ... and with the forward kinematics of the device resampler / output stage (KUKA, RR)
+   if (_robotType == RR || _robotType == KUKA || (_isTrqConOn && !_isParallelMechOrig)) f |= BATOTP_F_HOST_TRIG;
    P.flags = f;
    for (unsigned int j = 0; j < _nJoints && j < BATOTP_MAX_JOINTS; ++j)
    {
@@ -214,7 +215,11 @@ int BA::exportResampleParams(const Traj &traj, void *out) const
    const bool joint = _pathType == JOINT && _robotType == GENJNT && !_isCartVelConOn && !_isCartAccConOn;
    const bool cable = _pathType == CART && _robotType == CSPR3DOF && _nJoints == 3 && _nCart == 3 &&
                       (_isJntVelConOn || _isJntAccConOn || _isTrqConOn);
-   return (joint || cable) ? 0 : -1;
+   // JOINT paths of the robots with forward kinematics (reference robot.cpp:73-96): the tool point is recomputed after
+   // each resampling pass; its cos / sin come from the host libm (bit parity with the host resampler and the reference)
+   const bool kin = _pathType == JOINT && _nCart == 3 && ((_robotType == KUKA && _nJoints == 7) || (_robotType == RR && _nJoints == 2));
+   if (kin) R.flags |= BATOTP_F_HOST_TRIG;
+   return (joint || cable || kin) ? 0 : -1;
 }
 
 // Which configurations the device output stage takes over: JOINT paths of a robot without kinematic model,
@@ -232,7 +237,12 @@ int BA::exportOutputParams(void *out) const
    if (!(_outRes > 0) || !(_integRes > 0) || !(_outSmoothFact >= 1)) return -1;
    const bool joint = _pathType == JOINT && _robotType == GENJNT && !_isTrqConOn;
    const bool cable = _pathType == CART && _robotType == CSPR3DOF && _nJoints == 3 && _nCart == 3 && _isTrqConOn && _isParallelMechOrig && !_isSVD;
-   return (joint || cable) ? 0 : -1;
+   // JOINT paths of the robots with forward kinematics: Cartesian rows by Robot::fwdKin at the output points (reference
+   // ba.cpp:1722-1725) and, with torque constraints, the serial-robot torque recomputation (ba.cpp:1791-1827) with the
+   // two-link arm's closed form or the chain model
+   const bool kinRobot = _pathType == JOINT && _nCart == 3 && ((_robotType == KUKA && _nJoints == 7) || (_robotType == RR && _nJoints == 2));
+   const bool kin = kinRobot && (!_isTrqConOn || (!_isParallelMechOrig && (_robotType == RR || const_cast<Robot &>(myRobot).serialModel() != nullptr)));
+   return (joint || cable || kin) ? 0 : -1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -358,12 +368,12 @@ int BA::deviceBuildKnotModel(Traj &traj)
       std::vector<double> trig(4 * (size_t)N);
       for (int64_t i = 0; i < N; ++i)
       {
-         const double th1 = _DEG2RAD * traj.theta[0][i];
-         const double th2 = _DEG2RAD * traj.theta[1][i];
-         trig[i] = std::cos(th1);
-         trig[N + i] = std::cos(th2);
-         trig[2 * N + i] = std::cos(th1 + th2);
-         trig[3 * N + i] = sin(th2);
+         double tr[4];
+         Robot::planarRRDynTrig(_DEG2RAD * traj.theta[0][i], _DEG2RAD * traj.theta[1][i], tr);
+         trig[i] = tr[0];
+         trig[N + i] = tr[1];
+         trig[2 * N + i] = tr[2];
+         trig[3 * N + i] = tr[3];
       }
       rc = batotp_hip_upload_rr_trig(g.b, 0, trig.data());
       if (rc) return fail("upload_rr_trig", rc);
@@ -795,12 +805,12 @@ int BA::optimizeBatchOnDevice(std::vector<Traj> &trajs)
                if (rc) return fail("download_samples", rc);
                for (int64_t i = 0; i < N; ++i)
                {
-                  const double th1 = _DEG2RAD * samp[i];
-                  const double th2 = _DEG2RAD * samp[3 * N + i];
-                  trig[i] = std::cos(th1);
-                  trig[N + i] = std::cos(th2);
-                  trig[2 * N + i] = std::cos(th1 + th2);
-                  trig[3 * N + i] = sin(th2);
+                  double tr[4];
+                  Robot::planarRRDynTrig(_DEG2RAD * samp[i], _DEG2RAD * samp[3 * N + i], tr);
+                  trig[i] = tr[0];
+                  trig[N + i] = tr[1];
+                  trig[2 * N + i] = tr[2];
+                  trig[3 * N + i] = tr[3];
                }
                rc = batotp_hip_upload_rr_trig(g.b, (int32_t)k, trig.data());
                if (rc) return fail("upload_rr_trig", rc);
@@ -916,12 +926,16 @@ int BA::optimizeBatchOnDevice(std::vector<Traj> &trajs)
             t.trq.clear();
             if (nCa > 0)
             {
-               // cable robot: Cartesian rows and recomputed cable tensions come with the joints
+               // cable robot, robots with forward kinematics: Cartesian rows and (torque constraints on) the recomputed
+               // cable tensions / joint torques come with the joints
                t.cart.assign(_nCart, std::vector<double>());
                for (int j = 0; j < nCa; ++j) t.cart[j].assign(flatTh0 + (size_t)(nTh + j) * n, flatTh0 + (size_t)(nTh + j + 1) * n);
-               t.trq.assign(_nJoints, std::vector<double>());
-               for (int j = 0; j < nTq; ++j)
-                  t.trq[j].assign(flatTh0 + (size_t)(nTh + nCa + j) * n, flatTh0 + (size_t)(nTh + nCa + j + 1) * n);
+               if (nTq > 0)
+               {
+                  t.trq.assign(_nJoints, std::vector<double>());
+                  for (int j = 0; j < nTq; ++j)
+                     t.trq[j].assign(flatTh0 + (size_t)(nTh + nCa + j) * n, flatTh0 + (size_t)(nTh + nCa + j + 1) * n);
+               }
             }
             else
             {

@@ -23,6 +23,11 @@ namespace
 // right, (a0+a1)+a2 -- and row 2 through the scalar coefficient path, whose unrolled reduction adds
 // a0+(a1+a2).  The row-times-vector products of robot.cpp:170-172 use the same scalar reduction.
 // The KUKA example is sensitive to this at the ulp level.
+// (Robot::kinSinCos) Trigonometry of the forward kinematics: cos and sin of one angle as ONE glibc sincos() call.  That is what the reference's
+// optimised build makes of "c1=cos(t1); s1=sin(t1);" (robot.cpp:130-136) and of the two-link arm's cos(th1) / sin(th1)
+// (robot.cpp:198-199), and sincos() is not bit-identical to separate cos() / sin() calls in this glibc --
+// so it is spelled out instead of being left to the optimiser.  The device resampler / output stage take these values as
+// tables (BATOTP_F_HOST_TRIG), the checker computes them the same way.
 inline double sumSeq(double a0, double a1, double a2) { return (a0 + a1) + a2; }
 inline double sumTree(double a0, double a1, double a2) { return a0 + (a1 + a2); }
 
@@ -43,6 +48,20 @@ inline Mat3 mul(const Mat3 &L, const Mat3 &R)
    return out;
 }
 } // namespace
+
+void __attribute__((noinline)) Robot::kinSinCos(double angle, double *sinOut, double *cosOut) { ::sincos(angle, sinOut, cosOut); }
+
+namespace
+{
+double __attribute__((noinline)) plainCos(double x) { return std::cos(x); }
+} // namespace
+
+void Robot::planarRRDynTrig(double th1, double th2, double out[4])
+{
+   out[0] = plainCos(th1);
+   kinSinCos(th2, &out[3], &out[1]);
+   out[2] = plainCos(th1 + th2);
+}
 
 // reference robot.cpp:46-62
 int Robot::call_set_robotType(const std::string &robotTypeStr)
@@ -83,9 +102,7 @@ void Robot::kukaToolPoint(const Channels &theta, Channels &cart) const
       double c[7], s[7];
       for (int k = 0; k < 7; ++k)
       {
-         const double t = _DEG2RAD * theta[k][i];
-         c[k] = cos(t);
-         s[k] = sin(t);
+         kinSinCos(_DEG2RAD * theta[k][i], &s[k], &c[k]);
       }
       const double c1 = c[0], c2 = c[1], c3 = c[2], c4 = c[3], c5 = c[4], c6 = c[5], c7 = c[6];
       const double s1 = s[0], s2 = s[1], s3 = s[2], s4 = s[3], s5 = s[4], s6 = s[5], s7 = s[6];
@@ -122,8 +139,11 @@ void Robot::planarRRToolPoint(const Channels &theta, Channels &cart) const
    {
       const double q1 = _DEG2RAD * theta[0][i];
       const double q2 = _DEG2RAD * theta[1][i];
-      cart[0][i] = L1 * std::cos(q1) + L2 * std::cos(q1 + q2);
-      cart[1][i] = L1 * std::sin(q1) + L2 * std::sin(q1 + q2);
+      double s1, c1, s12, c12;
+      kinSinCos(q1, &s1, &c1);
+      kinSinCos(q1 + q2, &s12, &c12);
+      cart[0][i] = L1 * c1 + L2 * c12;
+      cart[1][i] = L1 * s1 + L2 * s12;
    }
 }
 
@@ -393,9 +413,9 @@ void Robot::planarRRDynamics(Channels &a1, Channels &a2, Channels &a3, Channels 
       const double ddth1 = _DEG2RAD * thetaD2[0][i];
       const double ddth2 = _DEG2RAD * thetaD2[1][i];
 
-      const double c1 = std::cos(th1);
-      const double c2 = std::cos(th2);
-      const double c12 = std::cos(th1 + th2);
+      double tr[4];
+      planarRRDynTrig(th1, th2, tr);
+      const double c1 = tr[0], c2 = tr[1], c12 = tr[2], s2 = tr[3];
 
       const double A11 = .25 * m1 * A1 * A1 + m2 * (A1 * A1 + .25 * A2 * A2 + A1 * A2 * c2);
       const double A12 = .5 * m2 * (.5 * A2 * A2 + A1 * A2 * c2);
@@ -404,7 +424,7 @@ void Robot::planarRRDynamics(Channels &a1, Channels &a2, Channels &a3, Channels 
       a1[0][i] = A11 * dth1 + A12 * dth2;
       a1[1][i] = A12 * dth1 + A22 * dth2;
 
-      const double ccFact = m2 * A1 * A2 * sin(th2);
+      const double ccFact = m2 * A1 * A2 * s2;
       a2[0][i] = A11 * ddth1 + A12 * ddth2 - ccFact * dth2 * (dth1 + .5 * dth2);
       a2[1][i] = A12 * ddth1 + A22 * ddth2 - .5 * ccFact * dth1 * dth1;
 

@@ -49,6 +49,13 @@ public:
    // (include/batotp_models.h: KUKA LWR IV+).  serialModel() returns nullptr when there is neither.
    void setSerialModel(const batotp_serial_model &m) { _serial = m; _hasSerial = true; }
    const batotp_serial_model *serialModel();
+   // extension: the trigonometry of the built-in models, spelled out call by call -- it is what the reference's optimised
+   // build calls, and the tables the device layer uploads (BATOTP_F_HOST_TRIG) are made with the same helpers.
+   //   kinSinCos        one glibc sincos(): "c=cos(t); s=sin(t);" of the forward kinematics (reference robot.cpp:130-136,198-199)
+   //   planarRRDynTrig  out = cos(th1), cos(th2), cos(th1+th2), sin(th2) of Robot::dynRR (robot.cpp:408-419): th2's cosine and
+   //                    sine as one sincos(), the other two as cos()
+   static void kinSinCos(double angle, double *sinOut, double *cosOut);
+   static void planarRRDynTrig(double th1, double th2, double out[4]);
 
 private:
    int _kind = 0;

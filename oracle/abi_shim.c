@@ -553,10 +553,14 @@ int batotp_hip_output(batotp_batch *b, const batotp_output_params *prm, int32_t 
     {
         const int cable = prm->path_type == BATOTP_PATH_CART && b->prob.robot_type == BATOTP_ROBOT_CSPR3DOF && prm->n_joints == 3 &&
                           b->prob.n_cart == 3 && (b->prob.flags & BATOTP_F_TRQ_ON) && (b->prob.flags & BATOTP_F_PARALLEL);
-        const int joint = (prm->path_type == BATOTP_PATH_JOINT || prm->path_type == 0) && !(b->prob.flags & BATOTP_F_TRQ_ON);
+        const int jointPath = prm->path_type == BATOTP_PATH_JOINT || prm->path_type == 0;
+        const int kin = jointPath && bo_fwdkin_trig_rows(b->prob.robot_type, prm->n_joints) != 0 && b->prob.n_cart >= 3;
+        const int serialTrq = jointPath && (b->prob.flags & BATOTP_F_TRQ_ON) && !(b->prob.flags & BATOTP_F_PARALLEL) &&
+                              (b->has_serial || b->prob.robot_type == BATOTP_ROBOT_RR);
+        const int joint = jointPath && (!(b->prob.flags & BATOTP_F_TRQ_ON) || serialTrq);
         if (!cable && !joint) return BATOTP_ERR_ARG;
         o = (batotp_output *)calloc(1, sizeof(*o));
-        o->nTheta = prm->n_joints; o->nCart = cable ? 3 : 0; o->nTrq = cable ? 3 : 0;
+        o->nTheta = prm->n_joints; o->nCart = cable ? 3 : (kin ? 3 : 0); o->nTrq = cable ? 3 : (serialTrq ? prm->n_joints : 0);
     }
     o->n_paths = n_paths; o->nJ = o->nTheta + o->nCart + o->nTrq;
     o->n = (int64_t *)calloc((size_t)n_paths, sizeof(int64_t));

@@ -330,7 +330,7 @@ int bo_precompute_kin(const batotp_problem *prob, bo_path *p, const double *y, d
 }
 
 /* Robot::dynRR, robot.cpp:377-431 */
-static void dyn_rr(const bo_path *p, const double *trig, double *a1, double *a2, double *a3, double *a4)
+void bo_dyn_rr(const bo_path *p, const double *trig, double *a1, double *a2, double *a3, double *a4)
 {
     int64_t n = p->n, i;
     const double *th0 = p->samp, *thD0 = p->samp + n, *thDD0 = p->samp + 2 * n;
@@ -345,7 +345,7 @@ static void dyn_rr(const bo_path *p, const double *trig, double *a1, double *a2,
         double ddth2 = BO_DEG2RAD * thDD1[i];
         double c1, c2, c12, s2, A11, A12, A22, ccFact;
         if (trig) { c1 = trig[i]; c2 = trig[n + i]; c12 = trig[2 * n + i]; s2 = trig[3 * n + i]; }
-        else { c1 = cos(th1); c2 = cos(th2); c12 = cos(th1 + th2); s2 = sin(th2); }
+        else { double tr[4]; bo_rr_dyn_trig(th1, th2, tr); c1 = tr[0]; c2 = tr[1]; c12 = tr[2]; s2 = tr[3]; }
 
         A11 = .25 * m1 * A1 * A1 + m2 * (A1 * A1 + .25 * A2 * A2 + A1 * A2 * c2);
         A12 = .5 * m2 * (.5 * A2 * A2 + A1 * A2 * c2);
@@ -395,7 +395,7 @@ int bo_precompute_dyn(const batotp_problem *prob, bo_path *p, const double *trig
             if (bo_dyn_serial(p->serial, p, trig, a1, a2, a3, a4) != 0) return -1;
         } else {
             if (prob->robot_type != BATOTP_ROBOT_RR) return -1; /* robot.cpp:349-360 */
-            dyn_rr(p, trig, a1, a2, a3, a4);
+            bo_dyn_rr(p, trig, a1, a2, a3, a4);
         }
     }
 

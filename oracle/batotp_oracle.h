@@ -117,6 +117,18 @@ int  bo_resample(const bo_resample_params *prm, int64_t n_in, const double *x, d
 int  bo_output(const batotp_problem *prob, const batotp_output_params *prm, const bo_path *p, const double *fwd_s, int64_t n_fwd,
                double t_step, double **out /* [n_theta + n_cart + n_trq][*n_out] */, int32_t *n_cart_out, int32_t *n_trq_out,
                int64_t *n_out, double *sres_out);
+/* Forward kinematics: Robot::fwdKinKuka robot.cpp:105-174, Robot::fwdKinRR robot.cpp:188-202, split into the
+ * trigonometry of the points (glibc sincos) and the arithmetic on it.  theta [n_joints][n]; trig [bo_fwdkin_trig_rows][n]: KUKA
+ * cos(t_k) k = 0..6 then sin(t_k), RR cos(th1), cos(th1+th2), sin(th1), sin(th1+th2); cart rows 0..2 (KUKA) / 0..1 (RR) of
+ * cart[.][n] are written.  -1 for robots without a model. */
+int  bo_fwdkin_trig_rows(int robot_type, int n_joints);
+int  bo_fwdkin_trig(int robot_type, int n_joints, const double *theta, int64_t n, double *trig);
+int  bo_fwdkin_from_trig(int robot_type, int n_joints, const double *trig, int64_t n, double *cart);
+int  bo_fwdkin(int robot_type, int n_joints, const double *theta, int64_t n, double *cart, double *trig_scratch);
+/* trigonometry of Robot::dynRR (robot.cpp:408-419): out = cos(th1), cos(th2), cos(th1+th2), sin(th2); th2 through one sincos() */
+void bo_rr_dyn_trig(double th1, double th2, double out[4]);
+/* Robot::dynRR (robot.cpp:377-431) on the samples of p (value, d/ds, d2/ds2 of the two joints); trig: optional [4][n] table */
+void bo_dyn_rr(const bo_path *p, const double *trig, double *a1, double *a2, double *a3, double *a4);
 /* Robot::setA for CSPR3DOF (robot.cpp:534-558), A row-major [3][3] */
 void bo_cspr_setA(const double *pmat, const double *theta, const double *cart, double *A);
 

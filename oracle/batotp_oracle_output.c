@@ -3,7 +3,8 @@
  *
  * Plain-C restatement of the output stage behind the hot path:
  * BA::interpOutputData (ba.cpp:1661-1931) for the configurations the device output stage covers --
- * JOINT paths of a robot without kinematic model, no torque constraints: the optimised s(t) is
+ * JOINT paths (robots without kinematic model; KUKA and the two-link arm with their forward kinematics, SURVEY.md 8 f-3;
+ * serial robots with the torque recomputation of ba.cpp:1791-1827) and CART paths of the 3-cable robot: the optimised s(t) is
  * re-sampled at constant time steps, the joint splines are evaluated there, the result is smoothed
  * and down-sampled (_outSmoothFact) and, when the output resolution is finer than the integration
  * step, re-interpolated.  It is the checker of batotp_hip_output.
@@ -95,9 +96,15 @@ int bo_output(const batotp_problem *prob, const batotp_output_params *prm, const
     const int nJ = prm->n_joints;
     const int cable = prm->path_type == BATOTP_PATH_CART && prob->robot_type == BATOTP_ROBOT_CSPR3DOF && nJ == 3 && p->n_cart == 3 &&
                       (prob->flags & BATOTP_F_TRQ_ON) && (prob->flags & BATOTP_F_PARALLEL);
-    const int joint = (prm->path_type == BATOTP_PATH_JOINT || prm->path_type == 0) && !(prob->flags & BATOTP_F_TRQ_ON);
+    const int jointPath = prm->path_type == BATOTP_PATH_JOINT || prm->path_type == 0;
+    /* JOINT path of a robot with forward kinematics (KUKA, RR): three Cartesian rows from the joints */
+    const int kin = jointPath && bo_fwdkin_trig_rows(prob->robot_type, nJ) != 0 && p->n_cart >= 3;
+    /* torque recomputation of a serial robot, ba.cpp:1791-1827: the two-link arm's closed form or a chain model */
+    const int serialTrq = jointPath && (prob->flags & BATOTP_F_TRQ_ON) && !(prob->flags & BATOTP_F_PARALLEL) &&
+                          (p->serial != NULL || prob->robot_type == BATOTP_ROBOT_RR) && nJ == p->n_theta;
+    const int joint = jointPath && (!(prob->flags & BATOTP_F_TRQ_ON) || serialTrq);
     if (nJ < 1 || nJ > p->n_theta || n_fwd < 4 || (!cable && !joint)) return -1;
-    const int nC = cable ? 3 : 0, nT = cable ? 3 : 0, C = nJ + nC + nT;
+    const int nC = cable ? 3 : (kin ? 3 : 0), nT = cable ? 3 : (serialTrq ? nJ : 0), C = nJ + nC + nT;
     double outRes = prm->out_res, smoothFact = prm->out_smooth_fact;
     const double outResUser = outRes;
     int reinterp = 0;
@@ -157,6 +164,47 @@ int bo_output(const batotp_problem *prob, const batotp_output_params *prm, const
                 }
                 x[(size_t)k * n + i] = sqrt(sumSQ);
             }
+    }
+
+    if (kin) {
+        /* Robot::fwdKin at the output points (ba.cpp:1722-1725).  The two-link arm's routine leaves the third row alone
+         * (robot.cpp:192-193): it keeps what the Traj held -- the knot samples of that channel -- cut or zero-extended to
+         * the new length */
+        double *trig = (double *)malloc(sizeof(double) * (size_t)bo_fwdkin_trig_rows(prob->robot_type, nJ) * (size_t)n);
+        if (prob->robot_type == BATOTP_ROBOT_RR) {
+            const double *old = p->samp + (size_t)(p->n_theta + 2) * 3 * (size_t)p->n;
+            for (int64_t i = 0; i < n; ++i) x[(size_t)(nJ + 2) * n + i] = i < p->n ? old[i] : 0.0;
+        }
+        bo_fwdkin(prob->robot_type, nJ, x, n, x + (size_t)nJ * n, trig);
+        free(trig);
+    }
+    if (serialTrq) {
+        /* ba.cpp:1744-1750, 1791-1827: "clamped" splines through the joint samples, value and derivatives at the END of the
+         * previous segment (the values are replaced too), Robot::dynSerial there, torque = a2 + a3 + a4 */
+        const double tfact = outRes / smoothFact;
+        for (int64_t i = 0; i < n; ++i) { seg[i] = (int32_t)(i - 1); tau[i] = 1; }
+        seg[0] = 0; tau[0] = 0;
+        bo_path q;
+        memset(&q, 0, sizeof(q));
+        q.n = n; q.n_theta = nJ;
+        q.samp = (double *)malloc(sizeof(double) * 3 * (size_t)nJ * (size_t)n);
+        double *c = (double *)calloc((size_t)4 * (size_t)n, sizeof(double));
+        for (int j = 0; j < nJ; ++j) {
+            memset(c, 0, sizeof(double) * 4 * (size_t)n);
+            bo_spline_coeffs(x + (size_t)j * n, n, c, 1);
+            double *sp = q.samp + (size_t)j * 3 * n;
+            bo_interp1_spline(c, n, seg, tau, n, tfact, sp, sp + n, sp + 2 * n);
+            memcpy(x + (size_t)j * n, sp, sizeof(double) * (size_t)n);
+        }
+        free(c);
+        double *a = (double *)malloc(sizeof(double) * 4 * (size_t)nJ * (size_t)n);
+        double *a1 = a, *a2 = a + (size_t)nJ * n, *a3 = a + 2 * (size_t)nJ * n, *a4 = a + 3 * (size_t)nJ * n;
+        if (p->serial) bo_dyn_serial(p->serial, &q, NULL, a1, a2, a3, a4); /* cos / sin: separate libm calls, as the host twin */
+        else bo_dyn_rr(&q, NULL, a1, a2, a3, a4);
+        for (int j = 0; j < nJ; ++j)
+            for (int64_t i = 0; i < n; ++i)
+                x[(size_t)(nJ + nC + j) * n + i] = a2[(size_t)j * n + i] + a3[(size_t)j * n + i] + a4[(size_t)j * n + i];
+        free(a); free(q.samp);
     }
 
     if (cable) {

@@ -2,8 +2,9 @@
  * batotp_oracle_resample.c -- TEST INFRASTRUCTURE ONLY (see batotp_oracle.h).
  *
  * Plain-C restatement of the path resampling that precedes the hot path, for the
- * path kinds the device resampler covers: JOINT paths of a robot without kinematic model and CART
- * paths of the 3-cable robot.  It is the checker of batotp_hip_resample.
+ * path kinds the device resampler covers: JOINT paths of a robot without kinematic model, JOINT paths of the
+ * robots with forward kinematics (KUKA, RR: batotp_oracle_kin.c) and CART paths of the 3-cable
+ * robot.  It is the checker of batotp_hip_resample.
  *
  * Pinning: tests/test_oracle_resample.py compares the knots it produces with the knots.npz
  * fixtures under tests/golden/ -- the knots behind the s-sdot / trajectory outputs that are
@@ -118,6 +119,14 @@ static void rs_invkin_cspr(rs_traj *t, const double pmat[9])
             }
             t->x[k * n + i] = sqrt(sumSQ);
         }
+}
+
+/* Robot::fwdKin (robot.cpp:73-96) on the stage's joint rows: KUKA writes the three Cartesian rows, the two-link arm the first two */
+static void rs_fwdkin(rs_traj *t, int robot_type)
+{
+    double *trig = (double *)malloc(sizeof(double) * (size_t)bo_fwdkin_trig_rows(robot_type, t->nJ) * (size_t)t->n);
+    bo_fwdkin(robot_type, t->nJ, t->x, t->n, t->x + (size_t)t->nJ * t->n, trig);
+    free(trig);
 }
 
 typedef struct rs_scale { double sLast, sResNew, teach, thetaF, cartF, sResi; } rs_scale;
@@ -294,7 +303,10 @@ int bo_resample(const bo_resample_params *prm, int64_t n_in, const double *x, do
 {
     const int joint = prm->path_type == BATOTP_PATH_JOINT && prm->robot_type == BATOTP_ROBOT_GENJNT;
     const int cable = prm->path_type == BATOTP_PATH_CART && prm->robot_type == BATOTP_ROBOT_CSPR3DOF && prm->n_joints == 3;
-    if ((!joint && !cable) || n_in < 4 || prm->n_cart < 3) return -1;
+    /* JOINT path of a robot with forward kinematics (KUKA, RR): SURVEY.md 8 f-3 */
+    const int kin = prm->path_type == BATOTP_PATH_JOINT && bo_fwdkin_trig_rows(prm->robot_type, prm->n_joints) != 0;
+    const int cartOn = (prm->flags & (BATOTP_F_CART_VEL_ON | BATOTP_F_CART_ACC_ON)) != 0;
+    if ((!joint && !cable && !kin) || n_in < 4 || prm->n_cart < 3) return -1;
     if (prm->s_weights[1] + prm->s_weights[2] < 1e-8) return -1; /* ba.cpp:416: nothing to do */
     rs_traj t;
     t.nJ = prm->n_joints; t.nC = prm->n_cart; t.C = t.nJ + t.nC; t.n = n_in; t.sres = sres_in;
@@ -310,6 +322,7 @@ int bo_resample(const bo_resample_params *prm, int64_t n_in, const double *x, do
         if (t.n < 4) st |= BATOTP_RS_TOO_SHORT;
     }
     if (!st && cable) rs_invkin_cspr(&t, prm->pmat);
+    if (!st && kin && cartOn) rs_fwdkin(&t, prm->robot_type); /* ba.cpp:247-256; otherwise the Cartesian rows stay as loaded */
     for (int pass = 0; pass < 2 && !st; ++pass) {
         double *sC = (double *)malloc(sizeof(double) * (size_t)t.n);
         rs_scale sc;
@@ -317,6 +330,7 @@ int bo_resample(const bo_resample_params *prm, int64_t n_in, const double *x, do
         if (!st) st |= pass == 0 ? rs_special(prm, &t, sC, &sc) : rs_regular(&t, sC, &sc);
         free(sC);
         if (!st && cable) rs_invkin_cspr(&t, prm->pmat); /* ba.cpp:630 */
+        if (!st && kin) rs_fwdkin(&t, prm->robot_type);   /* ba.cpp:626-628: after either pass, whatever the constraints */
     }
     *status = st;
     if (st) {

@@ -31,7 +31,7 @@ def _stage(src, dst):
 
 
 @pytest.mark.parametrize("mode", ["device-resample", "host-resample", "host-output"])
-@pytest.mark.parametrize("name", ["synth_cspr_s3", "synth_gen7dof_s1_vel", "synth_ur_s2", "GEN7DOF", "UR5", "RR"])
+@pytest.mark.parametrize("name", ["synth_cspr_s3", "synth_gen7dof_s1_vel", "synth_ur_s2", "GEN7DOF", "UR5", "RR", "RR_acc", "KUKA-LWR-IV", "KUKA_cartacc"])
 def test_batch_driver_files_equal_reference(tmp_path, oracle_lib, name, mode):
     """BA::optimizeBatch (the many-path extension) writes, for every copy of the path, the files the
     reference binary wrote for the single path -- with the resampling done behind the C-ABI

@@ -59,6 +59,56 @@ def test_cable_robot_every_branch_matches_the_oracle(hip_ctx, oracle_ctx, name):
     hb.close(); ob.close()
 
 
+@pytest.mark.parametrize("name", ["KUKA-LWR-IV", "RR", "RR_acc", "KUKA_trq"])
+def test_forward_kinematics_robots_every_branch_matches_the_oracle(hip_ctx, oracle_ctx, name):
+    """JOINT paths of the robots with forward kinematics (SURVEY.md 8 f-3): joint rows, Cartesian rows by Robot::fwdKin at
+    the output points and, with torque constraints, the serial-robot torque recomputation (reference ba.cpp:1791-1827: clamped
+    splines, Robot::dynRR or the chain model of BASELINE config 3) -- every branch of the stage, two paths of different length"""
+    case = Case(name)
+    short = Case(name)
+    short.y = np.ascontiguousarray(short.y[:, :max(40, case.n // 3)])
+    base = output_params(name) if name in OUTPUT_CASES else capi.OutputParams(case.problem.n_joints, capi.PATH_JOINT, case.problem.integ_res, 0.008, 5.0)
+    outs = []
+    for ctx in (hip_ctx, oracle_ctx):
+        b = capi.Batch(ctx, case.problem, [case.n, short.n], case.max_steps())
+        b.upload_knots(0, [case.y], [case.sres]); b.upload_knots(1, [short.y], [short.sres])
+        helpers.precompute_with_trig(ctx, b, case.problem, 2)
+        b.sweep(-1); b.sweep(+1)
+        outs.append(b)
+    hb, ob = outs
+    assert hb.results().tobytes() == ob.results().tobytes()
+    nJ = case.problem.n_joints
+    trq = bool(case.problem.flags & capi.F_TRQ_ON)
+    for prm in _variants(base):
+        h, o = capi.Output(hb, prm, 0, 2), capi.Output(ob, prm, 0, 2)
+        what = f"{name} out_res={prm.out_res} smooth={prm.out_smooth_fact}"
+        assert (h.n_theta, h.n_cart, h.n_trq) == (nJ, 3, nJ if trq else 0) == (o.n_theta, o.n_cart, o.n_trq), what
+        assert np.array_equal(h.n_pts, o.n_pts) and h.sres.tobytes() == o.sres.tobytes(), what
+        for k in range(2):
+            assert_bit_equal(h.rows(k), o.rows(k), f"{what}: path {k}")
+        h.close(); o.close()
+    hb.close(); ob.close()
+
+
+def test_forward_kinematics_with_the_device_libm_is_close(hip_ctx, oracle_ctx):
+    """without BATOTP_F_HOST_TRIG the tool point uses the device libm: same point counts, Cartesian rows within 1e-12 of the
+    host-trig result (the documented tolerance mode; joint rows do not depend on it)"""
+    case = Case("KUKA-LWR-IV")
+    prob = capi.Problem.from_buffer_copy(bytes(case.problem))
+    prob.flags &= ~capi.F_HOST_TRIG
+    rows = []
+    for p in (case.problem, prob):
+        b = capi.Batch(hip_ctx, p, [case.n], case.max_steps())
+        b.upload_knots(0, [case.y], [case.sres])
+        b.optimize()
+        o = capi.Output(b, output_params(case.name), 0, 1)
+        rows.append(o.rows(0))
+        o.close(); b.close()
+    nJ = case.problem.n_joints
+    assert_bit_equal(rows[0][:nJ], rows[1][:nJ], "joint rows")
+    assert rows[0].shape == rows[1].shape and np.max(np.abs(rows[0][nJ:] - rows[1][nJ:])) < 1e-12
+
+
 def test_every_branch_and_a_ragged_batch_match_the_oracle(hip_ctx, oracle_ctx):
     cases = [Case("synth_gen7dof_s0"), Case("synth_gen7dof_s0")]
     short = Case("synth_gen7dof_s0")

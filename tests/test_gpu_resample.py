@@ -44,6 +44,44 @@ def test_ragged_batch_with_failing_and_duplicated_paths(hip_ctx, oracle_ctx):
     assert_bit_equal(h.knots(2), c.y, "duplicated taught points are dropped first")
 
 
+@pytest.mark.parametrize("name", ["KUKA-LWR-IV", "RR"])
+def test_forward_kinematics_robots_ragged_batch(hip_ctx, oracle_ctx, name):
+    """JOINT paths of the robots with forward kinematics: the tool point is recomputed before the first pass
+    (Cartesian constraint on) and after each pass, with the cos / sin of the host libm; ragged batch incl. a degenerate path"""
+    c = ResampleCase(name)
+    n = c.x.shape[1]
+    rng = np.random.default_rng(5)
+    wob = c.x.copy()
+    wob[:c.params.n_joints] += rng.normal(0, 0.05, (c.params.n_joints, n))       # another path through the same region
+    xs = [c.x, c.x[:, :n // 2].copy(), c.x[:, ::-1].copy(), np.repeat(c.x[:, :1], 16, axis=1), wob, np.repeat(c.x, 2, axis=1)]
+    sr = [c.sres_in] * len(xs)
+    h = capi.Resampled(hip_ctx, c.params, xs, sr)
+    o = capi.Resampled(oracle_ctx, c.params, xs, sr)
+    assert int(h.status[3]) != 0 and int(h.status[0]) == 0
+    _same(h, o, f"ragged {name} batch")
+    assert_bit_equal(h.knots(0), c.y, "golden knots inside the batch")
+    assert_bit_equal(h.knots(5), c.y, "duplicated taught points are dropped first")
+    # Cartesian constraints off: the taught Cartesian rows pass through the first pass untouched (ba.cpp:258-262)
+    prm = capi.ResampleParams.from_buffer_copy(bytes(c.params))
+    prm.flags &= ~(capi.F_CART_VEL_ON | capi.F_CART_ACC_ON)
+    h2 = capi.Resampled(hip_ctx, prm, xs[:3], sr[:3])
+    o2 = capi.Resampled(oracle_ctx, prm, xs[:3], sr[:3])
+    _same(h2, o2, f"{name} without Cartesian constraints")
+
+
+def test_forward_kinematics_with_the_device_libm_is_close(hip_ctx):
+    """without BATOTP_F_HOST_TRIG the tool point comes from the device libm (last-bit differences against glibc): the
+    documented tolerance mode -- same knot count on the golden path, knots within 1e-9"""
+    c = ResampleCase("KUKA-LWR-IV")
+    prm = capi.ResampleParams.from_buffer_copy(bytes(c.params))
+    assert prm.flags & capi.F_HOST_TRIG
+    prm.flags &= ~capi.F_HOST_TRIG
+    r = capi.Resampled(hip_ctx, prm, [c.x], [c.sres_in])
+    assert int(r.status[0]) == 0 and int(r.n_knots[0]) == c.y.shape[1]
+    assert np.max(np.abs(r.knots(0) - c.y)) < 1e-9
+    r.close()
+
+
 @pytest.mark.parametrize("kind", ["gen7", "ur", "cspr"])
 def test_baseline_size_paths_match_oracle(hip_ctx, oracle_ctx, kind):
     """BASELINE.json-sized taught paths (tens of thousands of points, ~1e5 knots), several seeds per batch"""
@@ -93,7 +131,7 @@ def test_resampled_knots_feed_the_hot_path_on_the_device(hip_ctx):
     r.close()
 
 
-@pytest.mark.parametrize("name", ["synth_cspr_s3", "synth_gen7dof_s0", "synth_ur_s2", "GEN7DOF", "CSPR3DOF", "UR5"])
+@pytest.mark.parametrize("name", ["synth_cspr_s3", "synth_gen7dof_s0", "synth_ur_s2", "GEN7DOF", "CSPR3DOF", "UR5", "KUKA-LWR-IV", "KUKA_cartacc", "RR", "RR_acc"])
 def test_product_batch_driver_on_gpu(tmp_path, name):
     """batotp_amd/host/_build/batest_batch (BA::optimizeBatch over the HIP library, device resampler and device output
     stage where the configuration allows them) writes the reference binary's files for every copy of the path"""
