@@ -43,6 +43,7 @@ from batotp_amd import dist as bdist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 DUMP_KNOTS = os.path.join(ROOT, "batotp_amd", "host", "_build", "baknots")  # the product's host resampler as a tool (no device call)
 METRIC = "constraint-evaluated waypoints/sec + traversal-time err vs CPU ref"
+AS_WORDED_STEPS = 3     # timed steps of each BASELINE configuration as worded beside the headline (median reported as well)
 
 WORKLOADS = {
     # name: fine-path generator, config kwargs, knots per coarse point, capacity of a curve in points per knot
@@ -452,8 +453,11 @@ def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=
     local_knots = sum(knots_of(s) for s in chunk_sizes)     # (after the retries: replaced paths have other knot counts)
     barrier()
     t0 = time.perf_counter()
+    step_s = []
     for _ in range(steps):
-        one_pass(True, chunk_sizes)
+        ts = time.perf_counter()
+        one_pass(True, chunk_sizes)      # ends with the result rows on the host (and the all_gather): a complete step
+        step_s.append(time.perf_counter() - ts)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist_ctx is not None:
@@ -500,7 +504,16 @@ def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=
     dom_ms = 0.5 * (kernel_ms[3] + kernel_ms[4]) / launches
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     layout = "compact" if (prob.flags & capi.F_COMPACT_SPLINES) else "rows"
-    traffic, traffic_src = recorded_traffic(workload, chunk_sizes[0] if B else 0, layout)
+    traffic, traffic_src, issue_rec = recorded_traffic(workload, chunk_sizes[0] if B else 0, layout)
+    issue = None
+    if issue_rec:
+        # the issue side of the same kernel from the SQ counters of the matching recorded run: share of all SIMD cycles with a
+        # VALU instruction in flight x share of the 64 lanes that carry work = fraction of the fp64 vector pipes' lane-cycles used
+        vb, al = issue_rec["valu_busy_frac"], issue_rec["active_lanes_of_64"]
+        issue = {"valu_busy_frac": 0.5 * (vb["reverse"] + vb["forward"]), "active_lanes_of_64": 0.5 * (al["reverse"] + al["forward"]),
+                 "frac": 0.5 * (vb["reverse"] * al["reverse"] + vb["forward"] * al["forward"]) / 64.0,
+                 "by_direction": {"reverse": vb["reverse"] * al["reverse"] / 64.0, "forward": vb["forward"] * al["forward"] / 64.0},
+                 "source": issue_rec.get("source")}
     tk_ = max(local_knots, 1)
     r1_ms, r2_ms = max(kernel_ms[1] + kernel_ms[2], 1e-9), max(kernel_ms[3] + kernel_ms[4], 1e-9)
     rho_r, rho_f = steps_rev / tk_, steps_fwd / tk_
@@ -512,6 +525,8 @@ def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=
         "steps": steps,
         "warmup": warmup,
         "ms_per_step": 1e3 * elapsed / max(steps, 1),
+        "ms_per_step_median": 1e3 * float(np.median(step_s)) if step_s else None,   # this rank's steps, one by one
+        "ms_per_step_min_max": [1e3 * min(step_s), 1e3 * max(step_s)] if step_s else None,
         "higher_is_better": True,
         "scaling": c["scaling"],
         "vs_baseline": None,
@@ -539,7 +554,11 @@ def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=
         "paths_with_error_status": int(np.count_nonzero((res["status_rev"] | res["status_fwd"]) & ~np.uint32(capi.ST_BISECT_FAIL))) if B else 0,
         "hbm_bytes_resident": batch.nbytes() if batch is not None else 0,
         "gathered_rows": int(state["gathered"].shape[0]) if state["gathered"] is not None else 0,
-        "roofline": {"bound": "hbm", "kernel": f"k_sweep ({2 * launches} launches per step: reverse, forward; per-launch averages)",
+        # "bound" names the roofline the path is priced against (north_star: HBM GB/s vs peak); what the counters say limits the
+        # kernel is in "limited_by" / "issue": the sweep is an initial-value problem, bound by fp64 instruction issue on two
+        # wavefronts per SIMD, not by bytes (SURVEY.md 8d "honest expectation")
+        "roofline": {"bound": "hbm", "limited_by": "valu-issue (fp64 dependent chains, 2 wavefronts per SIMD)", "issue": issue,
+                     "kernel": f"k_sweep ({2 * launches} launches per step: reverse, forward; per-launch averages)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_src, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
                      "reverse": {"ms": kernel_ms[3], "algorithmic_bytes": bytes_rev}, "forward": {"ms": kernel_ms[4], "algorithmic_bytes": bytes_fwd}},
@@ -562,11 +581,11 @@ def recorded_traffic(workload, paths, layout):
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_sweep_traffic.json")))
     except Exception:
-        return None, None
+        return None, None, None
     for e in rec.get("runs", []):
         if e.get("workload") == workload and e.get("paths") == paths and e.get("layout") == layout:
-            return e.get("hbm_bytes_per_launch"), e.get("command")
-    return None, None
+            return e.get("hbm_bytes_per_launch"), e.get("command"), e.get("issue")
+    return None, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -635,7 +654,7 @@ def cpu_baseline(kept, budget_s, out_prm=None, want_output=False):
     wall, n_wp, rows, _ = cpu_batch(n_sample, passes=2)
     info = {"value": n_wp / wall, "unit": "waypoints/s", "cores": cores, "kind": "port", "single_thread_value": n_one / t_one,
             "sample": f"{n_sample} paths of the same workload ({D} distinct, N~{n_one}), OpenMP one path per thread on {cores} host "
-                      f"threads, same regions (K1-K4), oracle/ C restatement at -O2 -ffp-contract=off"}
+                      f"threads, same regions (K1-K4), oracle/ C restatement at -O3 -ffp-contract=off"}
     m = min(n_sample, kept["chunk0"], D)
     res = kept["res"]
     err = float(np.max(np.abs(res["t_total"][:m] - rows["t_total"][:m])))
@@ -736,25 +755,35 @@ def main():
         hip.set_sweep_hold(*args.hold)
 
     default_run = args.config == "fill7" and not args.paths and not args.knots
+    cpu_job = (None, None)
     out, kept = measure(hip, args.config, rank, world, args.steps, args.warmup, dist_ctx, args.paths, args.knots, args.group, args.ppw,
                         args.coefficient_rows, args.distinct, keep=True)
     workload = CONFIGS[args.config]["workload"]
     prob, batch = kept["prob"], kept["batch"]
     vel_acc_only = not (prob.flags & (capi.F_TRQ_ON | capi.F_CART_VEL_ON | capi.F_CART_ACC_ON))
 
-    if rank == 0 and not args.no_sides and batch is not None:
+    if not args.no_sides and batch is not None and vel_acc_only and kept["chunk0"] > 6144 and args.group in (0, 8):
         # the automatic loop form of the reverse sweep (flat stage / bisection loop) against the nested loops on the same
-        # batch: the result rows must be identical; untimed
-        if vel_acc_only and kept["chunk0"] > 6144 and args.group in (0, 8):   # up to 6144 paths the reverse sweep runs k_sweep1, not the flat loop
-            ref_rows = batch.results().tobytes()
-            hip.set_sweep_hold(-1, -1)
-            batch.sweep(-1); batch.sweep(+1)
-            nested_rev, nested_fwd = batch.kernel_ms(3), batch.kernel_ms(4)
-            same = batch.results().tobytes() == ref_rows
-            hip.set_sweep_hold(-2, -2)
-            out["nested_loop_cross_check"] = {"sweep_rev_ms": nested_rev, "sweep_fwd_ms": nested_fwd, "result_rows_identical": bool(same),
-                                              "what": "the same batch once more with the nested stage / bisection loops in both sweeps "
-                                                      "(the default runs the flat loop in the reverse sweep); untimed"}
+        # batch: the result rows must be identical; untimed.  EVERY rank checks its own batch (nobody waits in a barrier
+        # while rank 0 sweeps), the verdict is the AND over the ranks.  (Up to 6144 paths the reverse sweep runs k_sweep1.)
+        ref_rows = batch.results().tobytes()
+        launch_default = batch.last_sweep_launch(-1)
+        hip.set_sweep_hold(-1, -1)
+        batch.sweep(-1); batch.sweep(+1)
+        nested_rev, nested_fwd = batch.kernel_ms(3), batch.kernel_ms(4)
+        same = batch.results().tobytes() == ref_rows
+        hip.set_sweep_hold(-2, -2)
+        if dist_ctx is not None:
+            flag = torch.tensor([1 if same else 0], dtype=torch.int64, device=dist_ctx["dev"])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            same = bool(flag.item())
+        out["nested_loop_cross_check"] = {"sweep_rev_ms": nested_rev, "sweep_fwd_ms": nested_fwd, "result_rows_identical": bool(same),
+                                          "default_reverse_launch_lanes_ppw_hold": list(launch_default),
+                                          "flat_loop_gate": hip.flat_loop_status(),
+                                          "what": "the same batch once more with the nested stage / bisection loops in both sweeps (the default "
+                                                  "runs the flat loop in the reverse sweep when its gate -- validated toolchain + on-device "
+                                                  "canary -- is open: flat_loop_gate 1); every rank checks its own batch; untimed"}
+    if rank == 0 and not args.no_sides and batch is not None:
         # SURVEY.md 8f-2 beside the hot path: the output stage of the first paths of the batch on the device
         wcfg = WORKLOADS[workload]["cfg"]
         covered = (wcfg["robot"] == "GENJNT" and not (prob.flags & capi.F_TRQ_ON)) or \
@@ -774,17 +803,11 @@ def main():
                                    "out_res": out_prm.out_res, "out_smooth_fact": out_prm.out_smooth_fact,
                                    "what": "s(t) spline + re-sampling at constant time steps + joint spline evaluation + smoothing / "
                                            "down-sampling (+ re-interpolation when out_res < integ_res) on the device"}
-        # CPU baseline: the oracle (bit-identical port of the reference's path) on the host cores, bounded sample
-        if world == 1 and not args.no_cpu_baseline:
-            info, err, mism, th0 = cpu_baseline(kept, args.cpu_seconds, out_prm, hip_out0 is not None)
-            out["cpu_baseline"] = info
-            out["vs_cpu_baseline"] = out["value"] / info["value"]
-            out["traversal_time_err_s"] = err
-            out["step_count_mismatches"] = mism
-            if th0 is not None:
-                out["output_stage"]["identical_to_oracle"] = bool(th0.tobytes() == hip_out0.tobytes())
+        cpu_job = (out_prm, hip_out0)
     if batch is not None:
         batch.close()
+    # what the CPU baseline needs later lives on the host (the device batch is released now)
+    kept_host = {k: kept[k] for k in ("inp", "prob", "cap", "K", "res", "chunk0")} if (rank == 0 and kept is not None) else None
     kept = None
     hip.trim()
 
@@ -796,9 +819,10 @@ def main():
         worded = {}
         for name in ("cfg2", "cfg3", "cfg4", "cfg5"):
             try:
-                w, _ = measure(hip, name, rank, world, 1, 1, dist_ctx)
-                worded[name] = {k: w.get(k) for k in ("value", "unit", "ms_per_step", "scaling", "data", "config", "kernel_ms", "steps_per_knot",
-                                                       "us_per_integration_step", "gathered_rows", "curve_gather")}
+                w, _ = measure(hip, name, rank, world, AS_WORDED_STEPS, 1, dist_ctx)
+                worded[name] = {k: w.get(k) for k in ("value", "unit", "steps", "warmup", "ms_per_step", "ms_per_step_median", "ms_per_step_min_max",
+                                                       "scaling", "data", "config", "kernel_ms", "steps_per_knot", "steps_per_path",
+                                                       "us_per_integration_step", "gathered_rows", "curve_gather", "launch")}
                 worded[name]["roofline_frac"] = w["roofline"]["frac"]
             except Exception as e:  # the main line must not depend on a side measurement
                 if world > 1:
@@ -809,6 +833,17 @@ def main():
     hip.close()
     if dist_ctx is not None:
         dist.destroy_process_group()
+    # CPU baseline: the oracle (bit-identical port of the reference's path) on the host cores, bounded sample -- rank 0, after
+    # the last collective (the other ranks are done: nobody is parked in a barrier meanwhile), whatever the world size
+    if rank == 0 and not args.no_cpu_baseline and not args.no_sides and kept_host is not None and kept_host["chunk0"]:
+        out_prm, hip_out0 = cpu_job
+        info, err, mism, th0 = cpu_baseline(kept_host, args.cpu_seconds, out_prm, hip_out0 is not None)
+        out["cpu_baseline"] = info
+        out["vs_cpu_baseline"] = out["value"] / info["value"]
+        out["traversal_time_err_s"] = err
+        out["step_count_mismatches"] = mism
+        if th0 is not None and "output_stage" in out:
+            out["output_stage"]["identical_to_oracle"] = bool(th0.tobytes() == hip_out0.tobytes())
     if rank == 0:
         # RCCL writes a version banner through C stdio on rank 0: push it out first, so that the JSON line is the last line
         import ctypes
