@@ -210,6 +210,7 @@ class Library:
             "batotp_hip_set_overlap": [P, I32],
             "batotp_hip_set_sweep_hold": [P, I32, I32],
             "batotp_hip_set_sweep_prefetch": [P, I32, I32],
+            "batotp_hip_set_spline_tiles": [P, I32],
             "batotp_hip_flat_loop_status": [P, C.POINTER(I32)],
             "batotp_hip_toolchain": [C.c_char_p, C.c_char_p, I32],
             "batotp_hip_last_sweep_launch": [P, I32, C.POINTER(I32), C.POINTER(I32), C.POINTER(I32)],
@@ -286,6 +287,9 @@ class Context:
 
     def set_sweep_prefetch(self, reverse: int, forward: int):
         self.library.check(self.library.lib.batotp_hip_set_sweep_prefetch(self.handle, reverse, forward), "set_sweep_prefetch")
+
+    def set_spline_tiles(self, on: bool):
+        self.library.check(self.library.lib.batotp_hip_set_spline_tiles(self.handle, 1 if on else 0), "set_spline_tiles")
 
     def flat_loop_status(self) -> int:
         """1 = the automatic loop choice uses the flat loop; negative: why not (include/batotp_hip.h)"""

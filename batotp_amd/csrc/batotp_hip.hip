@@ -17,6 +17,7 @@
 #include "batotp_models.h"
 #include "kernels.hip.h"
 #include "sweep1.hip.h"
+#include "spline_tile.hip.h"
 #include "resample.hip.h"
 #include "output.hip.h"
 
@@ -90,6 +91,7 @@ struct batotp_ctx
    // May the AUTOMATIC choice use the flat stage / bisection loop?  0 = not decided yet, 1 = yes (this library was built by the
    // toolchain the loop was validated with and the canary of flatLoopStatus agreed with the nested loops on this device),
    // -1 = built by another toolchain, -2 = the canary disagreed, -3 = the canary could not run
+   int splineTiles = 1;   // K1 in tiles of knots (spline_tile.hip.h); 0 = the sequential lane-per-series kernel only
    int flatStatus = 0;
    char builtWith[192] = "";    // toolchain the gate compares (the real one unless BATOTP_ASSUME_TOOLCHAIN overrides it for a test)
 };
@@ -126,6 +128,11 @@ struct batotp_batch
    batotp_serial_model hModel;            // ... its host copy (the output stage needs `degrees` for its trig tables)
    double *dJTrig = nullptr; // [2*nJ][N] per path: host cosines / sines of the joint angles for the serial-chain dynamics
    bool hasSerial = false, jtrigSet = false;
+   // K1 in tiles (spline_tile.hip.h): tiles per path (prefix sums), boundary values between tiles, series left to the
+   // sequential kernel (short paths from the start; a series whose boundary comparison failed)
+   int *dTileOff = nullptr, *dDirty = nullptr;
+   double *dEdge = nullptr;
+   int totalTiles = 0, nchMax = 0;
    double *dUp = nullptr;    // compact splines: staging of host knots on their way into dKM
    int64_t upDoubles = 0;
    int64_t maxN = 0;
@@ -342,6 +349,13 @@ extern "C" int batotp_hip_set_sweep_prefetch(batotp_ctx *ctx, int32_t reverse, i
    return BATOTP_OK;
 }
 
+extern "C" int batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on)
+{
+   if (!ctx) return BATOTP_ERR_ARG;
+   ctx->splineTiles = on ? 1 : 0;
+   return BATOTP_OK;
+}
+
 extern "C" int batotp_hip_set_paths_per_wave(batotp_ctx *ctx, int32_t n)
 {
    if (!ctx || n < 0 || n > 64) return BATOTP_ERR_ARG;
@@ -417,7 +431,7 @@ extern "C" int batotp_hip_batch_destroy(batotp_batch *b)
    if (b->ctx) hipSetDevice(b->ctx->device);
    if (b->ctx && b->k3Pending) hipStreamSynchronize(b->ctx->stream2);
    if (b->dFwd == b->dRev) b->dFwd = nullptr; // BATOTP_F_CURVES_IN_PLACE: one buffer
-   void *ptrs[] = {b->dP, b->dPinfo, b->dY, b->dSC, b->dCoef, b->dSamp, b->dDyn, b->dTrig, b->dMvc, b->dRev, b->dFwd, b->dRes, b->dStage, b->dSink, b->dElim, b->dKM, b->dUp, b->dModel, b->dJTrig};
+   void *ptrs[] = {b->dP, b->dPinfo, b->dY, b->dSC, b->dCoef, b->dSamp, b->dDyn, b->dTrig, b->dMvc, b->dRev, b->dFwd, b->dRes, b->dStage, b->dSink, b->dElim, b->dKM, b->dUp, b->dModel, b->dJTrig, b->dTileOff, b->dDirty, b->dEdge};
    for (void *p : ptrs)
       if (p) hipFree(p);
    for (int k = 0; k < 5; ++k)
@@ -523,7 +537,22 @@ extern "C" int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *pr
    ALLOC(b->dSink, n_paths, int)
    ALLOC(b->dElim, b->compact ? 0 : off * (P.Cin > 4 * d ? P.Cin : 4 * d), double)
    ALLOC(b->dKM, b->compact ? off * P.Cin * 2 : 0, double)
+   std::vector<int> tileOff((size_t)n_paths + 1, 0);
+   {
+      b->nchMax = std::max(P.Cin, 4 * d);
+      for (int p = 0; p < n_paths; ++p)
+         tileOff[p + 1] = tileOff[p] + (n_knots[p] >= ST_MIN_KNOTS ? (int)((n_knots[p] + ST_T - 1) / ST_T) : 0);
+      b->totalTiles = tileOff[n_paths];
+   }
+   ALLOC(b->dTileOff, n_paths + 1, int)
+   ALLOC(b->dDirty, (size_t)n_paths * b->nchMax, int)
+   ALLOC(b->dEdge, (size_t)b->totalTiles * b->nchMax * 4, double)
 #undef ALLOC
+   if (hipMemcpy(b->dTileOff, tileOff.data(), sizeof(int) * tileOff.size(), hipMemcpyHostToDevice) != hipSuccess)
+   {
+      batotp_hip_batch_destroy(b);
+      return hipFail(hipGetLastError(), "batch_create (tile table)");
+   }
    hipError_t e = hipMemcpyAsync(b->dP, &P, sizeof(P), hipMemcpyHostToDevice, ctx->stream);
    if (e == hipSuccess) e = hipMemcpyAsync(b->dPinfo, b->pinfo.data(), sizeof(PathInfo) * n_paths, hipMemcpyHostToDevice, ctx->stream);
    if (e == hipSuccess) e = hipMemsetAsync(b->dRes, 0, sizeof(batotp_path_result) * n_paths, ctx->stream);
@@ -790,12 +819,32 @@ static int joinK3(batotp_batch *b)
 static void evStart(batotp_batch *b, int which) { hipEventRecord(b->ev[which][0], b->ctx->stream); }
 static void evStop(batotp_batch *b, int which) { hipEventRecord(b->ev[which][1], b->ctx->stream); b->evValid[which] = true; }
 
-static int launchSpline(batotp_batch *b, int nch, int mode, const double *src, int64_t srcStridePerKnot)
+// K1 of nch series per path: the tiled kernel (spline_tile.hip.h) for every path of at least ST_MIN_KNOTS knots, then the
+// sequential kernel for what is left (short paths; a series whose boundary comparison failed -- never observed).
+// pairs: the compact layout (in place in dKM); else channel-major rows `src` in, coefficient rows out.
+static int launchSpline(batotp_batch *b, int nch, int mode, const double *src, int64_t srcStridePerKnot, bool pairs = false)
 {
+   hipStream_t st = b->ctx->stream;
    const int threads = b->B * nch;
    const int bs = 64;
-   hipLaunchKernelGGL(k_spline, dim3((unsigned)((threads + bs - 1) / bs)), dim3(bs), 0, b->ctx->stream, b->dPinfo, b->B, nch, mode,
-                      b->P.C, b->P.Cin, b->P.d > 0 ? b->P.d : 1, src, srcStridePerKnot, b->dElim, b->dCoef);
+   const bool tiled = b->totalTiles > 0 && b->ctx->splineTiles != 0;
+   const int *only = nullptr;
+   if (tiled)
+   {
+      TileArgs a;
+      a.pinfo = b->dPinfo; a.tileOff = b->dTileOff; a.B = b->B; a.mode = mode; a.pairs = pairs ? 1 : 0; a.nch = nch;
+      a.C = b->P.C; a.Cin = b->P.Cin; a.d = b->P.d > 0 ? b->P.d : 1;
+      a.src = src; a.srcStride = srcStridePerKnot; a.km = b->dKM; a.coef = b->dCoef; a.edge = b->dEdge; a.dirty = b->dDirty;
+      hipLaunchKernelGGL(k_tile_dirty_init, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, b->dPinfo, b->B, nch, b->dDirty);
+      hipLaunchKernelGGL(k_spline_tile, dim3((unsigned)b->totalTiles, (unsigned)((nch + ST_CH - 1) / ST_CH)), dim3(ST_BLOCK), 0, st, a);
+      const int64_t slots = (int64_t)b->totalTiles * nch;
+      hipLaunchKernelGGL(k_spline_tile_check, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, a, b->totalTiles);
+      only = b->dDirty;
+   }
+   if (pairs) hipLaunchKernelGGL(k_spline_pairs, dim3((unsigned)((threads + bs - 1) / bs)), dim3(bs), 0, st, b->dPinfo, b->B, nch, b->dKM, only);
+   else
+      hipLaunchKernelGGL(k_spline, dim3((unsigned)((threads + bs - 1) / bs)), dim3(bs), 0, st, b->dPinfo, b->B, nch, mode,
+                         b->P.C, b->P.Cin, b->P.d > 0 ? b->P.d : 1, src, srcStridePerKnot, b->dElim, b->dCoef, only);
    HIP_TRY(hipGetLastError());
    return BATOTP_OK;
 }
@@ -817,8 +866,8 @@ extern "C" int batotp_hip_precompute(batotp_batch *b, int32_t stage)
       if (b->dSC) hipLaunchKernelGGL(k_sites, dim3(gridKnots), dim3(bs), 0, st, b->dPinfo, b->B, b->dSC, b->totalKnots);
       if (b->compact)
       {
-         const int threads = b->B * b->P.Cin;
-         hipLaunchKernelGGL(k_spline_pairs, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, b->dPinfo, b->B, b->P.Cin, b->dKM);
+         rc = launchSpline(b, b->P.Cin, 0, nullptr, 0, true);
+         if (rc) return rc;
       }
       else
       {

@@ -233,10 +233,11 @@ __device__ __forceinline__ void thomas_series(int N, const double *__restrict__ 
 template <bool SOL, bool PAIRS>
 __device__ __forceinline__ void spline_channel(const PathInfo *__restrict__ pinfo, int B, int nch, int mode, int C, int Cin, int d,
                                                const double *__restrict__ src, int64_t src_stride_per_knot,
-                                               double *__restrict__ scratch, double *__restrict__ coef)
+                                               double *__restrict__ scratch, double *__restrict__ coef, const int *__restrict__ only = nullptr)
 {
    const int t = blockIdx.x * blockDim.x + threadIdx.x;
    if (t >= B * nch) return;
+   if (only && !only[t]) return;   // series the tiled kernel (spline_tile.hip.h) has already solved
    const int p = t / nch, c = t - p * nch;
    const PathInfo pi = pinfo[p];
    const int N = (int)pi.n;
@@ -252,9 +253,9 @@ __device__ __forceinline__ void spline_channel(const PathInfo *__restrict__ pinf
 
 __global__ void __launch_bounds__(64) k_spline(const PathInfo *__restrict__ pinfo, int B, int nch, int mode, int C, int Cin, int d,
                                                const double *__restrict__ src, int64_t src_stride_per_knot,
-                                               double *__restrict__ scratch, double *__restrict__ coef)
+                                               double *__restrict__ scratch, double *__restrict__ coef, const int *__restrict__ only)
 {
-   spline_channel<false, false>(pinfo, B, nch, mode, C, Cin, d, src, src_stride_per_knot, scratch, coef);
+   spline_channel<false, false>(pinfo, B, nch, mode, C, Cin, d, src, src_stride_per_knot, scratch, coef, only);
 }
 
 __global__ void __launch_bounds__(64) k_spline_sol(const PathInfo *__restrict__ pinfo, int B, int nch, int C, const double *__restrict__ src,
@@ -264,9 +265,9 @@ __global__ void __launch_bounds__(64) k_spline_sol(const PathInfo *__restrict__ 
 }
 
 // compact splines of the hot path: km = [N][C][2] (value, second derivative) pairs per path, solved in place
-__global__ void __launch_bounds__(64) k_spline_pairs(const PathInfo *__restrict__ pinfo, int B, int C, double *__restrict__ km)
+__global__ void __launch_bounds__(64) k_spline_pairs(const PathInfo *__restrict__ pinfo, int B, int C, double *__restrict__ km, const int *__restrict__ only)
 {
-   spline_channel<true, true>(pinfo, B, C, 0, C, C, 1, km, (int64_t)C, km, nullptr);
+   spline_channel<true, true>(pinfo, B, C, 0, C, C, 1, km, (int64_t)C, km, nullptr, only);
 }
 
 // natural-spline second derivatives of arbitrary series: series k has n[k] values y[yOff[k] + i*ys] and leaves its

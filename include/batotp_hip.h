@@ -297,6 +297,12 @@ int  batotp_hip_last_sweep_launch(batotp_batch *batch, int32_t dir, int32_t *lan
  * the reverse curve ahead of its cursor (forward sweep only); -1 (default) = automatic: rows in the reverse sweep always, rows and
  * curve in the forward sweep while every path has a wavefront to itself (latency-bound regime).  Never changes a result. */
 int  batotp_hip_set_sweep_prefetch(batotp_ctx *ctx, int32_t reverse, int32_t forward);
+/* K1 (the spline build) in tiles of knots -- default on: the Thomas recurrences run from 48 knots before / beyond each chunk
+ * of 16 knots (they contract by 0.268 per knot: the warm-up arrives with the sequential value's bits), every warm-up value is
+ * compared bit for bit with the neighbouring chunk's, and a series with a disagreement is redone by the sequential kernel, so
+ * the result IS the sequential kernel's (batotp_amd/csrc/spline_tile.hip.h).  0 = the sequential lane-per-series kernel only
+ * (round 2's K1; the parity tests run both). */
+int  batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on);
 /* tuning knob: with overlap on, batotp_hip_pointwise_mvc returns at once and its kernel shares the GPU with the
  * sweeps that follow (second HIP stream; nothing in the sweeps reads its output); batotp_hip_get_results,
  * batotp_hip_download_mvc, batotp_hip_synchronize and the next batotp_hip_precompute wait for it.  Default off. */

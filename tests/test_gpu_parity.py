@@ -240,6 +240,56 @@ def test_flat_sweep_loop_capacity_and_max_time_status(hip_lib, oracle_ctx):
     ctx.close()
 
 
+@pytest.mark.parametrize("layout", ["rows", "pairs", "cable"])
+def test_spline_build_in_tiles_equals_the_sequential_kernel(hip_lib, oracle_ctx, layout):
+    """K1 in tiles of knots (spline_tile.hip.h: warm-up of 48 knots per chunk, every warm-up value compared bit for bit with
+    its neighbour's) against the sequential lane-per-series kernel and the oracle: coefficients of every channel identical,
+    on lengths around every boundary of the decomposition (the 1024-knot threshold, multiples of the 320-knot tile +- 1, a last
+    tile of one knot) and on long paths"""
+    rng = np.random.default_rng(11)
+    lengths = [1023, 1024, 1025, 1280, 1281, 1279, 1600, 1601, 1920 + 17, 40, 7, 3521, 6401, 20011]
+    if layout == "cable":
+        base = Case("synth_cspr_s3")
+        lengths = [n for n in lengths if n >= 64][:8]
+    else:
+        base = Case("synth_gen7dof_s0")
+    prob = capi.Problem.from_buffer_copy(bytes(base.problem))
+    if layout == "pairs":
+        prob.flags |= capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES
+    C_in = prob.n_joints + prob.n_cart
+    ys = []
+    for n in lengths:
+        if n <= base.n:
+            ys.append(np.ascontiguousarray(base.y[:, :n]))
+        else:   # longer than the golden path: a smooth random walk through the same region (any values do for K1)
+            t = np.linspace(0, 1, n)
+            y = np.stack([np.interp(t, np.linspace(0, 1, 40), rng.normal(0, 1, 40).cumsum()) for _ in range(C_in)])
+            if layout == "cable":
+                y[prob.n_joints:] = 0.3 * y[prob.n_joints:] / max(1.0, np.abs(y[prob.n_joints:]).max())
+                y[prob.n_joints + 2] += 2.0
+                y[:prob.n_joints] = np.abs(y[:prob.n_joints]) + 3.0
+            ys.append(np.ascontiguousarray(y))
+    out = {}
+    for tiles in (True, False):
+        ctx = capi.Context(hip_lib, 0)
+        ctx.set_spline_tiles(tiles)
+        b = capi.Batch(ctx, prob, [y.shape[1] for y in ys], 64)
+        for k, y in enumerate(ys):
+            b.upload_knots(k, [y], [base.sres])
+        b.precompute(0)
+        out[tiles] = [np.stack([b.coeffs(k, ch) for ch in range(prob.n_channels)]) for k in range(len(ys))]
+        b.close(); ctx.close()
+    ob = capi.Batch(oracle_ctx, prob, [y.shape[1] for y in ys], 64)
+    for k, y in enumerate(ys):
+        ob.upload_knots(k, [y], [base.sres])
+    ob.precompute(0)
+    for k in range(len(ys)):
+        assert_bit_equal(out[True][k], out[False][k], f"{layout}: path {k} (N = {lengths[k]}): tiles against the sequential kernel")
+        oc = np.stack([ob.coeffs(k, ch) for ch in range(prob.n_channels)])
+        assert_bit_equal(out[True][k], oc, f"{layout}: path {k} (N = {lengths[k]}): tiles against the oracle")
+    ob.close()
+
+
 def test_flat_sweep_loop_is_gated_by_toolchain_and_canary(hip_lib, oracle_ctx, monkeypatch):
     """the AUTOMATIC loop choice takes the flat reverse loop only if the library was built by the toolchain the loop was
     validated with and the on-device canary (nested against flat loop on ordinary, crawling and always-failing paths) found
