@@ -32,7 +32,7 @@ ST_MAX_INTEG_TIME, ST_CAPACITY, ST_BISECT_FAIL = 1 << 0, 1 << 1, 1 << 2
 ST_NONFINITE, ST_SHORT, ST_SEG_ERROR = 1 << 3, 1 << 4, 1 << 5
 
 # path kinds / status bits of the resampler
-PATH_JOINT, PATH_CART = 1, 2
+PATH_JOINT, PATH_CART, PATH_BOTH = 1, 2, 3
 RS_TOO_SHORT, RS_IDENTICAL, RS_CAPACITY, RS_SMALL_STEP, RS_SEG_ERROR = 1, 2, 4, 8, 16
 
 _d8 = C.c_double * 8
@@ -211,6 +211,7 @@ class Library:
             "batotp_hip_set_sweep_hold": [P, I32, I32],
             "batotp_hip_set_sweep_prefetch": [P, I32, I32],
             "batotp_hip_set_spline_tiles": [P, I32],
+            "batotp_hip_spline_tile_fallbacks": [P, C.POINTER(I32)],
             "batotp_hip_flat_loop_status": [P, C.POINTER(I32)],
             "batotp_hip_toolchain": [C.c_char_p, C.c_char_p, I32],
             "batotp_hip_last_sweep_launch": [P, I32, C.POINTER(I32), C.POINTER(I32), C.POINTER(I32)],
@@ -288,8 +289,9 @@ class Context:
     def set_sweep_prefetch(self, reverse: int, forward: int):
         self.library.check(self.library.lib.batotp_hip_set_sweep_prefetch(self.handle, reverse, forward), "set_sweep_prefetch")
 
-    def set_spline_tiles(self, on: bool):
-        self.library.check(self.library.lib.batotp_hip_set_spline_tiles(self.handle, 1 if on else 0), "set_spline_tiles")
+    def set_spline_tiles(self, on):
+        """True / False, or -1 for the automatic choice (tiles for small batches)"""
+        self.library.check(self.library.lib.batotp_hip_set_spline_tiles(self.handle, -1 if on == -1 else (1 if on else 0)), "set_spline_tiles")
 
     def flat_loop_status(self) -> int:
         """1 = the automatic loop choice uses the flat loop; negative: why not (include/batotp_hip.h)"""
@@ -322,10 +324,12 @@ class Resampled:
     def __init__(self, ctx: Context, prm: ResampleParams, x_list: Sequence[np.ndarray], sres_in: Sequence[float]):
         self.ctx, self.lib, self.L = ctx, ctx.library.lib, ctx.library
         self.n_paths = len(x_list)
-        self.n_ch = prm.n_joints + prm.n_cart
+        n_ch_in = prm.n_joints + prm.n_cart
+        # poses (path type BOTH, 6 rows) leave the resampler as position + quaternion: one row more
+        self.n_ch = n_ch_in + (1 if (prm.path_type == PATH_BOTH and prm.n_cart == 6) else 0)
         n_in = np.ascontiguousarray([x.shape[1] for x in x_list], dtype=np.int64)
         for x in x_list:
-            assert x.shape[0] == self.n_ch
+            assert x.shape[0] == n_ch_in
         flat = np.ascontiguousarray(np.concatenate([np.ascontiguousarray(x, dtype=np.float64).ravel() for x in x_list]))
         sr = np.ascontiguousarray(sres_in, dtype=np.float64)
         self.handle = C.c_void_p()
@@ -498,6 +502,11 @@ class Batch:
 
     def optimize(self):
         self.L.check(self.lib.batotp_hip_optimize(self.handle), "optimize")
+
+    def spline_tile_fallbacks(self) -> int:
+        n = C.c_int32(0)
+        self.L.check(self.lib.batotp_hip_spline_tile_fallbacks(self.handle, C.byref(n)), "spline_tile_fallbacks")
+        return n.value
 
     def last_sweep_launch(self, direction: int):
         """(lanes per path, paths per wavefront, hold of the flat loop or -1 for the nested loops) of the last launch"""

@@ -91,7 +91,7 @@ struct batotp_ctx
    // May the AUTOMATIC choice use the flat stage / bisection loop?  0 = not decided yet, 1 = yes (this library was built by the
    // toolchain the loop was validated with and the canary of flatLoopStatus agreed with the nested loops on this device),
    // -1 = built by another toolchain, -2 = the canary disagreed, -3 = the canary could not run
-   int splineTiles = 1;   // K1 in tiles of knots (spline_tile.hip.h); 0 = the sequential lane-per-series kernel only
+   int splineTiles = -1;  // K1 in tiles of knots (spline_tile.hip.h): -1 automatic (small batches), 1 always, 0 never
    int flatStatus = 0;
    char builtWith[192] = "";    // toolchain the gate compares (the real one unless BATOTP_ASSUME_TOOLCHAIN overrides it for a test)
 };
@@ -132,7 +132,7 @@ struct batotp_batch
    // sequential kernel (short paths from the start; a series whose boundary comparison failed)
    int *dTileOff = nullptr, *dDirty = nullptr;
    double *dEdge = nullptr;
-   int totalTiles = 0, nchMax = 0;
+   int totalTiles = 0, nchMax = 0, lastTileNch = 0;
    double *dUp = nullptr;    // compact splines: staging of host knots on their way into dKM
    int64_t upDoubles = 0;
    int64_t maxN = 0;
@@ -352,7 +352,24 @@ extern "C" int batotp_hip_set_sweep_prefetch(batotp_ctx *ctx, int32_t reverse, i
 extern "C" int batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on)
 {
    if (!ctx) return BATOTP_ERR_ARG;
-   ctx->splineTiles = on ? 1 : 0;
+   ctx->splineTiles = on < 0 ? -1 : (on ? 1 : 0);
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_spline_tile_fallbacks(batotp_batch *b, int32_t *series)
+{
+   if (!b || !series) return BATOTP_ERR_ARG;
+   *series = 0;
+   if (!b->totalTiles || b->lastTileNch == 0) return BATOTP_OK;
+   int rc = bind(b->ctx);
+   if (rc) return rc;
+   std::vector<int> d((size_t)b->B * b->lastTileNch);
+   HIP_TRY(hipMemcpy(d.data(), b->dDirty, sizeof(int) * d.size(), hipMemcpyDeviceToHost));
+   int cnt = 0;
+   for (int p = 0; p < b->B; ++p)
+      if (b->pinfo[p].n >= ST_MIN_KNOTS)
+         for (int c = 0; c < b->lastTileNch; ++c) cnt += d[(size_t)p * b->lastTileNch + c] ? 1 : 0;
+   *series = cnt;
    return BATOTP_OK;
 }
 
@@ -827,7 +844,12 @@ static int launchSpline(batotp_batch *b, int nch, int mode, const double *src, i
    hipStream_t st = b->ctx->stream;
    const int threads = b->B * nch;
    const int bs = 64;
-   const bool tiled = b->totalTiles > 0 && b->ctx->splineTiles != 0;
+   // Automatic choice (splineTiles = -1): tiles while the batch is too small to fill the GPU with one lane per series -- there
+   // the sequential kernel is a dependent chain of N steps whatever the batch (9.5 ms for ONE 6-joint path of 1e5 knots, 54 ms
+   // with the 28 dynamics channels of a 7-joint arm; tiles: 0.05 and 0.22 ms) -- and the lane-per-series kernel beyond:
+   // a chunk of 16 knots costs a tile 64 forward and 64 backward steps (the warm-ups), and the tiles of a CU are limited by
+   // LDS, so at 2048 paths x 7 series of 1e5 knots the tiles take 34 ms against 22 ms (16 384 paths: 285 against 156 ms).
+   const bool tiled = b->totalTiles > 0 && (b->ctx->splineTiles == 1 || (b->ctx->splineTiles < 0 && (int64_t)b->B * nch <= 4096));
    const int *only = nullptr;
    if (tiled)
    {
@@ -840,6 +862,7 @@ static int launchSpline(batotp_batch *b, int nch, int mode, const double *src, i
       const int64_t slots = (int64_t)b->totalTiles * nch;
       hipLaunchKernelGGL(k_spline_tile_check, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, a, b->totalTiles);
       only = b->dDirty;
+      b->lastTileNch = nch;
    }
    if (pairs) hipLaunchKernelGGL(k_spline_pairs, dim3((unsigned)((threads + bs - 1) / bs)), dim3(bs), 0, st, b->dPinfo, b->B, nch, b->dKM, only);
    else

@@ -367,6 +367,49 @@ __global__ void k_out_trq_sum(OutParams P, const OutPath *__restrict__ paths, in
          dy[((int64_t)1 * P.nJ + j) * n1 + i] + dy[((int64_t)2 * P.nJ + j) * n1 + i] + dy[((int64_t)3 * P.nJ + j) * n1 + i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pose rows of a BOTH path at the very end of the stage: BA::q2aaVect (ba.cpp:384-403) with q2aa (util.cpp:562-581).  The
+// working arrays carry position + quaternion (7 Cartesian rows), the result position + axis-angle (6).
+//   k_out_q_norm  the vector part's norm and q0 of every final point, packed [2][nF] per path at offF*2 (host atan2 table)
+//   k_out_q2aa    src [Rw][nF] -> dst [Rw - 1][nF]; at = atan2(norm, q0) per point from the host, or nullptr (device libm)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_out_q_norm(int nJ, int Rw, const OutPath *__restrict__ paths, int K, const double *__restrict__ src, double *__restrict__ pack,
+                             int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   const OutPath op = paths[out_find_path(paths, K, g, 3)];
+   const int i = (int)(g - op.offF), n = op.nF;
+   if (i >= n) return;
+   const double *__restrict__ q = src + op.offF * Rw + (int64_t)(nJ + 3) * n + i;
+   const double q1 = q[n], q2 = q[2 * (int64_t)n], q3 = q[3 * (int64_t)n];
+   pack[op.offF * 2 + i] = sqrt(q1 * q1 + q2 * q2 + q3 * q3);     // util.cpp:565
+   pack[op.offF * 2 + n + i] = q[0];
+}
+
+__global__ void k_out_q2aa(int nJ, int Rw, const OutPath *__restrict__ paths, int K, const double *__restrict__ src, const double *__restrict__ at,
+                           double *__restrict__ dst, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   const OutPath op = paths[out_find_path(paths, K, g, 3)];
+   const int i = (int)(g - op.offF), n = op.nF;
+   if (i >= n) return;
+   const double *__restrict__ s = src + op.offF * Rw + i;
+   double *__restrict__ o = dst + op.offF * (Rw - 1) + i;
+   for (int r = 0; r < nJ + 3; ++r) o[(int64_t)r * n] = s[(int64_t)r * n];
+   const double q0 = s[(int64_t)(nJ + 3) * n], q1 = s[(int64_t)(nJ + 4) * n], q2 = s[(int64_t)(nJ + 5) * n], q3 = s[(int64_t)(nJ + 6) * n];
+   const double norme = sqrt(q1 * q1 + q2 * q2 + q3 * q3);
+   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+   if (!(norme < 1e-6))
+   {
+      const double ang = at ? at[op.offF + i] : atan2(norme, q0);
+      const double theta = 2.0 * ang / norme;                        // util.cpp:573
+      a0 = theta * q1; a1 = theta * q2; a2 = theta * q3;
+   }
+   o[(int64_t)(nJ + 3) * n] = a0; o[(int64_t)(nJ + 4) * n] = a1; o[(int64_t)(nJ + 5) * n] = a2;
+}
+
 // (smooth_at: resample.hip.h)
 
 // moving average + linear down-sampling by the smoothing factor (ba.cpp:1838-1871): th2[R][n2] per path

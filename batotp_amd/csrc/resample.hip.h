@@ -639,6 +639,77 @@ __global__ void k_rs_pack_theta(RsParams P, const RsPath *__restrict__ paths, in
    for (int j = 0; j < P.nJ; ++j) out[pp.off * P.nJ + (int64_t)j * n + i] = x[pp.off * P.C + (int64_t)j * n + i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tool poses taught with the joints (path type BOTH, the UR5 example): BA::aa2qVect (ba.cpp:327-369) with aa2q
+// (util.cpp:534-555) -- Cartesian rows 3..5 hold the orientation as axis-angle on entry, rows 3..6 the quaternion on return,
+// successive quaternions kept on one hemisphere -- and, in the output stage, BA::q2aaVect (ba.cpp:384-403) with q2aa
+// (util.cpp:562-581).  Trigonometry by the same policy as the forward kinematics: tables from the host libm
+// (BATOTP_F_HOST_TRIG: sincos of the half angle, atan2) or the device libm.
+//   k_rs_aa_norm   one lane per point: the rotation angle |aa| (what the host needs for its table), packed [n] per path at off
+//   k_rs_aa2q      one lane per point: the quaternion of the point (before the hemisphere alignment)
+//   k_rs_qalign    one lane per path: q_i <- -q_i where it points away from its (aligned) predecessor; sequential, exact
+// ---------------------------------------------------------------------------------------------
+__global__ void k_rs_aa_norm(RsParams P, const RsPath *__restrict__ paths, int B, const double *__restrict__ x, double *__restrict__ ang, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   const int lo = rs_find_path(paths, B, g);
+   const RsPath pp = paths[lo];
+   const int i = (int)(g - pp.off), n = pp.n;
+   if (i >= n) return;
+   const double *__restrict__ r = x + pp.off * P.C + (int64_t)(P.nJ + 3) * n + i;
+   const double a0 = r[0], a1 = r[n], a2 = r[2 * (int64_t)n];
+   ang[g] = sqrt(a0 * a0 + a1 * a1 + a2 * a2);     // util.cpp:537
+}
+
+// trig: [2][n] per path at off*2 (sin, cos of half the angle) or nullptr
+__global__ void k_rs_aa2q(RsParams P, const RsPath *__restrict__ paths, int B, double *__restrict__ x, const double *__restrict__ trig, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   const int lo = rs_find_path(paths, B, g);
+   const RsPath pp = paths[lo];
+   const int i = (int)(g - pp.off), n = pp.n;
+   if (i >= n || pp.status) return;
+   double *__restrict__ r = x + pp.off * P.C + (int64_t)(P.nJ + 3) * n + i;
+   const double a0 = r[0], a1 = r[n], a2 = r[2 * (int64_t)n];
+   const double theta = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+   double q0 = 1.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+   if (!(theta < 1e-6))
+   {
+      double sh, ch;
+      if (trig) { sh = trig[pp.off * 2 + i]; ch = trig[pp.off * 2 + n + i]; }
+      else sincos(0.5 * theta, &sh, &ch);
+      q0 = ch;
+      q1 = a0 * sh / theta; q2 = a1 * sh / theta; q3 = a2 * sh / theta;   // util.cpp:551: aa[i]*sin_half_theta/theta
+   }
+   r[0] = q0; r[n] = q1; r[2 * (int64_t)n] = q2; r[3 * (int64_t)n] = q3;
+}
+
+__global__ void k_rs_qalign(RsParams P, const RsPath *__restrict__ paths, int B, double *__restrict__ x)
+{
+   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+   if (p >= B) return;
+   const RsPath pp = paths[p];
+   if (pp.status) return;
+   const int n = pp.n;
+   double *__restrict__ r = x + pp.off * P.C + (int64_t)(P.nJ + 3) * n;
+   // qprev starts as the first point's own quaternion (ba.cpp:339-340): the first point is never flipped unless q.q < 0
+   double p0 = r[0], p1 = r[n], p2 = r[2 * (int64_t)n], p3 = r[3 * (int64_t)n];
+   for (int i = 0; i < n; ++i)
+   {
+      double q0 = r[i], q1 = r[n + i], q2 = r[2 * (int64_t)n + i], q3 = r[3 * (int64_t)n + i];
+      double qdir = 0;
+      qdir += q0 * p0; qdir += q1 * p1; qdir += q2 * p2; qdir += q3 * p3;   // ba.cpp:347-351
+      if (qdir < 0.0)
+      {
+         q0 = -q0; q1 = -q1; q2 = -q2; q3 = -q3;
+         r[i] = q0; r[n + i] = q1; r[2 * (int64_t)n + i] = q2; r[3 * (int64_t)n + i] = q3;
+      }
+      p0 = q0; p1 = q1; p2 = q2; p3 = q3;
+   }
+}
+
 // zero the Cartesian channels of a stage (robot without kinematic model: ba.cpp:618-625)
 __global__ void k_rs_zero_cart(RsParams P, const RsPath *__restrict__ paths, int B, double *__restrict__ x, int64_t total)
 {

@@ -116,7 +116,8 @@ void BA::fillProblem(void *out) const
    if (_isPar2Ser) f |= BATOTP_F_PAR2SER;
    // cos/sin from the host libm: bit parity with the reference (RR), and with the host twin of the chain model
    // ... and with the forward kinematics of the device resampler / output stage (KUKA, RR)
-   if (_robotType == RR || _robotType == KUKA || (_isTrqConOn && !_isParallelMechOrig)) f |= BATOTP_F_HOST_TRIG;
+   //     and with the pose conversions of a BOTH path (atan2 of the output stage)
+   if (_robotType == RR || _robotType == KUKA || _pathType == BOTH || (_isTrqConOn && !_isParallelMechOrig)) f |= BATOTP_F_HOST_TRIG;
    P.flags = f;
    for (unsigned int j = 0; j < _nJoints && j < BATOTP_MAX_JOINTS; ++j)
    {
@@ -190,7 +191,7 @@ int BA::exportResampleParams(const Traj &traj, void *out) const
    R.n_joints = (int32_t)_nJoints;
    R.n_cart = (int32_t)_nCart;
    R.robot_type = _robotType;
-   R.path_type = (_pathType == JOINT) ? BATOTP_PATH_JOINT : (_pathType == CART ? BATOTP_PATH_CART : 0);
+   R.path_type = (_pathType == JOINT) ? BATOTP_PATH_JOINT : (_pathType == CART ? BATOTP_PATH_CART : (_pathType == BOTH ? BATOTP_PATH_BOTH : 0));
    R.scale_type = _scaleType;
    uint32_t f = 0;
    if (_isCartVelConOn) f |= BATOTP_F_CART_VEL_ON;
@@ -218,8 +219,11 @@ int BA::exportResampleParams(const Traj &traj, void *out) const
    // JOINT paths of the robots with forward kinematics (reference robot.cpp:73-96): the tool point is recomputed after
    // each resampling pass; its cos / sin come from the host libm (bit parity with the host resampler and the reference)
    const bool kin = _pathType == JOINT && _nCart == 3 && ((_robotType == KUKA && _nJoints == 7) || (_robotType == RR && _nJoints == 2));
-   if (kin) R.flags |= BATOTP_F_HOST_TRIG;
-   return (joint || cable || kin) ? 0 : -1;
+   // joints and tool poses taught together (the UR5 example): 6 pose rows, orientations as axis-angle -> quaternions
+   // (BA::aa2qVect, reference ba.cpp:327-369; sine / cosine of the half angle from the host libm)
+   const bool both = _pathType == BOTH && _nCart == 6;
+   if (kin || both) R.flags |= BATOTP_F_HOST_TRIG;
+   return (joint || cable || kin || both) ? 0 : -1;
 }
 
 // Which configurations the device output stage takes over: JOINT paths of a robot without kinematic model,
@@ -229,7 +233,7 @@ int BA::exportOutputParams(void *out) const
    batotp_output_params &O = *static_cast<batotp_output_params *>(out);
    std::memset(&O, 0, sizeof(O));
    O.n_joints = (int32_t)_nJoints;
-   O.path_type = (_pathType == JOINT) ? BATOTP_PATH_JOINT : (_pathType == CART ? BATOTP_PATH_CART : 0);
+   O.path_type = (_pathType == JOINT) ? BATOTP_PATH_JOINT : (_pathType == CART ? BATOTP_PATH_CART : (_pathType == BOTH ? BATOTP_PATH_BOTH : 0));
    O.integ_res = _integRes;
    O.out_res = _outRes;
    O.out_smooth_fact = _outSmoothFact;
@@ -242,7 +246,10 @@ int BA::exportOutputParams(void *out) const
    // two-link arm's closed form or the chain model
    const bool kinRobot = _pathType == JOINT && _nCart == 3 && ((_robotType == KUKA && _nJoints == 7) || (_robotType == RR && _nJoints == 2));
    const bool kin = kinRobot && (!_isTrqConOn || (!_isParallelMechOrig && (_robotType == RR || const_cast<Robot &>(myRobot).serialModel() != nullptr)));
-   return (joint || cable || kin) ? 0 : -1;
+   // joints and poses together: the pose rows are quaternions during the run (_nCart == 7) and leave as axis-angle
+   // (BA::q2aaVect, ba.cpp:384-403)
+   const bool both = _pathType == BOTH && (_nCart == 7 || _nCart == 6) && !_isTrqConOn;
+   return (joint || cable || kin || both) ? 0 : -1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -681,6 +688,11 @@ int BA::optimizeBatchOnDevice(std::vector<Traj> &trajs)
             trajs[p].sLastSec = -1;
          }
          _isInterpolated = true;
+         if (rsp.path_type == BATOTP_PATH_BOTH && _nCart == 6)
+         {
+            _nCart = 7;         // what aa2qVect leaves (reference ba.cpp:335): the pose rows are position + quaternion from here on
+            nCartRun = 7;
+         }
          float ms = 0;
          batotp_hip_resampled_ms(rs.r, &ms);
          _lastResampleMs = ms;
@@ -926,8 +938,9 @@ int BA::optimizeBatchOnDevice(std::vector<Traj> &trajs)
             t.trq.clear();
             if (nCa > 0)
             {
-               // cable robot, robots with forward kinematics: Cartesian rows and (torque constraints on) the recomputed
+               // cable robot, robots with forward kinematics, pose paths: Cartesian rows and (torque constraints on) the recomputed
                // cable tensions / joint torques come with the joints
+               if (_pathType == BOTH && nCa == 6) _nCart = 6;   // q2aaVect (reference ba.cpp:399): axis-angle again
                t.cart.assign(_nCart, std::vector<double>());
                for (int j = 0; j < nCa; ++j) t.cart[j].assign(flatTh0 + (size_t)(nTh + j) * n, flatTh0 + (size_t)(nTh + j + 1) * n);
                if (nTq > 0)
@@ -971,6 +984,7 @@ int BA::optimizeBatchOnDevice(std::vector<Traj> &trajs)
       _lastOutputMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tOut0).count();
       int failedDev = 0;
       for (size_t p = 0; p < trajs.size(); ++p) failedDev += ok[p] ? 0 : 1;
+      if (_pathType == BOTH && _nCart == 7) _nCart = 6;   // (no path reached the conversion: leave the object as q2aaVect would)
       return failedDev;
    }
 

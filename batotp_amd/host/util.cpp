@@ -356,8 +356,11 @@ std::array<double, 4> aa2q(std::array<double, 3> aa)
       q[0] = 1.0; q[1] = 0.0; q[2] = 0.0; q[3] = 0.0;
       return q;
    }
-   const double sinHalf = std::sin(0.5 * angle);
-   q[0] = std::cos(0.5 * angle);
+   // sine and cosine of the half angle as ONE glibc sincos(): what the reference's optimised build calls (util.cpp:547-548),
+   // spelled out because sincos() is not bit-identical to separate sin() / cos() calls in this glibc
+   double sinHalf, cosHalf;
+   ::sincos(0.5 * angle, &sinHalf, &cosHalf);
+   q[0] = cosHalf;
    for (int k = 0; k < 3; ++k) q[k + 1] = aa[k] * sinHalf / angle;
    return q;
 }

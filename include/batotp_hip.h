@@ -297,12 +297,17 @@ int  batotp_hip_last_sweep_launch(batotp_batch *batch, int32_t dir, int32_t *lan
  * the reverse curve ahead of its cursor (forward sweep only); -1 (default) = automatic: rows in the reverse sweep always, rows and
  * curve in the forward sweep while every path has a wavefront to itself (latency-bound regime).  Never changes a result. */
 int  batotp_hip_set_sweep_prefetch(batotp_ctx *ctx, int32_t reverse, int32_t forward);
-/* K1 (the spline build) in tiles of knots -- default on: the Thomas recurrences run from 48 knots before / beyond each chunk
- * of 16 knots (they contract by 0.268 per knot: the warm-up arrives with the sequential value's bits), every warm-up value is
- * compared bit for bit with the neighbouring chunk's, and a series with a disagreement is redone by the sequential kernel, so
- * the result IS the sequential kernel's (batotp_amd/csrc/spline_tile.hip.h).  0 = the sequential lane-per-series kernel only
- * (round 2's K1; the parity tests run both). */
+/* K1 (the spline build) in tiles of knots: the Thomas recurrences run from 48 knots before / beyond each chunk of 16 knots
+ * (they contract by 0.268 per knot: the warm-up arrives with the sequential value's bits), every warm-up value is compared
+ * bit for bit with the neighbouring chunk's, and a series with a disagreement is redone by the sequential kernel, so the
+ * result IS the sequential kernel's (batotp_amd/csrc/spline_tile.hip.h).  on: -1 (default) automatic -- tiles for batches of
+ * up to 4096 series (paths x channels), where the lane-per-series kernel is a dependent chain of N steps with most of the GPU
+ * idle (one 6-joint trajectory of 1e5 knots: 0.05 ms instead of 9.5 ms), the lane-per-series kernel beyond --, 1 always,
+ * 0 never (the parity tests run both). */
 int  batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on);
+/* diagnostic: series of the most recent tiled spline build of this batch whose boundary comparison failed and that the
+ * sequential kernel therefore recomputed (paths too short for tiles are not counted).  Expected: 0. */
+int  batotp_hip_spline_tile_fallbacks(batotp_batch *batch, int32_t *series);
 /* tuning knob: with overlap on, batotp_hip_pointwise_mvc returns at once and its kernel shares the GPU with the
  * sweeps that follow (second HIP stream; nothing in the sweeps reads its output); batotp_hip_get_results,
  * batotp_hip_download_mvc, batotp_hip_synchronize and the next batotp_hip_precompute wait for it.  Default off. */
@@ -313,13 +318,20 @@ int  batotp_hip_set_overlap(batotp_ctx *ctx, int32_t on);
  * the taught points and the final spline build: remClosePts (batotp/util.cpp:452-524), the two
  * BA::adjust_s passes (batotp/ba.cpp:412-638) with BA::interpSpecial (ba.cpp:651-781) and the
  * resampling BA::evalSplineFullTraj (ba.cpp:790-863), Robot::invKinCSPR3DOF (robot.cpp:243-278).
- * Supported: path_type JOINT on a robot without kinematic model (GENJNT) and path_type CART on the
+ * Supported: path_type JOINT on a robot without kinematic model (GENJNT), on KUKA (7 joints) and RR (2 joints) with
+ * their forward kinematics (Robot::fwdKinKuka / fwdKinRR, robot.cpp:105-202; flag BATOTP_F_HOST_TRIG: cos / sin of the
+ * joint angles from the host libm -- bit parity with the reference -- else the device libm), path_type BOTH with
+ * 6 pose rows (any robot type: nothing is recomputed from the joints), and path_type CART on the
  * cable robot (CSPR3DOF) with a joint constraint on, including the input decimation and smoothing of
  * ba.cpp:195-242 (smooth / decimate, util.cpp:263-290,347-356); timestamps only set sres_in (the caller
  * drops repeated ones first); no automatic integration resolution.  Anything else returns
  * BATOTP_ERR_ARG: the caller keeps using its host resampler for those. */
 #define BATOTP_PATH_JOINT 1   /* reference batotp/ba.h pathType JOINT */
 #define BATOTP_PATH_CART  2
+#define BATOTP_PATH_BOTH  3   /* joint rows AND tool poses taught together (the UR5 example): n_cart = 6 rows (x, y, z, rx, ry, rz:
+                                 axis-angle) go in, n_cart + 1 = 7 rows come out of the resampler -- BA::aa2qVect (ba.cpp:327-369) turns
+                                 the orientations into hemisphere-aligned quaternions, which is what is splined; the output stage
+                                 turns them back (BA::q2aaVect, ba.cpp:384-403) */
 
 /* per-path status bits of the resampler (0 = resampled) */
 #define BATOTP_RS_TOO_SHORT   1u  /* a stage has fewer than 4 points (reference switches to interpTrajLinear) */
@@ -373,7 +385,9 @@ int  batotp_hip_resampled_ms(batotp_resampled *r, float *ms);
  * down-sampled by _outSmoothFact (smooth, batotp/util.cpp:263-290; Spline::interp1linear,
  * spline.cpp:108-120) and, when out_res is finer than the integration step, re-interpolated
  * (ba.cpp:1873-1919).  Covered: JOINT paths of a robot without kinematic model and without torque
- * constraints (joint rows), and CART paths of the 3-cable robot with torque constraints (Cartesian rows,
+ * constraints (joint rows); JOINT paths of KUKA / RR (joint rows, three Cartesian rows by the forward kinematics at the
+ * output points and, with torque constraints, the serial-robot torque recomputation of ba.cpp:1791-1827 with Robot::dynRR or
+ * the batch's chain model); BOTH paths (joint rows and pose rows, quaternions back to axis-angle at the end); and CART paths of the 3-cable robot with torque constraints (Cartesian rows,
  * cable lengths by Robot::invKinCSPR3DOF, cable tensions recomputed as in ba.cpp:1744-1790 with
  * Robot::dynCSPR3DOF / setA / solveLinSys).  The batch must have completed the forward sweep.
  * Anything else returns BATOTP_ERR_ARG (the caller keeps its host code). */

@@ -72,6 +72,7 @@ int batotp_hip_set_paths_per_wave(batotp_ctx *ctx, int32_t n) { (void)ctx; (void
 int batotp_hip_set_sweep_hold(batotp_ctx *ctx, int32_t reverse, int32_t forward) { (void)ctx; (void)reverse; (void)forward; return BATOTP_OK; }
 int batotp_hip_set_sweep_prefetch(batotp_ctx *ctx, int32_t reverse, int32_t forward) { (void)ctx; (void)reverse; (void)forward; return BATOTP_OK; }
 int batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on) { (void)ctx; (void)on; return BATOTP_OK; }
+int batotp_hip_spline_tile_fallbacks(batotp_batch *b, int32_t *series) { if (!b || !series) return BATOTP_ERR_ARG; *series = 0; return BATOTP_OK; }
 /* the checker has one loop form (the reference's); the introspection calls of the product answer accordingly */
 int batotp_hip_flat_loop_status(batotp_ctx *ctx, int32_t *status) { if (!ctx || !status) return BATOTP_ERR_ARG; *status = -1; return BATOTP_OK; }
 int batotp_hip_toolchain(char *built_with, char *validated_with, int32_t cap)
@@ -449,7 +450,8 @@ int batotp_hip_resample(batotp_ctx *ctx, const batotp_resample_params *prm, int3
     struct timespec t0, t1;
     if (!ctx || !prm || !n_in || !x || !sres_in || !out || n_paths < 1) return BATOTP_ERR_ARG;
     *out = NULL;
-    C = prm->n_joints + prm->n_cart;
+    const int Cin = prm->n_joints + prm->n_cart;
+    C = Cin + ((prm->path_type == BATOTP_PATH_BOTH && prm->n_cart == 6) ? 1 : 0);   /* poses leave as position + quaternion */
     for (p = 0; p < n_paths; ++p)
         if (n_in[p] < 4) return BATOTP_ERR_ARG;
     r = (batotp_resampled *)calloc(1, sizeof(*r));
@@ -460,7 +462,7 @@ int batotp_hip_resample(batotp_ctx *ctx, const batotp_resample_params *prm, int3
     r->status = (uint32_t *)calloc((size_t)n_paths, sizeof(uint32_t));
     ys = (double **)calloc((size_t)n_paths, sizeof(double *));
     xoff = (int64_t *)calloc((size_t)n_paths, sizeof(int64_t));
-    for (p = 1; p < n_paths; ++p) xoff[p] = xoff[p - 1] + n_in[p - 1] * C;
+    for (p = 1; p < n_paths; ++p) xoff[p] = xoff[p - 1] + n_in[p - 1] * Cin;
     clock_gettime(CLOCK_MONOTONIC, &t0);
 #pragma omp parallel for schedule(dynamic, 1)
     for (p = 0; p < n_paths; ++p)
@@ -559,9 +561,10 @@ int batotp_hip_output(batotp_batch *b, const batotp_output_params *prm, int32_t 
         const int serialTrq = jointPath && (b->prob.flags & BATOTP_F_TRQ_ON) && !(b->prob.flags & BATOTP_F_PARALLEL) &&
                               (b->has_serial || b->prob.robot_type == BATOTP_ROBOT_RR);
         const int joint = jointPath && (!(b->prob.flags & BATOTP_F_TRQ_ON) || serialTrq);
-        if (!cable && !joint) return BATOTP_ERR_ARG;
+        const int both = prm->path_type == BATOTP_PATH_BOTH && b->prob.n_cart == 7 && !(b->prob.flags & BATOTP_F_TRQ_ON);
+        if (!cable && !joint && !both) return BATOTP_ERR_ARG;
         o = (batotp_output *)calloc(1, sizeof(*o));
-        o->nTheta = prm->n_joints; o->nCart = cable ? 3 : (kin ? 3 : 0); o->nTrq = cable ? 3 : (serialTrq ? prm->n_joints : 0);
+        o->nTheta = prm->n_joints; o->nCart = cable ? 3 : (both ? 6 : (kin ? 3 : 0)); o->nTrq = cable ? 3 : (serialTrq ? prm->n_joints : 0);
     }
     o->n_paths = n_paths; o->nJ = o->nTheta + o->nCart + o->nTrq;
     o->n = (int64_t *)calloc((size_t)n_paths, sizeof(int64_t));

@@ -125,6 +125,11 @@ int  bo_fwdkin_trig_rows(int robot_type, int n_joints);
 int  bo_fwdkin_trig(int robot_type, int n_joints, const double *theta, int64_t n, double *trig);
 int  bo_fwdkin_from_trig(int robot_type, int n_joints, const double *trig, int64_t n, double *cart);
 int  bo_fwdkin(int robot_type, int n_joints, const double *theta, int64_t n, double *cart, double *trig_scratch);
+/* tool poses: aa2q util.cpp:534-555, q2aa util.cpp:562-581, BA::aa2qVect ba.cpp:327-369, BA::q2aaVect ba.cpp:384-403 */
+void bo_aa2q(const double aa[3], double q[4]);
+void bo_q2aa(const double q[4], double aa[3]);
+void bo_aa2q_rows(double *rows, int64_t stride, int64_t n);
+void bo_q2aa_rows(double *rows, int64_t stride, int64_t n);
 /* trigonometry of Robot::dynRR (robot.cpp:408-419): out = cos(th1), cos(th2), cos(th1+th2), sin(th2); th2 through one sincos() */
 void bo_rr_dyn_trig(double th1, double th2, double out[4]);
 /* Robot::dynRR (robot.cpp:377-431) on the samples of p (value, d/ds, d2/ds2 of the two joints); trig: optional [4][n] table */

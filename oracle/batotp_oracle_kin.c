@@ -115,3 +115,52 @@ void bo_rr_dyn_trig(double th1, double th2, double out[4])
     sincos(th2, &out[3], &out[1]);
     out[2] = plain_cos(th1 + th2);
 }
+
+/* ---- tool poses: axis-angle <-> quaternion (SURVEY.md 8 f-3 / pose paths) ---------------------------------------------
+ * aa2q util.cpp:534-555, q2aa util.cpp:562-581, BA::aa2qVect ba.cpp:327-369 (successive quaternions kept on one hemisphere),
+ * BA::q2aaVect ba.cpp:384-403.  Trigonometry as the reference's optimised build calls it: sin and cos of the half angle are
+ * one sincos(), the inverse is one atan2(). */
+void bo_aa2q(const double aa[3], double q[4])
+{
+    const double theta = sqrt(aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2]);
+    if (theta < 1e-6) { q[0] = 1.0; q[1] = 0.0; q[2] = 0.0; q[3] = 0.0; return; }
+    double sh, ch;
+    sincos(0.5 * theta, &sh, &ch);
+    q[0] = ch;
+    for (int i = 0; i < 3; ++i) q[i + 1] = aa[i] * sh / theta;
+}
+
+void bo_q2aa(const double q[4], double aa[3])
+{
+    const double norme = sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (norme < 1e-6) { aa[0] = 0.0; aa[1] = 0.0; aa[2] = 0.0; return; }
+    const double theta = 2.0 * atan2(norme, q[0]) / norme;
+    for (int i = 0; i < 3; ++i) aa[i] = theta * q[i + 1];
+}
+
+/* rows[4][n] hold (rx, ry, rz, -) on entry (row stride `stride`) and the quaternions on return */
+void bo_aa2q_rows(double *rows, int64_t stride, int64_t n)
+{
+    double prev[4], q[4], aa[3];
+    aa[0] = rows[0]; aa[1] = rows[stride]; aa[2] = rows[2 * stride];
+    bo_aa2q(aa, prev);
+    for (int64_t i = 0; i < n; ++i) {
+        aa[0] = rows[i]; aa[1] = rows[stride + i]; aa[2] = rows[2 * stride + i];
+        bo_aa2q(aa, q);
+        double qdir = 0;
+        for (int j = 0; j < 4; ++j) qdir += q[j] * prev[j];
+        if (qdir < 0.0) for (int j = 0; j < 4; ++j) q[j] = -q[j];
+        for (int j = 0; j < 4; ++j) { prev[j] = q[j]; rows[(size_t)j * stride + i] = q[j]; }
+    }
+}
+
+/* rows[4][n] hold quaternions on entry and (rx, ry, rz) in their first three rows on return */
+void bo_q2aa_rows(double *rows, int64_t stride, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const double q[4] = {rows[i], rows[stride + i], rows[2 * stride + i], rows[3 * stride + i]};
+        double aa[3];
+        bo_q2aa(q, aa);
+        for (int j = 0; j < 3; ++j) rows[(size_t)j * stride + i] = aa[j];
+    }
+}

@@ -103,8 +103,11 @@ int bo_output(const batotp_problem *prob, const batotp_output_params *prm, const
     const int serialTrq = jointPath && (prob->flags & BATOTP_F_TRQ_ON) && !(prob->flags & BATOTP_F_PARALLEL) &&
                           (p->serial != NULL || prob->robot_type == BATOTP_ROBOT_RR) && nJ == p->n_theta;
     const int joint = jointPath && (!(prob->flags & BATOTP_F_TRQ_ON) || serialTrq);
-    if (nJ < 1 || nJ > p->n_theta || n_fwd < 4 || (!cable && !joint)) return -1;
-    const int nC = cable ? 3 : (kin ? 3 : 0), nT = cable ? 3 : (serialTrq ? nJ : 0), C = nJ + nC + nT;
+    /* joints and tool poses taught together (path type BOTH, the UR5 example): 7 Cartesian rows (position + quaternion) are
+     * evaluated like the joints and turned back into axis-angle at the very end (ba.cpp:1709-1742, 1920-1927) */
+    const int both = prm->path_type == BATOTP_PATH_BOTH && p->n_cart == 7 && !(prob->flags & BATOTP_F_TRQ_ON);
+    if (nJ < 1 || nJ > p->n_theta || n_fwd < 4 || (!cable && !joint && !both)) return -1;
+    const int nC = cable ? 3 : (both ? 7 : (kin ? 3 : 0)), nT = cable ? 3 : (serialTrq ? nJ : 0), C = nJ + nC + nT;
     double outRes = prm->out_res, smoothFact = prm->out_smooth_fact;
     const double outResUser = outRes;
     int reinterp = 0;
@@ -152,6 +155,9 @@ int bo_output(const batotp_problem *prob, const batotp_output_params *prm, const
     if (!cable) {
         for (int j = 0; j < nJ; ++j)
             bo_interp1_spline(p->coef + (size_t)j * 4 * (size_t)p->n, p->n, seg, tau, nOut, outRes, x + (size_t)j * n, d1, d2);
+        if (both)
+            for (int j = 0; j < nC; ++j)
+                bo_interp1_spline(p->coef + (size_t)(p->n_theta + j) * 4 * (size_t)p->n, p->n, seg, tau, nOut, outRes, x + (size_t)(nJ + j) * n, d1, d2);
     } else {
         for (int j = 0; j < nC; ++j)
             bo_interp1_spline(p->coef + (size_t)(p->n_theta + j) * 4 * (size_t)p->n, p->n, seg, tau, nOut, outRes, x + (size_t)(nJ + j) * n, d1, d2);
@@ -256,8 +262,14 @@ int bo_output(const batotp_problem *prob, const batotp_output_params *prm, const
         n = nUser;
         outRes = outResUser;
     }
+    int nCout = nC;
+    if (both) {
+        /* BA::q2aaVect (ba.cpp:384-403): rows nJ+3 .. nJ+6 (quaternion) -> nJ+3 .. nJ+5 (axis-angle), the seventh row goes */
+        bo_q2aa_rows(x + (size_t)(nJ + 3) * n, n, n);
+        nCout = 6;
+    }
     *out = x;
-    *n_cart_out = nC;
+    *n_cart_out = nCout;
     *n_trq_out = nT;
     *n_out = n;
     *sres_out = outRes;

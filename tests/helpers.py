@@ -54,9 +54,10 @@ class Case:
             self.y = np.ascontiguousarray(z["y"])
             self.sres = float(z["sres"])
             self.problem = problem_from_bytes(z["problem"])
-            if self.problem.robot_type in (capi.ROBOT_KUKA, capi.ROBOT_RR):
-                # what BA::fillProblem sets for the robots with forward kinematics since round 3 (the fixture's bytes are older):
-                # the output stage takes the cos / sin of its forward kinematics from the host libm
+            if self.problem.robot_type in (capi.ROBOT_KUKA, capi.ROBOT_RR) or self.problem.n_cart == 7:
+                # what BA::fillProblem sets for the robots with forward kinematics and for pose paths since round 3 (the fixture's
+                # bytes are older): the output stage takes the cos / sin of its forward kinematics (the atan2 of its pose
+                # conversion) from the host libm
                 self.problem.flags |= capi.F_HOST_TRIG
             self.ref = pathgen.read_s_sdot(os.path.join(self.dir, "ref_s-sdot.dat"))
         else:
@@ -174,7 +175,8 @@ def precompute_with_trig(ctx, b, prob, n_paths, serial_model=None):
 
 def assert_output_equals_reference_file(case, out, k=0):
     """the trajectory of path k rounded to float32 = the reference binary's traj_out.dat, byte for byte"""
-    sres32, n, theta32, cart32, trq32 = read_traj_out(os.path.join(case.dir, "ref_traj_out.dat"), case.problem.n_joints, case.problem.n_cart)
+    n_cart_file = 6 if case.problem.n_cart == 7 else case.problem.n_cart   # poses are written as axis-angle again (q2aaVect)
+    sres32, n, theta32, cart32, trq32 = read_traj_out(os.path.join(case.dir, "ref_traj_out.dat"), case.problem.n_joints, n_cart_file)
     assert int(out.n_pts[k]) == n, (case.name, int(out.n_pts[k]), n)
     assert np.float32(out.sres[k]) == sres32
     rows = out.rows(k)

@@ -277,6 +277,7 @@ def test_spline_build_in_tiles_equals_the_sequential_kernel(hip_lib, oracle_ctx,
         for k, y in enumerate(ys):
             b.upload_knots(k, [y], [base.sres])
         b.precompute(0)
+        assert b.spline_tile_fallbacks() == 0       # every warm-up arrived at its neighbour's bits
         out[tiles] = [np.stack([b.coeffs(k, ch) for ch in range(prob.n_channels)]) for k in range(len(ys))]
         b.close(); ctx.close()
     ob = capi.Batch(oracle_ctx, prob, [y.shape[1] for y in ys], 64)

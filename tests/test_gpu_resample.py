@@ -69,6 +69,27 @@ def test_forward_kinematics_robots_ragged_batch(hip_ctx, oracle_ctx, name):
     _same(h2, o2, f"{name} without Cartesian constraints")
 
 
+def test_pose_paths_ragged_batch(hip_ctx, oracle_ctx):
+    """path type BOTH (the UR5 example): six pose rows in, seven out -- BA::aa2qVect on the device (quaternion of every
+    taught point with the host's sincos of the half angle, sequential hemisphere alignment per path), then both passes on
+    joints AND poses; ragged batch incl. orientations that flip hemisphere and a (near-)zero rotation"""
+    c = ResampleCase("UR5")
+    nJ = c.params.n_joints
+    assert c.params.path_type == capi.PATH_BOTH and c.params.n_cart == 6 and c.y.shape[0] == nJ + 7
+    n = c.x.shape[1]
+    flip = c.x.copy()
+    flip[nJ + 3:nJ + 6, n // 2:] *= -1.0           # the same rotations by the opposite axis-angle vectors: q and -q ...
+    zero = c.x.copy()
+    zero[nJ + 3:nJ + 6, : n // 3] = 0.0            # no rotation at all on the first third (the theta < 1e-6 branch)
+    xs = [c.x, c.x[:, : n // 2].copy(), flip, zero, c.x[:, ::-1].copy()]
+    sr = [c.sres_in] * len(xs)
+    h = capi.Resampled(hip_ctx, c.params, xs, sr)
+    o = capi.Resampled(oracle_ctx, c.params, xs, sr)
+    assert not h.status.any()
+    _same(h, o, "ragged pose batch")
+    assert_bit_equal(h.knots(0), c.y, "golden knots inside the batch")
+
+
 def test_forward_kinematics_with_the_device_libm_is_close(hip_ctx):
     """without BATOTP_F_HOST_TRIG the tool point comes from the device libm (last-bit differences against glibc): the
     documented tolerance mode -- same knot count on the golden path, knots within 1e-9"""

@@ -108,9 +108,7 @@ def test_which_configurations_the_device_stages_cover():
     assert set(helpers.RESAMPLE_CASES) == {"CSPR3DOF", "CSPR3DOF_par", "GEN7DOF", "synth_cspr_s3", "synth_cspr_s5", "synth_cspr_s9_dup",
                                            "synth_cspr_s11_decim", "synth_gen7dof_s0", "synth_gen7dof_s1_vel", "synth_gen7dof_s6_dup",
                                            "synth_gen7dof_s10_decim", "synth_ur_s2",
-                                           # round 3: robots with forward kinematics, serial-robot torque recomputation
-                                           "KUKA-LWR-IV", "KUKA_cartacc", "RR", "RR_acc"}
-    assert set(helpers.OUTPUT_CASES) == set(helpers.RESAMPLE_CASES)
-    # pose paths (axis-angle <-> quaternion, path type BOTH) stay on the host
-    for name in ("UR5", "UR5_nocartacc"):
-        assert name in helpers.FULL_CASES and name not in helpers.RESAMPLE_CASES and name not in helpers.OUTPUT_CASES
+                                           # round 3: robots with forward kinematics, serial-robot torque recomputation,
+                                           # pose paths (path type BOTH: axis-angle <-> quaternion)
+                                           "KUKA-LWR-IV", "KUKA_cartacc", "RR", "RR_acc", "UR5", "UR5_nocartacc"}
+    assert set(helpers.OUTPUT_CASES) == set(helpers.RESAMPLE_CASES) == set(helpers.FULL_CASES)   # every shipped example and edited variant
