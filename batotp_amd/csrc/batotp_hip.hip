@@ -558,7 +558,7 @@ extern "C" int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *pr
    {
       b->nchMax = std::max(P.Cin, 4 * d);
       for (int p = 0; p < n_paths; ++p)
-         tileOff[p + 1] = tileOff[p] + (n_knots[p] >= ST_MIN_KNOTS ? (int)((n_knots[p] + ST_T - 1) / ST_T) : 0);
+         tileOff[p + 1] = tileOff[p] + (n_knots[p] >= ST_MIN_KNOTS ? (int)((n_knots[p] - 1 + ST_T - 1) / ST_T) : 0);   // the last knot joins the last tile
       b->totalTiles = tileOff[n_paths];
    }
    ALLOC(b->dTileOff, n_paths + 1, int)
@@ -847,7 +847,7 @@ static int launchSpline(batotp_batch *b, int nch, int mode, const double *src, i
    // Automatic choice (splineTiles = -1): tiles while the batch is too small to fill the GPU with one lane per series -- there
    // the sequential kernel is a dependent chain of N steps whatever the batch (9.5 ms for ONE 6-joint path of 1e5 knots, 54 ms
    // with the 28 dynamics channels of a 7-joint arm; tiles: 0.05 and 0.22 ms) -- and the lane-per-series kernel beyond:
-   // a chunk of 16 knots costs a tile 64 forward and 64 backward steps (the warm-ups), and the tiles of a CU are limited by
+   // a chunk of 16 knots costs a tile 80 forward and 80 backward steps (the warm-ups), and the tiles of a CU are limited by
    // LDS, so at 2048 paths x 7 series of 1e5 knots the tiles take 34 ms against 22 ms (16 384 paths: 285 against 156 ms).
    const bool tiled = b->totalTiles > 0 && (b->ctx->splineTiles == 1 || (b->ctx->splineTiles < 0 && (int64_t)b->B * nch <= 4096));
    const int *only = nullptr;

@@ -3,10 +3,12 @@
 //
 // The recurrences of the (1,4,1) system are sequential in the knot index and floating-point addition / division are not
 // associative, so they cannot become a scan.  But both are contractions: an error in d[i-1] reaches d[i] divided by the pivot
-// (x 0.268), an error in sol[i+1] reaches sol[i] multiplied by c (x 0.268).  A lane that starts the forward elimination K = 48
+// (x 0.268), an error in sol[i+1] reaches sol[i] multiplied by c (x 0.268).  A lane that starts the forward elimination K = 64
 // knots BEFORE the chunk it is responsible for, from the guess 0, arrives at the chunk with a value whose distance from the true
-// one has shrunk by 0.268^48 = 3.5e-28 -- twelve orders of magnitude below half an ulp -- i.e. with the true value's bits;
-// from there on it IS the sequential computation.  "With the true value's bits" is not assumed but CHECKED: every warm-up
+// one has shrunk by 0.268^64 = 2.6e-37 -- twenty orders of magnitude below half an ulp of the value it started from -- i.e.,
+// unless the series' curvature drops by more than those twenty orders within 64 knots (a kink followed by an exactly straight
+// stretch does that: the tail of the kink's influence then IS the value, and a warm-up from 0 misses it), with the true
+// value's bits; from there on it IS the sequential computation.  "With the true value's bits" is not assumed but CHECKED: every warm-up
 // value is compared bit for bit with the value the neighbouring chunk computed for the same knot (inside a tile through LDS,
 // between tiles through two doubles per series and tile in `edge`); the first chunk of a series starts from the true
 // boundary, so by induction a series whose comparisons all agree is the sequential result exactly.  A series with a
@@ -27,11 +29,11 @@
 namespace bk
 {
 
-constexpr int ST_T = 320;                       // knots per tile
-constexpr int ST_K = 48;                        // warm-up knots
+constexpr int ST_T = 256;                       // knots per tile (the last tile of a series also takes the last knot: up to ST_T + 1)
+constexpr int ST_K = 64;                        // warm-up knots
 constexpr int ST_L = 16;                        // knots per lane and pass
 constexpr int ST_CH = 8;                        // channels per block
-constexpr int ST_SPAN = ST_T + 2 * ST_K + 2;    // knots in LDS: [t0 - K - 1, t1 + K + 1)
+constexpr int ST_SPAN = ST_T + 2 * ST_K + 3;    // knots in LDS: [t0 - K - 1, t1 + K + 1)
 constexpr int ST_SPANP = ST_SPAN + 1;           // (odd row length: the channels of a knot fall into different banks)
 constexpr int ST_BLOCK = 256;
 constexpr int ST_MIN_KNOTS = 1024;              // shorter series take the sequential kernel
@@ -61,8 +63,8 @@ __global__ void __launch_bounds__(ST_BLOCK) k_spline_tile(TileArgs a)
 {
    __shared__ double Y[ST_CH][ST_SPANP];     // knot values
    __shared__ double D[ST_CH][ST_SPANP];     // eliminated right-hand sides d[i]
-   __shared__ double S[ST_CH][ST_T + 2];     // second derivatives sol[t0 .. t1]
-   __shared__ double warmF[ST_CH][(ST_T + ST_K) / ST_L + 2], warmB[ST_CH][ST_T / ST_L + 2];
+   __shared__ double S[ST_CH][ST_T + 3];     // second derivatives sol[t0 .. t1]
+   __shared__ double warmF[ST_CH][(ST_T + ST_K) / ST_L + 3], warmB[ST_CH][ST_T / ST_L + 3];
    __shared__ int bad;
 
    // which tile
@@ -77,7 +79,9 @@ __global__ void __launch_bounds__(ST_BLOCK) k_spline_tile(TileArgs a)
    const int N = (int)pi.n, n = N - 1;
    const int e0 = blockIdx.y * ST_CH;                           // first series of this block
    const int nc = (a.nch - e0) < ST_CH ? (a.nch - e0) : ST_CH;  // series of this block
-   const int t0 = tile * ST_T, t1 = (t0 + ST_T) < N ? (t0 + ST_T) : N;   // knots [t0, t1) are this tile's
+   // knots [t0, t1) are this tile's; the last tile of the series ends at N (ceil((N - 1) / ST_T) tiles: the last knot never
+   // gets a tile of its own -- its second derivative needs d[n - 1], which is its predecessor's)
+   const int t0 = tile * ST_T, t1 = (tile + 1 == a.tileOff[p + 1] - a.tileOff[p]) ? N : (t0 + ST_T);
    const int k0 = (t0 - ST_K - 1) > 0 ? (t0 - ST_K - 1) : 0;
    const int k1 = (t1 + ST_K + 1) < N ? (t1 + ST_K + 1) : N;    // knots [k0, k1) are in LDS
    const int tid = threadIdx.x;
@@ -297,8 +301,7 @@ __global__ void k_spline_tile_check(TileArgs a, int totalTiles)
    const int p = lo, tile = gt - a.tileOff[p], tiles = a.tileOff[p + 1] - a.tileOff[p];
    const double *__restrict__ ed = a.edge + g * 4;
    bool ok = true;
-   const int n = (int)a.pinfo[p].n - 1;
-   if (tile > 0 && tile * ST_T < n) ok = ok && __double_as_longlong(ed[0]) == __double_as_longlong(ed[1]);   // (a tile that starts at the last knot eliminates nothing)
+   if (tile > 0) ok = ok && __double_as_longlong(ed[0]) == __double_as_longlong(ed[1]);
    if (tile + 1 < tiles) ok = ok && __double_as_longlong(ed[2]) == __double_as_longlong(ed[3]);
    if (!ok) a.dirty[p * a.nch + tile_src_channel(a, e)] = 1;
 }

@@ -297,7 +297,7 @@ int  batotp_hip_last_sweep_launch(batotp_batch *batch, int32_t dir, int32_t *lan
  * the reverse curve ahead of its cursor (forward sweep only); -1 (default) = automatic: rows in the reverse sweep always, rows and
  * curve in the forward sweep while every path has a wavefront to itself (latency-bound regime).  Never changes a result. */
 int  batotp_hip_set_sweep_prefetch(batotp_ctx *ctx, int32_t reverse, int32_t forward);
-/* K1 (the spline build) in tiles of knots: the Thomas recurrences run from 48 knots before / beyond each chunk of 16 knots
+/* K1 (the spline build) in tiles of knots: the Thomas recurrences run from 64 knots before / beyond each chunk of 16 knots
  * (they contract by 0.268 per knot: the warm-up arrives with the sequential value's bits), every warm-up value is compared
  * bit for bit with the neighbouring chunk's, and a series with a disagreement is redone by the sequential kernel, so the
  * result IS the sequential kernel's (batotp_amd/csrc/spline_tile.hip.h).  on: -1 (default) automatic -- tiles for batches of

@@ -242,53 +242,66 @@ def test_flat_sweep_loop_capacity_and_max_time_status(hip_lib, oracle_ctx):
 
 @pytest.mark.parametrize("layout", ["rows", "pairs", "cable"])
 def test_spline_build_in_tiles_equals_the_sequential_kernel(hip_lib, oracle_ctx, layout):
-    """K1 in tiles of knots (spline_tile.hip.h: warm-up of 48 knots per chunk, every warm-up value compared bit for bit with
+    """K1 in tiles of knots (spline_tile.hip.h: warm-up of 64 knots per chunk, every warm-up value compared bit for bit with
     its neighbour's) against the sequential lane-per-series kernel and the oracle: coefficients of every channel identical,
-    on lengths around every boundary of the decomposition (the 1024-knot threshold, multiples of the 320-knot tile +- 1, a last
-    tile of one knot) and on long paths"""
+    on lengths around every boundary of the decomposition (the 1024-knot threshold, multiples of the 256-knot tile +- 1) and
+    on long paths.  Smooth paths: no series may need the sequential fallback.  A piecewise-linear path (kinks followed by
+    exactly straight stretches: the curvature drops by more than the 20 orders of magnitude a warm-up bridges) is where the
+    comparisons are EXPECTED to catch warm-ups that did not arrive -- same coefficients, through the fallback."""
     rng = np.random.default_rng(11)
-    lengths = [1023, 1024, 1025, 1280, 1281, 1279, 1600, 1601, 1920 + 17, 40, 7, 3521, 6401, 20011]
+    lengths = [1023, 1024, 1025, 1280, 1281, 1282, 1279, 1536, 1537, 1538, 1600, 40, 7, 3521, 6401, 20011]
     if layout == "cable":
         base = Case("synth_cspr_s3")
-        lengths = [n for n in lengths if n >= 64][:8]
+        lengths = [n for n in lengths if n >= 64][:9]
     else:
         base = Case("synth_gen7dof_s0")
     prob = capi.Problem.from_buffer_copy(bytes(base.problem))
     if layout == "pairs":
         prob.flags |= capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES
     C_in = prob.n_joints + prob.n_cart
-    ys = []
-    for n in lengths:
+
+    def smooth(n):
         if n <= base.n:
-            ys.append(np.ascontiguousarray(base.y[:, :n]))
-        else:   # longer than the golden path: a smooth random walk through the same region (any values do for K1)
-            t = np.linspace(0, 1, n)
-            y = np.stack([np.interp(t, np.linspace(0, 1, 40), rng.normal(0, 1, 40).cumsum()) for _ in range(C_in)])
-            if layout == "cable":
-                y[prob.n_joints:] = 0.3 * y[prob.n_joints:] / max(1.0, np.abs(y[prob.n_joints:]).max())
-                y[prob.n_joints + 2] += 2.0
-                y[:prob.n_joints] = np.abs(y[:prob.n_joints]) + 3.0
-            ys.append(np.ascontiguousarray(y))
-    out = {}
-    for tiles in (True, False):
+            return np.ascontiguousarray(base.y[:, :n])
+        # longer than the golden path: the golden rows stretched by cubic interpolation (any smooth values do for K1)
+        from scipy.interpolate import CubicSpline
+        t0, t = np.linspace(0, 1, base.n), np.linspace(0, 1, n)
+        return np.ascontiguousarray(np.stack([CubicSpline(t0, base.y[c])(t) for c in range(C_in)]))
+
+    def run(ys, tiles):
         ctx = capi.Context(hip_lib, 0)
         ctx.set_spline_tiles(tiles)
         b = capi.Batch(ctx, prob, [y.shape[1] for y in ys], 64)
         for k, y in enumerate(ys):
             b.upload_knots(k, [y], [base.sres])
-        b.precompute(0)
-        assert b.spline_tile_fallbacks() == 0       # every warm-up arrived at its neighbour's bits
-        out[tiles] = [np.stack([b.coeffs(k, ch) for ch in range(prob.n_channels)]) for k in range(len(ys))]
+        b.precompute(1)
+        co = [np.stack([b.coeffs(k, ch) for ch in range(C_in)]) for k in range(len(ys))]
+        fb = b.spline_tile_fallbacks() if tiles else 0
         b.close(); ctx.close()
+        return co, fb
+
+    ys = [smooth(n) for n in lengths]
+    tiled, fallbacks = run(ys, True)
+    seq, _ = run(ys, False)
+    assert fallbacks == 0, f"{fallbacks} series of smooth paths fell back to the sequential kernel"
     ob = capi.Batch(oracle_ctx, prob, [y.shape[1] for y in ys], 64)
     for k, y in enumerate(ys):
         ob.upload_knots(k, [y], [base.sres])
-    ob.precompute(0)
+    ob.precompute(1)
     for k in range(len(ys)):
-        assert_bit_equal(out[True][k], out[False][k], f"{layout}: path {k} (N = {lengths[k]}): tiles against the sequential kernel")
-        oc = np.stack([ob.coeffs(k, ch) for ch in range(prob.n_channels)])
-        assert_bit_equal(out[True][k], oc, f"{layout}: path {k} (N = {lengths[k]}): tiles against the oracle")
+        assert_bit_equal(tiled[k], seq[k], f"{layout}: path {k} (N = {lengths[k]}): tiles against the sequential kernel")
+        oc = np.stack([ob.coeffs(k, ch) for ch in range(C_in)])
+        assert_bit_equal(tiled[k], oc, f"{layout}: path {k} (N = {lengths[k]}): tiles against the oracle")
     ob.close()
+    # kinks and exactly straight stretches
+    n = 5000
+    t = np.linspace(0, 1, n)
+    kinky = np.ascontiguousarray(np.stack([np.interp(t, np.linspace(0, 1, 12), rng.integers(-4, 5, 12).astype(float)) for _ in range(C_in)]))
+    if layout == "cable":
+        kinky[: prob.n_joints] = np.abs(kinky[: prob.n_joints]) + 3.0
+    a, fb = run([kinky], True)
+    c, _ = run([kinky], False)
+    assert_bit_equal(a[0], c[0], f"{layout}: piecewise-linear path: tiles (with {fb} series through the fallback) against the sequential kernel")
 
 
 def test_flat_sweep_loop_is_gated_by_toolchain_and_canary(hip_lib, oracle_ctx, monkeypatch):
