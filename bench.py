@@ -333,6 +333,19 @@ def bytes_per_path(prob, C, n_mean, cap):
     return per_knot * n_mean + (16.0 if prob.flags & capi.F_CURVES_IN_PLACE else 32.0) * cap
 
 
+def plan_chunks(B, K, limit):
+    """a rank's share of B paths in chunks of at most `limit` paths (what fits its HBM): equal chunks, whole multiples of the K
+    distinct paths when there is more than one chunk (every chunk then holds the same distinct paths and runs through the same
+    resident batch)"""
+    n = 1
+    while (B + n - 1) // n > limit:
+        n += 1
+    bc = (B + n - 1) // n
+    if n > 1:
+        bc = max(K, (bc // K) * K)
+    return [min(bc, B - i * bc) for i in range((B + bc - 1) // bc)] if B else []
+
+
 def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=0, knots_override=0, group=0, ppw=0,
             coefficient_rows=False, distinct_override=0, keep=False):
     """run one configuration on this rank's share; returns (result dict, kept objects or None)"""
@@ -365,14 +378,7 @@ def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=
     free_b, _ = torch.cuda.mem_get_info()
     fit = max(1, int(0.93 * (free_b - (8 << 30)) / bytes_per_path(prob, C, float(inp.n_knots.mean()), cap)))
 
-    def split(limit):
-        n = 1
-        while (B + n - 1) // n > limit:
-            n += 1
-        bc = (B + n - 1) // n
-        if n > 1:
-            bc = max(K, (bc // K) * K)
-        return [min(bc, B - i * bc) for i in range((B + bc - 1) // bc)] if B else []
+    split = lambda limit: plan_chunks(B, K, limit)
     chunk_sizes = split(fit)
     batch = None
     while B and batch is None:
@@ -691,6 +697,31 @@ def launch_check(args, rank, world):
     rows = np.zeros(hi - lo, dtype=capi.RESULT_DTYPE)
     rows["n_fwd"] = np.arange(lo, hi) if c["scaling"] == "strong" else rank
     allrows = bdist.gather_results(rows) if world > 1 else rows
+    # the rank's chunk plan on a 288 GB GPU (same arithmetic as measure(): 93 % of the free memory less 8 GB) and the sizes of
+    # the curve gather (all_gather of the per-path point counts, then one packed (s, sdot) buffer per rank to
+    # rank 0) with nominal curve lengths -- the size exchange is real, the buffers are not allocated
+    w = WORKLOADS[c["workload"]]
+    cfgd = w["cfg"]
+    pr = capi.Problem()
+    pr.n_joints, pr.n_cart = cfgd["n_joints"], (cfgd["n_cart"] if (cfgd.get("cart_vel_on") or cfgd.get("is_parallel")) else 0)
+    pr.flags = (capi.F_TRQ_ON if cfgd.get("trq_on") else 0) | (capi.F_PARALLEL if cfgd.get("is_parallel") else 0)
+    if not (pr.flags & capi.F_TRQ_ON):
+        pr.flags |= capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES
+    knots = args.knots or c["knots"]
+    cap = int(knots * w["cap"]) + 1024
+    fit = max(1, int(0.93 * (288e9 - 8 * 2 ** 30) / bytes_per_path(pr, w["C"], float(knots), cap)))
+    B = hi - lo
+    K = max(1, min(args.distinct or c["distinct"], max(B, 1)))
+    chunks = plan_chunks(B, K, fit)
+    pts = (0.4 * knots * (1.0 + 0.5 * ((np.arange(lo, hi) % 7) / 7.0))).astype(np.int64)      # nominal forward-curve lengths
+    cnt = torch.zeros(max(1, -(-total // world) if c["scaling"] == "strong" else total), dtype=torch.int64)
+    cnt[: pts.shape[0]] = torch.from_numpy(pts)
+    allcnt = [torch.zeros_like(cnt) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(allcnt, cnt)
+    else:
+        allcnt = [cnt]
+    recv_points = [int(t.sum().item()) for t in allcnt]
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -698,7 +729,11 @@ def launch_check(args, rank, world):
     if rank == 0:
         print(json.dumps({"launch_check": True, "n_gpus": world, "config": args.config, "scaling": c["scaling"],
                           "paths_total": total if c["scaling"] == "strong" else total * world, "gathered_rows": int(allrows.shape[0]),
-                          "rows_in_rank_order": bool(np.all(np.diff(allrows["n_fwd"]) >= 0)), "max_over_ranks": float(t.item())}))
+                          "rows_in_rank_order": bool(np.all(np.diff(allrows["n_fwd"]) >= 0)), "max_over_ranks": float(t.item()),
+                          "paths_per_rank": B, "chunks_per_rank": chunks, "paths_that_fit_one_gpu": fit,
+                          "curve_gather": {"points_per_rank": recv_points, "GB_to_rank0": 16e-9 * sum(recv_points[1:]),
+                                           "what": "nominal forward-curve lengths; the per-path point counts were exchanged by all_gather "
+                                                   "exactly as batotp_amd.dist.gather_curves does before its grouped send/recv"}}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -170,6 +170,31 @@ def test_product_batch_driver_on_gpu(tmp_path, name):
         assert filecmp.cmp(tmp_path / d / "traj_out.dat", os.path.join(src, "ref_traj_out.dat"), shallow=False), name
 
 
+def test_product_batch_driver_over_all_devices_of_the_box(tmp_path):
+    """batest_batch --all-devices: BA::useAllDevices + BA::optimizeBatch over every GPU the box has (contiguous blocks of paths, a
+    host thread and a device context per GPU; on a one-GPU box that is one block on device 0) -- every path comes back in place
+    with the single-path files"""
+    import filecmp, os, shutil, subprocess
+    exe = os.path.join(helpers.ROOT, "batotp_amd", "host", "_build", "batest_batch")
+    name = "synth_gen7dof_s0"
+    src = os.path.join(helpers.GOLD, name)
+    for f in os.listdir(src):
+        if not f.startswith("ref_") and not f.endswith(".npz") and not f.endswith(".json"):
+            shutil.copy(os.path.join(src, f), tmp_path / f)
+    r = subprocess.run([exe, "config.dat", "9", "--all-devices"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "9 paths, 0 failed" in r.stdout
+    n_gpus = hip_device_count()
+    assert n_gpus >= 1 and (n_gpus == 1 or f"sharded over {min(n_gpus, 9)} devices" in r.stdout)
+    for d in ("out_first", "out_last"):
+        assert filecmp.cmp(tmp_path / d / "s-sdot.dat", os.path.join(src, "ref_s-sdot.dat"), shallow=False)
+        assert filecmp.cmp(tmp_path / d / "traj_out.dat", os.path.join(src, "ref_traj_out.dat"), shallow=False)
+
+
+def hip_device_count():
+    return capi.load_hip().device_count()
+
+
 def test_product_batch_driver_grows_a_shared_curve_buffer(tmp_path):
     """is_sdotOut = 0 (one curve buffer per path, BATOTP_F_CURVES_IN_PLACE) and a forward curve that does not fit the first
     capacity guess while the reverse curve does: the forward kernel gives up 64 points before unread reverse points, with
