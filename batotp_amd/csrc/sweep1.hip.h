@@ -46,6 +46,12 @@ __device__ __forceinline__ bool ratio_lt_uniform(double num, double den, double 
 #ifndef S1_SELECT
 #define S1_SELECT 0
 #endif
+// 1: a violated first check of a joint velocity / acceleration-only problem goes through the PREDICTED bisection first (see
+// accelPt): the speed at which the sddot intervals stop intersecting has a closed form there, the reference's candidate sequence
+// is replayed against it, and the constraint check only VERIFIES the predicted outcomes, four candidates per pass
+#ifndef S1_PREDICT
+#define S1_PREDICT 1
+#endif
 // tableau of ba.cpp:58-63 as a table: entry [6*k + m] = _B[k][m] (stage m + 1 combines the stage values k = 0..m)
 __constant__ double c_s1B[36] = {BK_B00, BK_B01, BK_B02, BK_B03, BK_B04, BK_B05,
                                  0, BK_B11, BK_B12, BK_B13, BK_B14, BK_B15,
@@ -72,6 +78,11 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    // wavefront were s_waitcnt without the windows: profiles/r02_e_*).
    __shared__ double2 winKAll[(FEAT < 0) ? S1_BLOCK / 64 : 1][(FEAT < 0) ? S1_WK * BATOTP_MAX_JOINTS : 1];
    __shared__ double2 winMAll[(DIR == 1) ? S1_BLOCK / 64 : 1][(DIR == 1) ? S1_WM : 1];
+#if S1_PREDICT
+   // predicted bisection: candidates and the last feasible speed known when each is tested; a column per lane (every lane of
+   // the wavefront holds the same numbers; own columns need neither a broadcast nor an exec mask)
+   __shared__ double predAll[(FEAT <= 0) ? S1_BLOCK / 64 : 1][(FEAT <= 0) ? 16 : 1][32];
+#endif
 #if S1_STAGE_LOOP
    // the stage values sdot_k, sddot_k (k = 0..6) of the step in flight: a slot per lane (every lane holds the same numbers; own
    // slots need neither a broadcast nor an exec mask), read back by the tableau combination of the later stages
@@ -508,6 +519,111 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       }
 #ifdef BK_PROFILE_SECTIONS
       ++nBis;
+#endif
+#if S1_PREDICT
+      if (FEAT <= 0 && accOn)
+      {
+         // PREDICTED BISECTION (joint velocity / acceleration limits only).  The sddot intervals of the joints are
+         // [-a_j - m_j x, a_j - m_j x] in x = sdot^2 with a_j = amax_j / |theta'_j|, m_j = theta''_j / theta'_j (ba.cpp:1526-1531), a
+         // joint that stands still allows x <= amax_j / |theta''_j| (ba.cpp:1519-1524): they stop intersecting at
+         //    x* = min( min over pairs i, j with m_j > m_i of (a_i + a_j) / (m_j - m_i),  min over standing joints ).
+         // With x* the outcome of every check of the reference's loop (ba.cpp:1267-1321) is known in advance, so its candidate
+         // sequence -- geometric shrinking until a feasible speed is found, then bisection until two successive feasible speeds
+         // agree to 1e-3 -- is replayed here on wavefront-uniform values at a few instructions per iteration instead of a
+         // constraint check per iteration.  x* is computed with approximate reciprocals and is only a PREDICTION: afterwards
+         // every candidate is put through the real check (verify(), four candidates per pass, one per slot), and the result is
+         // taken only if all outcomes are the predicted ones -- then the loop above would have produced exactly this sequence,
+         // this final speed and these sddot bounds (those of the check of the last candidate).  Any disagreement (a candidate
+         // within rounding of the boundary, a limit this prediction does not model: +-sddotMax), a failure exit or more than 16
+         // candidates: the generic replay below runs from the start, as if this block did not exist.
+         auto fastRcp = [](double d) { double r = __builtin_amdgcn_rcp(d); return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r); };
+         const bool use = jv && !(fabs(thD) < thrV);
+         const double rv = fastRcp(use ? thD : 1.0);
+         const double aj = use ? amaxj * fabs(rv) : kInf;
+         const double mj = use ? thD2 * rv : 0.0;
+         const bool standing = jv && !use && !(fabs(thD2) < thrA);
+         double xs = standing ? amaxj * fastRcp(fabs(thD2)) : kInf;
+#pragma unroll
+         for (int rr = 0; rr < 2; ++rr)
+         {
+            const int srcLane = (lane & 24) | (cslot + 4 * rr);     // joint cslot + 4 rr of this lane's own slot
+            const double ai = __shfl(aj, srcLane), mi = __shfl(mj, srcLane);
+            const double dm = mj - mi;
+            const double bnd = (ai + aj) * fastRcp(dm > 0.0 ? dm : 1.0);
+            xs = dmin(xs, dm > 0.0 ? bnd : kInf);
+         }
+         xs = grp_min<8>(xs);
+         xs = vmin_f64(xs, dpp_mov<DPP_ROW_ROR8>(xs));
+         xs = vmin_f64(xs, __shfl_xor(xs, 16));
+         const double xstar = xs;
+
+         double (*pcand)[32] = predAll[(FEAT <= 0) ? (threadIdx.x >> 6) : 0];
+         // state after the loop's first iteration (the violated first check: ba.cpp:1276-1285 with nIter = 0)
+         const double c0 = sdotTry;
+         double pLF = lowFact * 2.0, pH = c0, pL = dmax(.999 * 0.0, (1.0 - pLF) * c0), pGood = 0.0;
+         double pTry = .5 * (pH + pL);
+         int pGoodN = 0, nCand = 0;
+         unsigned pvMask = 0;
+         bool predicted = false;
+         // (the first iteration's own failure exits, ba.cpp:1305-1320: a collapsed bracket -- only at denormal speeds)
+         const int kEnd = ratio_lt_uniform(pH - pL, pH, 1e-20) ? 0 : 16;
+#pragma unroll 1
+         for (int k = 0; k < kEnd; ++k)
+         {
+            const double c = pTry;
+            pcand[k][lane] = c;
+            nCand = k + 1;
+            if (__builtin_amdgcn_readfirstlane((int)(c < 0.0))) break;                     // (failure exit of ba.cpp:1307: generic code)
+            if (__builtin_amdgcn_readfirstlane((int)(c * c > xstar)))
+            {
+               pvMask |= 1u << k;
+               if (pGoodN == 0)
+               {
+                  pLF = pLF * 2.0;                                                        // ba.cpp:1281-1285
+                  pH = c;
+                  pL = dmax(.999 * 0.0, (1.0 - pLF) * c);
+                  if (ratio_lt_uniform(pH - pL, pH, 1e-20)) break;                         // collapsed bracket (ba.cpp:1311-1315): generic code
+               }
+               else pH = c;
+            }
+            else
+            {
+               const bool convp = ratio_lt_uniform(fabs(c - pGood), c, sdotErrThresh);    // ba.cpp:1294 (c >= 0 here)
+               pGood = c;
+               ++pGoodN;
+               if (convp) { predicted = true; break; }
+               pL = c;
+            }
+            pTry = .5 * (pH + pL);
+         }
+         if (predicted)
+         {
+            bool agreed = true;
+#pragma unroll 1
+            for (int p0 = 0; p0 < nCand && agreed; p0 += 4)
+            {
+               const int left = nCand - p0;                       // candidates of this pass: min(left, 4)
+               const int idx = p0 + (cslot < left ? cslot : left - 1);
+               const double mine = pcand[idx][lane];
+               const bool violMine = verify(mine);                 // this slot's sddotL / sddotH stay in its lanes
+               const unsigned bal = (unsigned)__ballot(violMine);
+               const unsigned got = (bal & 1u) | ((bal >> 7) & 2u) | ((bal >> 14) & 4u) | ((bal >> 21) & 8u);
+               const unsigned valid = left >= 4 ? 0xFu : ((1u << left) - 1u);
+               agreed = ((got ^ (pvMask >> p0)) & valid) == 0u;
+            }
+            if (agreed)
+            {
+               sdotCur = pGood;                                    // the converged feasible speed, ba.cpp:1296-1302
+               const int src = 8 * ((nCand - 1) & 3);
+               sddotH = __shfl(sddotH, src);
+               sddotL = __shfl(sddotL, src);
+               sddot = (DIR == 1) ? sddotH : sddotL;
+               BK_TICK(tpp);
+               BK_ACC(cyD, tp2, tpp);
+               return;
+            }
+         }
+      }
 #endif
       // first check violated: replay of ba.cpp:1276-1321 from its first iteration, four candidates per pass.  The check of
       // the first candidate has just been done: it is folded into the first pass below (slot 0 re-evaluates it, same bits).
