@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    int nfail = 0;
 #ifdef BK_PROFILE_SECTIONS
    // diagnostic build: cycles in velocity limit / spline evaluation / first check / bisection passes, stages that bisect, passes
-   unsigned long long cyA = 0, cyB = 0, cyC = 0, cyD = 0, nBis = 0, nPass = 0, nStage = 0;
+   unsigned long long cyA = 0, cyB = 0, cyC = 0, cyD = 0, nBis = 0, nPass = 0, nStage = 0, cyP1 = 0, cyP2 = 0, cyP3 = 0, nAcc = 0;
 #endif
 
 #if S1_STAGE_LOOP
@@ -556,46 +556,63 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
          xs = vmin_f64(xs, dpp_mov<DPP_ROW_ROR8>(xs));
          xs = vmin_f64(xs, __shfl_xor(xs, 16));
          const double xstar = xs;
+         BK_TICK(tq1);
+         BK_ACC(cyP1, tp2, tq1);
 
          double (*pcand)[32] = predAll[(FEAT <= 0) ? (threadIdx.x >> 6) : 0];
          // state after the loop's first iteration (the violated first check: ba.cpp:1276-1285 with nIter = 0)
          const double c0 = sdotTry;
          double pLF = lowFact * 2.0, pH = c0, pL = dmax(.999 * 0.0, (1.0 - pLF) * c0), pGood = 0.0;
          double pTry = .5 * (pH + pL);
-         int pGoodN = 0, nCand = 0;
-         unsigned pvMask = 0;
+         int nCand = 0;
          bool predicted = false;
-         // (the first iteration's own failure exits, ba.cpp:1305-1320: a collapsed bracket -- only at denormal speeds)
-         const int kEnd = ratio_lt_uniform(pH - pL, pH, 1e-20) ? 0 : 16;
-#pragma unroll 1
-         for (int k = 0; k < kEnd; ++k)
+         // Speeds in the normal range only: every candidate is then positive and at least 2^-16 c0, the bracket of the search
+         // phase is [(1 - lowFact) c, c] with lowFact >= 0.02, so (H - L) / H >= 0.019 and the failure exits of ba.cpp:1305-1320
+         // (negative candidate, collapsed bracket, 100 iterations) cannot be taken within 16 candidates.
+         if (__ballot(c0 > 1e-280 && c0 < 1e280))
          {
-            const double c = pTry;
-            pcand[k][lane] = c;
-            nCand = k + 1;
-            if (__builtin_amdgcn_readfirstlane((int)(c < 0.0))) break;                     // (failure exit of ba.cpp:1307: generic code)
-            if (__builtin_amdgcn_readfirstlane((int)(c * c > xstar)))
+            // search for a first feasible speed (ba.cpp:1281-1285): the bracket shrinks below every violated candidate
+            int k = 0;
+            double c = pTry;
+#pragma unroll 1
+            for (; k < 15; ++k)
             {
-               pvMask |= 1u << k;
-               if (pGoodN == 0)
-               {
-                  pLF = pLF * 2.0;                                                        // ba.cpp:1281-1285
-                  pH = c;
-                  pL = dmax(.999 * 0.0, (1.0 - pLF) * c);
-                  if (ratio_lt_uniform(pH - pL, pH, 1e-20)) break;                         // collapsed bracket (ba.cpp:1311-1315): generic code
-               }
-               else pH = c;
+               if (!__ballot(c * c > xstar)) break;
+               pcand[k][lane] = -c;                       // predicted violated: recorded with the sign bit set
+               pLF = pLF * 2.0;
+               pH = c;
+               pL = dmax(.999 * 0.0, (1.0 - pLF) * c);
+               c = .5 * (pH + pL);
             }
-            else
+            if (k < 15)
             {
-               const bool convp = ratio_lt_uniform(fabs(c - pGood), c, sdotErrThresh);    // ba.cpp:1294 (c >= 0 here)
+               // c is the first predicted feasible candidate; it cannot end the loop (no feasible speed before it: ba.cpp:1294
+               // compares with sdotGood = 0).  Plain bisection from here (ba.cpp:1286-1303), one select-form body per candidate.
+               pcand[k][lane] = c;
                pGood = c;
-               ++pGoodN;
-               if (convp) { predicted = true; break; }
                pL = c;
+               ++k;
+               const double tLo = sdotErrThresh * (1.0 - 1e-13), tHi = sdotErrThresh * (1.0 + 1e-13);
+#pragma unroll 1
+               for (; k < 16; ++k)
+               {
+                  c = .5 * (pH + pL);
+                  const bool v = c * c > xstar;
+                  pcand[k][lane] = v ? -c : c;
+                  // convergence test of a feasible candidate, |c - good| / c < 1e-3 (ba.cpp:1294), decided by products when the
+                  // quotient is not within 1e-13 of the threshold (else: generic code)
+                  const double dist = fabs(c - pGood);
+                  const bool conv = !v && dist < tLo * c, unsure = !v && !conv && !(dist > tHi * c);
+                  pH = v ? c : pH;
+                  pL = v ? pL : c;
+                  pGood = v ? pGood : c;
+                  if (__ballot(conv || unsure)) { predicted = __ballot(conv) != 0; ++k; break; }
+               }
+               nCand = k;
             }
-            pTry = .5 * (pH + pL);
          }
+         BK_TICK(tq2);
+         BK_ACC(cyP2, tq1, tq2);
          if (predicted)
          {
             bool agreed = true;
@@ -603,16 +620,17 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
             for (int p0 = 0; p0 < nCand && agreed; p0 += 4)
             {
                const int left = nCand - p0;                       // candidates of this pass: min(left, 4)
-               const int idx = p0 + (cslot < left ? cslot : left - 1);
-               const double mine = pcand[idx][lane];
-               const bool violMine = verify(mine);                 // this slot's sddotL / sddotH stay in its lanes
-               const unsigned bal = (unsigned)__ballot(violMine);
-               const unsigned got = (bal & 1u) | ((bal >> 7) & 2u) | ((bal >> 14) & 4u) | ((bal >> 21) & 8u);
-               const unsigned valid = left >= 4 ? 0xFu : ((1u << left) - 1u);
-               agreed = ((got ^ (pvMask >> p0)) & valid) == 0u;
+               const double rec = pcand[p0 + (cslot < left ? cslot : left - 1)][lane];
+               const bool violMine = verify(fabs(rec));            // this slot's sddotL / sddotH stay in its lanes
+               agreed = __ballot(violMine != (__double2hiint(rec) < 0)) == 0;
             }
+            BK_TICK(tq3);
+            BK_ACC(cyP3, tq2, tq3);
             if (agreed)
             {
+#ifdef BK_PROFILE_SECTIONS
+               ++nAcc;
+#endif
                sdotCur = pGood;                                    // the converged feasible speed, ba.cpp:1296-1302
                const int src = 8 * ((nCand - 1) & 3);
                sddotH = __shfl(sddotH, src);
@@ -893,6 +911,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       double *q = a.prof + 8 * p;
       q[0] = (double)cyA; q[1] = (double)cyB; q[2] = (double)cyC; q[3] = (double)cyD; q[4] = (double)(tend - tstart);
       q[5] = (double)nStage; q[6] = (double)nBis; q[7] = (double)nPass;
+      if (a.B == 1) { q[8] = (double)cyP1; q[9] = (double)cyP2; q[10] = (double)cyP3; q[11] = (double)nAcc; }
    }
 #endif
 

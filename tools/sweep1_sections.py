@@ -40,3 +40,8 @@ for d, name in ((-1, "reverse"), (+1, "forward")):
           f"spline evaluation {raw[:,1].sum()/tot:.3f}, first check {raw[:,2].sum()/tot:.3f}, bisection passes {raw[:,3].sum()/tot:.3f}, "
           f"rest {1 - raw[:,:4].sum()/tot:.3f}; stages that bisect {bis/st:.3f}, passes per bisecting stage {ps/max(bis,1):.2f}, "
           f"cycles per pass {raw[:,3].sum()/max(ps,1):.0f}")
+    if a.paths == 1:
+        ex = b.mvc(0)[0][8:12]
+        if ex[3] > 0:
+            print(f"   predicted bisection: accepted {ex[3]:.0f} of {bis:.0f} bisecting stages; cycles per bisecting stage: x* {ex[0]/bis:.0f}, "
+                  f"replay of the candidate sequence {ex[1]/bis:.0f}, verification passes {ex[2]/bis:.0f}")
