@@ -27,6 +27,7 @@ F_JNT_ACC_ON, F_TRQ_ON, F_CART_VEL_ON, F_CART_ACC_ON = 1 << 0, 1 << 1, 1 << 2, 1
 F_PARALLEL, F_PAR2SER, F_HOST_TRIG, F_NO_SAMPLES, F_COMPACT_SPLINES = 1 << 4, 1 << 5, 1 << 6, 1 << 7, 1 << 8
 F_CURVES_IN_PLACE = 1 << 9  # the forward curve overwrites the reverse curve (one curve buffer per path)
 F_MVC_IN_CURVES = 1 << 10   # the pointwise evaluation writes into the curve buffers (valid until a sweep starts)
+F_SVD = 1 << 11             # solveLinSys by Jacobi SVD instead of LU (_isSVD)
 # per-path status bits
 ST_MAX_INTEG_TIME, ST_CAPACITY, ST_BISECT_FAIL = 1 << 0, 1 << 1, 1 << 2
 ST_NONFINITE, ST_SHORT, ST_SEG_ERROR = 1 << 3, 1 << 4, 1 << 5

@@ -388,6 +388,156 @@ __device__ void lu3_solve(const double *A /* row-major 3x3 */, const double *b, 
    x[0] = r0; x[1] = r1; x[2] = r2;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The isSVD = 1 branch of solveLinSys (util.cpp:421-438) for the 3x3 wrench systems: Eigen's two-sided Jacobi SVD
+// (JacobiSVD<MatrixXd>(A, ComputeThinU | ComputeThinV), Eigen 3.3) and its solve, written out: work matrix = A scaled by its
+// largest entry; sweeps over the pairs q < p; an off-diagonal pair above max(DBL_MIN, 2 eps max|diag|) is removed by a rotation
+// that makes the 2x2 block symmetric followed by the symmetric Jacobi rotation (JacobiRotation::makeJacobi), both accumulated
+// into U / V; singular values = |diag| x scale, descending; x = V diag(1/sigma) U^T b over the numerical rank (three-term sums
+// left to right).  Pinned by the reference binary's isSVD = 1 outputs (tests/golden/CSPR3DOF_svd, CSPR3DOF_par_svd).
+// ---------------------------------------------------------------------------------------------
+struct Rot2 { double c, s; };
+__device__ __forceinline__ void rot_pair(double &x, double &y, const Rot2 g)
+{
+   const double a = x, b = y;
+   x = g.c * a + g.s * b;       // apply_rotation_in_the_plane
+   y = -g.s * a + g.c * b;
+}
+__device__ inline void svd3_solve(const double *A /* row-major 3x3 */, const double *b, double *x)
+{
+   const double tiny = 2.2250738585072014e-308, eps = 2.220446049250313e-16;
+   double W[3][3], U[3][3], V[3][3];
+   double scale = 0.0;
+#pragma unroll
+   for (int k = 0; k < 9; ++k) scale = fmax(scale, fabs(A[k]));
+   if (scale == 0.0) scale = 1.0;
+#pragma unroll
+   for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+      {
+         W[i][j] = A[i * 3 + j] / scale;
+         U[i][j] = (i == j) ? 1.0 : 0.0;
+         V[i][j] = (i == j) ? 1.0 : 0.0;
+      }
+   double diagMax = fmax(fmax(fabs(W[0][0]), fabs(W[1][1])), fabs(W[2][2]));
+   for (int sweep = 0; sweep < 64; ++sweep)      // (Eigen loops until a sweep finds nothing; a 3x3 matrix needs a handful)
+   {
+      bool clean = true;
+#pragma unroll
+      for (int pq = 0; pq < 3; ++pq)
+      {
+         const int p = pq == 0 ? 1 : 2, q = pq == 2 ? 1 : 0;    // (1,0), (2,0), (2,1)
+         const double limit = fmax(tiny, 2.0 * eps * diagMax);
+         if (!(fabs(W[p][q]) > limit || fabs(W[q][p]) > limit)) continue;
+         clean = false;
+         double b00 = W[p][p], b01 = W[p][q], b10 = W[q][p], b11 = W[q][q];
+         Rot2 sym = {1.0, 0.0};
+         const double trace = b00 + b11, skew = b10 - b01;
+         if (!(fabs(skew) < tiny))
+         {
+            const double u = trace / skew;
+            const double h = sqrt(1.0 + u * u);
+            sym.s = 1.0 / h;
+            sym.c = u / h;
+         }
+         if (!(sym.c == 1.0 && sym.s == 0.0)) { rot_pair(b00, b10, sym); rot_pair(b01, b11, sym); }
+         Rot2 right = {1.0, 0.0};
+         {
+            const double twice = 2.0 * fabs(b01);
+            if (!(twice < tiny))
+            {
+               const double tau = (b00 - b11) / twice;
+               const double w = sqrt(tau * tau + 1.0);
+               const double t = tau > 0.0 ? 1.0 / (tau + w) : 1.0 / (tau - w);
+               const double sgn = t > 0.0 ? 1.0 : -1.0;
+               const double n = 1.0 / sqrt(t * t + 1.0);
+               right.s = -sgn * (b01 / fabs(b01)) * fabs(t) * n;
+               right.c = n;
+            }
+         }
+         const Rot2 rightT = {right.c, -right.s};
+         const Rot2 left = {sym.c * rightT.c - sym.s * rightT.s, sym.c * rightT.s + sym.s * rightT.c};
+         if (!(left.c == 1.0 && left.s == 0.0))
+         {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rot_pair(W[p][k], W[q][k], left);   // rows p, q of W
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rot_pair(U[k][p], U[k][q], left);   // columns p, q of U
+         }
+         if (!(rightT.c == 1.0 && rightT.s == 0.0))
+         {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rot_pair(W[k][p], W[k][q], rightT); // columns p, q of W
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rot_pair(V[k][p], V[k][q], rightT); // columns p, q of V
+         }
+         diagMax = fmax(diagMax, fmax(fabs(W[p][p]), fabs(W[q][q])));
+      }
+      if (clean) break;
+   }
+   double sg[3];
+#pragma unroll
+   for (int i = 0; i < 3; ++i)
+   {
+      const double d = W[i][i];
+      sg[i] = fabs(d);
+      if (d < 0.0) { U[0][i] = -U[0][i]; U[1][i] = -U[1][i]; U[2][i] = -U[2][i]; }
+   }
+#pragma unroll
+   for (int i = 0; i < 3; ++i) sg[i] *= scale;
+   int nonzero = 3;
+#pragma unroll
+   for (int i = 0; i < 3; ++i)
+   {
+      if (i >= nonzero) continue;
+      int at = i;
+#pragma unroll
+      for (int k = 1; k < 3; ++k)
+         if (k > i && sg[k] > sg[at]) at = k;
+      if (sg[at] == 0.0) { nonzero = i; continue; }
+      if (at != i)
+      {
+#pragma unroll
+         for (int k = 0; k < 3; ++k)
+            if (k == at)
+            {
+               swap_d(sg[i], sg[k]);
+#pragma unroll
+               for (int r = 0; r < 3; ++r) { swap_d(U[r][i], U[r][k]); swap_d(V[r][i], V[r][k]); }
+            }
+      }
+   }
+   if (sg[0] / sg[2] < 100.0 * eps) return;                       // util.cpp:424-426: reported ill-conditioned, x untouched
+   int rank = nonzero;
+   {
+      const double cut = fmax(sg[0] * (3.0 * eps), tiny);
+#pragma unroll
+      for (int k = 2; k >= 0; --k)
+         if (rank == k + 1 && sg[k] < cut) rank = k;
+   }
+   double y[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+   for (int k = 0; k < 3; ++k)
+      if (k < rank) y[k] = (1.0 / sg[k]) * ((U[0][k] * b[0] + U[1][k] * b[1]) + U[2][k] * b[2]);
+#pragma unroll
+   for (int r = 0; r < 3; ++r)
+   {
+      double acc = 0.0;
+      if (rank > 0) acc = V[r][0] * y[0];
+      if (rank > 1) acc = acc + V[r][1] * y[1];
+      if (rank > 2) acc = acc + V[r][2] * y[2];
+      x[r] = acc;
+   }
+}
+
+// solveLinSys (util.cpp:413-442): Eigen's partial-pivot LU, or its Jacobi SVD when the problem says so (BATOTP_F_SVD)
+__device__ __forceinline__ void solve3(unsigned flags, const double *A, const double *b, double *x)
+{
+   if (flags & BATOTP_F_SVD) svd3_solve(A, b, x);
+   else lu3_solve(A, b, x);
+}
+
 // Robot::setA (robot.cpp:534-558): A[i][j] = (cart[i] - pmat[i][j]) / theta[j]
 __device__ __forceinline__ void cspr_setA(const double *pmat, const double *th, const double *ca, double *A)
 {
@@ -442,10 +592,10 @@ __global__ void k_dynamics(DevProblem P, const DevProblem *__restrict__ dP, cons
             th[j] = sp[((int64_t)j * 3) * N + i];
          }
          cspr_setA(dP->pmat, th, ca, A);
-         lu3_solve(A, a1, xs); a1[0] = xs[0]; a1[1] = xs[1]; a1[2] = xs[2];
-         lu3_solve(A, a2, xs); a2[0] = xs[0]; a2[1] = xs[1]; a2[2] = xs[2];
-         lu3_solve(A, a3, xs); a3[0] = xs[0]; a3[1] = xs[1]; a3[2] = xs[2];
-         lu3_solve(A, a4, xs); a4[0] = xs[0]; a4[1] = xs[1]; a4[2] = xs[2];
+         solve3(P.flags, A, a1, xs); a1[0] = xs[0]; a1[1] = xs[1]; a1[2] = xs[2];
+         solve3(P.flags, A, a2, xs); a2[0] = xs[0]; a2[1] = xs[1]; a2[2] = xs[2];
+         solve3(P.flags, A, a3, xs); a3[0] = xs[0]; a3[1] = xs[1]; a3[2] = xs[2];
+         solve3(P.flags, A, a4, xs); a4[0] = xs[0]; a4[1] = xs[1]; a4[2] = xs[2];
       }
 #pragma unroll
       for (int j = 0; j < 3; ++j)
@@ -1048,7 +1198,7 @@ __device__ __forceinline__ bool verify_second_order(Pt<G, FEAT, UNI> &t, int j, 
                      if (jj == 1) As[k * 3 + 1] = na1;
                      if (jj == 2) As[k * 3 + 2] = na1;
                   }
-                  lu3_solve(As, bs, xs);
+                  solve3(t.flags, As, bs, xs);
                   sol[ii] = (jj == 0) ? xs[0] : (jj == 1) ? xs[1] : xs[2];
                }
                H = dmin(H, dmax(sol[0], sol[1]));

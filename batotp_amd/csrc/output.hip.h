@@ -34,6 +34,7 @@ struct OutParams
    int window;      // (int)_outSmoothFact when smoothing, else 0
    int reinterp;
    int compact;     // the batch keeps (value, second derivative) pairs instead of coefficient rows
+   int svd;         // BATOTP_F_SVD: the cable tensions through the Jacobi SVD instead of the LU
    int C, Cin;
    double outRes;
    double vfactT, afactT; // cable robot: 1/tfact and its square, tfact = outRes/smoothFact (ba.cpp:1754)
@@ -235,7 +236,7 @@ __global__ void k_out_trq(OutParams P, const OutPath *__restrict__ paths, int K,
       b[j] = a2 + a3 + a4;
    }
    cspr_setA(P.pmat, val, val + 3, A);
-   lu3_solve(A, b, xs);
+   solve3(P.svd ? (unsigned)BATOTP_F_SVD : 0u, A, b, xs);
    double *__restrict__ o = dst + op.off1 * P.R + i;
 #pragma unroll
    for (int r = 0; r < 6; ++r) o[(int64_t)r * n1] = val[r];

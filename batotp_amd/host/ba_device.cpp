@@ -114,6 +114,7 @@ void BA::fillProblem(void *out) const
    if (_isCartAccConOn) f |= BATOTP_F_CART_ACC_ON;
    if (_isParallelMechOrig) f |= BATOTP_F_PARALLEL;
    if (_isPar2Ser) f |= BATOTP_F_PAR2SER;
+   if (_isSVD) f |= BATOTP_F_SVD;
    // cos/sin from the host libm: bit parity with the reference (RR), and with the host twin of the chain model
    // ... and with the forward kinematics of the device resampler / output stage (KUKA, RR)
    //     and with the pose conversions of a BOTH path (atan2 of the output stage)
@@ -240,7 +241,7 @@ int BA::exportOutputParams(void *out) const
    if (_isInterpOnly) return -1;
    if (!(_outRes > 0) || !(_integRes > 0) || !(_outSmoothFact >= 1)) return -1;
    const bool joint = _pathType == JOINT && _robotType == GENJNT && !_isTrqConOn;
-   const bool cable = _pathType == CART && _robotType == CSPR3DOF && _nJoints == 3 && _nCart == 3 && _isTrqConOn && _isParallelMechOrig && !_isSVD;
+   const bool cable = _pathType == CART && _robotType == CSPR3DOF && _nJoints == 3 && _nCart == 3 && _isTrqConOn && _isParallelMechOrig;
    // JOINT paths of the robots with forward kinematics: Cartesian rows by Robot::fwdKin at the output points (reference
    // ba.cpp:1722-1725) and, with torque constraints, the serial-robot torque recomputation (ba.cpp:1791-1827) with the
    // two-link arm's closed form or the chain model

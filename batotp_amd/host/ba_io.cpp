@@ -210,13 +210,6 @@ int BA::finishConfig()
    for (unsigned int j = 0; j < _nJoints && j < _JntTrqMin.size() && j < _JntTrqMax.size(); ++j)
       if (std::isnan(_JntTrqMin[j])) _JntTrqMin[j] = -_JntTrqMax[j];   // NAN lower torque limit = symmetric limits
    _quadraticRadThresh = _cartThresh * _cartThresh;
-   if (_isSVD && _isParallelMech && _isTrqConOn)
-   {
-      // reference util.cpp:421-438 solves the wrench system with Eigen's JacobiSVD when isSVD = 1; only the LU solve
-      // (isSVD = 0, every shipped configuration) exists here -- refuse rather than answer with a different solver
-      printf("Error in readInputData(): isSVD = 1 (Jacobi-SVD solve of the cable wrench system) is not implemented; use isSVD = 0 (LU).\n");
-      return -1;
-   }
    if (_sWeights.size() < 3) _sWeights.resize(3, 0.0);
    const double wSum = _sWeights[0] + _sWeights[1] + _sWeights[2];
    if (wSum <= 0)

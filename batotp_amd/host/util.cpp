@@ -221,20 +221,156 @@ double findMedian(std::vector<double> &x)
    return .5 * (sorted[mid - 1] + sorted[mid]);
 }
 
-// Dense solve A x = b (reference util.cpp:413-442 calls Eigen's PartialPivLU; the SVD branch is
-// not used by any shipped configuration).  Same elimination order as Eigen's unblocked LU:
+// The isSVD = 1 branch of solveLinSys (reference util.cpp:421-438): Eigen's JacobiSVD<MatrixXd>(A, ComputeThinU | ComputeThinV)
+// and its solve(), written out for a square real matrix (Eigen 3.3: JacobiSVD.h, Jacobi.h, SVDBase.h).  Work matrix = A scaled by
+// its largest entry; sweeps over the index pairs q < p, each off-diagonal pair above max(DBL_MIN, 2 eps max|diag|) removed by a
+// left and a right plane rotation that are accumulated into U and V; singular values = |diagonal| x scale in descending order;
+// x = V diag(1/sigma) U^T b over the numerical rank.  The three-term sums of the last step are added left to right, which is what
+// reproduces the reference binary's isSVD = 1 outputs (tests/golden/CSPR3DOF_svd, CSPR3DOF_par_svd).
+namespace
+{
+struct PlaneRot { double c, s; };
+
+// x <- c x + s y,  y <- -s x + c y  over two strided vectors (Eigen: apply_rotation_in_the_plane)
+void rotatePair(double *x, int strideX, double *y, int strideY, int count, const PlaneRot &g)
+{
+   if (g.c == 1.0 && g.s == 0.0) return;
+   for (int k = 0; k < count; ++k)
+   {
+      const double a = x[k * strideX], b = y[k * strideY];
+      x[k * strideX] = g.c * a + g.s * b;
+      y[k * strideY] = -g.s * a + g.c * b;
+   }
+}
+
+// the rotation that diagonalises the symmetric 2x2 block [x y; y z] (Eigen: JacobiRotation::makeJacobi)
+PlaneRot symmetricJacobi(double x, double y, double z)
+{
+   PlaneRot g = {1.0, 0.0};
+   const double twice = 2.0 * std::abs(y);
+   if (twice < std::numeric_limits<double>::min()) return g;
+   const double tau = (x - z) / twice;
+   const double w = std::sqrt(tau * tau + 1.0);
+   const double t = tau > 0.0 ? 1.0 / (tau + w) : 1.0 / (tau - w);
+   const double sgn = t > 0.0 ? 1.0 : -1.0;
+   const double n = 1.0 / std::sqrt(t * t + 1.0);
+   g.s = -sgn * (y / std::abs(y)) * std::abs(t) * n;
+   g.c = n;
+   return g;
+}
+
+bool jacobiSvdSolve(const std::vector<std::vector<double>> &Av, const std::vector<double> &bv, std::vector<double> &xv)
+{
+   const int n = (int)bv.size();
+   const double tiny = std::numeric_limits<double>::min(), eps = std::numeric_limits<double>::epsilon();
+   std::vector<double> W((size_t)n * n), U((size_t)n * n, 0.0), V((size_t)n * n, 0.0), sigma(n);
+   double scale = 0.0;
+   for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) scale = std::max(scale, std::abs(Av[i][j]));
+   if (scale == 0.0) scale = 1.0;
+   double diagMax = 0.0;
+   for (int i = 0; i < n; ++i)
+   {
+      for (int j = 0; j < n; ++j) W[(size_t)i * n + j] = Av[i][j] / scale;
+      U[(size_t)i * n + i] = 1.0;
+      V[(size_t)i * n + i] = 1.0;
+      diagMax = std::max(diagMax, std::abs(W[(size_t)i * n + i]));
+   }
+   for (bool clean = false; !clean;)
+   {
+      clean = true;
+      for (int p = 1; p < n; ++p)
+         for (int q = 0; q < p; ++q)
+         {
+            const double limit = std::max(tiny, 2.0 * eps * diagMax);
+            if (!(std::abs(W[(size_t)p * n + q]) > limit || std::abs(W[(size_t)q * n + p]) > limit)) continue;
+            clean = false;
+            // 2x2 block (p,p) (p,q) / (q,p) (q,q): first a rotation that makes it symmetric, then the symmetric Jacobi rotation
+            double b00 = W[(size_t)p * n + p], b01 = W[(size_t)p * n + q], b10 = W[(size_t)q * n + p], b11 = W[(size_t)q * n + q];
+            PlaneRot sym = {1.0, 0.0};
+            const double trace = b00 + b11, skew = b10 - b01;
+            if (!(std::abs(skew) < tiny))
+            {
+               const double u = trace / skew;
+               const double h = std::sqrt(1.0 + u * u);
+               sym.s = 1.0 / h;
+               sym.c = u / h;
+            }
+            {
+               double row0[2] = {b00, b01}, row1[2] = {b10, b11};
+               rotatePair(row0, 1, row1, 1, 2, sym);
+               b00 = row0[0]; b01 = row0[1]; b11 = row1[1];
+            }
+            const PlaneRot right = symmetricJacobi(b00, b01, b11);
+            const PlaneRot rightT = {right.c, -right.s};
+            const PlaneRot left = {sym.c * rightT.c - sym.s * rightT.s, sym.c * rightT.s + sym.s * rightT.c};
+            rotatePair(&W[(size_t)p * n], 1, &W[(size_t)q * n], 1, n, left);          // rows p, q of W
+            rotatePair(&U[p], n, &U[q], n, n, left);                                    // columns p, q of U
+            rotatePair(&W[p], n, &W[q], n, n, rightT);                                  // columns p, q of W
+            rotatePair(&V[p], n, &V[q], n, n, rightT);                                  // columns p, q of V
+            diagMax = std::max(diagMax, std::max(std::abs(W[(size_t)p * n + p]), std::abs(W[(size_t)q * n + q])));
+         }
+   }
+   for (int i = 0; i < n; ++i)
+   {
+      const double d = W[(size_t)i * n + i];
+      sigma[i] = std::abs(d);
+      if (d < 0.0)
+         for (int r = 0; r < n; ++r) U[(size_t)r * n + i] = -U[(size_t)r * n + i];
+   }
+   for (int i = 0; i < n; ++i) sigma[i] *= scale;
+   int nonzero = n;
+   for (int i = 0; i < n; ++i)
+   {
+      int at = i;
+      for (int k = i + 1; k < n; ++k)
+         if (sigma[k] > sigma[at]) at = k;
+      if (sigma[at] == 0.0) { nonzero = i; break; }
+      if (at != i)
+      {
+         std::swap(sigma[i], sigma[at]);
+         for (int r = 0; r < n; ++r)
+         {
+            std::swap(U[(size_t)r * n + i], U[(size_t)r * n + at]);
+            std::swap(V[(size_t)r * n + i], V[(size_t)r * n + at]);
+         }
+      }
+   }
+   // reference util.cpp:424-426
+   if (sigma[0] / sigma[n - 1] < 100.0 * eps) return true;
+   int rank = nonzero;
+   {
+      const double cut = std::max(sigma[0] * ((double)n * eps), tiny);
+      while (rank > 0 && sigma[rank - 1] < cut) --rank;
+   }
+   std::vector<double> y(rank);
+   for (int k = 0; k < rank; ++k)
+   {
+      double acc = U[k] * bv[0];
+      for (int r = 1; r < n; ++r) acc += U[(size_t)r * n + k] * bv[r];
+      y[k] = (1.0 / sigma[k]) * acc;
+   }
+   for (int r = 0; r < n; ++r)
+   {
+      double acc = 0.0;
+      if (rank > 0)
+      {
+         acc = V[(size_t)r * n] * y[0];
+         for (int k = 1; k < rank; ++k) acc += V[(size_t)r * n + k] * y[k];
+      }
+      xv[r] = acc;
+   }
+   return false;
+}
+} // namespace
+
+// Dense solve A x = b (reference util.cpp:413-442 calls Eigen's PartialPivLU, or its JacobiSVD when isSVD is set).  Same elimination order as Eigen's unblocked LU:
 // first-max partial pivoting, column scaling by true division, rank-1 trailing update, then a
 // column-oriented unit-lower / upper substitution.  Returns isIllCond (always false here).
 bool solveLinSys(const std::vector<std::vector<double>> &Av, const std::vector<double> &bv,
                  std::vector<double> &xv, const bool isSVD)
 {
-   if (isSVD)
-   {
-      // reference util.cpp:421-438 (Eigen JacobiSVD): not implemented.  BA refuses such a configuration when it is
-      // loaded (ba_io.cpp); a direct caller gets the ill-conditioned answer (x untouched) instead of an LU result
-      printf("solveLinSys(): isSVD = 1 is not implemented (only the LU solve is).\n");
-      return true;
-   }
+   if (isSVD) return jacobiSvdSolve(Av, bv, xv);
    const int dim = (int)bv.size();
    std::vector<double> lu((size_t)dim * dim);
    std::vector<double> rhs(bv);

@@ -84,6 +84,10 @@ extern "C" {
                                             sweep invalidates the curves (the reverse sweep has to run again).  The overlap
                                             mode (batotp_hip_set_overlap) is ignored for such a batch.  Same results. */
 
+#define BATOTP_F_SVD             (1u<<11) /* _isSVD: solveLinSys (the 3x3 wrench systems of a parallel mechanism: per-knot conversion with
+                                            BATOTP_F_PAR2SER, every constraint check without it, the tensions of the output stage)
+                                            uses Eigen's two-sided Jacobi SVD instead of its partial-pivot LU (util.cpp:421-438) */
+
 /* per-path status bits written by the sweep kernel (the reference only printf()s these) */
 #define BATOTP_ST_MAX_INTEG_TIME (1u<<0) /* ba.cpp:1117-1122 (MAX_INTEGRATION_TIME)        */
 #define BATOTP_ST_CAPACITY       (1u<<1) /* output capacity max_steps exhausted            */

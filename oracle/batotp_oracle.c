@@ -410,7 +410,7 @@ int bo_precompute_dyn(const batotp_problem *prob, bo_path *p, const double *trig
             bo_cspr_setA(prob->pmat, th, ca, A);
             for (k = 0; k < 4; k++) {
                 for (j = 0; j < 3; j++) bs[j] = ak[k][(int64_t)j * n + i];
-                bo_solve_lin_sys(3, A, bs, xs);
+                bo_solve(prob, 3, A, bs, xs);
                 for (j = 0; j < 3; j++) ak[k][(int64_t)j * n + i] = xs[j];
             }
         }
@@ -599,7 +599,7 @@ static int verify_second_order(sweep_ctx *c, double sdotCur, double sddotMax)
                         bStar[k] = cStar1[k] - c->Apt[k * nJ + j] * trqLim[ii];
                         Astar[k * nJ + j] = -c->a1pt[k];
                     }
-                    bo_solve_lin_sys(nC, Astar, bStar, xStar);
+                    bo_solve(prob, nC, Astar, bStar, xStar);
                     sol[ii] = xStar[j];
                 }
                 c->sddot_h = dmin(c->sddot_h, dmax(sol[0], sol[1]));

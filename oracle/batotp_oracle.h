@@ -134,6 +134,11 @@ void bo_q2aa_rows(double *rows, int64_t stride, int64_t n);
 void bo_rr_dyn_trig(double th1, double th2, double out[4]);
 /* Robot::dynRR (robot.cpp:377-431) on the samples of p (value, d/ds, d2/ds2 of the two joints); trig: optional [4][n] table */
 void bo_dyn_rr(const bo_path *p, const double *trig, double *a1, double *a2, double *a3, double *a4);
+/* solveLinSys with isSVD = 1 (util.cpp:421-438): Eigen's two-sided Jacobi SVD and its solve, restated in batotp_oracle_svd.c.
+ * A row-major [n][n]; returns 1 (x untouched) if the system is reported ill-conditioned.  bo_solve picks by BATOTP_F_SVD. */
+int  bo_solve_lin_sys_svd(int n, const double *A, const double *b, double *x);
+void bo_solve(const batotp_problem *prob, int n, const double *A, const double *b, double *x);
+extern int bo_svd_order[2];
 /* Robot::setA for CSPR3DOF (robot.cpp:534-558), A row-major [3][3] */
 void bo_cspr_setA(const double *pmat, const double *theta, const double *cart, double *A);
 

@@ -239,7 +239,7 @@ int bo_output(const batotp_problem *prob, const batotp_output_params *prm, const
                 th[j] = x[(size_t)j * n + i];
             }
             bo_cspr_setA(prob->pmat, th, ca, A);
-            bo_solve_lin_sys(3, A, b, xs);
+            bo_solve(prob, 3, A, b, xs);
             for (int j = 0; j < 3; ++j) x[(size_t)(nJ + nC + j) * n + i] = xs[j];
         }
         free(cD2);

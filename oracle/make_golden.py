@@ -126,6 +126,9 @@ CASES = {
     "RR_acc": (shipped("RR", {"isJntAccConOn": 1, "JntAccLims": "900 900"}), True),  # torque + joint accel
     "UR5_nocartacc": (shipped("UR5", {"isCartAccConOn": 0}), True),
     "KUKA_cartacc": (shipped("KUKA-LWR-IV", {"isCartAccConOn": 1, "CartAccMax": 2.0}), True),
+    # solveLinSys through Eigen's Jacobi SVD (util.cpp:421-438): per-knot conversion (isPar2Ser = 1) / every constraint check (0)
+    "CSPR3DOF_svd": (shipped("CSPR3DOF", {"isSVD": 1}), True),
+    "CSPR3DOF_par_svd": (shipped("CSPR3DOF", {"isSVD": 1, "isPar2Ser": 0}), True),
     # synthetic inputs in the shapes of BASELINE configs 2, 4, 5 (small, kept in full)
     "synth_gen7dof_s0": (synth_gen7dof(0, 60), True),
     "synth_gen7dof_s1_vel": (synth_gen7dof(1, 40, jnt_acc_on=0), True),

@@ -106,14 +106,22 @@ def test_batch_driver_grows_a_shared_curve_buffer_when_only_the_forward_curve_ru
         assert not os.path.exists(many / d / "s-sdot.dat")
 
 
-def test_svd_solver_is_refused_not_silently_replaced(tmp_path, oracle_lib):
-    """isSVD = 1 on the cable robot asks for the Jacobi-SVD solve (reference util.cpp:421-438), which does not exist here:
-    the configuration is refused with a message instead of being answered by the LU solve"""
-    src = os.path.join(helpers.GOLD, "CSPR3DOF")
+def test_svd_solver_reproduces_the_reference_binary(tmp_path, oracle_lib):
+    """isSVD = 1 on the cable robot: solveLinSys goes through the two-sided Jacobi SVD of Eigen (reference util.cpp:421-438),
+    restated in the host library (util.cpp), the checker (batotp_oracle_svd.c) and the kernels.  The reference binary's own
+    isSVD = 1 outputs differ from its LU outputs in dozens of float32 values -- and are what the drop-in writes (the golden
+    cases CSPR3DOF_svd / CSPR3DOF_par_svd are part of FULL_CASES above); here: the two solvers really are different code paths"""
+    for name, other in (("CSPR3DOF_svd", "CSPR3DOF"), ("CSPR3DOF_par_svd", "CSPR3DOF_par")):
+        a = open(os.path.join(helpers.GOLD, name, "ref_s-sdot.dat"), "rb").read()
+        b = open(os.path.join(helpers.GOLD, other, "ref_s-sdot.dat"), "rb").read()
+        assert a != b
+    src = os.path.join(helpers.GOLD, "CSPR3DOF_par_svd")
     _stage(src, tmp_path)
-    _edit_config(tmp_path / "config.dat", {"isSVD": "1"})
-    r = subprocess.run([os.path.join(helpers.BUILD, "batest_oracle"), "config.dat"], cwd=tmp_path, capture_output=True, text=True)
-    assert r.returncode != 0 and "isSVD = 1" in r.stdout and not os.path.exists(tmp_path / "traj_out.dat")
+    r = subprocess.run([os.path.join(helpers.BUILD, "batest_batch_oracle"), "config.dat", "2"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    for d in ("out_first", "out_last"):
+        assert filecmp.cmp(tmp_path / d / "s-sdot.dat", os.path.join(src, "ref_s-sdot.dat"), shallow=False)
+        assert filecmp.cmp(tmp_path / d / "traj_out.dat", os.path.join(src, "ref_traj_out.dat"), shallow=False)
 
 
 @pytest.mark.parametrize("name,mode", [("synth_gen7dof_s1_vel", None), ("synth_cspr_s3", None), ("RR", "host-output")])

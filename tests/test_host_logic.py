@@ -110,5 +110,7 @@ def test_which_configurations_the_device_stages_cover():
                                            "synth_gen7dof_s10_decim", "synth_ur_s2",
                                            # round 3: robots with forward kinematics, serial-robot torque recomputation,
                                            # pose paths (path type BOTH: axis-angle <-> quaternion)
-                                           "KUKA-LWR-IV", "KUKA_cartacc", "RR", "RR_acc", "UR5", "UR5_nocartacc"}
+                                           "KUKA-LWR-IV", "KUKA_cartacc", "RR", "RR_acc", "UR5", "UR5_nocartacc",
+                                           # the cable robot with solveLinSys through the Jacobi SVD (isSVD = 1)
+                                           "CSPR3DOF_svd", "CSPR3DOF_par_svd"}
     assert set(helpers.OUTPUT_CASES) == set(helpers.RESAMPLE_CASES) == set(helpers.FULL_CASES)   # every shipped example and edited variant
