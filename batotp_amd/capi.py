@@ -212,6 +212,7 @@ class Library:
             "batotp_hip_set_sweep_hold": [P, I32, I32],
             "batotp_hip_set_sweep_prefetch": [P, I32, I32],
             "batotp_hip_set_spline_tiles": [P, I32],
+            "batotp_hip_set_fast_forward": [P, I32],
             "batotp_hip_spline_tile_fallbacks": [P, C.POINTER(I32)],
             "batotp_hip_flat_loop_status": [P, C.POINTER(I32)],
             "batotp_hip_toolchain": [C.c_char_p, C.c_char_p, I32],
@@ -289,6 +290,10 @@ class Context:
 
     def set_sweep_prefetch(self, reverse: int, forward: int):
         self.library.check(self.library.lib.batotp_hip_set_sweep_prefetch(self.handle, reverse, forward), "set_sweep_prefetch")
+
+    def set_fast_forward(self, on):
+        """certified fast-forward of the bisection (include/batotp_hip.h); never changes a result"""
+        self.library.check(self.library.lib.batotp_hip_set_fast_forward(self.handle, 1 if on else 0), "set_fast_forward")
 
     def set_spline_tiles(self, on):
         """True / False, or -1 for the automatic choice (tiles for small batches)"""

@@ -92,6 +92,7 @@ struct batotp_ctx
    // toolchain the loop was validated with and the canary of flatLoopStatus agreed with the nested loops on this device),
    // -1 = built by another toolchain, -2 = the canary disagreed, -3 = the canary could not run
    int splineTiles = -1;  // K1 in tiles of knots (spline_tile.hip.h): -1 automatic (small batches), 1 always, 0 never
+   int fastForward = 1;   // certified fast-forward of the bisection in the sweep kernels that have it (bisect_fast_forward)
    int flatStatus = 0;
    char builtWith[192] = "";    // toolchain the gate compares (the real one unless BATOTP_ASSUME_TOOLCHAIN overrides it for a test)
 };
@@ -353,6 +354,13 @@ extern "C" int batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on)
 {
    if (!ctx) return BATOTP_ERR_ARG;
    ctx->splineTiles = on < 0 ? -1 : (on ? 1 : 0);
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_set_fast_forward(batotp_ctx *ctx, int32_t on)
+{
+   if (!ctx) return BATOTP_ERR_ARG;
+   ctx->fastForward = on ? 1 : 0;
    return BATOTP_OK;
 }
 
@@ -1170,6 +1178,7 @@ static void launchSweep(batotp_batch *b, SweepArgs &a)
    // the forward sweep only while every path has a wavefront to itself -- there the sweep waits a third of its time for the
    // dependent loads of segment changes (SQ_WAIT_ANY at B = 1, profiles/), with many paths per wavefront it cost +5 %
    a.touch = (a.dir == -1) ? 1 : (ppw == 1 ? 3 : 0);
+   a.ff = b->ctx->fastForward;
    if (b->ctx->sweepTouch[a.dir == -1 ? 0 : 1] >= 0) a.touch = b->ctx->sweepTouch[a.dir == -1 ? 0 : 1];
    const unsigned waves = (unsigned)((b->B + ppw - 1) / ppw);
    const unsigned grid = (waves + (K4_BLOCK / 64) - 1) / (K4_BLOCK / 64);
@@ -1223,7 +1232,7 @@ static bool sweep1Applies(const batotp_batch *b)
 
 static void launchSweep1(batotp_batch *b, SweepArgs &a)
 {
-   a.ppw = 1; a.hold = -1; a.touch = 0;
+   a.ppw = 1; a.hold = -1; a.touch = 0; a.ff = b->ctx->fastForward;
    b->lastLanes[a.dir == -1 ? 0 : 1] = 64; b->lastPpw[a.dir == -1 ? 0 : 1] = 1; b->lastHold[a.dir == -1 ? 0 : 1] = -1;
    const unsigned grid = (unsigned)((b->B + (S1_BLOCK / 64) - 1) / (S1_BLOCK / 64));
    hipStream_t st = b->ctx->stream;

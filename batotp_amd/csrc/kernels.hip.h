@@ -1746,6 +1746,7 @@ struct SweepArgs
    int ppw;       // paths per wavefront, 1 .. 64/G
    int hold;      // FLAT kernels: a stage is started once hold/8 of the wavefront's live paths wait for one
    int touch;     // software prefetch: bit 0 = spline rows ahead of the cursor, bit 1 = reverse curve ahead of its cursor (forward sweep)
+   int ff;        // k_sweep1: certified fast-forward of the bisection (sweep1.hip.h), batotp_hip_set_fast_forward
 };
 
 // Butcher tableau of ba.cpp:58-63 (_B[k][j]; stage j+1 uses column j)

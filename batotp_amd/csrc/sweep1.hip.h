@@ -78,11 +78,6 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    // wavefront were s_waitcnt without the windows: profiles/r02_e_*).
    __shared__ double2 winKAll[(FEAT < 0) ? S1_BLOCK / 64 : 1][(FEAT < 0) ? S1_WK * BATOTP_MAX_JOINTS : 1];
    __shared__ double2 winMAll[(DIR == 1) ? S1_BLOCK / 64 : 1][(DIR == 1) ? S1_WM : 1];
-#if S1_PREDICT
-   // predicted bisection: candidates and the last feasible speed known when each is tested; a column per lane (every lane of
-   // the wavefront holds the same numbers; own columns need neither a broadcast nor an exec mask)
-   __shared__ double predAll[(FEAT <= 0) ? S1_BLOCK / 64 : 1][(FEAT <= 0) ? 16 : 1][32];
-#endif
 #if S1_STAGE_LOOP
    // the stage values sdot_k, sddot_k (k = 0..6) of the step in flight: a slot per lane (every lane holds the same numbers; own
    // slots need neither a broadcast nor an exec mask), read back by the tableau combination of the later stages
@@ -176,7 +171,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    // make knots seg and seg + 1 available in winK: a coalesced copy of the window that extends from seg in the direction of
    // travel (two knots of slack behind it).  Fixed stride of 8 slots per knot: Cartesian channels the batch may carry are not
    // copied; slots beyond the last joint hold a copy of joint 0.
-   auto needK = [&](int seg) {
+   auto needK = [&](int seg) __attribute__((always_inline)) {
       if (seg >= wK0 && seg + 1 < wK0 + wKn) return;
       int w = (DIR == 1) ? seg - 2 : seg + 4 - S1_WK;
       const int wmax = n - S1_WK;
@@ -209,7 +204,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
    };
    // the same for points k and k + 1 of the reverse curve (a few points behind k stay in the window for the back-steps)
-   auto needM = [&](int k) {
+   auto needM = [&](int k) __attribute__((always_inline)) {
       if (k >= wM0 && k + 1 < wM0 + wMn) return;
       int w = k - 16;
       const int wmax = nMvc - S1_WM;
@@ -236,7 +231,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    };
 
    // BA::updateCurSeg on the knot sites (ba.cpp:1617-1652): the literal walk, sites sres*k recomputed only when the cursor moves
-   auto walkC = [&](double sCur) {
+   auto walkC = [&](double sCur) __attribute__((always_inline)) {
       const int lastSeg = n - 2;
       for (;;)
       {
@@ -260,7 +255,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    };
 
    // BA::evalSplinePartials for joint velocity / acceleration limits only (ba.cpp:1341-1366)
-   auto evalPartials = [&](double sCur) {
+   auto evalPartials = [&](double sCur) __attribute__((always_inline)) {
       walkC(sCur);
       if (segC != rowSeg)
       {
@@ -333,7 +328,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
 
    // BA::updateCurSeg on the reverse curve (ba.cpp:1592, 1617-1652) with the segment's two points cached in registers:
    // the literal walk of update_cur_seg<2>
-   auto mvcWalk = [&](double sCur) {
+   auto mvcWalk = [&](double sCur) __attribute__((always_inline)) {
       if (mvcSeg == segMVC && sCur >= mS0 && sCur <= mS1)
       {
          tauMVC = (sCur - mS0) / (mS1 - mS0);
@@ -366,7 +361,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    };
 
    // BA::sdotLim (ba.cpp:1204-1236); theta' is the one of the previous evalSplinePartials call, as in the reference
-   auto sdotLim = [&](double sCur, double &sdot) {
+   auto sdotLim = [&](double sCur, double &sdot) __attribute__((always_inline)) {
       if (DIR == 1)
       {
          mvcWalk(sCur);
@@ -393,7 +388,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
 
    // BA::verifySecondOrderConstraints, joint acceleration family (ba.cpp:1514-1534); see verify_second_order for why the
    // reference's early exits are the reduced predicate
-   auto verify = [&](double sdotTry) -> bool {
+   auto verify = [&](double sdotTry) __attribute__((always_inline)) -> bool {
       const double sdotSQ = sdotTry * sdotTry;
       double H = sddotMax, L = -sddotMax;
       bool force = false;
@@ -492,7 +487,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    // BA::applyAccelConstraintsBisectionPt (ba.cpp:1248-1332) with four candidates per pass: the reference's loop is replayed
    // literally; a speculated candidate is used only if it is bit-identical to the value the replay asks for (see
    // apply_accel_bisection_spec).  Returns 0, or -1 on the failure exits (sddot untouched).
-   auto accelPt = [&](double sCur, double &sddot) {
+   auto accelPt = [&](double sCur, double &sddot) __attribute__((always_inline)) {
       const double sdotErrThresh = .001;
       double lowFact = .01;
       double sdotGood = 0;
@@ -520,129 +515,6 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
 #ifdef BK_PROFILE_SECTIONS
       ++nBis;
 #endif
-#if S1_PREDICT
-      if (FEAT <= 0 && accOn)
-      {
-         // PREDICTED BISECTION (joint velocity / acceleration limits only).  The sddot intervals of the joints are
-         // [-a_j - m_j x, a_j - m_j x] in x = sdot^2 with a_j = amax_j / |theta'_j|, m_j = theta''_j / theta'_j (ba.cpp:1526-1531), a
-         // joint that stands still allows x <= amax_j / |theta''_j| (ba.cpp:1519-1524): they stop intersecting at
-         //    x* = min( min over pairs i, j with m_j > m_i of (a_i + a_j) / (m_j - m_i),  min over standing joints ).
-         // With x* the outcome of every check of the reference's loop (ba.cpp:1267-1321) is known in advance, so its candidate
-         // sequence -- geometric shrinking until a feasible speed is found, then bisection until two successive feasible speeds
-         // agree to 1e-3 -- is replayed here on wavefront-uniform values at a few instructions per iteration instead of a
-         // constraint check per iteration.  x* is computed with approximate reciprocals and is only a PREDICTION: afterwards
-         // every candidate is put through the real check (verify(), four candidates per pass, one per slot), and the result is
-         // taken only if all outcomes are the predicted ones -- then the loop above would have produced exactly this sequence,
-         // this final speed and these sddot bounds (those of the check of the last candidate).  Any disagreement (a candidate
-         // within rounding of the boundary, a limit this prediction does not model: +-sddotMax), a failure exit or more than 16
-         // candidates: the generic replay below runs from the start, as if this block did not exist.
-         auto fastRcp = [](double d) { double r = __builtin_amdgcn_rcp(d); return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r); };
-         const bool use = jv && !(fabs(thD) < thrV);
-         const double rv = fastRcp(use ? thD : 1.0);
-         const double aj = use ? amaxj * fabs(rv) : kInf;
-         const double mj = use ? thD2 * rv : 0.0;
-         const bool standing = jv && !use && !(fabs(thD2) < thrA);
-         double xs = standing ? amaxj * fastRcp(fabs(thD2)) : kInf;
-#pragma unroll
-         for (int rr = 0; rr < 2; ++rr)
-         {
-            const int srcLane = (lane & 24) | (cslot + 4 * rr);     // joint cslot + 4 rr of this lane's own slot
-            const double ai = __shfl(aj, srcLane), mi = __shfl(mj, srcLane);
-            const double dm = mj - mi;
-            const double bnd = (ai + aj) * fastRcp(dm > 0.0 ? dm : 1.0);
-            xs = dmin(xs, dm > 0.0 ? bnd : kInf);
-         }
-         xs = grp_min<8>(xs);
-         xs = vmin_f64(xs, dpp_mov<DPP_ROW_ROR8>(xs));
-         xs = vmin_f64(xs, __shfl_xor(xs, 16));
-         const double xstar = xs;
-         BK_TICK(tq1);
-         BK_ACC(cyP1, tp2, tq1);
-
-         double (*pcand)[32] = predAll[(FEAT <= 0) ? (threadIdx.x >> 6) : 0];
-         // state after the loop's first iteration (the violated first check: ba.cpp:1276-1285 with nIter = 0)
-         const double c0 = sdotTry;
-         double pLF = lowFact * 2.0, pH = c0, pL = dmax(.999 * 0.0, (1.0 - pLF) * c0), pGood = 0.0;
-         double pTry = .5 * (pH + pL);
-         int nCand = 0;
-         bool predicted = false;
-         // Speeds in the normal range only: every candidate is then positive and at least 2^-16 c0, the bracket of the search
-         // phase is [(1 - lowFact) c, c] with lowFact >= 0.02, so (H - L) / H >= 0.019 and the failure exits of ba.cpp:1305-1320
-         // (negative candidate, collapsed bracket, 100 iterations) cannot be taken within 16 candidates.
-         if (__ballot(c0 > 1e-280 && c0 < 1e280))
-         {
-            // search for a first feasible speed (ba.cpp:1281-1285): the bracket shrinks below every violated candidate
-            int k = 0;
-            double c = pTry;
-#pragma unroll 1
-            for (; k < 15; ++k)
-            {
-               if (!__ballot(c * c > xstar)) break;
-               pcand[k][lane] = -c;                       // predicted violated: recorded with the sign bit set
-               pLF = pLF * 2.0;
-               pH = c;
-               pL = dmax(.999 * 0.0, (1.0 - pLF) * c);
-               c = .5 * (pH + pL);
-            }
-            if (k < 15)
-            {
-               // c is the first predicted feasible candidate; it cannot end the loop (no feasible speed before it: ba.cpp:1294
-               // compares with sdotGood = 0).  Plain bisection from here (ba.cpp:1286-1303), one select-form body per candidate.
-               pcand[k][lane] = c;
-               pGood = c;
-               pL = c;
-               ++k;
-               const double tLo = sdotErrThresh * (1.0 - 1e-13), tHi = sdotErrThresh * (1.0 + 1e-13);
-#pragma unroll 1
-               for (; k < 16; ++k)
-               {
-                  c = .5 * (pH + pL);
-                  const bool v = c * c > xstar;
-                  pcand[k][lane] = v ? -c : c;
-                  // convergence test of a feasible candidate, |c - good| / c < 1e-3 (ba.cpp:1294), decided by products when the
-                  // quotient is not within 1e-13 of the threshold (else: generic code)
-                  const double dist = fabs(c - pGood);
-                  const bool conv = !v && dist < tLo * c, unsure = !v && !conv && !(dist > tHi * c);
-                  pH = v ? c : pH;
-                  pL = v ? pL : c;
-                  pGood = v ? pGood : c;
-                  if (__ballot(conv || unsure)) { predicted = __ballot(conv) != 0; ++k; break; }
-               }
-               nCand = k;
-            }
-         }
-         BK_TICK(tq2);
-         BK_ACC(cyP2, tq1, tq2);
-         if (predicted)
-         {
-            bool agreed = true;
-#pragma unroll 1
-            for (int p0 = 0; p0 < nCand && agreed; p0 += 4)
-            {
-               const int left = nCand - p0;                       // candidates of this pass: min(left, 4)
-               const double rec = pcand[p0 + (cslot < left ? cslot : left - 1)][lane];
-               const bool violMine = verify(fabs(rec));            // this slot's sddotL / sddotH stay in its lanes
-               agreed = __ballot(violMine != (__double2hiint(rec) < 0)) == 0;
-            }
-            BK_TICK(tq3);
-            BK_ACC(cyP3, tq2, tq3);
-            if (agreed)
-            {
-#ifdef BK_PROFILE_SECTIONS
-               ++nAcc;
-#endif
-               sdotCur = pGood;                                    // the converged feasible speed, ba.cpp:1296-1302
-               const int src = 8 * ((nCand - 1) & 3);
-               sddotH = __shfl(sddotH, src);
-               sddotL = __shfl(sddotL, src);
-               sddot = (DIR == 1) ? sddotH : sddotL;
-               BK_TICK(tpp);
-               BK_ACC(cyD, tp2, tpp);
-               return;
-            }
-         }
-      }
-#endif
       // first check violated: replay of ba.cpp:1276-1321 from its first iteration, four candidates per pass.  The check of
       // the first candidate has just been done: it is folded into the first pass below (slot 0 re-evaluates it, same bits).
       // One replayed iteration is written as selects (the form of the flat loop in k_sweep: no divergent branches around the few
@@ -652,7 +524,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       bool fin = false, failed = false;
       // one iteration of the loop of ba.cpp:1267-1321 given the outcome of the check of sdotTry; leaves the next value to check
       // in sdotTry; returns true when the loop has ended (fin or failed)
-      auto iterate = [&](bool isViol) -> bool {
+      auto iterate = [&](bool isViol) __attribute__((always_inline)) -> bool {
          const bool first = (nIter == 0);
          const bool good = !isViol && !first;      // a feasible point after at least one violated one
          const bool shrink = isViol && nGood == 0; // ba.cpp:1281-1285: no feasible point known yet
@@ -677,6 +549,147 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       };
       // the first check (violated) is the loop's first iteration; the passes below start with its successor
       bool over = __builtin_amdgcn_readfirstlane((int)iterate(true)) != 0;
+#if S1_PREDICT
+      if (FEAT <= 0 && accOn && a.ff && !over)
+      {
+         // CERTIFIED FAST-FORWARD (joint velocity / acceleration limits only).  In x = sdot^2 the sddot intervals of the moving
+         // joints are [l_q, u_q] = [-a_q - m_q x, a_q - m_q x], a_q = amax_q / |theta'_q|, m_q = theta''_q / theta'_q
+         // (ba.cpp:1526-1531), beside [-sddotMax, sddotMax] (ba.cpp:1257); a joint that stands still allows x <= amax_q / |theta''_q|
+         // (ba.cpp:1519-1524).  g(x) = min u - max l = min over pairs of (a_i + a_j) - (m_j - m_i) x is concave, positive at 0 and
+         // vanishes at
+         //      x* = min over pairs with m_j > m_i of (a_i + a_j) / (m_j - m_i),
+         // so a check is a comparison of x with x* -- except within rounding of x*:
+         //  * the check's bounds differ from u_q, l_q by at most 3 eps (a_q + |m_q| x) (a product, a difference, a quotient, each
+         //    correctly rounded, eps = 2^-53): its decision is the exact one when |g(x)| > 6 eps E, E = max_q (a_q + |m_q| x);
+         //  * g concave, g(0) >= Smin = 2 min(min_q a_q, sddotMax), g(x*) = 0:  |g(x)| >= Smin |x - x*| / x* on both sides of x*;
+         //  * x* is computed with approximate reciprocals (4 eps each): a pair whose bound is below 2 x* has m_j - m_i >= Smin / (2 x*),
+         //    so its computed bound is off by at most 24 eps E / Smin relatively, and no other pair can come out below x* as long as
+         //    24 eps E / Smin < 1/2.
+         // With R = E(first candidate) / min(min_q a_q, sddotMax) the outcome of a check is certain when |x - x*| > 27 eps R x*;
+         // demanded here: |x - x*| > 2^-40 R x* (300 times that) and R < 2^30.  The standing joints' thresholds are the check's own
+         // quotients and comparisons.  The loop of ba.cpp:1267-1321 is then advanced, with its own update statements, through
+         // every iteration whose outcome is certain and that neither ends it nor can take a failure exit: speeds in the normal
+         // range are positive, the bracket of the search phase is [(1 - lowFact) c, c] with lowFact >= 0.02 (never collapsed), and
+         // the iteration count is kept below 90.  It stops in front of the first candidate that is within the band (the generic
+         // passes below go on from this state with real checks) or that would end the loop -- a feasible speed within 1e-3 of
+         // the previous one: it gets the real check, whose sddot bounds are the result.
+         // reciprocal to ~2 eps whatever the accuracy of v_rcp_f64's seed beyond 14 bits: two Newton steps
+         auto fastRcp = [](double d) {
+            double r = __builtin_amdgcn_rcp(d);
+            r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+            return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+         };
+         const bool use = jv && !(fabs(thD) < thrV);
+         const double rv = fastRcp(use ? thD : 1.0);
+         const double aj = use ? amaxj * fabs(rv) : kInf;
+         const double mj = use ? thD2 * rv : 0.0;
+         const double xTop = sdotH * sdotH;                        // the first candidate: no later one is larger
+         double aMin = aj, eMax = use ? aj + fabs(mj) * xTop : 0.0;
+         grp_min_max<8>(aMin, eMax);
+         const bool standing = jv && !use && !(fabs(thD2) < thrA);
+         double xForce = kInf;
+         if (__ballot(standing)) xForce = grp_min<8>(standing ? amaxj / fabs(thD2) : kInf);
+         double xs = (use && fabs(mj) > 0.0) ? (aj + sddotMax) * fastRcp(fabs(mj)) : kInf; // the pair of joint q with (u_0, l_0)
+#pragma unroll
+         for (int rr = 0; rr < 2; ++rr)
+         {
+            const int srcLane = (lane & 24) | (cslot + 4 * rr);     // joint cslot + 4 rr of this lane's own slot
+            const double ai = __shfl(aj, srcLane), mi = __shfl(mj, srcLane);
+            const double dm = mj - mi;
+            const double bnd = (ai + aj) * fastRcp(dm > 0.0 ? dm : 1.0);
+            xs = dmin(xs, dm > 0.0 ? bnd : kInf);
+         }
+         xs = grp_min<8>(xs);
+         xs = vmin_f64(xs, dpp_mov<DPP_ROW_ROR8>(xs));
+         xs = vmin_f64(xs, __shfl_xor(xs, 16));
+         const double xstar = dmin(xs, 4.0 * xTop);               // beyond 4 xTop: "never violated by the moving joints" just as well
+         const double R = eMax * fastRcp(dmin(aMin, sddotMax));
+         const double band = (R * 0x1p-40) * xstar;
+         // One threshold for the loops below.  A standing joint's threshold below the band around x* decides alone, and exactly
+         // (xh > xForce <=> xh - xForce > 0; the candidates it lets pass are more than the band below x*): threshold xForce, no
+         // band.  One above the band never matters (what exceeds it is violated by the moving joints for certain): threshold x*.
+         // One inside the band: no fast-forward.
+         const bool forceFirst = xForce < xstar - band;
+         const double xThr = forceFirst ? xForce : xstar;
+         const double bandThr = forceFirst ? -1.0 : band;
+         // magnitudes far inside the normal range (no overflow, no gradual underflow in the check or here); NaNs fail every test
+         const bool sane = (R < 0x1p30) & (aMin > 1e-100) & (eMax < 1e100) & (xTop > 1e-100) & (xTop < 1e100) & (xstar > 1e-100) &
+                           (forceFirst | (xForce > xstar + band));
+         BK_TICK(tq1);
+         BK_ACC(cyP1, tp2, tq1);
+         bool expectEnd = false;
+         if (__ballot(sane))
+         {
+            // every value below is the same in all lanes: the loop conditions are scalar branches on ballots
+            // (bitwise operators on purpose: '||' and '&&' become exec-mask branches around single compares)
+            int it = __builtin_amdgcn_readfirstlane(nIter);
+            bool inBand = false;
+            // the search for a first feasible speed (ba.cpp:1281-1285): the bracket shrinks below every violated candidate
+#pragma unroll 1
+            for (; it < 90; ++it)
+            {
+               const double c = sdotTry, d = c * c - xThr;           // c * c: sdotSQ of the check
+               inBand = !((fabs(d) > bandThr) & (c > 1e-100));
+               if (__ballot(inBand | !(d > 0.0))) break;
+               lowFact *= 2.0;
+               sdotH = c;
+               sdotL = dmax(.999 * 0.0, (1.0 - lowFact) * c);
+               sdotTry = .5 * (sdotH + sdotL);
+            }
+            if (!__ballot(inBand) && it < 90)
+            {
+               // sdotTry is feasible for certain and the first such speed: ba.cpp:1294 compares it with sdotGood = 0 and goes on
+               // (|c - 0| > 1e-3 c).  From here the plain bisection (ba.cpp:1286-1303): sdotGood == sdotL throughout, every
+               // candidate lies between this speed (> 1e-100) and the first candidate (< 1e50).
+               sdotGood = sdotTry; nGood = 1; sdotL = sdotTry;
+               ++it;
+               sdotTry = .5 * (sdotH + sdotL);
+               bool goesOn = true;
+               // ba.cpp:1294 is false for certain when |c - sdotGood| > 1e-3 c (1 + 3e-14): ratio_lt(., c, 1e-3) then answers "no"
+               // without dividing (its own margin is 1e-14 on the twice-rounded product) -- otherwise this candidate is, or may
+               // be, the last one and gets the real check and the real test
+               const double convThr = 1e-3 * (1.0 + 3e-14);
+#pragma unroll 1
+               for (; it < 90; ++it)
+               {
+                  const double c = sdotTry, d = c * c - xThr;
+                  const bool viol = d > 0.0;
+                  inBand = !(fabs(d) > bandThr);
+                  goesOn = viol | (fabs(c - sdotL) > convThr * c);
+                  if (__ballot(inBand | !goesOn)) break;
+                  sdotH = viol ? c : sdotH;
+                  sdotL = viol ? sdotL : c;
+                  sdotTry = .5 * (sdotH + sdotL);
+               }
+               sdotGood = sdotL;
+               expectEnd = !__ballot(inBand | goesOn);
+            }
+            nIter = it;
+         }
+         BK_TICK(tq2);
+         BK_ACC(cyP2, tq1, tq2);
+         if (expectEnd)
+         {
+            // the candidate that should end the loop: the real check and the real test (every slot evaluates the same speed)
+            const double c = sdotTry;
+            const bool violC = verify(c);
+            const bool convC = ratio_lt(fabs(c - sdotGood), c, sdotErrThresh);
+            BK_TICK(tq3);
+            BK_ACC(cyP3, tq2, tq3);
+            if (__ballot(!violC && convC))
+            {
+#ifdef BK_PROFILE_SECTIONS
+               ++nAcc;
+#endif
+               sdotCur = c;                                        // ba.cpp:1296-1302
+               sddot = (DIR == 1) ? sddotH : sddotL;
+               BK_TICK(tpp);
+               BK_ACC(cyD, tp2, tpp);
+               return;
+            }
+         }
+      }
+#endif
       while (!over)
       {
 #ifdef BK_PROFILE_SECTIONS

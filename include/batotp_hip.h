@@ -309,6 +309,13 @@ int  batotp_hip_set_sweep_prefetch(batotp_ctx *ctx, int32_t reverse, int32_t for
  * idle (one 6-joint trajectory of 1e5 knots: 0.05 ms instead of 9.5 ms), the lane-per-series kernel beyond --, 1 always,
  * 0 never (the parity tests run both). */
 int  batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on);
+/* the bisection of BA::applyAccelConstraintsBisectionPt (reference batotp/ba.cpp:1248-1332) in the one-path-per-wavefront sweep
+ * kernel (batotp_amd/csrc/sweep1.hip.h), problems with joint velocity / acceleration limits only: after a violated first check
+ * the kernel computes, in closed form, the speed at which the joints' sddot intervals stop intersecting, and takes every
+ * iteration of the loop whose outcome is CERTAIN given the rounding-error bounds of the check without running the check;
+ * candidates within the error band, and the last one (whose sddot bounds are the result), get the real check.  Results are
+ * identical with it on (default) and off (the parity tests run both).  on: 1 / 0. */
+int  batotp_hip_set_fast_forward(batotp_ctx *ctx, int32_t on);
 /* diagnostic: series of the most recent tiled spline build of this batch whose boundary comparison failed and that the
  * sequential kernel therefore recomputed (paths too short for tiles are not counted).  Expected: 0. */
 int  batotp_hip_spline_tile_fallbacks(batotp_batch *batch, int32_t *series);

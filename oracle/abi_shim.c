@@ -72,6 +72,7 @@ int batotp_hip_set_paths_per_wave(batotp_ctx *ctx, int32_t n) { (void)ctx; (void
 int batotp_hip_set_sweep_hold(batotp_ctx *ctx, int32_t reverse, int32_t forward) { (void)ctx; (void)reverse; (void)forward; return BATOTP_OK; }
 int batotp_hip_set_sweep_prefetch(batotp_ctx *ctx, int32_t reverse, int32_t forward) { (void)ctx; (void)reverse; (void)forward; return BATOTP_OK; }
 int batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on) { (void)ctx; (void)on; return BATOTP_OK; }
+int batotp_hip_set_fast_forward(batotp_ctx *ctx, int32_t on) { (void)ctx; (void)on; return BATOTP_OK; }
 int batotp_hip_spline_tile_fallbacks(batotp_batch *b, int32_t *series) { if (!b || !series) return BATOTP_ERR_ARG; *series = 0; return BATOTP_OK; }
 /* the checker has one loop form (the reference's); the introspection calls of the product answer accordingly */
 int batotp_hip_flat_loop_status(batotp_ctx *ctx, int32_t *status) { if (!ctx || !status) return BATOTP_ERR_ARG; *status = -1; return BATOTP_OK; }

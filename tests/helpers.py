@@ -292,7 +292,8 @@ def assert_bit_equal(a, b, what):
 def set_layout(ctx, layout):
     """sweep-kernel layout of a context: 0 (automatic), 1, 8, 16, 32 lanes per path, or "flatK": 8 lanes per path, 8 paths
     per wavefront and the flat stage / bisection loop with hold K in both directions (batotp_hip_set_sweep_hold; only
-    problems with joint velocity / acceleration limits alone use it, the others run the nested loops whatever K is)"""
+    problems with joint velocity / acceleration limits alone use it, the others run the nested loops whatever K is);
+    "64noff": 64 without the certified fast-forward of the bisection"""
     if isinstance(layout, str) and layout.startswith("flat"):
         k = int(layout[4:])
         ctx.set_sweep_group(8)
@@ -304,5 +305,9 @@ def set_layout(ctx, layout):
         ctx.set_sweep_group(int(g))
         ctx.set_paths_per_wave(64 // int(g))
         ctx.set_sweep_hold(int(k), int(k))
+    elif layout == "64noff":
+        # one path per wavefront (k_sweep1) with every iteration of the bisection checked (batotp_hip_set_fast_forward 0)
+        ctx.set_sweep_group(64)
+        ctx.set_fast_forward(False)
     else:
         ctx.set_sweep_group(int(layout))

@@ -44,7 +44,7 @@ def _run(ctx, prob, ys, sres, cap):
 
 
 @pytest.mark.parametrize("seed", range(6 * _SCALE))
-@pytest.mark.parametrize("lanes", [0, 8, "flat0", "flat4", 4, 2, "g4flat0", "g4flat8", "g2flat3", 64])
+@pytest.mark.parametrize("lanes", [0, 8, "flat0", "flat4", 4, 2, "g4flat0", "g4flat8", "g2flat3", 64, "64noff"])
 def test_random_velocity_acceleration_problems(hip_lib, oracle_ctx, seed, lanes):
     rng = np.random.default_rng(1000 + seed)
     nJ = int(rng.integers(1, 9))
@@ -71,6 +71,52 @@ def test_random_velocity_acceleration_problems(hip_lib, oracle_ctx, seed, lanes)
                 assert_bit_equal(ho[k][which][0], oo[k][which][0], f"seed {seed} path {k} curve {which} s")
                 assert_bit_equal(ho[k][which][1], oo[k][which][1], f"seed {seed} path {k} curve {which} sdot")
             assert_bit_equal(ho[k][2], oo[k][2], f"seed {seed} path {k} pointwise")
+
+
+@pytest.mark.parametrize("seed", range(16 * _SCALE))
+def test_certified_fast_forward_of_the_bisection_on_hard_problems(hip_lib, oracle_ctx, seed):
+    """k_sweep1 skips the checks of the bisection iterations whose outcome is certain (sweep1.hip.h): problems built to sit
+    near the edges of that certificate -- joints that almost stand still (theta' just above / below jntThresh, huge
+    a_q = amax / |theta'|), limits spread over six decades, joints that share one shape (pairs of constraint lines that are
+    nearly parallel), all eight joints in use -- against the oracle, bit for bit"""
+    rng = np.random.default_rng(7000 + seed)
+    nJ = int(rng.integers(2, 9))
+    n_paths = int(rng.integers(4, 12))
+    decades = rng.uniform(-3, 3, nJ)
+    vmax = list(10.0 ** rng.uniform(-1, 1.5, nJ))
+    amax = list(10.0 ** decades)
+    prob = capi.make_problem(nJ, 0, flags=capi.F_JNT_ACC_ON, jnt_vel_max=vmax, jnt_acc_max=amax,
+                             integ_res=float(rng.choice([0.002, 0.005, 0.02])), max_integ_time=1e5)
+    ys = []
+    for _ in range(n_paths):
+        n = int(rng.integers(16, 300))
+        y = _random_knots(rng, nJ, n, rng.uniform(0.2, 3.0))
+        kind = rng.integers(0, 4)
+        if kind == 0:      # a joint that barely moves: theta' around the threshold
+            y[rng.integers(0, nJ)] *= 10.0 ** rng.uniform(-9, -4)
+        elif kind == 1:    # two joints with the same shape (nearly parallel constraint lines)
+            a, b = rng.integers(0, nJ, 2)
+            y[b] = y[a] * (1.0 + 10.0 ** rng.uniform(-12, -3))
+        elif kind == 2:    # a joint that stands still exactly on part of the path
+            j = rng.integers(0, nJ)
+            y[j, n // 3: 2 * n // 3] = y[j, n // 3]
+        ys.append(np.ascontiguousarray(y))
+    sres = [float(rng.uniform(0.01, 0.2)) for _ in range(n_paths)]
+    cap = 80000
+    ro, oo = _run(oracle_ctx, prob, ys, sres, cap)
+    for layout in (64, "64noff"):
+        ctx = capi.Context(hip_lib, 0)
+        set_layout(ctx, layout)
+        p2 = capi.Problem.from_buffer_copy(bytes(prob))
+        p2.flags |= capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES
+        rh, ho = _run(ctx, p2, ys, sres, cap)
+        for f in rh.dtype.names:
+            assert np.array_equal(rh[f], ro[f]), (seed, layout, f)
+        for k in range(n_paths):
+            for which in (0, 1):
+                assert_bit_equal(ho[k][which][0], oo[k][which][0], f"seed {seed} {layout} path {k} curve {which} s")
+                assert_bit_equal(ho[k][which][1], oo[k][which][1], f"seed {seed} {layout} path {k} curve {which} sdot")
+        ctx.close()
 
 
 @pytest.mark.parametrize("seed", range(4 * _SCALE))

@@ -43,5 +43,6 @@ for d, name in ((-1, "reverse"), (+1, "forward")):
     if a.paths == 1:
         ex = b.mvc(0)[0][8:12]
         if ex[3] > 0:
-            print(f"   predicted bisection: accepted {ex[3]:.0f} of {bis:.0f} bisecting stages; cycles per bisecting stage: x* {ex[0]/bis:.0f}, "
-                  f"replay of the candidate sequence {ex[1]/bis:.0f}, verification passes {ex[2]/bis:.0f}")
+            print(f"   certified fast-forward of the bisection: {ex[3]:.0f} of {bis:.0f} bisecting stages ended by it (fast-forward + one real check); "
+                  f"cycles per bisecting stage: first iteration + x* and error band {ex[0]/bis:.0f}, fast-forward loop {ex[1]/bis:.0f}, "
+                  f"the last candidate's real check {ex[2]/bis:.0f}")
