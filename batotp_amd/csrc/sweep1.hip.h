@@ -291,10 +291,18 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
                for (int q = 0; q < 4; ++q) dynK[(FEAT == 2) ? q : 0] = kd[q];
             }
          }
+#if S1_SELECT
          A3 = jv ? 3 * k3 : 0.0;
          B2 = jv ? 2 * k2 : 0.0;
          A6 = jv ? 6 * k3 : 0.0;
          c1 = jv ? k1 : 0.0;
+#else
+         // lanes beyond the last joint carry joint 0's numbers; every use of thD / thD2 is behind `jv`
+         A3 = 3 * k3;
+         B2 = 2 * k2;
+         A6 = 6 * k3;
+         c1 = k1;
+#endif
          rowSeg = segC;
       }
       const double tau = tauC, tau2 = tau * tau;
@@ -383,7 +391,16 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
 #endif
       l = grp_min<8>(l);
       sdot = dmin(sdot, l);
-      if (FEAT >= 1 && cartVelOn && cq0 > quadA) sdot = dmin(sdot, cartVelMax / sqrt(cq0)); // ba.cpp:1225-1229
+      if (FEAT >= 1 && cartVelOn && cq0 > quadA)
+      {
+         // ba.cpp:1225-1229.  The quotient only matters when it is below sdot: cartVelMax^2 > sdot^2 cq0 (1 + 1e-12) =>
+         // the correctly rounded cartVelMax / sqrt(cq0) > sdot (three products, a root and a quotient are off by 5 eps together)
+         // => min(sdot, .) = sdot: root and division are skipped.  Overflow or a NaN make the test false or leave it right.
+         // (The same shortcut for the joint velocity limits -- a division per lane and a reduction -- measured slower: its
+         // ballot and branch in every stage cost more than the skipped quotients save, cfg 4 reverse 451 -> 482 ms.)
+         if (!(cartVelMax > 0.0 && cartVelMax * cartVelMax > ((sdot * sdot) * cq0) * (1.0 + 1e-12)))
+            sdot = dmin(sdot, cartVelMax / sqrt(cq0));
+      }
    };
 
    // BA::verifySecondOrderConstraints, joint acceleration family (ba.cpp:1514-1534); see verify_second_order for why the
@@ -550,27 +567,39 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       // the first check (violated) is the loop's first iteration; the passes below start with its successor
       bool over = __builtin_amdgcn_readfirstlane((int)iterate(true)) != 0;
 #if S1_PREDICT
-      if (FEAT <= 0 && accOn && a.ff && !over)
+      // where it applies: the check consists of constraints that are LINES in x = sdot^2 -- joint acceleration limits, and
+      // the torque limits of a mechanism whose a3 (the term in sdot) vanishes identically, i.e. the cable robot in serial form
+      // (robot.cpp:487-517: a3 = 0 at every knot, so its spline is 0 and tmp1 of ba.cpp:1497 is a4 exactly); no Cartesian
+      // acceleration limit (a quadratic in sddot, ba.cpp:1535-1579).  The torque lines take the joint lanes 4..7 of a slot:
+      // at most 4 joints.
+      bool ffApplies = a.ff && !over && !cartAccOn && (FEAT == 2 || accOn);
+      if (FEAT == 2) ffApplies = ffApplies && nJ <= 4 && !__ballot(jv && !(a3pt == 0.0));
+      if (ffApplies)
       {
-         // CERTIFIED FAST-FORWARD (joint velocity / acceleration limits only).  In x = sdot^2 the sddot intervals of the moving
-         // joints are [l_q, u_q] = [-a_q - m_q x, a_q - m_q x], a_q = amax_q / |theta'_q|, m_q = theta''_q / theta'_q
-         // (ba.cpp:1526-1531), beside [-sddotMax, sddotMax] (ba.cpp:1257); a joint that stands still allows x <= amax_q / |theta''_q|
-         // (ba.cpp:1519-1524).  g(x) = min u - max l = min over pairs of (a_i + a_j) - (m_j - m_i) x is concave, positive at 0 and
-         // vanishes at
-         //      x* = min over pairs with m_j > m_i of (a_i + a_j) / (m_j - m_i),
+         // CERTIFIED FAST-FORWARD.  In x = sdot^2 every constraint of the check is an interval [l_q(x), u_q(x)] for sddot with
+         //      u_q = au_q - m_q x,   l_q = al_q - m_q x:
+         //   joint acceleration, moving joint (ba.cpp:1526-1531):  au = -al = amax_q / |theta'_q|,  m = theta''_q / theta'_q;
+         //   torque, |a1_q| >= thresh (ba.cpp:1495-1509, a3 = 0):  au, al = max, min of (tmax_q - a4_q) / a1_q, (tmin_q - a4_q) / a1_q,
+         //                                                         m = a2_q / a1_q;
+         //   [-sddotMax, sddotMax] (ba.cpp:1257):                  au = -al = sddotMax, m = 0;
+         // and a joint that stands still allows x <= amax_q / |theta''_q| (ba.cpp:1519-1524).
+         // g(x) = min u - max l = min over pairs (i, j) of (au_j - al_i) - (m_j - m_i) x is concave and vanishes at
+         //      x* = min over pairs with m_j > m_i of (au_j - al_i) / (m_j - m_i),
          // so a check is a comparison of x with x* -- except within rounding of x*:
-         //  * the check's bounds differ from u_q, l_q by at most 3 eps (a_q + |m_q| x) (a product, a difference, a quotient, each
-         //    correctly rounded, eps = 2^-53): its decision is the exact one when |g(x)| > 6 eps E, E = max_q (a_q + |m_q| x);
-         //  * g concave, g(0) >= Smin = 2 min(min_q a_q, sddotMax), g(x*) = 0:  |g(x)| >= Smin |x - x*| / x* on both sides of x*;
-         //  * x* is computed with approximate reciprocals (4 eps each): a pair whose bound is below 2 x* has m_j - m_i >= Smin / (2 x*),
-         //    so its computed bound is off by at most 24 eps E / Smin relatively, and no other pair can come out below x* as long as
-         //    24 eps E / Smin < 1/2.
-         // With R = E(first candidate) / min(min_q a_q, sddotMax) the outcome of a check is certain when |x - x*| > 27 eps R x*;
-         // demanded here: |x - x*| > 2^-40 R x* (300 times that) and R < 2^30.  The standing joints' thresholds are the check's own
-         // quotients and comparisons.  The loop of ba.cpp:1267-1321 is then advanced, with its own update statements, through
-         // every iteration whose outcome is certain and that neither ends it nor can take a failure exit: speeds in the normal
-         // range are positive, the bracket of the search phase is [(1 - lowFact) c, c] with lowFact >= 0.02 (never collapsed), and
-         // the iteration count is kept below 90.  It stops in front of the first candidate that is within the band (the generic
+         //  * the check's bounds differ from u_q, l_q by at most 4 eps e_q(x), e_q = amax_q / |theta'_q| + |m_q| x resp.
+         //    (|tmax_q| + |tmin_q| + 2 |a4_q| + |a2_q| x) / |a1_q| (two or three correctly rounded operations and a quotient,
+         //    eps = 2^-53): its decision is the exact one when |g(x)| > 8 eps E, E = max_q e_q(x);
+         //  * g concave with g(0) = Smin = min au - max al > 0 (demanded) and g(x*) = 0:  |g(x)| >= Smin |x - x*| / x* on both
+         //    sides of x*;
+         //  * x* is computed with approximate reciprocals (2 eps each): a pair whose bound is below 2 x* has m_j - m_i >= Smin / (2 x*),
+         //    so its computed bound is off by at most 32 eps E / Smin relatively, and no other pair can come out below x* as long
+         //    as 32 eps E / Smin < 1/2.
+         // With R = 2 E(first candidate) / Smin the outcome of a check is certain when |x - x*| > 20 eps R x*; demanded here:
+         // |x - x*| > 2^-40 R x* (400 times that) and R < 2^30.  The standing joints' thresholds are the check's own quotients and
+         // comparisons.  The loop of ba.cpp:1267-1321 is then advanced, with its own update statements, through every iteration
+         // whose outcome is certain and that neither ends it nor can take a failure exit: speeds in the normal range are
+         // positive, the bracket of the search phase is [(1 - lowFact) c, c] with lowFact >= 0.02 (never collapsed), and the
+         // iteration count is kept below 90.  It stops in front of the first candidate that is within the band (the generic
          // passes below go on from this state with real checks) or that would end the loop -- a feasible speed within 1e-3 of
          // the previous one: it gets the real check, whose sddot bounds are the result.
          // reciprocal to ~2 eps whatever the accuracy of v_rcp_f64's seed beyond 14 bits: two Newton steps
@@ -579,41 +608,71 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
             r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
             return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
          };
-         const bool use = jv && !(fabs(thD) < thrV);
-         const double rv = fastRcp(use ? thD : 1.0);
-         const double aj = use ? amaxj * fabs(rv) : kInf;
-         const double mj = use ? thD2 * rv : 0.0;
          const double xTop = sdotH * sdotH;                        // the first candidate: no later one is larger
-         double aMin = aj, eMax = use ? aj + fabs(mj) * xTop : 0.0;
-         grp_min_max<8>(aMin, eMax);
-         const bool standing = jv && !use && !(fabs(thD2) < thrA);
+         // this lane's line: the acceleration line of its joint ...
+         const bool use = accOn && jv && !(fabs(thD) < thrV);
+         bool valid = use;
+         double au, al, mj, ej;
+         {
+            const double rv = fastRcp(use ? thD : 1.0);
+            au = amaxj * fabs(rv);
+            al = -au;
+            mj = thD2 * rv;
+            ej = au + fabs(mj) * xTop;
+         }
+         if (FEAT == 2)
+         {
+            // ... or, in the joint lanes 4..7 of the slot, the torque line of joint j - 4 (computed in that joint's lane)
+            const bool useT = jv && !(fabs(a1pt) < thrV);
+            const double r1 = fastRcp(useT ? a1pt : 1.0);
+            const double q0 = (tmaxj - a4pt) * r1, q1 = (tminj - a4pt) * r1;
+            const double tu = dmax(q0, q1), tl = dmin(q0, q1), tm = a2pt * r1;
+            const double te = (fabs(tmaxj) + fabs(tminj) + 2.0 * fabs(a4pt) + fabs(a2pt) * xTop) * fabs(r1);
+            const int src = (lane & 24) | (j & 3);
+            const double su = __shfl(tu, src), sl = __shfl(tl, src), sm = __shfl(tm, src), se = __shfl(te, src);
+            const int sv = __shfl((int)useT, src);
+            if (j >= 4) { au = su; al = sl; mj = sm; ej = se; valid = sv != 0; }
+         }
+         au = valid ? au : kInf;
+         al = valid ? al : -kInf;
+         mj = valid ? mj : 0.0;
+         ej = valid ? ej : 0.0;
+         double uMin = au, lMax = al;
+         grp_min_max<8>(uMin, lMax);
+         const double eMax = grp_max<8>(ej);
+         const double sMin2 = .5 * (dmin(uMin, sddotMax) - dmax(lMax, -sddotMax));
+         const bool standing = accOn && jv && !use && !(fabs(thD2) < thrA);
          double xForce = kInf;
          if (__ballot(standing)) xForce = grp_min<8>(standing ? amaxj / fabs(thD2) : kInf);
-         double xs = (use && fabs(mj) > 0.0) ? (aj + sddotMax) * fastRcp(fabs(mj)) : kInf; // the pair of joint q with (u_0, l_0)
+         // the pairs of this lane's line with (u_0, l_0): as the upper line when m > 0, as the lower line when m < 0
+         double xs = kInf;
+         if (valid && mj > 0.0) xs = (au + sddotMax) * fastRcp(mj);
+         if (valid && mj < 0.0) xs = (sddotMax - al) * fastRcp(-mj);
 #pragma unroll
          for (int rr = 0; rr < 2; ++rr)
          {
-            const int srcLane = (lane & 24) | (cslot + 4 * rr);     // joint cslot + 4 rr of this lane's own slot
-            const double ai = __shfl(aj, srcLane), mi = __shfl(mj, srcLane);
+            // this lane's line as the upper one, line cslot + 4 rr of its own slot as the lower one
+            const int srcLane = (lane & 24) | (cslot + 4 * rr);
+            const double ali = __shfl(al, srcLane), mi = __shfl(mj, srcLane);
             const double dm = mj - mi;
-            const double bnd = (ai + aj) * fastRcp(dm > 0.0 ? dm : 1.0);
+            const double bnd = (au - ali) * fastRcp(dm > 0.0 ? dm : 1.0);
             xs = dmin(xs, dm > 0.0 ? bnd : kInf);
          }
          xs = grp_min<8>(xs);
          xs = vmin_f64(xs, dpp_mov<DPP_ROW_ROR8>(xs));
          xs = vmin_f64(xs, __shfl_xor(xs, 16));
-         const double xstar = dmin(xs, 4.0 * xTop);               // beyond 4 xTop: "never violated by the moving joints" just as well
-         const double R = eMax * fastRcp(dmin(aMin, sddotMax));
+         const double xstar = dmin(xs, 4.0 * xTop);               // beyond 4 xTop: "never violated by the lines" just as well
+         const double R = eMax * fastRcp(sMin2 > 0.0 ? sMin2 : 1.0);
          const double band = (R * 0x1p-40) * xstar;
          // One threshold for the loops below.  A standing joint's threshold below the band around x* decides alone, and exactly
          // (xh > xForce <=> xh - xForce > 0; the candidates it lets pass are more than the band below x*): threshold xForce, no
-         // band.  One above the band never matters (what exceeds it is violated by the moving joints for certain): threshold x*.
+         // band.  One above the band never matters (what exceeds it is violated by the lines for certain): threshold x*.
          // One inside the band: no fast-forward.
          const bool forceFirst = xForce < xstar - band;
          const double xThr = forceFirst ? xForce : xstar;
          const double bandThr = forceFirst ? -1.0 : band;
          // magnitudes far inside the normal range (no overflow, no gradual underflow in the check or here); NaNs fail every test
-         const bool sane = (R < 0x1p30) & (aMin > 1e-100) & (eMax < 1e100) & (xTop > 1e-100) & (xTop < 1e100) & (xstar > 1e-100) &
+         const bool sane = (R < 0x1p30) & (sMin2 > 1e-100) & (eMax < 1e100) & (xTop > 1e-100) & (xTop < 1e100) & (xstar > 1e-100) &
                            (forceFirst | (xForce > xstar + band));
          BK_TICK(tq1);
          BK_ACC(cyP1, tp2, tq1);

@@ -172,7 +172,7 @@ def test_random_taught_paths_through_the_resampler_and_output_stage(hip_ctx, ora
 
 
 @pytest.mark.parametrize("par2ser", [0, 1])
-@pytest.mark.parametrize("seed", range(3 * _SCALE))
+@pytest.mark.parametrize("seed", range(5 * _SCALE))
 def test_random_cable_robot_problems(hip_lib, oracle_ctx, seed, par2ser):
     """3-cable robot: cable tension limits (parallel-mechanism torque branch or its serial conversion), cable velocity /
     acceleration limits, Cartesian speed limit; random platform paths inside the workspace"""
@@ -201,9 +201,11 @@ def test_random_cable_robot_problems(hip_lib, oracle_ctx, seed, par2ser):
         theta = np.stack([np.sqrt(((cart - pm[:, k:k + 1]) ** 2).sum(axis=0)) for k in range(3)])
         ys.append(np.ascontiguousarray(np.vstack([theta, cart])))
         sres.append(float(rng.uniform(0.005, 0.03)))
-    for lanes in (0, 8):
+    # 64 / "64noff": one path per wavefront with and without the certified fast-forward of the bisection (which covers the
+    # serial form's torque lines: a3 = 0)
+    for lanes in (0, 8, 64, "64noff"):
         ctx = capi.Context(hip_lib, 0)
-        ctx.set_sweep_group(lanes)
+        set_layout(ctx, lanes)
         outs = []
         for c in (ctx, oracle_ctx):
             b = capi.Batch(c, prob, [y.shape[1] for y in ys], 4000)
