@@ -7,7 +7,7 @@ BA::verifySecondOrderConstraints in their order: reference batotp/ba.cpp:1495-15
 lines in x = sdot^2 -- joint acceleration limits, torque limits with a3 = 0, the clamp +-sddotMax, standing joints -- and the
 kernel's computation of x*, R and the band, with the approximate reciprocals replaced by exact ones perturbed by a few ulps.
 Then it probes candidates at relative distances 1e-16 .. 1e-2 on both sides of x*: wherever the certificate says "certain", the
-real check must agree.  It also reports how close to x* the first disagreement WITHOUT the band lies, i.e. the margin the band has.
+real check must agree; and the disagreements of the bare comparison must all lie deep inside the band (its margin).
 """
 import numpy as np
 import pytest
@@ -130,7 +130,7 @@ def test_certain_candidates_get_the_outcome_of_the_real_check(kind):
     rng = np.random.default_rng({"plain": 1, "slow joint": 2, "standing joint": 3, "parallel lines": 4, "torque": 5}[kind])
     deltas = np.concatenate([10.0 ** np.linspace(-16, -2, 57), [0.05, 0.3]])
     used = probes = skipped = 0
-    closest = []          # per problem: the band and the smallest |delta| at which the bare comparison with x* was wrong
+    closest = []          # per problem: the band and the largest |delta| at which the bare comparison with x* was wrong
     for _ in range(400):
         A, v, D, thr_v, thr_a, sddot_max, trq = _problem(rng, kind)
         # a first candidate above the crossing: scan up from a feasible speed until the real check fails
@@ -148,7 +148,7 @@ def test_certain_candidates_get_the_outcome_of_the_real_check(kind):
             continue
         x_thr, band_thr, xstar, R = cert
         used += 1
-        first_wrong = INF
+        last_wrong = 0.0
         for sgn in (-1.0, 1.0):
             for dl in deltas:
                 c = np.sqrt(x_thr * (1.0 + sgn * dl))
@@ -162,9 +162,9 @@ def test_certain_candidates_get_the_outcome_of_the_real_check(kind):
                     probes += 1
                     assert predicted == real, (kind, dl, sgn, R, band_thr / xstar, cert)
                 elif predicted != real:
-                    first_wrong = min(first_wrong, dl)
-        if band_thr > 0 and first_wrong < INF:
-            closest.append((band_thr / xstar, first_wrong))
+                    last_wrong = max(last_wrong, abs(d) / xstar)
+        if band_thr > 0 and last_wrong > 0.0:
+            closest.append((band_thr / xstar, last_wrong))
     assert used > 150 and probes > 10000, (used, probes, skipped)
     # the band is not vacuous -- inside it the bare comparison does go wrong now and then -- and it has room to spare: only far
     # inside it (over 6000 problems of these five kinds the farthest wrong comparison lay at 3.7e-4 of the band's width)
