@@ -60,6 +60,12 @@ __constant__ double c_s1B[36] = {BK_B00, BK_B01, BK_B02, BK_B03, BK_B04, BK_B05,
                                  0, 0, 0, 0, BK_B44, BK_B45,
                                  0, 0, 0, 0, 0, BK_B55};
 
+// A condition on path-level values, which are the same in every lane of the wavefront (one path per wavefront): evaluated as a
+// ballot it becomes a scalar branch.  Written as a plain `if`, the compiler cannot know that the lanes agree and wraps the branch
+// and every loop around it in exec-mask bookkeeping (a dozen scalar instructions per cursor-walk iteration) for a divergence that
+// never happens.  NOT for conditions that differ between joints (lanes) or candidate slots.
+#define S1_UNI(c) (__ballot(c) != 0)
+
 constexpr int S1_BLOCK = 256;
 constexpr int S1_WK = 64;   // knots per spline window (compact splines: 64 knots x 8 joint slots x 16 B = 8 KB per path)
 constexpr int S1_WM = 256;  // points per reverse-curve window (4 KB per path)
@@ -172,7 +178,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    // travel (two knots of slack behind it).  Fixed stride of 8 slots per knot: Cartesian channels the batch may carry are not
    // copied; slots beyond the last joint hold a copy of joint 0.
    auto needK = [&](int seg) __attribute__((always_inline)) {
-      if (seg >= wK0 && seg + 1 < wK0 + wKn) return;
+      if (S1_UNI(seg >= wK0 && seg + 1 < wK0 + wKn)) return;
       int w = (DIR == 1) ? seg - 2 : seg + 4 - S1_WK;
       const int wmax = n - S1_WK;
       w = w > wmax ? wmax : w;
@@ -205,7 +211,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    };
    // the same for points k and k + 1 of the reverse curve (a few points behind k stay in the window for the back-steps)
    auto needM = [&](int k) __attribute__((always_inline)) {
-      if (k >= wM0 && k + 1 < wM0 + wMn) return;
+      if (S1_UNI(k >= wM0 && k + 1 < wM0 + wMn)) return;
       int w = k - 16;
       const int wmax = nMvc - S1_WM;
       w = w > wmax ? wmax : w;
@@ -235,16 +241,16 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       const int lastSeg = n - 2;
       for (;;)
       {
-         if (sCur >= sSeg && sCur <= sNext) break;
+         if (S1_UNI(sCur >= sSeg && sCur <= sNext)) break;
          bool moved = false;
-         if (sCur > sSeg)
+         if (S1_UNI(sCur > sSeg))
          {
-            if (segC >= lastSeg) { segC = lastSeg; break; }
+            if (S1_UNI(segC >= lastSeg)) { segC = lastSeg; break; }
             ++segC; moved = true;
          }
-         if (sCur < sSeg)
+         if (S1_UNI(sCur < sSeg))
          {
-            if (segC <= 0) { segC = 0; break; }
+            if (S1_UNI(segC <= 0)) { segC = 0; break; }
             --segC; moved = true;
          }
          if (!moved) { status |= BATOTP_ST_NONFINITE; break; }
@@ -257,7 +263,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    // BA::evalSplinePartials for joint velocity / acceleration limits only (ba.cpp:1341-1366)
    auto evalPartials = [&](double sCur) __attribute__((always_inline)) {
       walkC(sCur);
-      if (segC != rowSeg)
+      if (S1_UNI(segC != rowSeg))
       {
          double k3, k2, k1;
          if (FEAT < 0)
@@ -337,7 +343,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    // BA::updateCurSeg on the reverse curve (ba.cpp:1592, 1617-1652) with the segment's two points cached in registers:
    // the literal walk of update_cur_seg<2>
    auto mvcWalk = [&](double sCur) __attribute__((always_inline)) {
-      if (mvcSeg == segMVC && sCur >= mS0 && sCur <= mS1)
+      if (S1_UNI(mvcSeg == segMVC && sCur >= mS0 && sCur <= mS1))
       {
          tauMVC = (sCur - mS0) / (mS1 - mS0);
          return;
@@ -349,16 +355,16 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
          needM(segMVC);
          pa = winM[segMVC - wM0];
          pb = winM[segMVC + 1 - wM0];
-         if (sCur >= pa.x && sCur <= pb.x) break;
+         if (S1_UNI(sCur >= pa.x && sCur <= pb.x)) break;
          bool moved = false;
-         if (sCur > pa.x)
+         if (S1_UNI(sCur > pa.x))
          {
-            if (segMVC >= lastSeg) { segMVC = lastSeg; break; }
+            if (S1_UNI(segMVC >= lastSeg)) { segMVC = lastSeg; break; }
             ++segMVC; moved = true;
          }
-         if (sCur < pa.x)
+         if (S1_UNI(sCur < pa.x))
          {
-            if (segMVC <= 0) { segMVC = 0; break; }
+            if (S1_UNI(segMVC <= 0)) { segMVC = 0; break; }
             --segMVC; moved = true;
          }
          if (!moved) { status |= BATOTP_ST_NONFINITE; break; }
@@ -391,14 +397,14 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
 #endif
       l = grp_min<8>(l);
       sdot = dmin(sdot, l);
-      if (FEAT >= 1 && cartVelOn && cq0 > quadA)
+      if (FEAT >= 1 && cartVelOn && S1_UNI(cq0 > quadA))
       {
          // ba.cpp:1225-1229.  The quotient only matters when it is below sdot: cartVelMax^2 > sdot^2 cq0 (1 + 1e-12) =>
          // the correctly rounded cartVelMax / sqrt(cq0) > sdot (three products, a root and a quotient are off by 5 eps together)
          // => min(sdot, .) = sdot: root and division are skipped.  Overflow or a NaN make the test false or leave it right.
          // (The same shortcut for the joint velocity limits -- a division per lane and a reduction -- measured slower: its
          // ballot and branch in every stage cost more than the skipped quotients save, cfg 4 reverse 451 -> 482 ms.)
-         if (!(cartVelMax > 0.0 && cartVelMax * cartVelMax > ((sdot * sdot) * cq0) * (1.0 + 1e-12)))
+         if (!S1_UNI(cartVelMax > 0.0 && cartVelMax * cartVelMax > ((sdot * sdot) * cq0) * (1.0 + 1e-12)))
             sdot = dmin(sdot, cartVelMax / sqrt(cq0));
       }
    };
@@ -524,7 +530,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
 #ifdef BK_PROFILE_SECTIONS
       ++nStage;
 #endif
-      if (!firstViol)
+      if (!S1_UNI(firstViol)) // every slot has checked the same speed
       {
          sddot = (DIR == 1) ? sddotH : sddotL;
          return;
@@ -931,7 +937,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
 #endif
    while (!done)
    {
-      if (i >= cap || i + 64 >= revStart + (int64_t)segMVC) { endStatus = BATOTP_ST_CAPACITY; break; }
+      if (S1_UNI(i >= cap || i + 64 >= revStart + (int64_t)segMVC)) { endStatus = BATOTP_ST_CAPACITY; break; }
       if (DIR == 1) mvcWalk(s0v + h * v0); // Euler predictor, ba.cpp:1055-1065: only the move of the reverse-curve cursor survives
 
 #if S1_STAGE_LOOP
@@ -971,8 +977,8 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       sCurPt = s0v; sdCurPt = v0;
       if (writer) out[DIR == 1 ? i : cap - 1 - i] = make_double2(s0v, v0);
 
-      if (sCur * DIR > sLast) { nPts = i + 1; done = true; }                                // ba.cpp:1109-1115
-      else if (i > maxIntegSteps) { endStatus = BATOTP_ST_MAX_INTEG_TIME; break; }            // ba.cpp:1117-1122
+      if (S1_UNI(sCur * DIR > sLast)) { nPts = i + 1; done = true; }                        // ba.cpp:1109-1115
+      else if (S1_UNI(i > maxIntegSteps)) { endStatus = BATOTP_ST_MAX_INTEG_TIME; break; }    // ba.cpp:1117-1122
       else ++i;
    }
 #undef S1_STAGE
