@@ -46,9 +46,10 @@ __device__ __forceinline__ bool ratio_lt_uniform(double num, double den, double 
 #ifndef S1_SELECT
 #define S1_SELECT 0
 #endif
-// 1: a violated first check of a joint velocity / acceleration-only problem goes through the PREDICTED bisection first (see
-// accelPt): the speed at which the sddot intervals stop intersecting has a closed form there, the reference's candidate sequence
-// is replayed against it, and the constraint check only VERIFIES the predicted outcomes, four candidates per pass
+// 1: a violated first check of a problem whose constraints are lines in sdot^2 goes through the CERTIFIED FAST-FORWARD of the
+// bisection first (see accelPt): the speed at which the sddot intervals stop intersecting has a closed form there, and the
+// iterations of the reference's loop whose outcome is certain given the check's rounding-error bound are taken without their
+// checks (batotp_hip_set_fast_forward switches it off at run time; 0 here compiles it out)
 #ifndef S1_PREDICT
 #define S1_PREDICT 1
 #endif
