@@ -4,13 +4,15 @@
 // Same arithmetic, same order, same results as k_sweep (kernels.hip.h) -- BA::sweep and everything it calls, reference
 // batotp/ba.cpp:979-1195, 1204-1236, 1248-1332, 1341-1439, 1449-1581, 1590-1652 -- written for the fewest instructions per
 // stage instead of for generality:
-//   * a lone wavefront issues one vector instruction every 4 cycles whatever its number of active lanes
-//     (MI355X_MICROARCH.md), and the scalar instructions of divergent control flow cost as much: k_sweep's 405 VALU + 250
-//     SALU instructions per stage evaluation are the 5170 cycles measured at B = 1 (profiles/r02_c_*).  So: the six stages
-//     are straight-line code with their tableau column as literals (no selects on the stage number, no table look-ups), one
-//     joint per lane without per-lane loops, the constraint families that are off compiled out, the stage's spline row and
-//     the knot sites of its segment kept in registers, and the bisection -- a quarter of the stages need it -- evaluates four
-//     candidates of the reference's (deterministic) candidate sequence per pass, as the 32-lane layout of k_sweep does;
+//   * a lone wavefront issues a vector instruction every 4-8 cycles whatever its number of active lanes (MI355X_MICROARCH.md;
+//     tools/micro/half_wave_issue.hip: an fp64 FMA 5.4-5.7 cycles with 8, 32 or 64 active lanes), and the scalar instructions
+//     of divergent control flow cost as much: k_sweep's 405 VALU + 250 SALU instructions per stage evaluation are the 5170
+//     cycles measured at B = 1 (profiles/r02_c_*).  So: the six stages are straight-line code with their tableau column as
+//     literals (no selects on the stage number, no table look-ups), one joint per lane without per-lane loops, the constraint
+//     families that are off compiled out, the stage's spline row and the knot sites of its segment kept in registers,
+//     conditions on path-level values as scalar branches (S1_UNI), and the bisection -- a quarter of the stages need it --
+//     either fast-forwarded (S1_PREDICT) or evaluating four candidates of the reference's (deterministic) candidate sequence
+//     per pass, as the 32-lane layout of k_sweep does;
 //   * lanes: lane = slot * 8 + joint, 4 candidate slots x 8 joint lanes; the other 32 lanes of the wavefront exit.
 #pragma once
 #include "kernels.hip.h"
@@ -32,20 +34,12 @@ __device__ __forceinline__ bool ratio_lt_uniform(double num, double den, double 
    return res;
 }
 
-// Two build variants measured in round 3 and NOT taken (profiles/r03_a_sweep1_code_size_ab.txt), kept behind macros so that the
-// measurement can be repeated (tools/ab_sweep1.sh):
-//   S1_STAGE_LOOP 1: the six stages of a step as one loop body (stage values in LDS, tableau from a table): the kernels shrink
-//     from 54-92 KB to 23-38 KB -- well inside the 64 KB instruction cache two CUs share -- and get SLOWER: BASELINE config 2 as
-//     worded 425-430 ms per step against 374 ms unrolled, config 4 1221-1290 ms against 1046 ms.  Instruction fetch is not what
-//     the lone wavefront waits for; the LDS round trips and the lost scheduling freedom of the loop cost more than fetch saves.
-//   S1_SELECT 1: the per-lane conditions of the constraint checks as selects (every lane computes its quotients, no exec-mask
-//     branches): 1-5 % slower than the branches (config 4: 1290 against 1221 ms, both with the stage loop).
-#ifndef S1_STAGE_LOOP
-#define S1_STAGE_LOOP 0
-#endif
-#ifndef S1_SELECT
-#define S1_SELECT 0
-#endif
+// Build variants measured in round 3 and not taken (profiles/r03_a_sweep1_code_size_ab.txt, r03_i_*; the code is in the history):
+// the six stages of a step as one loop body (kernels of 23-38 KB instead of 54-92 KB: 14-17 % slower -- instruction fetch is not
+// what the lone wavefront waits for); the per-lane conditions of the checks as selects (1-5 % slower); all 64 lanes with the
+// upper bounds of a check in one half of a slot and the lower bounds in the other (one division per lane, k_sweep<16>'s layout:
+// -2 % on the cable robot whose check has four divisions per lane, +3 % on the vel/acc problems -- LDS and memory instructions
+// of 64 lanes take longer than those of 32).
 // 1: a violated first check of a problem whose constraints are lines in sdot^2 goes through the CERTIFIED FAST-FORWARD of the
 // bisection first (see accelPt): the speed at which the sddot intervals stop intersecting has a closed form there, and the
 // iterations of the reference's loop whose outcome is certain given the check's rounding-error bound are taken without their
@@ -85,11 +79,6 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    // wavefront were s_waitcnt without the windows: profiles/r02_e_*).
    __shared__ double2 winKAll[(FEAT < 0) ? S1_BLOCK / 64 : 1][(FEAT < 0) ? S1_WK * BATOTP_MAX_JOINTS : 1];
    __shared__ double2 winMAll[(DIR == 1) ? S1_BLOCK / 64 : 1][(DIR == 1) ? S1_WM : 1];
-#if S1_STAGE_LOOP
-   // the stage values sdot_k, sddot_k (k = 0..6) of the step in flight: a slot per lane (every lane holds the same numbers; own
-   // slots need neither a broadcast nor an exec mask), read back by the tableau combination of the later stages
-   __shared__ double vwAll[S1_BLOCK / 64][14][32];
-#endif
    stage_limits(a.dP, lim);
    const int lane = threadIdx.x & 63;
    const int p = blockIdx.x * (S1_BLOCK / 64) + (threadIdx.x >> 6);
@@ -165,11 +154,6 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    unsigned long long cyA = 0, cyB = 0, cyC = 0, cyD = 0, nBis = 0, nPass = 0, nStage = 0, cyP1 = 0, cyP2 = 0, cyP3 = 0, nAcc = 0;
 #endif
 
-#if S1_STAGE_LOOP
-   double (*vw)[32] = vwAll[threadIdx.x >> 6];
-#pragma unroll
-   for (int k = 0; k < 14; ++k) vw[k][lane] = 0.0; // w1..w6 start at 0, as the unrolled form's variables do
-#endif
    double2 *winK = winKAll[(FEAT < 0) ? (threadIdx.x >> 6) : 0];
    double2 *winM = winMAll[(DIR == 1) ? (threadIdx.x >> 6) : 0];
    int wK0 = 0, wKn = 0; // knots [wK0, wK0 + wKn) are in winK, layout [knot][8 joint slots]
@@ -298,18 +282,11 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
                for (int q = 0; q < 4; ++q) dynK[(FEAT == 2) ? q : 0] = kd[q];
             }
          }
-#if S1_SELECT
-         A3 = jv ? 3 * k3 : 0.0;
-         B2 = jv ? 2 * k2 : 0.0;
-         A6 = jv ? 6 * k3 : 0.0;
-         c1 = jv ? k1 : 0.0;
-#else
          // lanes beyond the last joint carry joint 0's numbers; every use of thD / thD2 is behind `jv`
          A3 = 3 * k3;
          B2 = 2 * k2;
          A6 = 6 * k3;
          c1 = k1;
-#endif
          rowSeg = segC;
       }
       const double tau = tauC, tau2 = tau * tau;
@@ -386,16 +363,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       sdot = dmin(sdot, sdotCap);
       sdot = dmax(sdot, sdotMin);
       double l = kInf;
-#if S1_SELECT
-      {
-         // select form: the quotient of every lane, kept where the reference's condition holds (no exec-mask branch around
-         // it; a lane without joint has thD = 0 and discards its infinity)
-         const double q = fabs(vmaxj / thD);
-         l = (jv && fabs(thD) > thrV) ? dmin(l, q) : l;
-      }
-#else
       if (jv && fabs(thD) > thrV) l = dmin(l, fabs(vmaxj / thD));
-#endif
       l = grp_min<8>(l);
       sdot = dmin(sdot, l);
       if (FEAT >= 1 && cartVelOn && S1_UNI(cq0 > quadA))
@@ -416,36 +384,6 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       const double sdotSQ = sdotTry * sdotTry;
       double H = sddotMax, L = -sddotMax;
       bool force = false;
-#if S1_SELECT
-      if (FEAT == 2)
-      {
-         // torque limits of a serial robot, ba.cpp:1495-1509, select form (both quotients in every lane)
-         const double tmp1 = a3pt * sdotTry + a4pt;
-         const double tmp2 = a2pt * sdotSQ + tmp1;
-         const double s0 = (tmaxj - tmp2) / a1pt;
-         const double s1 = (tminj - tmp2) / a1pt;
-         const bool use = jv && !(fabs(a1pt) < thrV);
-         H = use ? dmin(H, dmax(s0, s1)) : H;
-         L = use ? dmax(L, dmin(s0, s1)) : L;
-      }
-      if (accOn)
-      {
-         // joint acceleration limits, ba.cpp:1514-1534, select form: lanes whose joint stands still (or that carry no joint:
-         // thD = thD2 = 0) discard their quotients; the zero-velocity test on sdot^2 (a third division) stays behind a branch
-         // that is taken only when some joint stands still
-         const double vpt = thD;
-         const bool still = fabs(vpt) < thrV;
-         const int svpt = sgn(vpt);
-         const double vTerm = thD2 * sdotSQ;
-         const double hq = (svpt * amaxj - vTerm) / vpt, lq = (-svpt * amaxj - vTerm) / vpt;
-         const bool use = jv && !still;
-         H = use ? dmin(H, hq) : H;
-         L = use ? dmax(L, lq) : L;
-         const bool probe = jv && still && !(fabs(thD2) < thrA);
-         if (__builtin_amdgcn_readfirstlane((int)(__ballot(probe) != 0)))
-            force = probe && (sdotSQ > amaxj / fabs(thD2));
-      }
-#else
       if (FEAT == 2 && jv)
       {
          // torque limits of a serial robot, ba.cpp:1495-1509
@@ -477,7 +415,6 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
             L = dmax(L, (-svpt * amaxj - vTerm) / vpt);
          }
       }
-#endif
       double Hred = force ? -kInf : H;
       grp_min_max<8>(Hred, L);
       sddotH = Hred;
@@ -941,26 +878,6 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       if (S1_UNI(i >= cap || i + 64 >= revStart + (int64_t)segMVC)) { endStatus = BATOTP_ST_CAPACITY; break; }
       if (DIR == 1) mvcWalk(s0v + h * v0); // Euler predictor, ba.cpp:1055-1065: only the move of the reverse-curve cursor survives
 
-#if S1_STAGE_LOOP
-      // The six stages as ONE loop body (the unrolled form is 9-11 KB of code per stage: 61-92 KB per kernel against an
-      // instruction cache of 64 KB shared by two CUs).  The partial sums run over the stage values kept in LDS, in the order
-      // of the unrolled expressions: B0m*v0 + B1m*v1 + ... (stage m uses column m of the tableau, ba.cpp:58-63, 1072-1079).
-#pragma unroll 1
-      for (int st = 0; st < 6; ++st)
-      {
-         double sdT = c_s1B[st] * v0, sddT = c_s1B[st] * w0;
-#pragma unroll 1
-         for (int k = 1; k <= st; ++k)
-         {
-            const double bk = c_s1B[6 * k + st];
-            sdT = sdT + bk * vw[k][lane];
-            sddT = sddT + bk * vw[7 + k][lane];
-         }
-         double &vst = vw[st + 1][lane], &wst = vw[7 + st + 1][lane];
-         S1_STAGE(sdT, sddT, vst, wst)
-      }
-      v6 = vw[6][lane]; w6 = vw[13][lane];
-#else
       S1_STAGE(BK_B00 * v0, BK_B00 * w0, v1, w1)
       S1_STAGE(BK_B01 * v0 + BK_B11 * v1, BK_B01 * w0 + BK_B11 * w1, v2, w2)
       S1_STAGE(BK_B02 * v0 + BK_B12 * v1 + BK_B22 * v2, BK_B02 * w0 + BK_B12 * w1 + BK_B22 * w2, v3, w3)
@@ -969,7 +886,6 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
                BK_B04 * w0 + BK_B14 * w1 + BK_B24 * w2 + BK_B34 * w3 + BK_B44 * w4, v5, w5)
       S1_STAGE(BK_B05 * v0 + BK_B15 * v1 + BK_B25 * v2 + BK_B35 * v3 + BK_B45 * v4 + BK_B55 * v5,
                BK_B05 * w0 + BK_B15 * w1 + BK_B25 * w2 + BK_B35 * w3 + BK_B45 * w4 + BK_B55 * w5, v6, w6)
-#endif
       s6v = sCur;
 
       // FSAL shift and publish, ba.cpp:1096-1100
