@@ -58,7 +58,10 @@ __constant__ double c_s1B[36] = {BK_B00, BK_B01, BK_B02, BK_B03, BK_B04, BK_B05,
 // A condition on path-level values, which are the same in every lane of the wavefront (one path per wavefront): evaluated as a
 // ballot it becomes a scalar branch.  Written as a plain `if`, the compiler cannot know that the lanes agree and wraps the branch
 // and every loop around it in exec-mask bookkeeping (a dozen scalar instructions per cursor-walk iteration) for a divergence that
-// never happens.  NOT for conditions that differ between joints (lanes) or candidate slots.
+// never happens.  NOT for conditions that differ between joints (lanes) or candidate slots.  Measured per use on BASELINE
+// config 4 (1024 wavefronts, repeatable to 0.1 %): the reverse-curve walk gains most (forward sweep 438 -> 403 ms); the knot-cursor
+// walk walkC is the exception -- its loop leaves at the first test nearly always, and there the ballot's round trip through the
+// scalar unit costs more than the exec-mask form (449 / 403 ms plain against 469 / 420 ms): it keeps plain conditions.
 #define S1_UNI(c) (__ballot(c) != 0)
 
 constexpr int S1_BLOCK = 256;
@@ -226,16 +229,16 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       const int lastSeg = n - 2;
       for (;;)
       {
-         if (S1_UNI(sCur >= sSeg && sCur <= sNext)) break;
+         if (sCur >= sSeg && sCur <= sNext) break;
          bool moved = false;
-         if (S1_UNI(sCur > sSeg))
+         if (sCur > sSeg)
          {
-            if (S1_UNI(segC >= lastSeg)) { segC = lastSeg; break; }
+            if (segC >= lastSeg) { segC = lastSeg; break; }
             ++segC; moved = true;
          }
-         if (S1_UNI(sCur < sSeg))
+         if (sCur < sSeg)
          {
-            if (S1_UNI(segC <= 0)) { segC = 0; break; }
+            if (segC <= 0) { segC = 0; break; }
             --segC; moved = true;
          }
          if (!moved) { status |= BATOTP_ST_NONFINITE; break; }
