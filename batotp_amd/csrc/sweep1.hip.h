@@ -298,16 +298,20 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       if (FEAT >= 1 && cartAny)
       {
          // Cartesian velocity / acceleration along s and the quadratic's coefficients, ba.cpp:1368-1385, 1423-1439
-         double v[3], ac[3];
+         double v[3];
 #pragma unroll
          for (int q = 0; q < 3; ++q)
-         {
             v[q] = (cA3[(FEAT >= 1) ? q : 0] * tau2 + cB2[(FEAT >= 1) ? q : 0] * tau + cC1[(FEAT >= 1) ? q : 0]) * vfact;
-            ac[q] = (cA6[(FEAT >= 1) ? q : 0] * tau + cB2[(FEAT >= 1) ? q : 0]) * afact;
-         }
          cq0 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
-         cq1 = 2 * (v[0] * ac[0] + v[1] * ac[1] + v[2] * ac[2]);
-         cq2 = ac[0] * ac[0] + ac[1] * ac[1] + ac[2] * ac[2];
+         if (cartAccOn)
+         {
+            // the acceleration along s and the other two coefficients are read by the Cartesian acceleration limit only
+            double ac[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) ac[q] = (cA6[(FEAT >= 1) ? q : 0] * tau + cB2[(FEAT >= 1) ? q : 0]) * afact;
+            cq1 = 2 * (v[0] * ac[0] + v[1] * ac[1] + v[2] * ac[2]);
+            cq2 = ac[0] * ac[0] + ac[1] * ac[1] + ac[2] * ac[2];
+         }
       }
       if (FEAT == 2)
       {
