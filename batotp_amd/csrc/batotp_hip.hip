@@ -857,7 +857,11 @@ static int launchSpline(batotp_batch *b, int nch, int mode, const double *src, i
    // with the 28 dynamics channels of a 7-joint arm; tiles: 0.05 and 0.22 ms) -- and the lane-per-series kernel beyond:
    // a chunk of 16 knots costs a tile 80 forward and 80 backward steps (the warm-ups), and the tiles of a CU are limited by
    // LDS, so at 2048 paths x 7 series of 1e5 knots the tiles take 34 ms against 22 ms (16 384 paths: 285 against 156 ms).
-   const bool tiled = b->totalTiles > 0 && (b->ctx->splineTiles == 1 || (b->ctx->splineTiles < 0 && (int64_t)b->B * nch <= 4096));
+   // Coefficient rows switch later than pairs: the lane-per-series kernel writes them as 32-byte pieces with a stride of a whole
+   // row, the tiles store them coalesced from LDS (1024 cable-robot paths of 2e5 knots, 6 + 12 series per path: 785 against
+   // 978 ms of precompute per 4096 paths; 1024 GEN7DOF paths x 7 series as pairs: 12.3 against 7.4 ms).
+   const int64_t tileLimit = pairs ? 4096 : 16384;
+   const bool tiled = b->totalTiles > 0 && (b->ctx->splineTiles == 1 || (b->ctx->splineTiles < 0 && (int64_t)b->B * nch <= tileLimit));
    const int *only = nullptr;
    if (tiled)
    {

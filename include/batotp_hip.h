@@ -305,7 +305,7 @@ int  batotp_hip_set_sweep_prefetch(batotp_ctx *ctx, int32_t reverse, int32_t for
  * (they contract by 0.268 per knot: the warm-up arrives with the sequential value's bits), every warm-up value is compared
  * bit for bit with the neighbouring chunk's, and a series with a disagreement is redone by the sequential kernel, so the
  * result IS the sequential kernel's (batotp_amd/csrc/spline_tile.hip.h).  on: -1 (default) automatic -- tiles for batches of
- * up to 4096 series (paths x channels), where the lane-per-series kernel is a dependent chain of N steps with most of the GPU
+ * up to 4096 series (paths x channels; 16 384 where coefficient rows are written), where the lane-per-series kernel is a dependent chain of N steps with most of the GPU
  * idle (one 6-joint trajectory of 1e5 knots: 0.05 ms instead of 9.5 ms), the lane-per-series kernel beyond --, 1 always,
  * 0 never (the parity tests run both). */
 int  batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on);
