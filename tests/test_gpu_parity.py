@@ -670,6 +670,19 @@ def _batch_as_worded(hip_lib, oracle_ctx, config, n_paths, sample):
                 assert_bit_equal(s, oo[key][0], f"{config} path {p} {key}.s")
                 assert_bit_equal(sd, oo[key][1], f"{config} path {p} {key}.sdot")
                 assert s[0] == 0.0 and np.all(np.diff(s) > 0)
+    # the same batch again with every bisection iteration checked (batotp_hip_set_fast_forward 0): every result row and the
+    # sampled curves must come out the same -- the certified fast-forward never changes a result, at full size either
+    kept = {p: (b.curve(p, -1), b.curve(p, 1)) for p in sample if ok[p]}
+    ctx.set_fast_forward(False)
+    b.precompute(0); b.sweep(-1); b.sweep(+1)
+    res2 = b.results()
+    for f in res.dtype.names:
+        assert np.array_equal(res2[f], res[f]), (config, "fast-forward off", f)
+    for p, (rev, fwd) in kept.items():
+        for which, before in ((-1, rev), (1, fwd)):
+            s, sd = b.curve(p, which)
+            assert_bit_equal(s, before[0], f"{config} path {p} curve {which} s, fast-forward off")
+            assert_bit_equal(sd, before[1], f"{config} path {p} curve {which} sdot, fast-forward off")
     b.close()
     ctx.trim()
     ctx.close()
