@@ -1242,8 +1242,19 @@ static void launchSweep1(batotp_batch *b, SweepArgs &a)
    hipStream_t st = b->ctx->stream;
    if (featureLevel(b) == 2)
    {
-      if (a.dir == 1) hipLaunchKernelGGL((k_sweep1<2, 1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
-      else hipLaunchKernelGGL((k_sweep1<2, -1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
+      // the fast-forward of the bisection in the form that fits the mechanism: a parallel robot converted to serial form has
+      // a3 = 0 (tension bounds are lines in sdot^2), a serial chain has friction (bounds quadratic in sdot)
+      const bool lines = (b->P.flags & BATOTP_F_PARALLEL) != 0;
+      if (lines)
+      {
+         if (a.dir == 1) hipLaunchKernelGGL((k_sweep1<2, 1, 0>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
+         else hipLaunchKernelGGL((k_sweep1<2, -1, 0>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
+      }
+      else
+      {
+         if (a.dir == 1) hipLaunchKernelGGL((k_sweep1<2, 1, 1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
+         else hipLaunchKernelGGL((k_sweep1<2, -1, 1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
+      }
    }
    else if (featureLevel(b) == 1)
    {

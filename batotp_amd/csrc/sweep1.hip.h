@@ -71,7 +71,10 @@ constexpr int S1_WM = 256;  // points per reverse-curve window (4 KB per path)
 // FEAT: -1 = compact splines ((value, second derivative) pairs), 0 = coefficient rows, 1 = coefficient rows + the Cartesian
 // speed / acceleration limits (ba.cpp:1225-1229, 1423-1439, 1535-1579), 2 = those + torque limits of a
 // serial robot (a1..a4 splines, ba.cpp:1387-1405, 1495-1509; BASELINE config 3).  DIR: -1 reverse, +1 forward.
-template <int FEAT, int DIR>
+// FF (FEAT == 2 only): which form of the certified fast-forward of the bisection the instantiation carries -- 0: constraints that are
+// lines in sdot^2 (the cable robot in serial form, whose a3 vanishes), 1: the general form for serial chains (a3 != 0).  One form
+// per kernel: with both in one instantiation the cable robot's sweeps were 2 % slower for code they never run.
+template <int FEAT, int DIR, int FF = 0>
 __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
 {
    __shared__ double lim[6][8];
@@ -523,9 +526,9 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
       // (robot.cpp:487-517: a3 = 0 at every knot, so its spline is 0 and tmp1 of ba.cpp:1497 is a4 exactly); no Cartesian
       // acceleration limit (a quadratic in sddot, ba.cpp:1535-1579).  The torque lines take the joint lanes 4..7 of a slot:
       // at most 4 joints.
-      bool ffApplies = a.ff && !over && !cartAccOn && (FEAT == 2 || accOn);
+      bool ffApplies = FF == 0 && a.ff && !over && !cartAccOn && (FEAT == 2 || accOn);
       if (FEAT == 2) ffApplies = ffApplies && nJ <= 4 && !__ballot(jv && !(a3pt == 0.0));
-      if (ffApplies)
+      if (FF == 0 && ffApplies)
       {
          // CERTIFIED FAST-FORWARD.  In x = sdot^2 every constraint of the check is an interval [l_q(x), u_q(x)] for sddot with
          //      u_q = au_q - m_q x,   l_q = al_q - m_q x:
@@ -681,6 +684,124 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
          if (expectEnd)
          {
             // the candidate that should end the loop: the real check and the real test (every slot evaluates the same speed)
+            const double c = sdotTry;
+            const bool violC = verify(c);
+            const bool convC = ratio_lt(fabs(c - sdotGood), c, sdotErrThresh);
+            BK_TICK(tq3);
+            BK_ACC(cyP3, tq2, tq3);
+            if (__ballot(!violC && convC))
+            {
+#ifdef BK_PROFILE_SECTIONS
+               ++nAcc;
+#endif
+               sdotCur = c;                                        // ba.cpp:1296-1302
+               sddot = (DIR == 1) ? sddotH : sddotL;
+               BK_TICK(tpp);
+               BK_ACC(cyD, tp2, tpp);
+               return;
+            }
+         }
+      }
+      if (FEAT == 2 && FF == 1 && a.ff && !over && !cartAccOn)
+      {
+         // CERTIFIED FAST-FORWARD, general form for serial torque limits (a3 != 0: the KUKA chain's friction, the two-link arm; more
+         // than 4 joints).  The bounds of the check are then quadratics in sdot,
+         //      torque, |a1_q| >= thresh (ba.cpp:1495-1509):  (t_q - a4_q - a3_q c - a2_q c^2) / a1_q  for t_q = tmax_q, tmin_q,
+         //      joint acceleration (ba.cpp:1526-1531):        +-amax_q / |theta'_q| - (theta''_q / theta'_q) c^2,
+         // and g(c) = min u - max l has no closed-form first zero worth its price (15 x 15 pairs, a root each) and is not concave.
+         // Instead every candidate gets an APPROXIMATE check: the bounds from coefficients divided once by a1_q resp. theta'_q
+         // (reciprocals to 2 eps), six rounded operations per bound and no division, then the same min / max reduction as the
+         // real check.  The real check's bounds differ from the exact ones by at most 6 eps e_q (ba.cpp's three or four rounded
+         // operations and a quotient), e_q = (|tmax_q| + |tmin_q| + 2 |a4_q| + |a3_q| c + |a2_q| c^2) / |a1_q| resp.
+         // amax_q / |theta'_q| + |theta''_q / theta'_q| c^2, the approximate ones by at most 8 eps e_q: where the approximate
+         // g(c) is farther from 0 than 28 eps E, E = max_q e_q at the first candidate, the real check decides the same way.
+         // Demanded: |g(c)| > 2^-44 E (18 times that).  Standing joints: the check's own quotient, exactly.  The loop of
+         // ba.cpp:1267-1321 is advanced through the certain iterations as above; the first uncertain candidate goes to the generic
+         // passes below, the candidate that would end the loop gets the real check (its sddot bounds are the result).
+         auto fastRcp = [](double d) {
+            double r = __builtin_amdgcn_rcp(d);
+            r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+            return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+         };
+         const double cTop = sdotH, xTop = cTop * cTop;           // the first candidate: no later one is larger
+         // acceleration line of this lane's joint: u = aa - ma x, l = -aa - ma x
+         const bool useA = accOn && jv && !(fabs(thD) < thrV);
+         const double ra = fastRcp(useA ? thD : 1.0);
+         const double aa = useA ? amaxj * fabs(ra) : kInf;
+         const double ma = useA ? thD2 * ra : 0.0;
+         // torque bounds of this lane's joint: u = tu - tb c - tm x, l = tl - tb c - tm x
+         const bool useT = jv && !(fabs(a1pt) < thrV);
+         const double r1 = fastRcp(useT ? a1pt : 1.0);
+         const double q0 = (tmaxj - a4pt) * r1, q1 = (tminj - a4pt) * r1;
+         const double tu = useT ? dmax(q0, q1) : kInf, tl = useT ? dmin(q0, q1) : -kInf;
+         const double tb = useT ? a3pt * r1 : 0.0, tm = useT ? a2pt * r1 : 0.0;
+         double eq = useA ? aa + fabs(ma) * xTop : 0.0;
+         const double eT = (fabs(tmaxj) + fabs(tminj) + 2.0 * fabs(a4pt) + fabs(a3pt) * cTop + fabs(a2pt) * xTop) * fabs(r1);
+         eq = useT ? dmax(eq, eT) : eq;
+         const double eMax = grp_max<8>(eq);
+         const double bandG = eMax * 0x1p-44;
+         const bool standing = accOn && jv && !useA && !(fabs(thD2) < thrA);
+         double xForce = kInf;
+         if (__ballot(standing)) xForce = grp_min<8>(standing ? amaxj / fabs(thD2) : kInf);
+         // magnitudes far inside the normal range; NaNs fail every test
+         const bool sane = (eMax > 1e-100) & (eMax < 1e100) & (cTop > 1e-100) & (cTop < 1e50);
+         // d(c) > 0 <=> violated, |d(c)| > bandG <=> certain: -g(c) of the approximate check, +inf where a standing joint forbids c
+         auto dOf = [&](double c) __attribute__((always_inline)) -> double {
+            const double x = c * c;
+            const double tt = tb * c + tm * x;
+            double U = vmin_f64(aa - ma * x, tu - tt), Lw = vmax_f64(-aa - ma * x, tl - tt);
+            grp_min_max<8>(U, Lw);
+            const double g = vmin_f64(U, sddotMax) - vmax_f64(Lw, -sddotMax);
+            return (x > xForce) ? kInf : -g;
+         };
+         BK_TICK(tq1);
+         BK_ACC(cyP1, tp2, tq1);
+         bool expectEnd = false;
+         if (__ballot(sane))
+         {
+            int it = __builtin_amdgcn_readfirstlane(nIter);
+            bool inBand = false;
+            // the search for a first feasible speed (ba.cpp:1281-1285)
+#pragma unroll 1
+            for (; it < 90; ++it)
+            {
+               const double c = sdotTry, d = dOf(c);
+               inBand = !((fabs(d) > bandG) & (c > 1e-100));
+               if (__ballot(inBand | !(d > 0.0))) break;
+               lowFact *= 2.0;
+               sdotH = c;
+               sdotL = dmax(.999 * 0.0, (1.0 - lowFact) * c);
+               sdotTry = .5 * (sdotH + sdotL);
+            }
+            if (!__ballot(inBand) && it < 90)
+            {
+               // the first feasible speed: ba.cpp:1294 compares it with sdotGood = 0 and goes on; then the plain bisection
+               sdotGood = sdotTry; nGood = 1; sdotL = sdotTry;
+               ++it;
+               sdotTry = .5 * (sdotH + sdotL);
+               bool goesOn = true;
+               const double convThr = 1e-3 * (1.0 + 3e-14);
+#pragma unroll 1
+               for (; it < 90; ++it)
+               {
+                  const double c = sdotTry, d = dOf(c);
+                  const bool viol = d > 0.0;
+                  inBand = !(fabs(d) > bandG);
+                  goesOn = viol | (fabs(c - sdotL) > convThr * c);
+                  if (__ballot(inBand | !goesOn)) break;
+                  sdotH = viol ? c : sdotH;
+                  sdotL = viol ? sdotL : c;
+                  sdotTry = .5 * (sdotH + sdotL);
+               }
+               sdotGood = sdotL;
+               expectEnd = !__ballot(inBand | goesOn);
+            }
+            nIter = it;
+         }
+         BK_TICK(tq2);
+         BK_ACC(cyP2, tq1, tq2);
+         if (expectEnd)
+         {
             const double c = sdotTry;
             const bool violC = verify(c);
             const bool convC = ratio_lt(fabs(c - sdotGood), c, sdotErrThresh);
