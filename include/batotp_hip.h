@@ -310,9 +310,11 @@ int  batotp_hip_set_sweep_prefetch(batotp_ctx *ctx, int32_t reverse, int32_t for
  * 0 never (the parity tests run both). */
 int  batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on);
 /* the bisection of BA::applyAccelConstraintsBisectionPt (reference batotp/ba.cpp:1248-1332) in the one-path-per-wavefront sweep
- * kernel (batotp_amd/csrc/sweep1.hip.h), problems with joint velocity / acceleration limits only: after a violated first check
- * the kernel computes, in closed form, the speed at which the joints' sddot intervals stop intersecting, and takes every
- * iteration of the loop whose outcome is CERTAIN given the rounding-error bounds of the check without running the check;
+ * kernel (batotp_amd/csrc/sweep1.hip.h), problems with joint velocity / acceleration limits and / or serial torque limits (no
+ * Cartesian acceleration limit): after a violated first check the kernel computes the speed at which the joints' sddot intervals
+ * stop intersecting (closed form where the constraints are lines in sdot^2, a division-free approximate check per candidate
+ * otherwise), and takes every iteration of the loop whose outcome is CERTAIN given the rounding-error bounds of the check without
+ * running the check;
  * candidates within the error band, and the last one (whose sddot bounds are the result), get the real check.  Results are
  * identical with it on (default) and off (the parity tests run both).  on: 1 / 0. */
 int  batotp_hip_set_fast_forward(batotp_ctx *ctx, int32_t on);

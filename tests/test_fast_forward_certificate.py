@@ -16,14 +16,14 @@ EPS = 2.0 ** -53
 INF = np.inf
 
 
-def _real_check(x, c, A, v, D, thr_v, thr_a, sddot_max, trq):
+def _real_check(x, c, A, v, D, thr_v, thr_a, sddot_max, trq, a3=None):
     """verify_second_order for line constraints; x = fl(c*c).  Returns violated (bool).  ba.cpp:1495-1534 in order."""
     H, L = sddot_max, -sddot_max
     force = False
     if trq is not None:
         a1, a2, a4, tmax, tmin = trq
         for q in range(len(a1)):
-            tmp1 = 0.0 * c + a4[q]                      # a3 = 0: a3*sdot + a4
+            tmp1 = (0.0 if a3 is None else a3[q]) * c + a4[q]   # a3*sdot + a4 (a3 = 0: the cable robot)
             if not (abs(a1[q]) < thr_v):
                 tmp2 = a2[q] * x + tmp1
                 s0 = (tmax[q] - tmp2) / a1[q]
@@ -170,3 +170,88 @@ def test_certain_candidates_get_the_outcome_of_the_real_check(kind):
     # inside it (over 6000 problems of these five kinds the farthest wrong comparison lay at 3.7e-4 of the band's width)
     for rel_band, dl in closest:
         assert dl < 0.1 * rel_band
+
+
+def _approx_check(rng, c_top, A, v, D, thr_v, thr_a, sddot_max, trq, a3):
+    """the division-free check of the general form (sweep1.hip.h, 'general form for serial torque limits'): returns d(c) and the band"""
+    x_top = c_top * c_top
+    aa = np.full(len(A), INF); ma = np.zeros(len(A)); e = [0.0]
+    x_force = INF
+    for q in range(len(A)):
+        if abs(v[q]) < thr_v:
+            if not (abs(D[q]) < thr_a):
+                x_force = min(x_force, A[q] / abs(D[q]))
+        else:
+            ra = _rcp(rng, v[q])
+            aa[q] = A[q] * abs(ra); ma[q] = D[q] * ra
+            e.append(aa[q] + abs(ma[q]) * x_top)
+    a1, a2, a4, tmax, tmin = trq
+    n = len(a1)
+    tu = np.full(n, INF); tl = np.full(n, -INF); tb = np.zeros(n); tm = np.zeros(n)
+    for q in range(n):
+        if not (abs(a1[q]) < thr_v):
+            r1 = _rcp(rng, a1[q])
+            q0, q1 = (tmax[q] - a4[q]) * r1, (tmin[q] - a4[q]) * r1
+            tu[q], tl[q], tb[q], tm[q] = max(q0, q1), min(q0, q1), a3[q] * r1, a2[q] * r1
+            e.append((abs(tmax[q]) + abs(tmin[q]) + 2.0 * abs(a4[q]) + abs(a3[q]) * c_top + abs(a2[q]) * x_top) * abs(r1))
+    band = max(e) * 2.0 ** -44
+
+    def d_of(c):
+        x = c * c
+        U, Lw = sddot_max, -sddot_max
+        for q in range(len(A)):
+            U = min(U, aa[q] - ma[q] * x); Lw = max(Lw, -aa[q] - ma[q] * x)
+        for q in range(n):
+            tt = tb[q] * c + tm[q] * x
+            U = min(U, tu[q] - tt); Lw = max(Lw, tl[q] - tt)
+        return INF if x > x_force else -(U - Lw)
+    return d_of, band
+
+
+def test_the_division_free_check_of_the_general_form_certifies_the_real_one():
+    """serial torque limits with friction (a3 != 0: bounds quadratic in sdot): wherever |d(c)| exceeds the band, the real check of
+    ba.cpp:1495-1534 decides as sign(d) says; probed densely around the crossing found by bisection on the real check"""
+    rng = np.random.default_rng(77)
+    used = probes = 0
+    worst = 0.0
+    for _ in range(500):
+        A, v, D, thr_v, thr_a, sddot_max, _ = _problem(rng, "plain")
+        n = len(A)
+        a1 = rng.normal(size=n) * 10.0 ** rng.uniform(-2, 1)
+        a2 = rng.normal(size=n) * 10.0 ** rng.uniform(-2, 2)
+        a3 = rng.normal(size=n) * 10.0 ** rng.uniform(-2, 1)
+        a4 = rng.normal(size=n)
+        tmax = np.abs(a4) + 10.0 ** rng.uniform(-1, 2, n)
+        tmin = -np.abs(a4) - 10.0 ** rng.uniform(-1, 2, n)
+        trq = (a1, a2, a4, tmax, tmin)
+        chk = lambda c: _real_check(c * c, c, A, v, D, thr_v, thr_a, sddot_max, trq, a3)
+        c0 = None
+        for c in 10.0 ** np.linspace(-4, 6, 41):
+            if chk(c):
+                c0 = c
+                break
+        if c0 is None or c0 == 1e-4:
+            continue
+        d_of, band = _approx_check(rng, c0, A, v, D, thr_v, thr_a, sddot_max, trq, a3)
+        lo, hi = 0.0, c0                          # the crossing below c0 the bisection would approach
+        for _ in range(200):
+            mid = 0.5 * (lo + hi)
+            if chk(mid):
+                hi = mid
+            else:
+                lo = mid
+        used += 1
+        for sgn in (-1.0, 1.0):
+            for dl in 10.0 ** np.linspace(-16, -1, 61):
+                c = hi * (1.0 + sgn * dl)
+                if not (0.0 < c <= c0):
+                    continue
+                d = d_of(c)
+                real = chk(c)
+                if abs(d) > band:
+                    probes += 1
+                    assert (d > 0.0) == real, (dl, sgn, d, band)
+                elif (d > 0.0) != real and band > 0:
+                    worst = max(worst, abs(d) / band)
+    assert used > 200 and probes > 10000, (used, probes)
+    assert worst < 0.1          # wrong signs of the approximate check occur only deep inside the band

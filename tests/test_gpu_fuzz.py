@@ -274,11 +274,12 @@ def test_random_two_link_arm_with_torque_limits(hip_lib, oracle_ctx, seed):
     ys = [np.ascontiguousarray(np.vstack([y, np.zeros((prob.n_cart, y.shape[1]))])) for y in ys]
     sres = [float(rng.uniform(0.2, 2.0)) for _ in ys]
     outs = []
-    for lanes, c in ((0, None), (8, None), (4, None), (2, None), (-1, oracle_ctx)):
+    # 64 / "64noff": one path per wavefront with and without the certified fast-forward of the bisection (general form: a3 != 0)
+    for lanes, c in ((0, None), (8, None), (4, None), (2, None), (64, None), ("64noff", None), (-1, oracle_ctx)):
         ctx = c
         if ctx is None:
             ctx = capi.Context(hip_lib, 0)
-            ctx.set_sweep_group(lanes)
+            set_layout(ctx, lanes)
         b = capi.Batch(ctx, prob, [y.shape[1] for y in ys], 30000)
         for k, y in enumerate(ys):
             b.upload_knots(k, [y], [sres[k]])
