@@ -180,6 +180,7 @@ class Library:
             "batotp_hip_ctx_trim": [P],
             "batotp_hip_fp64_kat": [P, I64, D, D, D, D, D],
             "batotp_hip_div6_kat": [P, I64, D, D],
+            "batotp_hip_sdiv_kat": [P, I64, D, D, D, C.POINTER(I32)],
             "batotp_hip_batch_create": [P, C.POINTER(Problem), I32, C.POINTER(C.c_int64), I64, C.POINTER(P)],
             "batotp_hip_batch_destroy": [P],
             "batotp_hip_upload_knots": [P, I32, I32, D, D],
@@ -210,6 +211,7 @@ class Library:
             "batotp_hip_set_paths_per_wave": [P, I32],
             "batotp_hip_set_overlap": [P, I32],
             "batotp_hip_set_sweep_hold": [P, I32, I32],
+            "batotp_hip_set_flat_form": [P, I32],
             "batotp_hip_set_sweep_prefetch": [P, I32, I32],
             "batotp_hip_set_spline_tiles": [P, I32],
             "batotp_hip_set_fast_forward": [P, I32],
@@ -287,6 +289,10 @@ class Context:
 
     def set_sweep_hold(self, reverse: int, forward: int):
         self.library.check(self.library.lib.batotp_hip_set_sweep_hold(self.handle, reverse, forward), "set_sweep_hold")
+
+    def set_flat_form(self, form: int):
+        """1 = k_sweep8 (default), 0 = the flat instantiation of the general kernel (include/batotp_hip.h)"""
+        self.library.check(self.library.lib.batotp_hip_set_flat_form(self.handle, form), "set_flat_form")
 
     def set_sweep_prefetch(self, reverse: int, forward: int):
         self.library.check(self.library.lib.batotp_hip_set_sweep_prefetch(self.handle, reverse, forward), "set_sweep_prefetch")
@@ -426,6 +432,15 @@ class Output:
         v = C.c_float(0)
         self.L.check(self.lib.batotp_hip_output_ms(self.handle, C.byref(v)), "output_ms")
         return float(v.value)
+
+
+def sdiv_kat(ctx: "Context", a: np.ndarray, b: np.ndarray):
+    """(a / b as k_sweep8 divides by a shared reciprocal, which operand pairs went through the reciprocal)"""
+    a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+    q = np.empty_like(a); w = np.empty(a.size, dtype=np.int32)
+    ctx.library.check(ctx.library.lib.batotp_hip_sdiv_kat(ctx.handle, a.size, _dptr(a), _dptr(b), _dptr(q),
+                                                          w.ctypes.data_as(C.POINTER(C.c_int32))), "sdiv_kat")
+    return q, w.astype(bool)
 
 
 def div6_kat(ctx: "Context", a: np.ndarray) -> np.ndarray:

@@ -17,6 +17,7 @@
 #include "batotp_models.h"
 #include "kernels.hip.h"
 #include "sweep1.hip.h"
+#include "sweep8.hip.h"
 #include "spline_tile.hip.h"
 #include "resample.hip.h"
 #include "output.hip.h"
@@ -92,6 +93,7 @@ struct batotp_ctx
    // toolchain the loop was validated with and the canary of flatLoopStatus agreed with the nested loops on this device),
    // -1 = built by another toolchain, -2 = the canary disagreed, -3 = the canary could not run
    int splineTiles = -1;  // K1 in tiles of knots (spline_tile.hip.h): -1 automatic (small batches), 1 always, 0 never
+   int flatForm = 1;      // flat loop of the 8-lane layout: 1 = k_sweep8 (sweep8.hip.h), 0 = k_sweep's own flat instantiation (A/B, parity)
    int fastForward = 1;   // certified fast-forward of the bisection in the sweep kernels that have it (bisect_fast_forward)
    int flatStatus = 0;
    char builtWith[192] = "";    // toolchain the gate compares (the real one unless BATOTP_ASSUME_TOOLCHAIN overrides it for a test)
@@ -108,6 +110,7 @@ struct batotp_batch
    std::vector<PathInfo> pinfo; // host mirror
    bool needPar = false;        // some path may run the parallel-mechanism torque branch
    bool k3Pending = false;      // an overlapped per-knot evaluation may still be running on ctx->stream2
+   bool lastForm8[2] = {false, false}; // the most recent sweep per direction ran k_sweep8
    bool compact = false;        // BATOTP_F_COMPACT_SPLINES: dElim holds the second derivatives, there is no dCoef
    bool kinDone = false, dynDone = false, sitesSet = false, revDone = false, trigSet = false;
    bool inPlace = false;   // BATOTP_F_CURVES_IN_PLACE: dFwd aliases dRev
@@ -342,6 +345,13 @@ extern "C" int batotp_hip_set_sweep_hold(batotp_ctx *ctx, int32_t reverse, int32
    return BATOTP_OK;
 }
 
+extern "C" int batotp_hip_set_flat_form(batotp_ctx *ctx, int32_t form)
+{
+   if (!ctx || form < 0 || form > 1) return BATOTP_ERR_ARG;
+   ctx->flatForm = form;
+   return BATOTP_OK;
+}
+
 extern "C" int batotp_hip_set_sweep_prefetch(batotp_ctx *ctx, int32_t reverse, int32_t forward)
 {
    if (!ctx || reverse < -1 || reverse > 3 || forward < -1 || forward > 3) return BATOTP_ERR_ARG;
@@ -423,6 +433,25 @@ extern "C" int batotp_hip_div6_kat(batotp_ctx *ctx, int64_t n, const double *a, 
    hipError_t e = hipStreamSynchronize(ctx->stream);
    hipFree(d);
    if (e != hipSuccess) return hipFail(e, "div6_kat");
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_sdiv_kat(batotp_ctx *ctx, int64_t n, const double *a, const double *b, double *q, int32_t *in_window)
+{
+   if (!ctx || n <= 0 || !a || !b || !q || !in_window) return BATOTP_ERR_ARG;
+   int rc = bind(ctx);
+   if (rc) return rc;
+   double *d = nullptr;
+   const size_t sz = sizeof(double) * (size_t)n;
+   HIP_TRY(hipMalloc((void **)&d, 4 * sz));
+   hipMemcpyAsync(d, a, sz, hipMemcpyHostToDevice, ctx->stream);
+   hipMemcpyAsync(d + n, b, sz, hipMemcpyHostToDevice, ctx->stream);
+   hipLaunchKernelGGL(k_kat_sdiv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, d, d + n, d + 2 * n, reinterpret_cast<int *>(d + 3 * n));
+   hipMemcpyAsync(q, d + 2 * n, sz, hipMemcpyDeviceToHost, ctx->stream);
+   hipMemcpyAsync(in_window, d + 3 * n, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+   hipError_t e = hipStreamSynchronize(ctx->stream);
+   hipFree(d);
+   if (e != hipSuccess) return hipFail(e, "sdiv_kat");
    return BATOTP_OK;
 }
 
@@ -1206,9 +1235,18 @@ static void launchSweep(batotp_batch *b, SweepArgs &a)
    // Cartesian limits always run the nested loops, and so do paths with uploaded (non-uniform) sites.
    const bool flat = (G == 8 || G == 4 || G == 2) && hold >= 0 && featureLevel(b) <= 0 && uni;
    b->lastLanes[a.dir == -1 ? 0 : 1] = G; b->lastPpw[a.dir == -1 ? 0 : 1] = ppw; b->lastHold[a.dir == -1 ? 0 : 1] = flat ? hold : -1;
+   // the flat loop of the 8-lane layout written for the instruction count (sweep8.hip.h); 32-bit step counters
+   const bool form8 = flat && (G == 8 || G == 4) && b->ctx->flatForm == 1 && b->cap < ((int64_t)1 << 30);
+   b->lastForm8[a.dir == -1 ? 0 : 1] = form8;
 #define LAUNCH_K4(F)                                                                           \
    do {                                                                                        \
-      if (flat) hipLaunchKernelGGL((k_sweep<G, F, true, ((G == 8 || G == 4 || G == 2) && F <= 0)>), dim3(grid), dim3(K4_BLOCK), 0, st, a);  \
+      if (form8 && F <= 0)                                                                     \
+      {                                                                                        \
+         constexpr int F8 = F <= 0 ? F : 0, G8 = G == 4 ? 4 : 8;                               \
+         if (a.dir == 1) hipLaunchKernelGGL((k_sweep8<G8, F8, 1>), dim3(grid), dim3(S8_BLOCK), 0, st, a);  \
+         else hipLaunchKernelGGL((k_sweep8<G8, F8, -1>), dim3(grid), dim3(S8_BLOCK), 0, st, a);    \
+      }                                                                                        \
+      else if (flat) hipLaunchKernelGGL((k_sweep<G, F, true, ((G == 8 || G == 4 || G == 2) && F <= 0)>), dim3(grid), dim3(K4_BLOCK), 0, st, a);  \
       else if (uni) hipLaunchKernelGGL((k_sweep<G, F, true>), dim3(grid), dim3(K4_BLOCK), 0, st, a);      \
       else hipLaunchKernelGGL((k_sweep<G, F, false>), dim3(grid), dim3(K4_BLOCK), 0, st, a);        \
    } while (0)

@@ -1,0 +1,603 @@
+// sweep8.hip.h -- K4 for large batches of velocity / acceleration-only problems (round 4): the flat stage / bisection loop of
+// k_sweep<8, FEAT <= 0, true, true> (kernels.hip.h) written for the instruction count.
+//
+// Same decomposition: a path = 8 lanes (lane j = joint j), up to 8 paths per wavefront, every path of a wavefront is either
+// waiting for its next stage or inside a constraint check; a pass of the loop runs the stage prologue for the waiting paths
+// once `hold`/8 of the live paths wait, then one constraint check + bisection update for every path inside one.  Same
+// arithmetic: every fp64 operation of BA::sweep (ba.cpp:979-1195), sdotLim (:1204-1236), evalsdot (:1590-1607), updateCurSeg
+// (:1617-1652), applyAccelConstraintsBisectionPt (:1248-1332), evalSplinePartials (:1341-1413) and
+// verifySecondOrderConstraints (:1514-1534, joint acceleration family) in the reference's order, uncontracted.
+//
+// What differs from the general kernel is the code around the arithmetic (profiles/r03_c: a third of its loop was exec-mask
+// bookkeeping the compiler generated for nested divergent branches and loops with several exits):
+//   * one level of divergence per block (waiting paths / checking paths); everything inside is straight-line select code;
+//   * the segment walks are wavefront-uniform loops ("while any lane moved") over select-form steps;
+//   * rare cases (a joint that stands still, a threshold test that needs its true quotient, a segment change, the end of a
+//     step) sit behind wavefront-uniform branches on ballots and cost nothing when no lane needs them;
+//   * the reverse-curve segment of the forward sweep is kept in registers and updated by ONE 16-byte load per move;
+//   * curve points leave through LDS, four at a time: one 64-byte store per path and four steps instead of four 16-byte
+//     stores (the reverse sweep's 16 384 descending streams lost their partly written lines from the L2 between the stores:
+//     3.0x the curve bytes written, profiles/r03_e).
+// Results are bit-identical to k_sweep's (every sweep test runs both; tests/test_gpu_parity.py, tests/test_gpu_fuzz.py).
+#pragma once
+#include "kernels.hip.h"
+
+namespace bk
+{
+
+constexpr int S8_BLOCK = 256;
+
+// (num / den) < thr as ratio_lt (kernels.hip.h) decides it, in two parts: the product form, and whether it was decisive
+__device__ __forceinline__ bool s8_ratio_lt_fast(double num, double den, double thr, bool &decided)
+{
+   const double p = thr * den;
+   const bool ok = (den > 0.0) & (num >= 0.0) & (p > 1e-290) & (p < 1e290);
+   const bool lt = num < p * (1.0 - 1e-14), gt = num > p * (1.0 + 1e-14);
+   decided = ok & (lt | gt);
+   return lt;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Division by a value that stays the same for several quotients (theta' of the evaluation point divides the two bounds of
+// every constraint check of a stage and the velocity limit of the next stage).  hipcc lowers an fp64 `a / b` to
+//    ds = v_div_scale(b, b, a); ns = v_div_scale(a, b, a); r = v_rcp(ds); two Newton steps on r (four FMAs);
+//    q = ns * r; rem = fma(-ds, q, ns); v_div_fmas(rem, r, q); v_div_fixup(., b, a)
+// where both v_div_scale return their operand unchanged, v_div_fmas is a plain FMA and v_div_fixup returns its first
+// operand unless an operand is zero / infinite / NaN, the quotient leaves the normal range or the exponents are extreme
+// (ISA: scaling when the numerator's biased exponent is <= 53, the denominator or its reciprocal is denormal, the
+// exponents differ by >= 768, or the quotient is denormal).  For |a|, |b| in [2^-350, 2^350] none of that applies, the
+// refined reciprocal depends on b alone, and a quotient is the last three operations of the SAME sequence: the same bits
+// as `a / b` by construction (checked on the device against `/` for 2^22 operand pairs incl. the edges of the window:
+// batotp_hip_fp64_kat, tests/test_gpu_parity.py::test_shared_reciprocal_division...).  Outside the window the callers use `/`.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr double S8_DIV_LO = 0x1p-350, S8_DIV_HI = 0x1p350;
+__device__ __forceinline__ bool s8_div_window(double x) { return (fabs(x) >= S8_DIV_LO) & (fabs(x) <= S8_DIV_HI); }
+__device__ __forceinline__ double s8_rcp_refined(double den)
+{
+   double r = __builtin_amdgcn_rcp(den);
+   double e = __builtin_fma(-den, r, 1.0);
+   r = __builtin_fma(r, e, r);
+   e = __builtin_fma(-den, r, 1.0);
+   r = __builtin_fma(r, e, r);
+   return r;
+}
+__device__ __forceinline__ double s8_div_by(double num, double den, double r)
+{
+   const double q = num * r;
+   const double rem = __builtin_fma(-den, q, num);
+   return __builtin_fma(rem, r, q);
+}
+
+// known-answer test of the shared-reciprocal division against `/` (batotp_hip_fp64_kat)
+__global__ void k_kat_sdiv(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ q, int *__restrict__ inWindow)
+{
+   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   const bool ok = s8_div_window(a[i]) & s8_div_window(b[i]);
+   inWindow[i] = ok ? 1 : 0;
+   q[i] = ok ? s8_div_by(a[i], b[i], s8_rcp_refined(b[i])) : a[i] / b[i];
+}
+
+// G lanes per path (8: one joint per lane, 4: joints j and j + 4 in lane j), up to 64 / G paths per wavefront
+template <int G, int FEAT, int DIR>
+__global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a)
+{
+   static_assert(FEAT == -1 || FEAT == 0, "velocity / acceleration-only problems");
+   static_assert(G == 8 || G == 4, "lanes per path");
+   constexpr int PER = 8 / G;
+   __shared__ double lim[6][8];
+   __shared__ double rk[7][6];                 // rk[st][k] = weight of stage value k in stage st (column st-1 of ba.cpp:58-63), 0 for k >= st
+   __shared__ double2 pts[S8_BLOCK / G][4];    // curve points of a path waiting for their 64-byte store
+   if (threadIdx.x < 42)
+   {
+      const double tab[42] = {0, 0, 0, 0, 0, 0,
+                              BK_B00, 0, 0, 0, 0, 0,
+                              BK_B01, BK_B11, 0, 0, 0, 0,
+                              BK_B02, BK_B12, BK_B22, 0, 0, 0,
+                              BK_B03, BK_B13, BK_B23, BK_B33, 0, 0,
+                              BK_B04, BK_B14, BK_B24, BK_B34, BK_B44, 0,
+                              BK_B05, BK_B15, BK_B25, BK_B35, BK_B45, BK_B55};
+      (&rk[0][0])[threadIdx.x] = tab[threadIdx.x];
+   }
+   stage_limits(a.dP, lim);
+
+   const int lane = threadIdx.x & 63;
+   const int wave = blockIdx.x * (S8_BLOCK / 64) + (threadIdx.x >> 6);
+   const int j = lane % G;
+   const int slot = lane / G;
+   const int p = wave * a.ppw + slot;
+   if (slot >= a.ppw || p >= a.B) return; // whole groups leave together; DPP never crosses groups
+   const bool writer = (j == 0);
+   const PathInfo pi = a.pinfo[p];
+   const int n = (int)pi.n;
+   const int64_t cap = a.cap;
+   double2 *mypts = pts[threadIdx.x / G];
+
+   // bootstrap (ba.cpp:1021-1041) through the general kernel's device functions; the loop below carries its own state
+   Pt<G, FEAT, true> t;
+   pt_init(t, a.P, pi, a.sC, a.coef, a.km, lim, j, DIR);
+
+   double2 *out = (DIR == 1 ? a.fwd : a.rev) + (int64_t)p * cap; // may alias the reverse curve (curves in place)
+   batotp_path_result *__restrict__ r = a.res + p;
+   const double2 *mvc = nullptr; // the reverse curve the forward sweep follows
+   int nMvc = 0;
+   if (DIR == 1)
+   {
+      const int64_t nRev = r->n_rev;
+      if (nRev < 2)
+      {
+         if (writer) { r->n_fwd = 0; r->steps_fwd = 0; r->t_total = 0; r->status_fwd = r->status_rev | BATOTP_ST_CAPACITY; r->n_bisect_fail_fwd = 0; }
+         return;
+      }
+      mvc = a.rev + (int64_t)p * cap + (cap - nRev);
+      nMvc = (int)nRev;
+      t.mvc = reinterpret_cast<const double *>(mvc);
+      t.nMvc = nMvc;
+   }
+   // curves in place (kernels.hip.h, BK_CURVE_FULL): slot i must have been left behind by the reverse-curve cursor
+   const int64_t revStart = (DIR == 1 && a.fwd == a.rev) ? cap - (int64_t)nMvc : ((int64_t)1 << 62);
+
+   const double absh = a.P.integ_res;
+   const double h = DIR * absh;
+   const int64_t maxIntegSteps = (int64_t)floor(a.P.max_integ_time / a.P.integ_res) + 1;
+   const double sres = pi.sres_c;
+   const double sEnd = sres * (double)(n - 1);
+   const double sLast = (DIR == 1) ? sEnd : 0.0;
+   double s0v = (DIR == 1) ? 0.0 : sEnd;
+   double v0, w0 = 0;
+   if (DIR == 1) { t.segC = 0; t.tauC = 0; t.segMVC = 0; t.tauMVC = 0; }
+   else { t.segC = n - 2; t.tauC = 1; t.segMVC = n - 2; t.tauMVC = 1; }
+   t.sCur = s0v;
+   t.sdotCur = 0;
+#pragma unroll 1
+   for (int pass = 0; pass < 2; ++pass)
+   {
+      accel_pt(t, j, w0);
+      if (pass == 0) { v0 = .1 * h * w0; t.sdotMin = v0; }
+      else v0 = t.sdotCur;
+      sdot_lim(t, j, v0);
+      if (pass == 0) { t.sdotMin = v0; t.sdotCur = v0; }
+   }
+   const double vBoot = v0;
+
+   // ---- the loop's own state -------------------------------------------------------------------
+   // lane constants: joints jj[q] = j + q G of this lane
+   bool jOn[PER];
+   int jAt[PER];
+   double vmax[PER], amax[PER];
+   // this lane's coefficients on the cursor's segment: c1, 2 c2, 3 c3, 6 c3 (the products the reference forms first:
+   // (3*c3)*tau2, (2*c2)*tau, (6*c3)*tau, ba.cpp:1358-1360); theta', theta'' of the last evaluation point; the refined
+   // reciprocal of theta' (s8_rcp_refined) and whether theta' lies in the window in which it may be used
+   double c1[PER], c2x2[PER], c3x3[PER], c3x6[PER], thD[PER], thD2[PER], rD[PER];
+   double sa[PER]; // sgn(theta') * amax of ba.cpp:1526-1531 where theta' != 0: amax with the sign of theta' (1.0 * amax and -1.0 * amax are exact)
+   bool rOk[PER];
+#pragma unroll
+   for (int q = 0; q < PER; ++q)
+   {
+      jOn[q] = (j + q * G) < t.nJ;
+      jAt[q] = jOn[q] ? j + q * G : 0;
+      vmax[q] = t.vmax[q]; amax[q] = t.amax[q];
+      c1[q] = jOn[q] ? t.rowTh[q].c1 : 0.0; c2x2[q] = jOn[q] ? 2 * t.rowTh[q].c2 : 0.0;
+      c3x3[q] = jOn[q] ? 3 * t.rowTh[q].c3 : 0.0; c3x6[q] = jOn[q] ? 6 * t.rowTh[q].c3 : 0.0;
+      thD[q] = t.thD[q]; thD2[q] = t.thD2[q];
+      rOk[q] = s8_div_window(thD[q]);
+      rD[q] = s8_rcp_refined(thD[q]);
+      sa[q] = (thD[q] < 0.0) ? -amax[q] : amax[q];
+   }
+   const bool accOn = (t.flags & BATOTP_F_JNT_ACC_ON) != 0;
+   const double thrV = t.thrV, thrA = t.thrA, vfact = t.vfact, afact = t.afact;
+   const double sdotCap = t.sdotCap, sddotMax = t.sddotMax, sdotMin = t.sdotMin;
+   const int lastSeg = n - 2;
+   const int nIn = t.nIn;
+   const double2 *__restrict__ km = t.km;
+   const double *__restrict__ coef = t.coef;
+   const int rowStride = t.C * 4;
+   int seg = t.segC, rowSeg = t.rowSeg;
+   double sSeg = sres * (double)seg, sNext = sres * (double)(seg + 1); // sites of the cursor's segment
+   // reverse-curve cursor (forward sweep): segment and its two points
+   int segM = 0;
+   double mS0 = 0, mD0 = 0, mS1 = 0, mD1 = 0;
+   if (DIR == 1)
+   {
+      segM = t.segMVC;
+      const double2 qa = mvc[segM], qb = mvc[segM + 1];
+      mS0 = qa.x; mD0 = qa.y; mS1 = qb.x; mD1 = qb.y;
+   }
+   unsigned status = t.status;
+   int nfail = t.nfail;
+   double sdotCur = t.sdotCur;
+   double sddotL = t.sddotL, sddotH = t.sddotH;
+
+   double v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+   double w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, w6 = 0;
+   double sPrev = s0v, sdPrev = v0, sCurPt = s0v, sdCurPt = v0; // last two published points, for the end snap
+   double sCur = s0v; // traj.sCur
+
+   const int iMax = (maxIntegSteps > 0x3ffffff0) ? 0x3ffffff0 : (int)maxIntegSteps;
+   const int capI = (int)cap;
+   // first slot the forward curve must not reach: revStart + segM - 64 (in-place curves)
+   const int revStartI = (revStart > 0x3fffffff) ? 0x3fffffff : (int)revStart; // (the launcher keeps cap below 2^30)
+#define S8_CURVE_FULL(i) ((i) >= capI || (DIR == 1 && (i) + 64 >= revStartI + segM))
+
+   // point 0: straight to HBM, and into the group of four it belongs to
+   {
+      const int idx0 = (DIR == 1) ? 0 : capI - 1;
+      if (writer) { out[idx0] = make_double2(s0v, v0); mypts[idx0 & 3] = make_double2(s0v, v0); }
+   }
+   int flushedTo = (DIR == 1) ? 0 : capI; // forward: points [0, flushedTo) are in HBM; reverse: points [flushedTo, cap)
+
+   const double floorV = 0.0 / absh; // ba.cpp:1050-1051,1085
+   int nPts = 0, i = 1;
+   unsigned endStatus = 0;
+   int st = (DIR == 1) ? 0 : 1;
+   constexpr int PH_FIRST = 0, PH_ENDED = 1, PH_CHECK = 2, PH_DEAD = 3;
+   int phase = PH_FIRST;
+   if (S8_CURVE_FULL(i)) { endStatus = BATOTP_ST_CAPACITY; phase = PH_DEAD; }
+   double sN = 0, wN = 0;
+   double lowFact = .01, sdotGood = 0, sdotL = 0, sdotH = 0, sdotTry = 0;
+   int nGood = 0, nIter = 0;
+   bool stageFailed = false; // the bisection of the stage that ended failed: sddotArr[st] keeps its previous value (ba.cpp:1091 ignores the code)
+   const int hold = a.hold;
+
+   for (;;)
+   {
+      const unsigned long long mAlive = __ballot(phase != PH_DEAD);
+      if (mAlive == 0) break;
+      const unsigned long long mWait = __ballot(phase < PH_CHECK);
+      const bool startNow = (mWait == mAlive) || (__popcll(mWait) * 8 >= __popcll(mAlive) * hold);
+      if (startNow && mWait != 0)
+      {
+         if (phase < PH_CHECK)
+         {
+            // ---- the stage that ended: keep its values --------------------------------------------
+            if (phase == PH_ENDED)
+            {
+               phase = PH_FIRST;
+               const double vN = sdotCur;
+               const int stW = stageFailed ? 0 : st; // a failed bisection leaves sddotArr[st] as it was
+               v1 = (st == 1) ? vN : v1; w1 = (stW == 1) ? wN : w1;
+               v2 = (st == 2) ? vN : v2; w2 = (stW == 2) ? wN : w2;
+               v3 = (st == 3) ? vN : v3; w3 = (stW == 3) ? wN : w3;
+               v4 = (st == 4) ? vN : v4; w4 = (stW == 4) ? wN : w4;
+               v5 = (st == 5) ? vN : v5; w5 = (stW == 5) ? wN : w5;
+               const bool stepEnd = (st == 6);
+               st = stepEnd ? st : st + 1;
+               if (__ballot(stepEnd) != 0)
+               {
+                  if (stepEnd)
+                  {
+                     // FSAL shift and publish, ba.cpp:1096-1100 (stage 6: position sN, values vN, wN or the stale sddotArr[6])
+                     const double wE = stageFailed ? w6 : wN;
+                     s0v = sN; v0 = vN; w0 = wE; w6 = wE;
+                     sPrev = sCurPt; sdPrev = sdCurPt;
+                     sCurPt = s0v; sdCurPt = v0;
+                     const int idx = (DIR == 1) ? i : capI - 1 - i;
+                     mypts[idx & 3] = make_double2(s0v, v0); // every lane of the group holds the same pair
+                     st = (DIR == 1) ? 0 : 1;
+                     const bool fin = sCur * DIR > sLast;      // ba.cpp:1109-1115
+                     const bool late = !fin && (i > iMax);     // ba.cpp:1117-1122
+                     nPts = fin ? i + 1 : nPts;
+                     i = (fin || late) ? i : i + 1;
+                     const bool full = !fin && !late && S8_CURVE_FULL(i);
+                     endStatus = late ? (unsigned)BATOTP_ST_MAX_INTEG_TIME : (full ? (unsigned)BATOTP_ST_CAPACITY : endStatus);
+                     phase = (fin || late || full) ? PH_DEAD : phase;
+                     // a complete group of four points: one 64-byte store (not for the step that ends the path: its last
+                     // point is still to be snapped onto the path end)
+                     const bool chunk = !fin && ((DIR == 1) ? ((idx & 3) == 3) : ((idx & 3) == 0));
+                     if (__ballot(chunk) != 0)
+                     {
+                        if (chunk)
+                        {
+                           const int base = idx & ~3;
+                           const int lo = (DIR == 1) ? base : idx, hi = (DIR == 1) ? idx : ((base + 3 < capI) ? base + 3 : capI - 1);
+                           const int at = base + j;
+                           if (j < 4 && at >= lo && at <= hi) out[at] = mypts[j];
+                           flushedTo = (DIR == 1) ? idx + 1 : idx;
+                        }
+                     }
+                  }
+               }
+            }
+            if (phase != PH_DEAD)
+            {
+               if (DIR == 1)
+               {
+                  // forward predictor (ba.cpp:1055-1065): only the move of the reverse-curve cursor survives
+                  const bool pred = (st == 0);
+                  if (__ballot(pred) != 0)
+                  {
+                     if (pred)
+                     {
+                        sCur = s0v + h * v0;
+#include "sweep8_mvcwalk.inc"
+                        st = 1;
+                     }
+                  }
+               }
+               // ---- tableau combination, ba.cpp:1073-1085 ---------------------------------------------
+               const double *bc = rk[st];
+               double sdotT = 0, sddotT = 0;
+               // stage st adds the terms k < st only (a stale stage value may be infinite: 0 * inf must not enter the sum)
+               sdotT += bc[0] * v0; sddotT += bc[0] * w0;
+               { const double a1 = sdotT + bc[1] * v1, b1 = sddotT + bc[1] * w1; sdotT = (st > 1) ? a1 : sdotT; sddotT = (st > 1) ? b1 : sddotT; }
+               { const double a2 = sdotT + bc[2] * v2, b2 = sddotT + bc[2] * w2; sdotT = (st > 2) ? a2 : sdotT; sddotT = (st > 2) ? b2 : sddotT; }
+               { const double a3 = sdotT + bc[3] * v3, b3 = sddotT + bc[3] * w3; sdotT = (st > 3) ? a3 : sdotT; sddotT = (st > 3) ? b3 : sddotT; }
+               { const double a4 = sdotT + bc[4] * v4, b4 = sddotT + bc[4] * w4; sdotT = (st > 4) ? a4 : sdotT; sddotT = (st > 4) ? b4 : sddotT; }
+               { const double a5 = sdotT + bc[5] * v5, b5 = sddotT + bc[5] * w5; sdotT = (st > 5) ? a5 : sdotT; sddotT = (st > 5) ? b5 : sddotT; }
+               sN = s0v + h * sdotT;
+               double vN = v0 + h * sddotT;
+               vN = dmax(vN, floorV); // ba.cpp:1085
+               sCur = sN;
+
+               // ---- sdotLim, ba.cpp:1204-1236 (theta' of the PREVIOUS evaluation point) -----------------
+               if (DIR == 1)
+               {
+                  // evalsdot, ba.cpp:1590-1607
+#include "sweep8_mvcwalk.inc"
+                  const double tauM = (sCur - mS0) / (mS1 - mS0);
+                  const double sdotMVC = dmax(mD0 + tauM * (mD1 - mD0), sdotMin);
+                  vN = (vN > sdotMVC) ? sdotMVC : vN;
+               }
+               vN = dmin(vN, sdotCap);
+               vN = dmax(vN, sdotMin);
+               {
+                  double lim1 = kInf;
+                  bool slowDiv = false; // a quotient outside the window of the shared reciprocal
+#pragma unroll
+                  for (int q = 0; q < PER; ++q)
+                  {
+                     const bool on = jOn[q] && fabs(thD[q]) > thrV;
+                     const bool fast = rOk[q] & s8_div_window(vmax[q]);
+                     const double qv = fabs(s8_div_by(vmax[q], thD[q], rD[q]));
+                     lim1 = (on & fast) ? dmin(lim1, qv) : lim1;
+                     slowDiv |= on & !fast;
+                  }
+                  if (__ballot(slowDiv) != 0)
+                  {
+#pragma unroll
+                     for (int q = 0; q < PER; ++q)
+                     {
+                        const bool on = jOn[q] && fabs(thD[q]) > thrV;
+                        const bool fast = rOk[q] & s8_div_window(vmax[q]);
+                        if (on && !fast) lim1 = dmin(lim1, fabs(vmax[q] / thD[q]));
+                     }
+                  }
+                  lim1 = grp_min<G>(lim1);
+                  vN = dmin(vN, lim1);
+               }
+               sdotCur = vN;
+               // applyAccelConstraintsBisectionPt, ba.cpp:1250-1265
+               lowFact = .01; sdotGood = 0; nGood = 0; sdotL = 0; sdotH = vN; sdotTry = vN; nIter = 0; stageFailed = false;
+
+               // ---- evalSplinePartials, ba.cpp:1341-1413: updateCurSeg (ba.cpp:1617-1652) on the sites sres*k ----
+               if (__ballot(!((sCur >= sSeg) & (sCur <= sNext))) != 0)
+               {
+                  for (;;)
+                  {
+                     sSeg = sres * (double)seg;
+                     sNext = sres * (double)(seg + 1);
+                     const bool inside = (sCur >= sSeg) & (sCur <= sNext);
+                     const bool up = !inside & (sCur > sSeg), down = !inside & (sCur < sSeg);
+                     status |= (!inside & !up & !down) ? (unsigned)BATOTP_ST_NONFINITE : 0u;
+                     const bool mvUp = up & (seg < lastSeg), mvDn = down & (seg > 0);
+                     seg = mvUp ? seg + 1 : (mvDn ? seg - 1 : seg);
+                     if (__ballot(mvUp | mvDn) == 0) break;
+                  }
+               }
+               const double tau = (sCur - sSeg) / (sNext - sSeg);
+               const bool chg = (seg != rowSeg);
+               if (__ballot(chg) != 0)
+               {
+                  if (chg)
+                  {
+#pragma unroll
+                     for (int q = 0; q < PER; ++q)
+                     {
+                        if (FEAT < 0)
+                        {
+                           const unsigned at = (unsigned)(seg * nIn + jAt[q]);
+                           const double2 kl = km[at], kr = km[at + nIn]; // knots seg and seg + 1 of this joint
+                           const double solL = kl.y, solR = kr.y, yL = kl.x, yR = kr.x;
+                           // emit_segment's formulas (spline.cpp:203-209)
+                           const double c3 = div6(solR - solL);
+                           const double c2 = solL / 2.0;
+                           c1[q] = yR - yL - div6(solR + 2 * solL);
+                           c2x2[q] = 2 * c2; c3x3[q] = 3 * c3; c3x6[q] = 6 * c3;
+                        }
+                        else
+                        {
+                           const Coef4 k = *reinterpret_cast<const Coef4 *>(coef + (unsigned)(seg * rowStride) + jAt[q] * 4);
+                           c1[q] = k.c1; c2x2[q] = 2 * k.c2; c3x3[q] = 3 * k.c3; c3x6[q] = 6 * k.c3;
+                        }
+                     }
+                     rowSeg = seg;
+                  }
+               }
+               {
+                  const double tau2 = tau * tau;
+#pragma unroll
+                  for (int q = 0; q < PER; ++q)
+                  {
+                     thD[q] = (c3x3[q] * tau2 + c2x2[q] * tau + c1[q]) * vfact;
+                     thD2[q] = (c3x6[q] * tau + c2x2[q]) * afact;
+                     rOk[q] = s8_div_window(thD[q]);
+                     rD[q] = s8_rcp_refined(thD[q]);
+                     sa[q] = (thD[q] < 0.0) ? -amax[q] : amax[q];
+                  }
+               }
+               phase = PH_CHECK;
+            }
+         }
+      }
+      if (phase == PH_CHECK)
+      {
+         // ---- verifySecondOrderConstraints, ba.cpp:1514-1534, at sdotTry ---------------------------------
+         const double sdotSQ = sdotTry * sdotTry;
+         double H = sddotMax, L = -sddotMax;
+         bool force = false;
+         if (accOn)
+         {
+            bool rare = false; // a joint that stands still, or a quotient outside the window of the shared reciprocal
+#pragma unroll
+            for (int q = 0; q < PER; ++q)
+            {
+               const bool slow = fabs(thD[q]) < thrV;
+               const double vTerm = thD2[q] * sdotSQ;
+               const double nH = sa[q] - vTerm, nL = -sa[q] - vTerm; // (theta' = 0 lies outside the window: the literal form below)
+               const bool fast = rOk[q] & s8_div_window(nH) & s8_div_window(nL);
+               const double qH = s8_div_by(nH, thD[q], rD[q]);
+               const double qL = s8_div_by(nL, thD[q], rD[q]);
+               const bool use = jOn[q] & !slow & fast;
+               H = use ? dmin(H, qH) : H;
+               L = use ? dmax(L, qL) : L;
+               rare |= jOn[q] & (slow | !fast);
+            }
+            if (__ballot(rare) != 0)
+            {
+#pragma unroll
+               for (int q = 0; q < PER; ++q)
+               {
+                  const bool slow = fabs(thD[q]) < thrV;
+                  const int svpt = sgn(thD[q]);
+                  const double vTerm = thD2[q] * sdotSQ;
+                  const double nH = svpt * amax[q] - vTerm, nL = -svpt * amax[q] - vTerm;
+                  const bool fast = rOk[q] & s8_div_window(sa[q] - vTerm) & s8_div_window(-sa[q] - vTerm);
+                  if (jOn[q] && !slow && !fast)
+                  {
+                     H = dmin(H, nH / thD[q]);
+                     L = dmax(L, nL / thD[q]);
+                  }
+                  // a joint that stands still (ba.cpp:1519-1524)
+                  if (jOn[q] && slow && !(fabs(thD2[q]) < thrA)) force |= sdotSQ > amax[q] / fabs(thD2[q]);
+               }
+            }
+         }
+         double Hred = force ? -kInf : H;
+         grp_min_max<G>(Hred, L);
+         sddotH = Hred; sddotL = L;
+         const bool isViol = L > Hred;
+
+         // ---- one pass of the loop of ba.cpp:1267-1321, as selects -----------------------------------------
+         const bool first = (nIter == 0);
+         const bool fin0 = !isViol && first; // the common case: the first check passes, nothing else happens
+         bool fin = fin0, failed = false;
+         if (__ballot(!fin0) != 0)
+         {
+            const bool good = !isViol && !first;      // a feasible point after at least one violated one
+            const bool shrink = isViol && nGood == 0; // ba.cpp:1281-1285: no feasible point known yet
+            const double lowFact2 = lowFact * 2.0;
+            const double sdotLShrunk = dmax(.999 * 0.0, (1.0 - lowFact2) * sdotTry);
+            // ba.cpp:1294-1303: two successive feasible points closer than 1e-3 (relative), or a negative one
+            bool dec1;
+            const double num1 = fabs(sdotTry - sdotGood);
+            bool close = s8_ratio_lt_fast(num1, sdotTry, .001, dec1);
+            if (__ballot(good & !dec1) != 0) close = dec1 ? close : (num1 / sdotTry < .001);
+            const bool conv = good && (close || sdotTry < 0.0);
+            fin = fin0 || conv;
+            lowFact = shrink ? lowFact2 : lowFact;
+            sdotH = isViol ? sdotTry : sdotH;
+            sdotL = shrink ? sdotLShrunk : ((good && !conv) ? sdotTry : sdotL);
+            sdotGood = good ? sdotTry : sdotGood;
+            nGood += good ? 1 : 0;
+            sdotCur = conv ? sdotTry : sdotCur;
+            // ba.cpp:1305-1320
+            bool dec2;
+            const double num2 = sdotH - sdotL;
+            bool tiny = s8_ratio_lt_fast(num2, sdotH, 1e-20, dec2);
+            if (__ballot((nGood == 0) & !fin & !dec2) != 0) tiny = dec2 ? tiny : (num2 / sdotH < 1e-20);
+            const bool collapsed = (nGood == 0) && tiny;
+            failed = !fin && (nIter + 1 > 100 || sdotTry < 0.0 || collapsed);
+            nIter += fin ? 0 : 1;
+            sdotTry = (fin || failed) ? sdotTry : .5 * (sdotH + sdotL);
+            status |= failed ? (unsigned)BATOTP_ST_BISECT_FAIL : 0u;
+            nfail += failed ? 1 : 0;
+            stageFailed = failed;
+         }
+         wN = fin ? ((DIR == 1) ? sddotH : sddotL) : wN;
+         phase = (fin || failed) ? PH_ENDED : phase;
+      }
+   }
+
+   status |= endStatus;
+   if (endStatus != 0)
+   {
+      if (writer)
+      {
+         if (DIR == 1) { r->n_fwd = 0; r->steps_fwd = i; r->t_total = 0; r->status_fwd = status; r->n_bisect_fail_fwd = nfail; }
+         else { r->n_rev = 0; r->steps_rev = i; r->t_rev = 0; r->status_rev = (r->status_rev & BATOTP_ST_SEG_ERROR) | status; r->n_bisect_fail_rev = nfail; }
+      }
+      return;
+   }
+
+   // end snap onto sLast, ba.cpp:1132-1134; forward: last sdot <- reverse curve's last sdot, ba.cpp:1140
+   {
+      const double sRat = (sLast - sPrev) / (sCurPt - sPrev);
+      sdCurPt = sdPrev + sRat * (sdCurPt - sdPrev);
+      sCurPt = sLast;
+      if (DIR == 1) sdCurPt = mvc[nMvc - 1].y;
+   }
+   const double tElapsed = absh * (double)(nPts - 1); // ba.cpp:1112
+   int64_t nOut = nPts;
+
+   if (nPts >= 4)
+   {
+      // the snapped point joins the points still waiting in LDS; what has not reached HBM yet goes now
+      const int idxLast = (DIR == 1) ? nPts - 1 : capI - nPts;
+      mypts[idxLast & 3] = make_double2(sCurPt, sdCurPt);
+      const int base = idxLast & ~3;
+      const int at = base + j;
+      const int lo = (DIR == 1) ? (flushedTo > base ? flushedTo : base) : idxLast;
+      const int hi = (DIR == 1) ? idxLast : ((flushedTo - 1 < base + 3) ? flushedTo - 1 : base + 3);
+      if (j < 4 && at >= lo && at <= hi) out[at] = mypts[j];
+   }
+   else
+   {
+      // ba.cpp:1171-1184: re-interpolate linearly in time to four points.  The points of so short a curve are all still
+      // here: point 0 = the start, point nPts-2 = (sPrev, sdPrev), point nPts-1 = the snapped end.
+      status |= BATOTP_ST_SHORT; nOut = 4;
+      if (writer)
+      {
+         double ps[3], pd[3], tIn[3];
+         const double sInit = (DIR == 1) ? 0.0 : sEnd;
+         for (int k = 0; k < nPts; ++k)
+         {
+            const double2 q = (k == nPts - 1) ? make_double2(sCurPt, sdCurPt) : (k == 0 ? make_double2(sInit, vBoot) : make_double2(sPrev, sdPrev));
+            ps[k] = q.x; pd[k] = q.y;
+            tIn[k] = absh * (double)k;
+         }
+         if (DIR != 1)
+         {
+            for (int k = 0; k < nPts / 2; ++k)
+            {
+               swap_d(ps[k], ps[nPts - 1 - k]);
+               swap_d(pd[k], pd[nPts - 1 - k]);
+            }
+         }
+         const double tResNew = tIn[nPts - 1] / 3.;
+         int cur = 0;
+         for (int k = 0; k < 4; ++k)
+         {
+            const double tn = tResNew * (double)k;
+            while (!(tn < tIn[cur + 1] || cur == nPts - 2)) ++cur;
+            const double tauR = (tn - tIn[cur]) / (tIn[cur + 1] - tIn[cur]);
+            out[DIR == 1 ? k : cap - 4 + k] = make_double2(ps[cur] + (ps[cur + 1] - ps[cur]) * tauR, pd[cur] + (pd[cur + 1] - pd[cur]) * tauR);
+         }
+      }
+   }
+
+   if (writer)
+   {
+      if (DIR == 1)
+      {
+         r->n_fwd = nOut; r->steps_fwd = nPts - 1; r->t_total = tElapsed; r->status_fwd = status; r->n_bisect_fail_fwd = nfail;
+      }
+      else
+      {
+         r->n_rev = nOut; r->steps_rev = nPts - 1; r->t_rev = tElapsed;
+         r->status_rev = (r->status_rev & BATOTP_ST_SEG_ERROR) | status; r->n_bisect_fail_rev = nfail;
+      }
+   }
+}
+#undef S8_CURVE_FULL
+
+} // namespace bk

@@ -172,6 +172,11 @@ int  batotp_hip_fp64_kat(batotp_ctx *ctx, int64_t n, const double *a, const doub
 /* q[i] = a[i] / 6.0 computed the way the compact spline form (BATOTP_F_COMPACT_SPLINES) divides:
  * through the reciprocal with one exact residual correction; must equal the IEEE quotient */
 int  batotp_hip_div6_kat(batotp_ctx *ctx, int64_t n, const double *a, double *q);
+/* known-answer test of the division through a shared refined reciprocal (batotp_amd/csrc/sweep8.hip.h: the last three
+ * operations of hipcc's own fp64 division sequence, valid for operands in [2^-350, 2^350]; the sweep kernel k_sweep8 uses it
+ * for the quotients by theta' of reference batotp/ba.cpp:1223 and :1526-1531): q[i] = the kernel's a[i] / b[i] -- through the
+ * reciprocal when both operands lie in the window (in_window[i] = 1), by the hardware sequence otherwise. */
+int  batotp_hip_sdiv_kat(batotp_ctx *ctx, int64_t n, const double *a, const double *b, double *q, int32_t *in_window);
 
 /* ---- batch lifetime --------------------------------------------------------------------- */
 /* n_knots[b] = number of uniform-s knots of path b (>=4); max_steps = per-path capacity of each
@@ -282,6 +287,12 @@ int  batotp_hip_set_paths_per_wave(batotp_ctx *ctx, int32_t n);
  * path: results are bit-identical in every test (tests/test_gpu_parity.py, test_gpu_fuzz.py) and bench.py re-checks the
  * result rows of every run against the nested loops.  DESIGN.md 4 has the history. */
 int  batotp_hip_set_sweep_hold(batotp_ctx *ctx, int32_t reverse, int32_t forward);
+/* which code runs that flat loop in the 8-lane layout: 1 (default) = k_sweep8 (batotp_amd/csrc/sweep8.hip.h: the same loop and
+ * arithmetic -- reference batotp/ba.cpp:1053-1123 with sdotLim :1204-1236 and the bisection :1248-1332 -- hand-structured for
+ * the instruction count: one level of divergence, wavefront-uniform segment walks, curve points stored 64 bytes at a time),
+ * 0 = the flat instantiation of the general kernel k_sweep (kept for A/B runs and as a second implementation the parity tests
+ * compare).  Never changes a result. */
+int  batotp_hip_set_flat_form(batotp_ctx *ctx, int32_t form);
 /* The gate of that automatic choice.  The flat loop's torque instantiation gave wrong results with the toolchain named
  * below for a reason that is not understood and is not compiled; the instantiations that ship passed the whole
  * parity / fuzz suite with exactly that toolchain.  So the automatic choice takes the flat loop only if (a) the library was

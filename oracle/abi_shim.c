@@ -54,6 +54,12 @@ int batotp_hip_ctx_create(int device, batotp_ctx **out)
 }
 int batotp_hip_ctx_destroy(batotp_ctx *ctx) { free(ctx); return BATOTP_OK; }
 const char *batotp_hip_last_error(void) { return "(oracle shim)"; }
+int batotp_hip_sdiv_kat(batotp_ctx *ctx, int64_t n, const double *a, const double *b, double *q, int32_t *in_window)
+{
+    (void)ctx;
+    for (int64_t i = 0; i < n; ++i) { q[i] = a[i] / b[i]; in_window[i] = 0; }
+    return BATOTP_OK;
+}
 int batotp_hip_div6_kat(batotp_ctx *ctx, int64_t n, const double *a, double *q)
 {
     int64_t i;
@@ -72,6 +78,7 @@ int batotp_hip_set_paths_per_wave(batotp_ctx *ctx, int32_t n) { (void)ctx; (void
 int batotp_hip_set_sweep_hold(batotp_ctx *ctx, int32_t reverse, int32_t forward) { (void)ctx; (void)reverse; (void)forward; return BATOTP_OK; }
 int batotp_hip_set_sweep_prefetch(batotp_ctx *ctx, int32_t reverse, int32_t forward) { (void)ctx; (void)reverse; (void)forward; return BATOTP_OK; }
 int batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on) { (void)ctx; (void)on; return BATOTP_OK; }
+int batotp_hip_set_flat_form(batotp_ctx *ctx, int32_t form) { (void)ctx; (void)form; return BATOTP_OK; }
 int batotp_hip_set_fast_forward(batotp_ctx *ctx, int32_t on) { (void)ctx; (void)on; return BATOTP_OK; }
 int batotp_hip_spline_tile_fallbacks(batotp_batch *b, int32_t *series) { if (!b || !series) return BATOTP_ERR_ARG; *series = 0; return BATOTP_OK; }
 /* the checker has one loop form (the reference's); the introspection calls of the product answer accordingly */

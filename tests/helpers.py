@@ -294,7 +294,14 @@ def set_layout(ctx, layout):
     per wavefront and the flat stage / bisection loop with hold K in both directions (batotp_hip_set_sweep_hold; only
     problems with joint velocity / acceleration limits alone use it, the others run the nested loops whatever K is);
     "64noff": 64 without the certified fast-forward of the bisection"""
-    if isinstance(layout, str) and layout.startswith("flat"):
+    if isinstance(layout, str) and layout.startswith("oldflat"):
+        # the flat instantiation of the general kernel instead of k_sweep8 (batotp_hip_set_flat_form 0)
+        k = int(layout[7:])
+        ctx.set_sweep_group(8)
+        ctx.set_paths_per_wave(8)
+        ctx.set_sweep_hold(k, k)
+        ctx.set_flat_form(0)
+    elif isinstance(layout, str) and layout.startswith("flat"):
         k = int(layout[4:])
         ctx.set_sweep_group(8)
         ctx.set_paths_per_wave(8)

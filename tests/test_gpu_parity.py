@@ -43,6 +43,34 @@ def test_division_by_six_through_the_reciprocal_is_the_ieee_quotient(hip_ctx):
     assert_bit_equal(capi.div6_kat(hip_ctx, a), a / 6.0, "x / 6.0")
 
 
+def test_shared_reciprocal_division_is_the_ieee_quotient(hip_ctx):
+    """k_sweep8 divides the bounds of a constraint check and the velocity limit by theta' through ONE refined reciprocal
+    (the last three operations of the hardware's own division sequence) when both operands lie in [2^-350, 2^350]"""
+    rng = np.random.default_rng(4242)
+    n = 1 << 21
+    a = rng.standard_normal(n) * 2.0 ** rng.integers(-360, 360, n)
+    b = rng.standard_normal(n) * 2.0 ** rng.integers(-360, 360, n)
+    # mantissa patterns that stress the rounding of the quotient: all-ones divisors, exact quotients and their neighbours
+    k = rng.integers(1, 1 << 52, 1 << 18).astype(np.float64)
+    m = rng.integers(1, 1 << 26, 1 << 18).astype(np.float64)
+    ones = np.nextafter(2.0 ** rng.integers(-300, 300, 1 << 18).astype(np.float64), 0.0)
+    a2 = np.concatenate([k * m, np.nextafter(k * m, np.inf), np.nextafter(k * m, -np.inf), k, k, np.full(8, 2.0 ** -350), np.full(8, 2.0 ** 350)])
+    b2 = np.concatenate([m, m, m, ones, np.nextafter(ones, -np.inf),
+                         np.array([2.0 ** -350, 2.0 ** 350, np.nextafter(2.0 ** -350, 0), np.nextafter(2.0 ** 350, np.inf), 1.0, 3.0, -7.0, 1e-300]),
+                         np.array([2.0 ** -350, 2.0 ** 350, np.nextafter(2.0 ** -350, 0), np.nextafter(2.0 ** 350, np.inf), 1.0, 3.0, -7.0, 1e300])])
+    edge = np.array([0.0, -0.0, 1e-320, 1e308, np.inf, -np.inf, np.nan, 5.0, -5.0])
+    a3, b3 = np.repeat(edge, edge.size), np.tile(edge, edge.size)
+    a, b = np.concatenate([a, a2, a3]), np.concatenate([b, b2, b3])
+    q, used = capi.sdiv_kat(hip_ctx, a, b)
+    with np.errstate(all="ignore"):
+        want = a / b
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(q), nan)
+    assert_bit_equal(q[~nan], want[~nan], "a / b through the shared reciprocal")
+    inside = (np.abs(a) >= 2.0 ** -350) & (np.abs(a) <= 2.0 ** 350) & (np.abs(b) >= 2.0 ** -350) & (np.abs(b) <= 2.0 ** 350)
+    assert np.array_equal(used, inside) and np.count_nonzero(used) > n // 2
+
+
 def _compare(case, ho, oo):
     for key in ("coef", "samp", "dyn", "mvc"):
         if key in oo:
