@@ -266,10 +266,20 @@ extern "C" int batotp_hip_ctx_create(int device, batotp_ctx **out)
    if (!c) return BATOTP_ERR_ALLOC;
    c->device = device;
    {
-      // a test can pretend the library came from another compiler (tests/test_gpu_parity.py: the automatic choice must then
-      // run the nested loops); nothing else reads the variable
+      // a test can pretend the library came from ANOTHER compiler (tests/test_gpu_parity.py: the automatic choice must then
+      // run the nested loops).  The variable can only close the gate: a value equal to the validated string is ignored, so
+      // nobody opens the gate of a library from an unvalidated compiler through the environment.
       const char *assume = getenv("BATOTP_ASSUME_TOOLCHAIN");
-      strncpy(c->builtWith, (assume && assume[0]) ? assume : kBuiltWith, sizeof(c->builtWith) - 1);
+      const bool closes = assume && assume[0] && strcmp(assume, kFlatValidatedWith) != 0;
+      strncpy(c->builtWith, closes ? assume : kBuiltWith, sizeof(c->builtWith) - 1);
+      if (strcmp(c->builtWith, kFlatValidatedWith) != 0)
+      {
+         static bool told = false;
+         if (!told) fprintf(stderr, "batotp_hip: built with \"%s\", the flat sweep loop was validated with \"%s\": large batches run the nested loops "
+                                    "(about 20 %% slower) until the parity / fuzz suite has run with this compiler and kFlatValidatedWith is updated\n",
+                            c->builtWith, kFlatValidatedWith);
+         told = true;
+      }
    }
    e = hipSetDevice(device);
    if (e != hipSuccess) { delete c; return hipFail(e, "hipSetDevice"); }
@@ -1119,7 +1129,7 @@ static int flatCanaryOnce(batotp_ctx *ctx, bool compact, bool *same)
       }
    }
    std::vector<batotp_path_result> rows[2];
-   std::vector<double2> curves[2];
+   std::vector<double2> curves[2], curvesF[2];
    const int holdSaved[2] = {ctx->sweepHold[0], ctx->sweepHold[1]}, groupSaved = ctx->sweepGroup, ppwSaved = ctx->pathsPerWave;
    ctx->sweepGroup = 8; ctx->pathsPerWave = 8;
    rc = batotp_hip_upload_knots(b, 0, B, y.data(), sres.data());
@@ -1127,11 +1137,15 @@ static int flatCanaryOnce(batotp_ctx *ctx, bool compact, bool *same)
    for (int form = 0; form < 2 && !rc; ++form)
    {
       ctx->sweepHold[0] = form == 0 ? -1 : 4; // nested, then the flat loop as the automatic choice would run it
+      ctx->sweepHold[1] = form == 0 ? -1 : 8;
       rc = batotp_hip_sweep(b, -1);
+      if (!rc) rc = batotp_hip_sweep(b, +1);
       rows[form].resize(B);
       if (!rc) rc = batotp_hip_get_results(b, rows[form].data());
       curves[form].resize((size_t)B * (size_t)cap);
+      curvesF[form].resize((size_t)B * (size_t)cap);
       if (!rc && hipMemcpy(curves[form].data(), b->dRev, sizeof(double2) * curves[form].size(), hipMemcpyDeviceToHost) != hipSuccess) rc = BATOTP_ERR_HIP;
+      if (!rc && hipMemcpy(curvesF[form].data(), b->dFwd, sizeof(double2) * curvesF[form].size(), hipMemcpyDeviceToHost) != hipSuccess) rc = BATOTP_ERR_HIP;
    }
    ctx->sweepHold[0] = holdSaved[0]; ctx->sweepHold[1] = holdSaved[1]; ctx->sweepGroup = groupSaved; ctx->pathsPerWave = ppwSaved;
    batotp_hip_batch_destroy(b);
@@ -1144,6 +1158,9 @@ static int flatCanaryOnce(batotp_ctx *ctx, bool compact, bool *same)
       if (n > 0) ++finished; else ++stalled;
       const size_t at = (size_t)p * (size_t)cap + (size_t)(cap - n);
       if (n > 0 && memcmp(&curves[0][at], &curves[1][at], sizeof(double2) * (size_t)n) != 0) eq = false;
+      const int64_t nf = rows[0][p].n_fwd;
+      const size_t atF = (size_t)p * (size_t)cap;
+      if (nf > 0 && memcmp(&curvesF[0][atF], &curvesF[1][atF], sizeof(double2) * (size_t)nf) != 0) eq = false;
    }
    // the canary must contain both populations, otherwise it says nothing
    if (eq && (finished < 4 || stalled < 4))
@@ -1224,8 +1241,14 @@ static void launchSweep(batotp_batch *b, SweepArgs &a)
    // a canary on this device --, the nested loops for the forward sweep (which does not gain)
    if (hold == -2)
    {
-      const bool candidate = a.dir == -1 && (G == 8 || G == 4 || G == 2) && featureLevel(b) <= 0 && uni;
-      hold = (candidate && flatLoopStatus(b->ctx) == 1) ? 4 : -1;
+      // reverse: hold 4 (round 2: 855 against 1130 ms on the UR6 bench batch).  Forward: k_sweep8 with hold 8 -- the nested
+      // loops' schedule, every path of the wavefront starts its stage together -- because that kernel executes 9 % fewer
+      // vector and 37 % fewer scalar instructions than the nested form of k_sweep (round 4: 444 against 560 ms at 16 384
+      // paths, profiles/r04_a_*); the general kernel's own flat form does not gain in the forward sweep and keeps the nested loops
+      const bool candidate = (G == 8 || G == 4 || G == 2) && featureLevel(b) <= 0 && uni;
+      const bool fwd8 = G == 8 && b->ctx->flatForm == 1 && b->cap < ((int64_t)1 << 30);
+      hold = -1;
+      if (candidate && (a.dir == -1 || fwd8) && flatLoopStatus(b->ctx) == 1) hold = a.dir == -1 ? 4 : 8;
    }
    if (hold > 8) hold = 8;
    a.hold = hold;
@@ -1341,7 +1364,7 @@ extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
    }
    if (lanes == 64 && !sweep1Applies(b)) lanes = 32; // a parallel mechanism's torque limits, uploaded sites: the general kernel
    // the gate of the flat loop (its canary launches sweeps of its own) is settled before this sweep's timed region starts
-   if (dir == -1 && b->ctx->sweepHold[0] == -2 && (lanes == 8 || lanes == 4 || lanes == 2) && featureLevel(b) <= 0) (void)flatLoopStatus(b->ctx);
+   if (b->ctx->sweepHold[dir == -1 ? 0 : 1] == -2 && (lanes == 8 || lanes == 4 || lanes == 2) && featureLevel(b) <= 0) (void)flatLoopStatus(b->ctx);
    evStart(b, which);
    switch (lanes)
    {

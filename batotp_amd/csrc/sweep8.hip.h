@@ -26,6 +26,12 @@ namespace bk
 {
 
 constexpr int S8_BLOCK = 256;
+#ifndef S8_TAB_FAST
+#define S8_TAB_FAST 1   // tableau combination without selects while every stage value is finite
+#endif
+#ifndef S8_KINDS
+#define S8_KINDS 0      // 1: bisection update in blocks by situation -- measured 5 % SLOWER than one block of selects (the guards of four blocks cost more than the selects they save: profiles/r04_b_*)
+#endif
 
 // (num / den) < thr as ratio_lt (kernels.hip.h) decides it, in two parts: the product form, and whether it was decisive
 __device__ __forceinline__ bool s8_ratio_lt_fast(double num, double den, double thr, bool &decided)
@@ -236,6 +242,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
    double sN = 0, wN = 0;
    double lowFact = .01, sdotGood = 0, sdotL = 0, sdotH = 0, sdotTry = 0;
    int nGood = 0, nIter = 0;
+   bool wild = !(fabs(v0) < kInf) | !(fabs(w0) < kInf); // a non-finite stage value has been kept (sticky; see the tableau combination)
    bool stageFailed = false; // the bisection of the stage that ended failed: sddotArr[st] keeps its previous value (ba.cpp:1091 ignores the code)
    const int hold = a.hold;
 
@@ -254,6 +261,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
             {
                phase = PH_FIRST;
                const double vN = sdotCur;
+               wild |= !(fabs(vN) < kInf) | !(fabs(wN) < kInf);
                const int stW = stageFailed ? 0 : st; // a failed bisection leaves sddotArr[st] as it was
                v1 = (st == 1) ? vN : v1; w1 = (stW == 1) ? wN : w1;
                v2 = (st == 2) ? vN : v2; w2 = (stW == 2) ? wN : w2;
@@ -317,13 +325,27 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                // ---- tableau combination, ba.cpp:1073-1085 ---------------------------------------------
                const double *bc = rk[st];
                double sdotT = 0, sddotT = 0;
-               // stage st adds the terms k < st only (a stale stage value may be infinite: 0 * inf must not enter the sum)
-               sdotT += bc[0] * v0; sddotT += bc[0] * w0;
-               { const double a1 = sdotT + bc[1] * v1, b1 = sddotT + bc[1] * w1; sdotT = (st > 1) ? a1 : sdotT; sddotT = (st > 1) ? b1 : sddotT; }
-               { const double a2 = sdotT + bc[2] * v2, b2 = sddotT + bc[2] * w2; sdotT = (st > 2) ? a2 : sdotT; sddotT = (st > 2) ? b2 : sddotT; }
-               { const double a3 = sdotT + bc[3] * v3, b3 = sddotT + bc[3] * w3; sdotT = (st > 3) ? a3 : sdotT; sddotT = (st > 3) ? b3 : sddotT; }
-               { const double a4 = sdotT + bc[4] * v4, b4 = sddotT + bc[4] * w4; sdotT = (st > 4) ? a4 : sdotT; sddotT = (st > 4) ? b4 : sddotT; }
-               { const double a5 = sdotT + bc[5] * v5, b5 = sddotT + bc[5] * w5; sdotT = (st > 5) ? a5 : sdotT; sddotT = (st > 5) ? b5 : sddotT; }
+               // Stage st adds the terms k < st only.  The weights of the others are +0 in the table, and adding their products
+               // changes nothing as long as every stage value is finite (x + (+-0) = x: a partial sum starts as 0 + b0 v0 and
+               // is therefore never -0); a path that ever kept a non-finite stage value (0 * inf = NaN) takes the literal form.
+               if (S8_TAB_FAST && __ballot(wild) == 0)
+               {
+                  sdotT += bc[0] * v0; sddotT += bc[0] * w0;
+                  sdotT += bc[1] * v1; sddotT += bc[1] * w1;
+                  sdotT += bc[2] * v2; sddotT += bc[2] * w2;
+                  sdotT += bc[3] * v3; sddotT += bc[3] * w3;
+                  sdotT += bc[4] * v4; sddotT += bc[4] * w4;
+                  sdotT += bc[5] * v5; sddotT += bc[5] * w5;
+               }
+               else
+               {
+                  sdotT += bc[0] * v0; sddotT += bc[0] * w0;
+                  { const double a1 = sdotT + bc[1] * v1, b1 = sddotT + bc[1] * w1; sdotT = (st > 1) ? a1 : sdotT; sddotT = (st > 1) ? b1 : sddotT; }
+                  { const double a2 = sdotT + bc[2] * v2, b2 = sddotT + bc[2] * w2; sdotT = (st > 2) ? a2 : sdotT; sddotT = (st > 2) ? b2 : sddotT; }
+                  { const double a3 = sdotT + bc[3] * v3, b3 = sddotT + bc[3] * w3; sdotT = (st > 3) ? a3 : sdotT; sddotT = (st > 3) ? b3 : sddotT; }
+                  { const double a4 = sdotT + bc[4] * v4, b4 = sddotT + bc[4] * w4; sdotT = (st > 4) ? a4 : sdotT; sddotT = (st > 4) ? b4 : sddotT; }
+                  { const double a5 = sdotT + bc[5] * v5, b5 = sddotT + bc[5] * w5; sdotT = (st > 5) ? a5 : sdotT; sddotT = (st > 5) ? b5 : sddotT; }
+               }
                sN = s0v + h * sdotT;
                double vN = v0 + h * sddotT;
                vN = dmax(vN, floorV); // ba.cpp:1085
@@ -477,6 +499,68 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
          sddotH = Hred; sddotL = L;
          const bool isViol = L > Hred;
 
+#if S8_KINDS
+         // ---- one pass of the loop of ba.cpp:1267-1321.  A path is in one of four situations; each block runs under the
+         // lanes in it and is skipped when there are none (the common pass holds one or two kinds):
+         //   first check passed (fin0)                      -> the stage is done, nothing else happens
+         //   violated, no feasible point known yet (search) -> ba.cpp:1276-1285: shrink the lower end geometrically
+         //   violated, a feasible point is known (upper)    -> ba.cpp:1278: the candidate becomes the upper end
+         //   feasible after a violation (good)              -> ba.cpp:1288-1303: convergence test, else new lower end
+         const bool first = (nIter == 0);
+         const bool fin0 = !isViol && first;
+         const bool search = isViol && nGood == 0, upper = isViol && nGood != 0, good = !isViol && !first;
+         bool fin = fin0, failed = false;
+         if (__ballot(search) != 0)
+         {
+            if (search)
+            {
+               lowFact *= 2.0;
+               sdotH = sdotTry;
+               sdotL = dmax(.999 * 0.0, (1.0 - lowFact) * sdotH);
+               // ba.cpp:1305-1319
+               bool dec2;
+               const double num2 = sdotH - sdotL;
+               bool tiny = s8_ratio_lt_fast(num2, sdotH, 1e-20, dec2);
+               if (__ballot(!dec2) != 0) tiny = dec2 ? tiny : (num2 / sdotH < 1e-20);
+               failed = (nIter + 1 > 100) || (sdotTry < 0.0) || tiny;
+            }
+         }
+         if (__ballot(upper) != 0)
+         {
+            if (upper)
+            {
+               sdotH = sdotTry;
+               failed = (nIter + 1 > 100) || (sdotTry < 0.0);
+            }
+         }
+         if (__ballot(good) != 0)
+         {
+            if (good)
+            {
+               // ba.cpp:1294-1303: two successive feasible points closer than 1e-3 (relative), or a negative one
+               bool dec1;
+               const double num1 = fabs(sdotTry - sdotGood);
+               bool close = s8_ratio_lt_fast(num1, sdotTry, .001, dec1);
+               if (__ballot(!dec1) != 0) close = dec1 ? close : (num1 / sdotTry < .001);
+               const bool conv = close || sdotTry < 0.0;
+               sdotGood = sdotTry;
+               nGood += 1;
+               sdotCur = conv ? sdotTry : sdotCur;
+               sdotL = conv ? sdotL : sdotTry;
+               fin = conv;
+               failed = !conv && ((nIter + 1 > 100) || (sdotTry < 0.0));
+            }
+         }
+         if (__ballot(!fin0) != 0)
+         {
+            const bool on = !fin && !failed;
+            nIter += fin ? 0 : 1;
+            sdotTry = on ? .5 * (sdotH + sdotL) : sdotTry;
+            status |= failed ? (unsigned)BATOTP_ST_BISECT_FAIL : 0u;
+            nfail += failed ? 1 : 0;
+            stageFailed = failed;
+         }
+#else
          // ---- one pass of the loop of ba.cpp:1267-1321, as selects -----------------------------------------
          const bool first = (nIter == 0);
          const bool fin0 = !isViol && first; // the common case: the first check passes, nothing else happens
@@ -513,6 +597,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
             nfail += failed ? 1 : 0;
             stageFailed = failed;
          }
+#endif
          wN = fin ? ((DIR == 1) ? sddotH : sddotL) : wN;
          phase = (fin || failed) ? PH_ENDED : phase;
       }

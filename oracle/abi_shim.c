@@ -659,3 +659,29 @@ int batotp_hip_output_ms(batotp_output *o, float *ms)
     *ms = o->ms;
     return BATOTP_OK;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* ORACLE-ONLY test hooks (not part of include/batotp_hip.h): one call of the reference's       */
+/* per-point routines on a path of a batch whose precompute has run -- replays of the fp64       */
+/* known-answer vectors read out of the reference binary (oracle/make_golden_f64.py)             */
+/* ------------------------------------------------------------------------------------------ */
+int batotp_oracle_kat_accel(batotp_batch *b, int32_t path, int32_t dir, double s_cur, double sdot_cur, int64_t cur_seg_c, double sddot_in,
+                            double *out5 /* sdotCur, sddot, sddotL, sddotH, curSegC */, int32_t *n_iter, int32_t *rc)
+{
+    int64_t seg = 0;
+    if (!b || path < 0 || path >= b->n_paths || !b->kin_done || !out5 || !n_iter || !rc) return BATOTP_ERR_ARG;
+    bo_kat_accel(&b->prob, b->path[path], dir, s_cur, sdot_cur, cur_seg_c, sddot_in, &out5[0], &out5[1], &out5[2], &out5[3], n_iter, rc, &seg);
+    out5[4] = (double)seg;
+    return BATOTP_OK;
+}
+
+int batotp_oracle_kat_sdot_lim(batotp_batch *b, int32_t path, int32_t dir, double s_cur, double sdot_in, double sdot_min,
+                               const double *theta_d_pt, double cart_coeff0, const double *mvc_s, const double *mvc_sdot, int64_t n_mvc,
+                               int64_t cur_seg_mvc, double *out2 /* sdot, curSegMVC */)
+{
+    int64_t seg = 0;
+    if (!b || path < 0 || path >= b->n_paths || !b->kin_done || !theta_d_pt || !out2) return BATOTP_ERR_ARG;
+    bo_kat_sdot_lim(&b->prob, b->path[path], dir, s_cur, sdot_in, sdot_min, theta_d_pt, cart_coeff0, mvc_s, mvc_sdot, n_mvc, cur_seg_mvc, &out2[0], &seg);
+    out2[1] = (double)seg;
+    return BATOTP_OK;
+}

@@ -967,3 +967,50 @@ void bo_point_eval(const batotp_problem *prob, const bo_path *p, int dir, double
     *sddot_h = c->sddot_h;
     *n_iter = nIter;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Per-point known-answer hooks for the fp64 vectors read out of the reference binary with a    */
+/* debugger (oracle/make_golden_f64.py, tests/golden/<case>/ref_point_kats.npz): ONE call of     */
+/* the reference routine from the cursor state the reference had at that call.                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* BA::applyAccelConstraintsBisectionPt (ba.cpp:1248-1332) entered with traj.sCur, traj.sdotCur, traj.curSegC and the
+ * caller's sddot as given; returns what the reference leaves in traj.sdotCur, sddot, traj.sddotL/H, nIter, the int it
+ * returns and traj.curSegC */
+void bo_kat_accel(const batotp_problem *prob, const bo_path *p, int dir, double s_cur, double sdot_cur, int64_t cur_seg_c,
+                  double sddot_in, double *sdot_out, double *sddot_out, double *sddot_l, double *sddot_h, int32_t *n_iter,
+                  int32_t *rc, int64_t *cur_seg_out)
+{
+    sweep_ctx cx;
+    sweep_ctx *c = &cx;
+    double sddot = sddot_in;
+    int nIter = 0;
+    ctx_init(c, prob, p, dir);
+    c->cur_seg_c = cur_seg_c;
+    c->s_cur = s_cur;
+    c->sdot_cur = sdot_cur;
+    *rc = apply_accel_bisection(c, &sddot, &nIter);
+    *sdot_out = c->sdot_cur; *sddot_out = sddot; *sddot_l = c->sddot_l; *sddot_h = c->sddot_h;
+    *n_iter = nIter; *cur_seg_out = c->cur_seg_c;
+}
+
+/* BA::sdotLim (ba.cpp:1204-1236) entered with traj.sCur, the caller's sdot, BA::_sdotMin, the point buffers
+ * traj.thetaDpt / traj.CartAccCoeffs[0] of the PREVIOUS evaluation point and, in the forward sweep, the reverse curve
+ * with its cursor traj.curSegMVC; returns sdot and the cursor */
+void bo_kat_sdot_lim(const batotp_problem *prob, const bo_path *p, int dir, double s_cur, double sdot_in, double sdot_min,
+                     const double *theta_d_pt, double cart_coeff0, const double *mvc_s, const double *mvc_sdot, int64_t n_mvc,
+                     int64_t cur_seg_mvc, double *sdot_out, int64_t *cur_seg_mvc_out)
+{
+    sweep_ctx cx;
+    sweep_ctx *c = &cx;
+    double sdot = sdot_in;
+    int i;
+    ctx_init(c, prob, p, dir);
+    c->s_cur = s_cur;
+    c->sdot_min = sdot_min;
+    for (i = 0; i < p->n_theta; i++) c->thetaDpt[i] = theta_d_pt[i];
+    c->cart_acc[0] = cart_coeff0;
+    c->mvc_s = mvc_s; c->mvc_sdot = mvc_sdot; c->n_mvc = n_mvc; c->cur_seg_mvc = cur_seg_mvc;
+    sdot_lim(c, &sdot);
+    *sdot_out = sdot; *cur_seg_mvc_out = c->cur_seg_mvc;
+}

@@ -101,6 +101,15 @@ void bo_pointwise_mvc(const batotp_problem *prob, bo_path *p);
 void bo_point_eval(const batotp_problem *prob, const bo_path *p, int dir, double s, double sdot_in,
                    double *sdot_out, double *sddot_l, double *sddot_h, int32_t *n_iter, int32_t *rc);
 
+/* one call of applyAccelConstraintsBisectionPt / sdotLim from a given cursor state: replays of the fp64 known-answer
+ * vectors read out of the reference binary (oracle/make_golden_f64.py) */
+void bo_kat_accel(const batotp_problem *prob, const bo_path *p, int dir, double s_cur, double sdot_cur, int64_t cur_seg_c,
+                  double sddot_in, double *sdot_out, double *sddot_out, double *sddot_l, double *sddot_h, int32_t *n_iter,
+                  int32_t *rc, int64_t *cur_seg_out);
+void bo_kat_sdot_lim(const batotp_problem *prob, const bo_path *p, int dir, double s_cur, double sdot_in, double sdot_min,
+                     const double *theta_d_pt, double cart_coeff0, const double *mvc_s, const double *mvc_sdot, int64_t n_mvc,
+                     int64_t cur_seg_mvc, double *sdot_out, int64_t *cur_seg_mvc_out);
+
 /* Path resampling before the hot path: remClosePts (util.cpp:452-524), the two
  * BA::adjust_s passes (ba.cpp:412-638), BA::interpSpecial (ba.cpp:651-781), the resampling
  * BA::evalSplineFullTraj (ba.cpp:790-863) and Robot::invKinCSPR3DOF (robot.cpp:243-278) for one path.

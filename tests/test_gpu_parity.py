@@ -366,7 +366,8 @@ def test_flat_sweep_loop_is_gated_by_toolchain_and_canary(hip_lib, oracle_ctx, m
         b.close(); ctx.close()
     expect_real = 1 if built == validated else -1
     assert seen["real"][0] == expect_real, seen
-    assert seen["real"][1] == (8, 8, 4 if expect_real == 1 else -1) and seen["real"][2] == (8, 8, -1), seen
+    # gate open: reverse = flat loop with hold 4, forward = k_sweep8 with hold 8 (the nested loops' schedule in the leaner kernel)
+    assert seen["real"][1] == (8, 8, 4 if expect_real == 1 else -1) and seen["real"][2] == (8, 8, 8 if expect_real == 1 else -1), seen
     assert seen["other"][0] == -1 and seen["other"][1] == (8, 8, -1) and seen["other"][2] == (8, 8, -1), seen
 
 
