@@ -277,6 +277,33 @@ def assert_matches_reference(case, out):
         for (sres, s, sd), (ms, msd) in zip(case.ref, (out["rev"], out["fwd"])):
             assert np.array_equal(s, ms.astype(np.float32))
             assert np.array_equal(sd, msd.astype(np.float32))
+    assert_matches_reference_f64(case, out)
+
+
+def f64_digest(s, sd):
+    return hashlib.sha256(np.ascontiguousarray(s, dtype="<f8").tobytes() + np.ascontiguousarray(sd, dtype="<f8").tobytes()).hexdigest()
+
+
+def assert_matches_reference_f64(case, out):
+    """fp64 bit equality with what the reference binary held in memory at the return of each BA::sweep (traj.sMVC, traj.sdot,
+    traj.tTotalTraj read under rocgdb by oracle/make_golden_f64.py): every point of both curves for the small cases, their
+    sha256 for the BASELINE-size ones"""
+    f = os.path.join(case.dir, "expected_f64.json")
+    if not os.path.exists(f):
+        return      # (tests/golden_self: no reference exists for those)
+    e = json.load(open(f))
+    r = out["result"]
+    assert float(r["t_total"]).hex() == e["t_total_hex"], (case.name, float(r["t_total"]).hex(), e["t_total_hex"])
+    assert float(r["t_rev"]) == e["t_rev"], (case.name, float(r["t_rev"]), e["t_rev"])
+    assert f64_digest(*out["rev"]) == e["sha256_rev_f64"], case.name
+    assert f64_digest(*out["fwd"]) == e["sha256_fwd_f64"], case.name
+    g = os.path.join(case.dir, "ref_curves_f64.npz")
+    if os.path.exists(g):
+        z = np.load(g)
+        assert_bit_equal(out["rev"][0], z["rev_s"], f"{case.name}: reverse s vs the reference's fp64 memory")
+        assert_bit_equal(out["rev"][1], z["rev_sd"], f"{case.name}: reverse sdot vs the reference's fp64 memory")
+        assert_bit_equal(out["fwd"][0], z["fwd_s"], f"{case.name}: forward s vs the reference's fp64 memory")
+        assert_bit_equal(out["fwd"][1], z["fwd_sd"], f"{case.name}: forward sdot vs the reference's fp64 memory")
 
 
 def assert_bit_equal(a, b, what):

@@ -35,6 +35,58 @@ def test_oracle_reproduces_reference_digest(oracle_ctx, name):
     assert np.array_equal(z["fwd_sd"], out["fwd"][1].astype(np.float32)[::64])
 
 
+def _oracle_batch(oracle_ctx, case):
+    from batotp_amd import capi
+    b = capi.Batch(oracle_ctx, case.problem, [case.n], case.max_steps())
+    b.upload_knots(0, [case.y], [case.sres])
+    helpers.precompute_with_trig(oracle_ctx, b, case.problem, 1, None)
+    return b
+
+
+@pytest.mark.parametrize("name", helpers.FULL_CASES)
+def test_oracle_replays_the_reference_per_point_known_answers(oracle_ctx, name):
+    """SURVEY.md 8c iii: ~250 sampled calls of BA::applyAccelConstraintsBisectionPt (ba.cpp:1248-1332) and ~300 of BA::sdotLim
+    (ba.cpp:1204-1236) per case, cursor state on entry and results on return read out of the running reference binary
+    (oracle/make_golden_f64.py): the oracle's routines, started from the same state, must leave the same fp64 bits"""
+    import ctypes as C
+    import os
+    case = Case(name)
+    z = np.load(os.path.join(case.dir, "ref_point_kats.npz"))
+    ref = np.load(os.path.join(case.dir, "ref_curves_f64.npz"))
+    lib = oracle_ctx.library.lib
+    b = _oracle_batch(oracle_ctx, case)
+    D = C.POINTER(C.c_double)
+    lib.batotp_oracle_kat_accel.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int64, C.c_double, D,
+                                            C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.batotp_oracle_kat_sdot_lim.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, D, C.c_double, D, D,
+                                               C.c_int64, C.c_int64, D]
+    assert z["accel"].size >= 200 and z["sdot_lim"].size >= 200
+    n_fail = 0
+    for k in z["accel"]:
+        out5 = (C.c_double * 5)()
+        n_iter, rc = C.c_int32(0), C.c_int32(0)
+        assert lib.batotp_oracle_kat_accel(b.handle, 0, int(k["dir"]), float(k["s_cur"]), float(k["sdot_in"]), int(k["seg_in"]),
+                                           float(k["sddot_in"]), out5, C.byref(n_iter), C.byref(rc)) == 0
+        got = np.array(out5[:4])
+        want = np.array([k["sdot_out"], k["sddot_out"], k["sddot_l"], k["sddot_h"]])
+        helpers.assert_bit_equal(got, want, f"{name}: applyAccelConstraintsBisectionPt at s = {float(k['s_cur'])!r}")
+        assert (n_iter.value, rc.value, int(out5[4])) == (int(k["n_iter"]), int(k["rc"]), int(k["seg_out"])), (name, k)
+        n_fail += rc.value != 0
+    rev_s, rev_sd = np.ascontiguousarray(ref["rev_s"]), np.ascontiguousarray(ref["rev_sd"])
+    for k in z["sdot_lim"]:
+        out2 = (C.c_double * 2)()
+        th = np.ascontiguousarray(k["theta_d_pt"], dtype=np.float64)
+        fwd = int(k["dir"]) == 1
+        assert lib.batotp_oracle_kat_sdot_lim(b.handle, 0, int(k["dir"]), float(k["s_cur"]), float(k["sdot_in"]), float(k["sdot_min"]),
+                                              th.ctypes.data_as(D), float(k["cart0"]),
+                                              rev_s.ctypes.data_as(D) if fwd else None, rev_sd.ctypes.data_as(D) if fwd else None,
+                                              rev_s.size if fwd else 0, int(k["seg_mvc_in"]), out2) == 0
+        helpers.assert_bit_equal(np.array([out2[0]]), np.array([k["sdot_out"]]), f"{name}: sdotLim at s = {float(k['s_cur'])!r}")
+        if fwd:
+            assert int(out2[1]) == int(k["seg_mvc_out"]), (name, k)
+    b.close()
+
+
 def test_bisection_failure_branch_is_pinned():
     """one golden case makes the reference print a bisection failure (stale sddot, ignored -1)"""
     assert Case.__init__  # keep import
