@@ -143,7 +143,20 @@ class ResampleParams(C.Structure):
         ("jnt_thresh", C.c_double), ("cart_thresh", C.c_double),
         ("pmat", C.c_double * 9),
         ("input_decim_fact", C.c_int32), ("smooth_window", C.c_int32),
+        # automatic integration resolution (flags & RS_AUTO_INTEG_RES): inputs of the rule
+        ("jnt_vel_max", C.c_double * MAX_JOINTS), ("jnt_acc_max", C.c_double * MAX_JOINTS),
+        ("cart_vel_max", C.c_double), ("cart_acc_max", C.c_double), ("quad_rad_thresh", C.c_double),
+        ("degrees", C.c_int32), ("reserved", C.c_int32),
     ]
+
+    @classmethod
+    def from_bytes(cls, raw: bytes):
+        """a struct stored by an earlier round (shorter: without the inputs of the automatic integration resolution)"""
+        raw = bytes(raw)
+        return cls.from_buffer_copy(raw + b"\0" * max(0, C.sizeof(cls) - len(raw)))
+
+
+RS_AUTO_INTEG_RES = 1 << 16
 
 
 class OutputParams(C.Structure):
@@ -221,6 +234,9 @@ class Library:
             "batotp_hip_last_sweep_launch": [P, I32, C.POINTER(I32), C.POINTER(I32), C.POINTER(I32)],
             "batotp_hip_resample": [P, C.POINTER(ResampleParams), I32, C.POINTER(C.c_int64), D, D, C.POINTER(P)],
             "batotp_hip_resampled_destroy": [P],
+            "batotp_hip_resampled_auto": [P, D, D, C.POINTER(I32)],
+            "batotp_hip_upload_forward_curve": [P, I32, D, D, I64, C.c_double],
+            "batotp_hip_set_path_integ_res": [P, I32, I32, D],
             "batotp_hip_resampled_info": [P, C.POINTER(C.c_int64), D, C.POINTER(C.c_uint32)],
             "batotp_hip_resampled_knots_device": [P, C.POINTER(P), C.POINTER(C.c_int64)],
             "batotp_hip_resampled_download": [P, I32, D],
@@ -352,6 +368,12 @@ class Resampled:
         self.status = np.zeros(self.n_paths, dtype=np.uint32)
         self.L.check(self.lib.batotp_hip_resampled_info(self.handle, self.n_knots.ctypes.data_as(C.POINTER(C.c_int64)), _dptr(self.sres),
                                                         self.status.ctypes.data_as(C.POINTER(C.c_uint32))), "resampled_info")
+
+    def auto(self):
+        """(integ_res[n_paths], s_weights[n_paths][3], scale_type[n_paths]) the automatic integration resolution left"""
+        ir = np.zeros(self.n_paths); sw = np.zeros((self.n_paths, 3)); st = np.zeros(self.n_paths, dtype=np.int32)
+        self.L.check(self.lib.batotp_hip_resampled_auto(self.handle, _dptr(ir), _dptr(sw), st.ctypes.data_as(C.POINTER(C.c_int32))), "resampled_auto")
+        return ir, sw, st
 
     def close(self):
         if self.handle:
@@ -510,6 +532,15 @@ class Batch:
         a = np.ascontiguousarray(s, dtype=np.float64)
         b = np.ascontiguousarray(sdot, dtype=np.float64)
         self.L.check(self.lib.batotp_hip_upload_curve(self.handle, path, _dptr(a), _dptr(b), a.size), "upload_curve")
+
+    def upload_forward_curve(self, path: int, s: np.ndarray, sdot: np.ndarray, t_total: float):
+        a = np.ascontiguousarray(s, dtype=np.float64)
+        b = np.ascontiguousarray(sdot, dtype=np.float64)
+        self.L.check(self.lib.batotp_hip_upload_forward_curve(self.handle, path, _dptr(a), _dptr(b), a.size, float(t_total)), "upload_forward_curve")
+
+    def set_path_integ_res(self, path0: int, integ_res):
+        v = np.ascontiguousarray(integ_res, dtype=np.float64)
+        self.L.check(self.lib.batotp_hip_set_path_integ_res(self.handle, path0, v.size, _dptr(v)), "set_path_integ_res")
 
     # ---- hot path ----------------------------------------------------------------------------
     def precompute(self, stage: int = 0):

@@ -544,6 +544,7 @@ extern "C" int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *pr
       pi.koff = off;
       pi.n = n_knots[p];
       pi.parallel_now = (prob->flags & BATOTP_F_PARALLEL) ? 1 : 0;
+      pi.integ_res = prob->integ_res;
       off += n_knots[p];
       if (n_knots[p] > b->maxN) b->maxN = n_knots[p];
    }
@@ -1072,6 +1073,46 @@ extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
       b->revStale = true; b->fwdStale = true;
    }
    return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_upload_forward_curve(batotp_batch *b, int32_t path, const double *s, const double *sdot, int64_t n, double t_total)
+{
+   if (!b || !s || !sdot || path < 0 || path >= b->B || n < 2 || n > b->cap) return BATOTP_ERR_ARG;
+   if (b->inPlace || b->mvcInCurves) { snprintf(g_err, sizeof(g_err), "upload_forward_curve: not for batches that share curve slots"); return BATOTP_ERR_STATE; }
+   int rc = bind(b->ctx);
+   if (rc) return rc;
+   double *tmp = nullptr;
+   rc = xferReserve(b->ctx, sizeof(double) * 2 * (size_t)n, &tmp);
+   if (rc) return rc;
+   hipMemcpyAsync(tmp, s, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, b->ctx->stream);
+   hipMemcpyAsync(tmp + n, sdot, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, b->ctx->stream);
+   const int bs = 256;
+   hipLaunchKernelGGL(k_curve_pack, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, b->ctx->stream, b->dFwd + (int64_t)path * b->cap, tmp, tmp + n, n);
+   batotp_path_result r;
+   hipMemcpyAsync(&r, b->dRes + path, sizeof(r), hipMemcpyDeviceToHost, b->ctx->stream);
+   hipError_t e = hipStreamSynchronize(b->ctx->stream);
+   if (e == hipSuccess)
+   {
+      r.n_fwd = n; r.steps_fwd = n - 1; r.t_total = t_total; r.status_fwd = 0; r.status_rev &= BATOTP_ST_SEG_ERROR;
+      if (r.n_rev < 2) r.n_rev = 2; // the sweeps of this path ran elsewhere (the output stage only asks for a forward curve)
+      e = hipMemcpy(b->dRes + path, &r, sizeof(r), hipMemcpyHostToDevice);
+   }
+   if (e != hipSuccess) return hipFail(e, "upload_forward_curve");
+   b->revDone = true;
+   b->fwdStale = false;
+   b->mvcValid = false;
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_set_path_integ_res(batotp_batch *b, int32_t path0, int32_t n, const double *integ_res)
+{
+   if (!b || !integ_res || path0 < 0 || n < 0 || path0 + n > b->B) return BATOTP_ERR_ARG;
+   for (int k = 0; k < n; ++k)
+      if (!(integ_res[k] > 0) && integ_res[k] == integ_res[k]) return BATOTP_ERR_ARG; // positive or NaN (the rule's result without Cartesian limits)
+   int rc = bind(b->ctx);
+   if (rc) return rc;
+   for (int k = 0; k < n; ++k) b->pinfo[path0 + k].integ_res = integ_res[k];
+   return pushPinfo(b);
 }
 
 // ---------------------------------------------------------------------------------------------

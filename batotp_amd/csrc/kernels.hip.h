@@ -69,6 +69,8 @@ struct PathInfo
    double vfact, afact;
    int32_t parallel_now; // BA::_isParallelMech as seen by the sweep
    int32_t uniform;      // sC[i] == sres_c * i exactly (sites can be computed instead of loaded)
+   double integ_res;     // BA::_integRes of THIS path (batotp_problem.integ_res unless batotp_hip_set_path_integ_res changed it:
+                         // the automatic integration resolution of ba.cpp:493-556 derives it from the path)
 };
 
 struct alignas(32) Coef4
@@ -1099,14 +1101,8 @@ __device__ __forceinline__ void mvc_walk(Pt<G, FEAT, UNI> &t)
 template <int G, int FEAT, bool UNI>
 __device__ __forceinline__ double eval_sdot(Pt<G, FEAT, UNI> &t)
 {
-#ifdef BK_OLD_MVC
-   update_cur_seg<2>(t.mvc, 0.0, t.nMvc, t.sCur, t.segMVC, t.tauMVC, t.status);
-   const double sd0 = t.mvc[t.segMVC * 2 + 1], sd1 = t.mvc[(t.segMVC + 1) * 2 + 1];
-   const double v = sd0 + t.tauMVC * (sd1 - sd0);
-#else
    mvc_walk(t);
    const double v = t.mvcD0 + t.tauMVC * (t.mvcD1 - t.mvcD0);
-#endif
    return dmax(v, t.sdotMin);
 }
 
@@ -1530,8 +1526,8 @@ __device__ __forceinline__ void pt_init(Pt<G, FEAT, UNI> &t, const DevProblem &P
    t.quadA = P.quad_thresh * pi.afact;
    t.quadA2 = P.quad_thresh * P.quad_thresh * pi.afact * pi.afact;
    const double sLastKnot = (UNI || pi.uniform) ? pi.sres_c * (double)(t.n - 1) : t.sC[t.n - 1]; // uniform: as k_sites computes it
-   t.sdotCap = sLastKnot / P.integ_res;                      // ba.cpp:1216
-   t.sddotMax = 2 * sLastKnot / (P.integ_res * P.integ_res); // ba.cpp:1257
+   t.sdotCap = sLastKnot / pi.integ_res;                       // ba.cpp:1216
+   t.sddotMax = 2 * sLastKnot / (pi.integ_res * pi.integ_res); // ba.cpp:1257
    t.cartAccMaxSQ = P.cart_acc_max * P.cart_acc_max;
    t.cartVelMax = P.cart_vel_max;
    t.pmat = &lim[4][0];
@@ -1881,9 +1877,9 @@ __global__ void __launch_bounds__(K4_BLOCK, (G > 1 && G < 8) ? 1 : (FEAT <= 1 &&
    const int64_t revStart = (dir == 1 && a.fwd == a.rev) ? cap - (int64_t)t.nMvc : ((int64_t)1 << 62);
 #define BK_CURVE_FULL(i) ((i) >= cap || (i) + 64 >= revStart + (int64_t)t.segMVC)
 
-   const double absh = a.P.integ_res;
+   const double absh = pi.integ_res;
    const double h = dir * absh;
-   const int64_t maxIntegSteps = (int64_t)floor(a.P.max_integ_time / a.P.integ_res) + 1;
+   const int64_t maxIntegSteps = (int64_t)floor(a.P.max_integ_time / pi.integ_res) + 1;
    const double sEnd = UNI ? pi.sres_c * (double)(n - 1) : t.sC[n - 1];
    double sLast;
    double s0v, s6v = 0;                             // sArr[0], sArr[6] (the other stage positions are not reused)
@@ -2083,11 +2079,7 @@ __global__ void __launch_bounds__(K4_BLOCK, (G > 1 && G < 8) ? 1 : (FEAT <= 1 &&
             {
                // forward predictor: evalsdot's cursor walk at s0 + h*sdot0, nothing else is kept
                t.sCur = s0v + h * v0;
-#ifdef BK_OLD_MVC
-               update_cur_seg<2>(t.mvc, 0.0, t.nMvc, t.sCur, t.segMVC, t.tauMVC, t.status);
-#else
                mvc_walk(t);
-#endif
                t.sCur = sStart;
                continue;
             }

@@ -29,6 +29,9 @@ struct RsParams
    double thetaRes, cartRes; // of the current pass
    double thresh;            // remClosePts threshold of the driving channel set
    double pmat[9];
+   // automatic integration resolution (reference ba.cpp:462-470, 493-556): inputs of the rule
+   int autoOn, degrees;
+   double vmax[8], amax[8], cartVelMax, cartAccMax, quadThresh;
 };
 
 struct RsPath
@@ -43,6 +46,10 @@ struct RsPath
    int64_t offOut;
    int32_t n0;    // points the stage arrays reserve for this path (n <= n0; remClosePts shrinks n)
    int32_t pad;
+   // what the reference keeps in the BA object across the two adjust_s passes and the automatic integration resolution
+   // rewrites PER PATH: _sWeights[1], _sWeights[2], _scaleType, _integRes
+   double sw1, sw2, integRes;
+   int32_t scaleType, pad2;
 };
 
 // status bits of the resampler
@@ -247,6 +254,40 @@ __global__ void k_rs_seglen(RsParams P, const RsPath *__restrict__ paths, int B,
    cartArc[g] = sqrt(sq);
 }
 
+// ba.cpp:493-556 once the arc lengths of a pass are known: the path's integration step, s weights, scale type and the Cartesian
+// resolution of the pass.  std::min / std::max in the reference's argument order (their NaN behaviour is part of the result: a
+// robot without Cartesian limits gets 0/0 here, and keeps it).
+__device__ __forceinline__ void rs_auto_rule(const RsParams &P, RsPath &pp, double thetaLast, double cartLast, double minCartPerTheta, double &cartRes)
+{
+   if (cartLast < cartRes && pp.scaleType == 2)
+   {
+      pp.sw1 = pp.sw1 + pp.sw2;
+      pp.sw2 = 0;
+      pp.scaleType = 1;
+   }
+   const double weightIn = pp.sw1 + pp.sw2;
+   double cartRat = 500.0 * cartLast;
+   double thetaRat = thetaLast;
+   if (!P.degrees) thetaRat *= 180.0 / 3.14159265358979323846;
+   const double lo = 0.004, hi = 0.2, K = 0.0003;
+   double step = K * P.cartAccMax / P.cartVelMax;
+   for (int j = 0; j < P.nJ; ++j) step = dmax(step, K * P.amax[j] / P.vmax[j]);
+   step = dmin(step, hi);
+   const double ratio = cartRat / thetaRat;
+   double byJoints = hi * ratio * ratio;
+   double byWindow = hi * minCartPerTheta * minCartPerTheta;
+   byWindow = dmax(byWindow, 0.016);
+   byJoints = dmin(byJoints, byWindow);
+   if (byJoints < step) step = byJoints;
+   step = dmax(step, lo);
+   pp.integRes = step;
+   const double rescale = weightIn / (cartRat + thetaRat);
+   cartRat *= rescale;
+   thetaRat *= rescale;
+   if (thetaRat > pp.sw1) { pp.sw1 = thetaRat; pp.sw2 = cartRat; }
+   if (pp.sw2 > 0) cartRes = dmin(cartRes, cartRes * pp.sw2 / pp.sw1);
+}
+
 __global__ void k_rs_scan(RsParams P, RsPath *__restrict__ paths, int B, double *__restrict__ thetaArc, double *__restrict__ cartArc, int special)
 {
    const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -258,6 +299,11 @@ __global__ void k_rs_scan(RsParams P, RsPath *__restrict__ paths, int B, double 
    // thetaNorm[i+1] = thetaNorm[i] + dtheta (ba.cpp:452-470); step lengths are loaded a batch at a time
    constexpr int CH = 16;
    double tacc = 0, cacc = 0;
+   // automatic integration resolution, ba.cpp:441-446, 462-470: the smallest Cartesian advance per joint-space advance over
+   // windows of 5 degrees (a sequential scan with marks: it rides on the running sums)
+   const bool autoOn = P.autoOn != 0;
+   double minCartPerTheta = 1.0 / P.quadThresh, window = 5.0, tMark = 0, cMark = 0;
+   if (!P.degrees) window *= 3.14159265358979323846 / 180.0;
    int i = 1;
    for (; i + CH <= n; i += CH)
    {
@@ -269,28 +315,40 @@ __global__ void k_rs_scan(RsParams P, RsPath *__restrict__ paths, int B, double 
       {
          tacc = tacc + dt[k]; ta[i + k] = tacc;
          cacc = cacc + dc[k]; ca[i + k] = cacc;
+         if (autoOn)
+         {
+            const double dTh = tacc - tMark, dCa = cacc - cMark;
+            if (dTh > window) { minCartPerTheta = dmin(minCartPerTheta, 3.0 * dCa / dTh); tMark = tacc; cMark = cacc; }
+         }
       }
    }
    for (; i < n; ++i)
    {
       tacc = tacc + ta[i]; ta[i] = tacc;
       cacc = cacc + ca[i]; ca[i] = cacc;
+      if (autoOn)
+      {
+         const double dTh = tacc - tMark, dCa = cacc - cMark;
+         if (dTh > window) { minCartPerTheta = dmin(minCartPerTheta, 3.0 * dCa / dTh); tMark = tacc; cMark = cacc; }
+      }
    }
    if (tacc < P.thetaRes) { pp.status |= RS_IDENTICAL; return; }
 
+   double cartRes = P.cartRes;
+   if (autoOn) rs_auto_rule(P, pp, tacc, cacc, minCartPerTheta, cartRes);
    const double sResi = pp.sres;
    const double ptsLast = (double)(n - 1); // traj.ptsOrig is 0,1,2,.. at both call sites
    double sLast = 0, sResNew = 0;
-   switch (P.scaleType)
+   switch (pp.scaleType)
    {
    case 0: sLast = sResi * ptsLast; sResNew = sResi; break;
    case 1: sLast = tacc; sResNew = P.thetaRes; break;
-   default: sLast = cacc; sResNew = P.cartRes; break;
+   default: sLast = cacc; sResNew = cartRes; break;
    }
    double cartFact = 0;
-   if (cacc >= P.cartRes) cartFact = P.sW[2] * sLast / cacc;
+   if (cacc >= cartRes) cartFact = pp.sw2 * sLast / cacc;
    const double teachFact = P.sW[0] * sLast / (sResi * ptsLast);
-   const double thetaFact = P.sW[1] * sLast / tacc;
+   const double thetaFact = pp.sw1 * sLast / tacc;
    pp.sLast = sLast; pp.sResNew = sResNew; pp.tTeachFact = teachFact; pp.thetaFact = thetaFact; pp.cartFact = cartFact;
    pp.sresNew = sLast / (n - 1); // traj.sres = sLast/(nPts-1), ba.cpp:585
    if (special)

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
 
    const double sres = pi.sres_c, vfact = pi.vfact, afact = pi.afact;
    const double thrV = a.P.jnt_thresh * vfact, thrA = a.P.jnt_thresh * afact;
-   const double absh = a.P.integ_res;
+   const double absh = pi.integ_res; // BA::_integRes of this path
    const double h = DIR * absh;
    const double sEnd = sres * (double)(n - 1);
    const double sdotCap = sEnd / absh;                 // ba.cpp:1216

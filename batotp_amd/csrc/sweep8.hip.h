@@ -143,9 +143,9 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
    // curves in place (kernels.hip.h, BK_CURVE_FULL): slot i must have been left behind by the reverse-curve cursor
    const int64_t revStart = (DIR == 1 && a.fwd == a.rev) ? cap - (int64_t)nMvc : ((int64_t)1 << 62);
 
-   const double absh = a.P.integ_res;
+   const double absh = pi.integ_res;
    const double h = DIR * absh;
-   const int64_t maxIntegSteps = (int64_t)floor(a.P.max_integ_time / a.P.integ_res) + 1;
+   const int64_t maxIntegSteps = (int64_t)floor(a.P.max_integ_time / pi.integ_res) + 1;
    const double sres = pi.sres_c;
    const double sEnd = sres * (double)(n - 1);
    const double sLast = (DIR == 1) ? sEnd : 0.0;

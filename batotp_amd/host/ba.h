@@ -155,9 +155,10 @@ public:
    int writeOutputData(Traj &myTraj);
    int optimize(Traj &myTraj);
 
-   // Extension: resample every path on the host, then run precompute + both sweeps for all of
-   // them as ONE device batch and finish each with interpOutputData().  Requires
-   // setIsAutoIntegRes(false) (one integration step for the whole batch).  Returns the number of
+   // Extension: resample every path, run precompute + both sweeps and the output stage for all of them as ONE device
+   // batch.  With the automatic integration resolution (the class default) every path integrates with the step the rule
+   // derives from it (batotp_hip_set_path_integ_res); the BA object's own _integRes / _sWeights / _scaleType are left
+   // as configured.  Returns the number of
    // paths that failed (0 = all good), -1 if the batch could not be run at all.
    int optimizeBatch(std::vector<Traj> &trajs);
    // Extension: select the HIP device used by this object (default 0).
@@ -168,13 +169,12 @@ public:
    // keeps the single device of setDevice(); useAllDevices() lists every visible device and returns their number.
    void setDevices(const std::vector<int> &devices) { _devices = devices; }
    int useAllDevices();
-   // Extension: optimizeBatch() resamples the taught paths on the device when the configuration is
-   // one batotp_hip_resample covers (exportResampleParams); false keeps the host resampler.
+   // (round 3 switch between a host and a device resampler; since round 4 the resampling always runs behind the C-ABI --
+   // batotp_hip_resample -- and the call is kept for source compatibility only)
    void setDeviceResample(bool on) { _deviceResample = on; }
    // milliseconds the last optimizeBatch() spent resampling (device kernels, or host wall clock)
    double getLastResampleMs() const { return _lastResampleMs; }
-   // Extension: optimizeBatch() runs the output stage (interpOutputData) on the device when the configuration is
-   // one batotp_hip_output covers (exportOutputParams); false keeps the host code.
+   // (likewise for the output stage, batotp_hip_output; kept for source compatibility)
    void setDeviceOutput(bool on) { _deviceOutput = on; }
    // milliseconds the last optimizeBatch() spent in the output stage: wall clock incl. downloads, and device kernels
    double getLastOutputMs() const { return _lastOutputMs; }
@@ -187,8 +187,8 @@ public:
    // layer (struct batotp_problem of include/batotp_hip.h).
    void exportProblem(void *batotp_problem_out) const { fillProblem(batotp_problem_out); }
    // Extension: the resampling parameters (struct batotp_resample_params) of the current
-   // configuration.  Returns 0 when the device resampler covers this configuration and `traj`
-   // (batotp_hip_resample, include/batotp_hip.h), -1 when the host resampler has to be used.
+   // configuration.  Returns 0 when batotp_hip_resample (include/batotp_hip.h) covers this configuration and `traj`,
+   // -1 otherwise (interpInputData then fails with a message: there is no host resampler any more).
    int exportResampleParams(const Traj &traj, void *batotp_resample_params_out) const;
    // Extension: the first step of interpInputData (ba.cpp:100-127): drop samples with a repeated timestamp and take the
    // input resolution from the timestamps.  To be called before exportResampleParams on freshly loaded data.
@@ -352,21 +352,22 @@ private:
    void fillProblem(void *prob) const;     // BA configuration -> batotp_problem
    int deviceBuildKnotModel(Traj &traj);   // ba.cpp:299-305 on the GPU (B = 1)
    int deviceSweep(Traj &traj);            // ba.cpp:979-1195 on the GPU (B = 1)
+   int uploadTrajSplines(void *batch, Traj &traj, int nCartChannels, bool withDynamics); // knot model of a Traj -> path 0 of a batch
+   void unpackOutputRows(Traj &t, const double *rows, long long n, int nTheta, int nCartRows, int nTrq, double sresOut, long long nFwd,
+                         double tTotal, bool shortCurve, double integRes); // finished rows -> Traj (reference ba.cpp:1829-1836, 1920-1931)
    // serial-chain dynamics on the device: set the model on the batch and upload the host cosines / sines of the
    // joint angles of path k (samples = knot values [nJoints][N], row stride N)
    int deviceSerialDynamicsInputs(void *batch, int pathIndex, const double *const *thetaRows, long long N);
 
    inline void setErrorOptimization(const ErrorOptimization &e) { _errorOptimization = e; }
 
-   // ---- host resampling (ba_input.cpp) -----------------------------------------------------------
+   // ---- before the hot path (ba_input.cpp: bookkeeping; the resampling itself runs behind the C-ABI) -------------
    int prepareKnots(Traj &traj);           // interpInputData up to the final knot grid
-   int evalSplineFullTraj(Traj &myTraj, const double oldRes, double newRes);
-   int adjust_s(Traj &traj, std::string interpType);
-   int interpSpecial(Traj &myTraj, const InterpVars &myInterpVars);
-   int evalSplinePoint(Traj &traj);        // host spline evaluation used by interpSpecial()
-   int aa2qVect(std::vector<std::vector<double>> &pose);
-   int q2aaVect(std::vector<std::vector<double>> &pose);
-   int interpTrajLinear(Traj &traj, const int nPtsNew);
+   void stretchShortPath(Traj &traj, unsigned int nNew); // fewer than four points (reference ba.cpp:2768-2794)
+   int interpolateOnly(Traj &traj);        // interpolate-only mode (reference ba.cpp:139-159)
+   int keepTaughtSpacing(Traj &traj);      // s = teach time: adjust_s has nothing to do (reference ba.cpp:416)
+   int deviceResampleOne(Traj &traj);      // reference ba.cpp:160-297 through batotp_hip_resample (B = 1)
+   int deviceOutputOne(Traj &traj, const void *batotp_output_params_in); // reference ba.cpp:1661-1931 through batotp_hip_output (B = 1)
 
    // ---- file IO (ba_io.cpp) -------------------------------------------------------------------------
    int finishConfig();                     // derived settings + checks shared by readConfigData / loadConfigData

@@ -182,9 +182,7 @@ int BA::deviceSerialDynamicsInputs(void *batch, int pathIndex, const double *con
    return 0;
 }
 
-// Which configurations the device resampler takes over (the rest of prepareKnots' branches --
-// timestamps, decimation / smoothing, pose paths, robots with forward kinematics, automatic
-// integration resolution -- stay on the host).
+// Which configurations batotp_hip_resample covers (what it does not, interpInputData refuses with a message).
 int BA::exportResampleParams(const Traj &traj, void *out) const
 {
    batotp_resample_params &R = *static_cast<batotp_resample_params *>(out);
@@ -210,7 +208,20 @@ int BA::exportResampleParams(const Traj &traj, void *out) const
          for (int c = 0; c < 3; ++c) R.pmat[r * 3 + c] = A[r][c];
    }
 
-   if (_isAutoIntegRes || _isInterpOnly) return -1;
+   if (_isAutoIntegRes)
+   {
+      // the class default (reference ba.h:309): both adjust_s passes derive _integRes, _sWeights, _scaleType and the Cartesian
+      // resolution from the path (ba.cpp:462-470, 493-556); these are the inputs of that rule
+      R.flags |= BATOTP_RS_AUTO_INTEG_RES;
+      for (unsigned int j = 0; j < _nJoints && j < BATOTP_MAX_JOINTS; ++j)
+      {
+         if (j < _JntVelMax.size()) R.jnt_vel_max[j] = _JntVelMax[j];
+         if (j < _JntAccMax.size()) R.jnt_acc_max[j] = _JntAccMax[j];
+      }
+      R.cart_vel_max = _CartVelMax; R.cart_acc_max = _CartAccMax; R.quad_rad_thresh = _quadraticRadThresh;
+      R.degrees = _areJointAnglesDegrees ? 1 : 0;
+   }
+   if (_isInterpOnly) return -1;
    if (traj.nPts < 4) return -1; // (timestamps: call dropRepeatedTimestamps first; they only set traj.sres)
    if (_sWeights[1] + _sWeights[2] < 1e-8) return -1;
    if (_nJoints > BATOTP_MAX_JOINTS || _nCart > BATOTP_MAX_CART || _nCart < 3) return -1;
@@ -225,6 +236,75 @@ int BA::exportResampleParams(const Traj &traj, void *out) const
    const bool both = _pathType == BOTH && _nCart == 6;
    if (kin || both) R.flags |= BATOTP_F_HOST_TRIG;
    return (joint || cable || kin || both) ? 0 : -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// reference ba.cpp:160-297 for ONE path behind the C-ABI: taught points in, uniform-s knots back in traj.theta / traj.cart
+// ---------------------------------------------------------------------------------------------
+int BA::deviceResampleOne(Traj &traj)
+{
+   batotp_resample_params rsp;
+   if (exportResampleParams(traj, &rsp) != 0)
+   {
+      printf("interpInputData(): robotType=%s with pathType=%s is not covered by the device resampler.\n", _robotTypeStr.c_str(), _pathTypeStr.c_str());
+      return -1;
+   }
+   if (gpuAcquire() != 0) return -1;
+   const int64_t n = traj.nPts;
+   const int rowsIn = (int)(_nJoints + _nCart);
+   std::vector<double> x((size_t)n * rowsIn, 0.0);
+   for (unsigned int j = 0; j < _nJoints && j < traj.theta.size(); ++j)
+      if (traj.theta[j].size() >= (size_t)n) std::copy(traj.theta[j].begin(), traj.theta[j].begin() + n, x.begin() + (size_t)j * n);
+   for (unsigned int j = 0; j < _nCart && j < traj.cart.size(); ++j)
+      if (traj.cart[j].size() >= (size_t)n) std::copy(traj.cart[j].begin(), traj.cart[j].begin() + n, x.begin() + (size_t)(_nJoints + j) * n);
+   const double sresIn = traj.sres;
+   ResampledGuard rs;
+   int rc = batotp_hip_resample(_gpu->ctx, &rsp, 1, &n, x.data(), &sresIn, &rs.r);
+   if (rc) return fail("resample", rc);
+   int64_t nKnots = 0;
+   double sres = 0;
+   uint32_t status = 0;
+   rc = batotp_hip_resampled_info(rs.r, &nKnots, &sres, &status);
+   if (rc) return fail("resampled_info", rc);
+   if (status)
+   {
+      // the reference's own exits (ba.cpp:176-181, 484-488, 607-611; spline.cpp:84-88)
+      if (status & BATOTP_RS_TOO_SHORT) printf("Input trajectory has less than one site after remClosePts() so no optimization will be performed.\n");
+      else if (status & BATOTP_RS_IDENTICAL) printf("Input trajectory points are all identical no optimization will be performed.\n");
+      else if (status & BATOTP_RS_SMALL_STEP) printf("adjust_s(): s-resolution is too small between two points. aborting... \n");
+      else if (status & BATOTP_RS_SEG_ERROR) printf("Error: division by zero in findInterpSegs().\n");
+      else printf("interpInputData(): the device resampler ended with status 0x%x.\n", status);
+      return -1;
+   }
+   const bool poses = rsp.path_type == BATOTP_PATH_BOTH && _nCart == 6;
+   if (poses) _nCart = 7; // what aa2qVect leaves (reference ba.cpp:335): position + quaternion rows from here on
+   const int rowsOut = (int)(_nJoints + _nCart);
+   std::vector<double> y((size_t)nKnots * rowsOut);
+   rc = batotp_hip_resampled_download(rs.r, 0, y.data());
+   if (rc) return fail("resampled_download", rc);
+   traj.theta.assign(_nJoints, std::vector<double>());
+   traj.cart.assign(_nCart, std::vector<double>());
+   for (unsigned int j = 0; j < _nJoints; ++j) traj.theta[j].assign(y.begin() + (size_t)j * nKnots, y.begin() + (size_t)(j + 1) * nKnots);
+   for (unsigned int j = 0; j < _nCart; ++j)
+      traj.cart[j].assign(y.begin() + (size_t)(_nJoints + j) * nKnots, y.begin() + (size_t)(_nJoints + j + 1) * nKnots);
+   traj.nPts = (unsigned int)nKnots;
+   traj.sres = sres;
+   if (_isAutoIntegRes)
+   {
+      // what the rule leaves in the BA object (reference ba.cpp:493-556)
+      double integ = 0, sw[3] = {0, 0, 0};
+      int32_t scale = 0;
+      rc = batotp_hip_resampled_auto(rs.r, &integ, sw, &scale);
+      if (rc) return fail("resampled_auto", rc);
+      printf("InterpInputData(): Final integ. res is %0.6f s.\n", integ);
+      _integRes = integ;
+      _sWeights[1] = sw[1]; _sWeights[2] = sw[2];
+      _scaleType = scale;
+   }
+   float ms = 0;
+   batotp_hip_resampled_ms(rs.r, &ms);
+   _lastResampleMs = ms;
+   return 0;
 }
 
 // Which configurations the device output stage takes over: JOINT paths of a robot without kinematic model,
@@ -413,6 +493,43 @@ int BA::deviceBuildKnotModel(Traj &traj)
    return 0;
 }
 
+// the knot model of a Traj (sites, spline coefficient rows of joints / Cartesian channels / dynamics coefficients) into path 0
+// of a batch of one -- what the step-by-step API carries from call to call in the public Traj arrays
+int BA::uploadTrajSplines(void *batch, Traj &traj, int nCartChannels, bool withDynamics)
+{
+   batotp_batch *b = static_cast<batotp_batch *>(batch);
+   const size_t N = (size_t)traj.nPtsC;
+   int rc = batotp_hip_upload_path_sites(b, 0, traj.sC.data(), traj.vFact, traj.aFact, _isParallelMech ? 1 : 0);
+   if (rc) return fail("upload_path_sites", rc);
+   std::vector<double> flat;
+   int ch = 0;
+   for (unsigned int j = 0; j < _nJoints; ++j, ++ch)
+   {
+      coeffsToVector(traj.thetaC[j], N, flat);
+      rc = batotp_hip_upload_coeffs(b, 0, ch, flat.data());
+      if (rc) return fail("upload_coeffs(theta)", rc);
+   }
+   for (int j = 0; j < nCartChannels; ++j, ++ch)
+   {
+      coeffsToVector(traj.cartC[j], N, flat);
+      rc = batotp_hip_upload_coeffs(b, 0, ch, flat.data());
+      if (rc) return fail("upload_coeffs(cart)", rc);
+   }
+   if (withDynamics)
+   {
+      const int d = (int)traj.a1C.size();
+      const std::vector<Spline::splineCoeffs> *akC[4] = {&traj.a1C, &traj.a2C, &traj.a3C, &traj.a4C};
+      for (int k = 0; k < 4; ++k)
+         for (int r = 0; r < d; ++r, ++ch)
+         {
+            coeffsToVector((*akC[k])[r], N, flat);
+            rc = batotp_hip_upload_coeffs(b, 0, ch, flat.data());
+            if (rc) return fail("upload_coeffs(dyn)", rc);
+         }
+   }
+   return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // sweep (reference ba.cpp:979-1195) on the GPU, one path
 // ---------------------------------------------------------------------------------------------
@@ -449,36 +566,7 @@ int BA::deviceSweep(Traj &traj)
    BatchGuard g;
    int rc = batotp_hip_batch_create(_gpu->ctx, &prob, 1, &N, cap, &g.b);
    if (rc) return fail("batch_create", rc);
-
-   rc = batotp_hip_upload_path_sites(g.b, 0, traj.sC.data(), traj.vFact, traj.aFact, _isParallelMech ? 1 : 0);
-   if (rc) return fail("upload_path_sites", rc);
-
-   std::vector<double> flat;
-   int ch = 0;
-   for (unsigned int j = 0; j < _nJoints; ++j, ++ch)
-   {
-      coeffsToVector(traj.thetaC[j], (size_t)N, flat);
-      rc = batotp_hip_upload_coeffs(g.b, 0, ch, flat.data());
-      if (rc) return fail("upload_coeffs(theta)", rc);
-   }
-   for (int j = 0; j < prob.n_cart; ++j, ++ch)
-   {
-      coeffsToVector(traj.cartC[j], (size_t)N, flat);
-      rc = batotp_hip_upload_coeffs(g.b, 0, ch, flat.data());
-      if (rc) return fail("upload_coeffs(cart)", rc);
-   }
-   if (haveDyn)
-   {
-      const int d = (int)traj.a1C.size();
-      const std::vector<Spline::splineCoeffs> *akC[4] = {&traj.a1C, &traj.a2C, &traj.a3C, &traj.a4C};
-      for (int k = 0; k < 4; ++k)
-         for (int r = 0; r < d; ++r, ++ch)
-         {
-            coeffsToVector((*akC[k])[r], (size_t)N, flat);
-            rc = batotp_hip_upload_coeffs(g.b, 0, ch, flat.data());
-            if (rc) return fail("upload_coeffs(dyn)", rc);
-         }
-   }
+   if (uploadTrajSplines(g.b, traj, prob.n_cart, haveDyn) != 0) return -1;
    if (_integDir == 1)
    {
       if (traj.sMVC.size() < 2 || traj.sMVC.size() != traj.sdot.size() || traj.nPts != traj.sMVC.size())
@@ -619,36 +707,141 @@ int BA::optimizeBatch(std::vector<Traj> &trajs)
    return broken ? -1 : failed;
 }
 
+// rows of one finished trajectory (joints, then Cartesian rows, then torques, each n points) into the Traj, the way
+// interpOutputData leaves it (reference ba.cpp:1829-1836, 1920-1931)
+void BA::unpackOutputRows(Traj &t, const double *rows, long long n, int nTheta, int nCartRows, int nTrq, double sresOut, long long nFwd, double tTotal,
+                          bool shortCurve, double integRes)
+{
+   t.theta.assign(_nJoints, std::vector<double>());
+   for (unsigned int j = 0; j < _nJoints; ++j) t.theta[j].assign(rows + (size_t)j * n, rows + (size_t)(j + 1) * n);
+   t.trq.clear();
+   if (nCartRows > 0)
+   {
+      // cable robot, robots with forward kinematics, pose paths: Cartesian rows and (torque constraints on) the recomputed
+      // cable tensions / joint torques come with the joints
+      if (_pathType == BOTH && nCartRows == 6) _nCart = 6;   // q2aaVect (reference ba.cpp:399): axis-angle again
+      t.cart.assign(_nCart, std::vector<double>());
+      for (int j = 0; j < nCartRows; ++j) t.cart[j].assign(rows + (size_t)(nTheta + j) * n, rows + (size_t)(nTheta + j + 1) * n);
+      if (nTrq > 0)
+      {
+         t.trq.assign(_nJoints, std::vector<double>());
+         for (int j = 0; j < nTrq; ++j) t.trq[j].assign(rows + (size_t)(nTheta + nCartRows + j) * n, rows + (size_t)(nTheta + nCartRows + j + 1) * n);
+      }
+   }
+   else
+   {
+      // no kinematic model: the Cartesian rows are zeros that interpOutputData sizes (ba.cpp:1829-1836), smooths and
+      // down-samples with the joints (ba.cpp:1861-1869) but does not re-interpolate (ba.cpp:1899); the writer keeps them
+      // only if their length ends up equal to the joints'
+      double outResEff = _outRes, smoothEff = _outSmoothFact;
+      if (_outRes < integRes) { outResEff = integRes; smoothEff *= std::max(_outRes / outResEff, 1.); }
+      const double tStep = shortCurve ? tTotal / 3. : integRes;
+      const double tLast = tStep * (double)(nFwd - 1);
+      int nCartPts = std::max((int)(smoothEff * std::ceil(tLast / outResEff + 1.)), 4);
+      if (smoothEff > 1.5) nCartPts = std::max((int)((nCartPts - 1) / smoothEff) + 1, 4);
+      t.cart.assign(_nCart, std::vector<double>((size_t)nCartPts, 0.0));
+   }
+   t.nPts = (unsigned int)n;
+   t.sres = sresOut;
+   t.tTotalTraj = tTotal;
+}
+
+// ---------------------------------------------------------------------------------------------
+// reference ba.cpp:1661-1931 for ONE path behind the C-ABI: the knot model and the forward curve of the Traj go into a batch
+// of one, batotp_hip_output runs, the finished rows come back
+// ---------------------------------------------------------------------------------------------
+int BA::deviceOutputOne(Traj &traj, const void *prmIn)
+{
+   const batotp_output_params &prm = *static_cast<const batotp_output_params *>(prmIn);
+   if (gpuAcquire() != 0) return -1;
+   const int64_t N = traj.nPtsC, nF = (int64_t)traj.sMVC.size();
+   if (N < 4 || (int64_t)traj.sC.size() != N || traj.thetaC.size() < _nJoints)
+   {
+      printf("batotp: interpOutputData() called on a trajectory without spline interpolants (call interpInputData first).\n");
+      return -1;
+   }
+   batotp_problem prob;
+   fillProblem(&prob);
+   const bool haveCart = traj.cartC.size() >= _nCart && _nCart > 0 && traj.cartC[0].c0.size() >= (size_t)N;
+   const bool haveDyn = _isTrqConOn && traj.a1C.size() > 0;
+   prob.n_cart = haveCart ? (int32_t)_nCart : 0;
+   if (!haveDyn && !_isTrqConOn) prob.flags &= ~(uint32_t)BATOTP_F_TRQ_ON;
+   BatchGuard g;
+   int rc = batotp_hip_batch_create(_gpu->ctx, &prob, 1, &N, nF + 8, &g.b);
+   if (rc) return fail("batch_create", rc);
+   if (uploadTrajSplines(g.b, traj, prob.n_cart, haveDyn) != 0) return -1;
+   if (_isTrqConOn && !_isParallelMechOrig && _robotType != RR)
+   {
+      if (!myRobot.serialModel()) { printf("No dynamics model provided for robotType=%s.\n", _robotTypeStr.c_str()); return -1; }
+      rc = batotp_hip_set_serial_model(g.b, myRobot.serialModel());
+      if (rc) return fail("set_serial_model", rc);
+   }
+   if (nF == 4 && traj.tMVC.size() == 4 && traj.tMVC[1] != _integRes)
+   {
+      // the four-point fix-up of a curve of fewer than four integration steps (ba.cpp:1171-1184) spaces its points by T/3:
+      // the batch entry carries that in the sweep's status word, the step-by-step Traj does not
+      printf("interpOutputData(): a curve of fewer than four integration steps goes through optimizeBatch().\n");
+      return -1;
+   }
+   rc = batotp_hip_upload_forward_curve(g.b, 0, traj.sMVC.data(), traj.sdot.data(), nF, traj.tTotalTraj);
+   if (rc) return fail("upload_forward_curve", rc);
+   OutputGuard og;
+   rc = batotp_hip_output(g.b, &prm, 0, 1, &og.o);
+   if (rc) return fail("output", rc);
+   int64_t nOut = 0;
+   double sresOut = 0;
+   rc = batotp_hip_output_info(og.o, &nOut, &sresOut);
+   if (rc) return fail("output_info", rc);
+   int32_t nTh = 0, nCa = 0, nTq = 0;
+   rc = batotp_hip_output_channels(og.o, &nTh, &nCa, &nTq);
+   if (rc) return fail("output_channels", rc);
+   if (nOut < 1) { printf("interpOutputData(): the device output stage produced no trajectory.\n"); return -1; }
+   std::vector<double> rows((size_t)nOut * (size_t)(nTh + nCa + nTq));
+   rc = batotp_hip_output_download(og.o, 0, rows.data());
+   if (rc) return fail("output_download", rc);
+   float ms = 0;
+   batotp_hip_output_ms(og.o, &ms);
+   _lastOutputKernelMs = ms;
+   unpackOutputRows(traj, rows.data(), nOut, nTh, nCa, nTq, sresOut, nF, traj.tTotalTraj, false, _integRes);
+   if (_nCart == 7) _nCart = 6; // the pose rows left as axis-angle (reference ba.cpp:1920-1927)
+   return 0;
+}
+
 int BA::optimizeBatchOnDevice(std::vector<Traj> &trajs)
 {
    setErrorOptimization(NO_ERROR);
-   if (_isAutoIntegRes)
+   if (trajs.empty()) return 0;
+   if (_isInterpOnly || _sWeights[1] + _sWeights[2] < 1e-8)
    {
-      printf("optimizeBatch(): call setIsAutoIntegRes(false) first (one integration step per batch).\n");
+      printf("optimizeBatch(): the interpolate-only mode and paths whose s is the teach time go through optimize(), one path at a time.\n");
       return -1;
    }
-   if (trajs.empty()) return 0;
    if (gpuAcquire() != 0) return -1;
 
    std::vector<int> ok(trajs.size(), 0);
    std::vector<int64_t> nKnots;
    std::vector<size_t> live;
-   unsigned int nCartRun = _nCart; // Cartesian channels during the run (6 -> 7 when poses become quaternions)
+   const unsigned int nCartTaught = _nCart;
+   // whatever happens below, the object leaves with the number of Cartesian rows it came with (pose paths run with 7)
+   struct CartGuard { unsigned int &ref; unsigned int keep; ~CartGuard() { ref = keep; } } cartGuard{_nCart, nCartTaught};
    const int nInTaught = (int)(_nJoints + _nCart);
-   const std::chrono::steady_clock::time_point tResample0 = std::chrono::steady_clock::now();
 
-   // 1) resampling to uniform-s knots.  On the device when the configuration allows it
-   //    (batotp_hip_resample); the knots then never leave HBM.
+   // 1) resampling to uniform-s knots behind the C-ABI (batotp_hip_resample); the knots never leave HBM
    ResampledGuard rs;
-   bool onDevice = _deviceResample;
    batotp_resample_params rsp;
-   for (size_t p = 0; p < trajs.size() && onDevice; ++p)
+   for (size_t p = 0; p < trajs.size(); ++p)
    {
-      dropRepeatedTimestamps(trajs[p]); // idempotent; prepareKnots would do the same first
-      if (exportResampleParams(trajs[p], &rsp) != 0) onDevice = false;
+      dropRepeatedTimestamps(trajs[p]);
+      if (trajs[p].nPts >= 2 && trajs[p].nPts < 4) stretchShortPath(trajs[p], 4);
+      if (exportResampleParams(trajs[p], &rsp) != 0)
+      {
+         printf("optimizeBatch(): path %d (robotType=%s, pathType=%s, %u points) is not covered by the device resampler.\n", (int)p, _robotTypeStr.c_str(),
+                _pathTypeStr.c_str(), trajs[p].nPts);
+         return -1;
+      }
    }
-   std::vector<double> sresKnots;
-   if (onDevice)
+   std::vector<double> sresKnots, integOf;
+   std::vector<int64_t> nAll(trajs.size());
    {
       std::vector<int64_t> nTaught(trajs.size());
       std::vector<double> sresTaught(trajs.size());
@@ -668,80 +861,56 @@ int BA::optimizeBatchOnDevice(std::vector<Traj> &trajs)
       }
       int rcR = batotp_hip_resample(_gpu->ctx, &rsp, (int32_t)trajs.size(), nTaught.data(), x.data(), sresTaught.data(), &rs.r);
       if (rcR) return fail("resample", rcR);
-      std::vector<int64_t> nK(trajs.size());
-      std::vector<double> sr(trajs.size());
+      std::vector<double> sr(trajs.size()), integ(trajs.size());
       std::vector<uint32_t> st(trajs.size());
-      rcR = batotp_hip_resampled_info(rs.r, nK.data(), sr.data(), st.data());
+      rcR = batotp_hip_resampled_info(rs.r, nAll.data(), sr.data(), st.data());
       if (rcR) return fail("resampled_info", rcR);
-      for (size_t p = 0; p < trajs.size(); ++p)
-         if (st[p] & (BATOTP_RS_TOO_SHORT | BATOTP_RS_CAPACITY)) onDevice = false; // rare branches: let the host resampler take them
-      if (onDevice)
-      {
-         for (size_t p = 0; p < trajs.size(); ++p)
-         {
-            if (st[p]) continue; // the reference returns -1 for this path (identical points / degenerate s)
-            ok[p] = 1;
-            live.push_back(p);
-            nKnots.push_back(nK[p]);
-            sresKnots.push_back(sr[p]);
-            trajs[p].sres = sr[p];
-            trajs[p].nPts = (int)nK[p];
-            trajs[p].sLastSec = -1;
-         }
-         _isInterpolated = true;
-         if (rsp.path_type == BATOTP_PATH_BOTH && _nCart == 6)
-         {
-            _nCart = 7;         // what aa2qVect leaves (reference ba.cpp:335): the pose rows are position + quaternion from here on
-            nCartRun = 7;
-         }
-         float ms = 0;
-         batotp_hip_resampled_ms(rs.r, &ms);
-         _lastResampleMs = ms;
-      }
-      else
-      {
-         batotp_hip_resampled_destroy(rs.r);
-         rs.r = nullptr;
-      }
-   }
-   if (!onDevice)
-   {
-      // host resampling of every path; the configuration fields it may rewrite are restored
-      // after each path so that all paths see the same problem
-      const std::vector<double> sWeights0 = _sWeights;
-      const int scaleType0 = _scaleType;
-      const unsigned int nCart0 = _nCart;
-      const bool par0 = _isParallelMech;
-      nCartRun = nCart0;
+      rcR = batotp_hip_resampled_auto(rs.r, integ.data(), nullptr, nullptr);
+      if (rcR) return fail("resampled_auto", rcR);
       for (size_t p = 0; p < trajs.size(); ++p)
       {
-         _sWeights = sWeights0; _scaleType = scaleType0; _nCart = nCart0; _isParallelMech = par0;
-         if (prepareKnots(trajs[p]) != 0 || trajs[p].nPts < 4) continue;
-         nCartRun = _nCart; // 6 -> 7 when poses were converted to quaternions
+         if (st[p]) continue; // the reference returns -1 for this path (identical points / degenerate s)
          ok[p] = 1;
          live.push_back(p);
-         nKnots.push_back((int64_t)trajs[p].nPts);
+         nKnots.push_back(nAll[p]);
+         sresKnots.push_back(sr[p]);
+         integOf.push_back(_isAutoIntegRes ? integ[p] : _integRes);
+         trajs[p].sres = sr[p];
+         trajs[p].nPts = (unsigned int)nAll[p];
+         trajs[p].sLastSec = -1;
       }
-      _nCart = nCartRun;
-      _lastResampleMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tResample0).count();
+      _isInterpolated = true;
+      if (rsp.path_type == BATOTP_PATH_BOTH && _nCart == 6) _nCart = 7; // what aa2qVect leaves (reference ba.cpp:335)
+      float ms = 0;
+      batotp_hip_resampled_ms(rs.r, &ms);
+      _lastResampleMs = ms;
    }
    if (live.empty()) return (int)trajs.size();
 
    batotp_problem prob;
    fillProblem(&prob);
+   batotp_output_params outPrm;
+   if (exportOutputParams(&outPrm) != 0)
    {
-      // when the output stage runs on the device nothing on the host reads knot samples or coefficient rows: joint
-      // velocity/acceleration-only problems then keep their splines as (value, second derivative) pairs (same results,
-      // less than half the memory per path)
-      batotp_output_params probe;
-      if (_deviceOutput && exportOutputParams(&probe) == 0 && !_isTrqConOn && !_isCartVelConOn && !_isCartAccConOn)
-         prob.flags |= BATOTP_F_NO_SAMPLES | BATOTP_F_COMPACT_SPLINES;
+      printf("optimizeBatch(): robotType=%s with pathType=%s%s is not covered by the device output stage.\n", _robotTypeStr.c_str(), _pathTypeStr.c_str(),
+             _isTrqConOn ? " and torque constraints" : "");
+      return -1;
    }
+   // nothing on the host reads knot samples or coefficient rows: joint velocity/acceleration-only problems keep their
+   // splines as (value, second derivative) pairs (same results, less than half the memory per path)
+   if (!_isTrqConOn && !_isCartVelConOn && !_isCartAccConOn) prob.flags |= BATOTP_F_NO_SAMPLES | BATOTP_F_COMPACT_SPLINES;
    // the reverse curves are only read back for s-sdot.dat: without it one curve buffer per path is enough (the forward curve
    // replaces the reverse curve, as traj.sMVC / traj.sdot do in the reference)
    if (!is_sdotOut) prob.flags |= BATOTP_F_CURVES_IN_PLACE;
    const int nIn = (int)(_nJoints + _nCart);
-   const int64_t maxIntegSteps = (int64_t)std::floor(_maxIntegTime / _integRes) + 1;
+   // integration steps a path may take (ba.cpp:984): per path with the automatic integration resolution (a NaN step --
+   // the rule's result for a robot without Cartesian limits -- allows none)
+   int64_t maxIntegSteps = 1;
+   for (size_t k = 0; k < live.size(); ++k)
+   {
+      const double h = integOf[k];
+      if (h > 0) maxIntegSteps = std::max<int64_t>(maxIntegSteps, (int64_t)std::floor(_maxIntegTime / h) + 1);
+   }
    int64_t nMax = 0;
    for (size_t k = 0; k < nKnots.size(); ++k) nMax = std::max(nMax, nKnots[k]);
    // Capacity of a curve in points.  The single-path API allows maxIntegSteps + 2 like the reference's unbounded arrays
@@ -754,15 +923,9 @@ int BA::optimizeBatchOnDevice(std::vector<Traj> &trajs)
    int rc = 0;
    const double *yDev = nullptr;
    std::vector<int64_t> offAll(trajs.size(), 0);
-   if (onDevice)
-   {
-      rc = batotp_hip_resampled_knots_device(rs.r, &yDev, nullptr);
-      if (rc) return fail("resampled_knots_device", rc);
-      std::vector<int64_t> nAll(trajs.size());
-      rc = batotp_hip_resampled_info(rs.r, nAll.data(), nullptr, nullptr);
-      if (rc) return fail("resampled_info", rc);
-      for (size_t p = 1; p < trajs.size(); ++p) offAll[p] = offAll[p - 1] + nAll[p - 1];
-   }
+   rc = batotp_hip_resampled_knots_device(rs.r, &yDev, nullptr);
+   if (rc) return fail("resampled_knots_device", rc);
+   for (size_t p = 1; p < trajs.size(); ++p) offAll[p] = offAll[p - 1] + nAll[p - 1];
    for (;;)
    {
       if (g.b) { batotp_hip_batch_destroy(g.b); g.b = nullptr; }
@@ -770,35 +933,20 @@ int BA::optimizeBatchOnDevice(std::vector<Traj> &trajs)
       if (2 * cap >= 3 * nMax) prob.flags |= BATOTP_F_MVC_IN_CURVES; else prob.flags &= ~(uint32_t)BATOTP_F_MVC_IN_CURVES;
       rc = batotp_hip_batch_create(_gpu->ctx, &prob, (int32_t)live.size(), nKnots.data(), cap, &g.b);
       if (rc) return fail("batch_create", rc);
-
-      if (onDevice)
+      if (_isAutoIntegRes)
       {
-         // runs of consecutive surviving paths are contiguous in the resampler's output
-         size_t k = 0;
-         while (k < live.size())
-         {
-            size_t e = k + 1;
-            while (e < live.size() && live[e] == live[e - 1] + 1) ++e;
-            rc = batotp_hip_upload_knots_device(g.b, (int32_t)k, (int32_t)(e - k), yDev + offAll[live[k]] * nIn, sresKnots.data() + k);
-            if (rc) return fail("upload_knots_device", rc);
-            k = e;
-         }
+         rc = batotp_hip_set_path_integ_res(g.b, 0, (int32_t)live.size(), integOf.data());
+         if (rc) return fail("set_path_integ_res", rc);
       }
-      else
+      // runs of consecutive surviving paths are contiguous in the resampler's output
+      size_t k = 0;
+      while (k < live.size())
       {
-         std::vector<double> y;
-         for (size_t k = 0; k < live.size(); ++k)
-         {
-            Traj &t = trajs[live[k]];
-            const int64_t N = nKnots[k];
-            y.assign((size_t)nIn * N, 0.0);
-            for (unsigned int j = 0; j < _nJoints; ++j) std::copy(t.theta[j].begin(), t.theta[j].begin() + N, y.begin() + (size_t)j * N);
-            for (unsigned int j = 0; j < _nCart && j < t.cart.size(); ++j)
-               if (t.cart[j].size() >= (size_t)N) std::copy(t.cart[j].begin(), t.cart[j].begin() + N, y.begin() + (size_t)(_nJoints + j) * N);
-            const double sres = t.sres;
-            rc = batotp_hip_upload_knots(g.b, (int32_t)k, 1, y.data(), &sres);
-            if (rc) return fail("upload_knots", rc);
-         }
+         size_t e = k + 1;
+         while (e < live.size() && live[e] == live[e - 1] + 1) ++e;
+         rc = batotp_hip_upload_knots_device(g.b, (int32_t)k, (int32_t)(e - k), yDev + offAll[live[k]] * nIn, sresKnots.data() + k);
+         if (rc) return fail("upload_knots_device", rc);
+         k = e;
       }
       rc = batotp_hip_precompute(g.b, 1);
       if (rc) return fail("precompute(kinematics)", rc);
@@ -807,14 +955,14 @@ int BA::optimizeBatchOnDevice(std::vector<Traj> &trajs)
          if (_robotType == RR)
          {
             std::vector<double> samp, trig;
-            for (size_t k = 0; k < live.size(); ++k)
+            for (size_t q = 0; q < live.size(); ++q)
             {
-               const int64_t N = nKnots[k];
+               const int64_t N = nKnots[q];
                samp.resize(6 * (size_t)N);
                trig.resize(4 * (size_t)N);
-               rc = batotp_hip_download_samples(g.b, (int32_t)k, 0, samp.data());
+               rc = batotp_hip_download_samples(g.b, (int32_t)q, 0, samp.data());
                if (rc) return fail("download_samples", rc);
-               rc = batotp_hip_download_samples(g.b, (int32_t)k, 1, samp.data() + 3 * N);
+               rc = batotp_hip_download_samples(g.b, (int32_t)q, 1, samp.data() + 3 * N);
                if (rc) return fail("download_samples", rc);
                for (int64_t i = 0; i < N; ++i)
                {
@@ -825,7 +973,7 @@ int BA::optimizeBatchOnDevice(std::vector<Traj> &trajs)
                   trig[2 * N + i] = tr[2];
                   trig[3 * N + i] = tr[3];
                }
-               rc = batotp_hip_upload_rr_trig(g.b, (int32_t)k, trig.data());
+               rc = batotp_hip_upload_rr_trig(g.b, (int32_t)q, trig.data());
                if (rc) return fail("upload_rr_trig", rc);
             }
          }
@@ -838,17 +986,17 @@ int BA::optimizeBatchOnDevice(std::vector<Traj> &trajs)
             }
             std::vector<double> samp;
             std::vector<const double *> rows(_nJoints);
-            for (size_t k = 0; k < live.size(); ++k)
+            for (size_t q = 0; q < live.size(); ++q)
             {
-               const int64_t N = nKnots[k];
+               const int64_t N = nKnots[q];
                samp.resize(3 * (size_t)N * _nJoints);
                for (unsigned int j = 0; j < _nJoints; ++j)
                {
-                  rc = batotp_hip_download_samples(g.b, (int32_t)k, (int32_t)j, samp.data() + 3 * (size_t)N * j);
+                  rc = batotp_hip_download_samples(g.b, (int32_t)q, (int32_t)j, samp.data() + 3 * (size_t)N * j);
                   if (rc) return fail("download_samples", rc);
                   rows[j] = samp.data() + 3 * (size_t)N * j;
                }
-               if (deviceSerialDynamicsInputs(g.b, (int)k, rows.data(), (long long)N) != 0) return -1;
+               if (deviceSerialDynamicsInputs(g.b, (int)q, rows.data(), (long long)N) != 0) return -1;
             }
          }
          rc = batotp_hip_precompute(g.b, 2);
@@ -863,17 +1011,17 @@ int BA::optimizeBatchOnDevice(std::vector<Traj> &trajs)
       if (rc) return fail("get_results", rc);
 
       size_t outOfRoom = 0, firstOut = 0;
-      for (size_t k = 0; k < res.size(); ++k)
+      for (size_t q = 0; q < res.size(); ++q)
       {
-         const uint32_t st = res[k].status_rev | res[k].status_fwd;
+         const uint32_t st = res[q].status_rev | res[q].status_fwd;
          // with one curve buffer per path (BATOTP_F_CURVES_IN_PLACE) the forward sweep gives up as soon as its curve comes
          // within 64 points of the reverse points still to be read -- long before steps_fwd reaches cap
-         const bool inPlaceFull = (prob.flags & BATOTP_F_CURVES_IN_PLACE) && res[k].n_rev > 0 && (res[k].status_fwd & BATOTP_ST_CAPACITY) &&
-                                  !(res[k].status_fwd & BATOTP_ST_NONFINITE);
-         if ((st & BATOTP_ST_CAPACITY) && !(st & BATOTP_ST_MAX_INTEG_TIME) && !(res[k].status_rev & BATOTP_ST_NONFINITE) &&
-             (res[k].n_rev == 0 || res[k].n_fwd == 0) && (res[k].steps_rev + 1 >= cap || res[k].steps_fwd + 1 >= cap || inPlaceFull))
+         const bool inPlaceFull = (prob.flags & BATOTP_F_CURVES_IN_PLACE) && res[q].n_rev > 0 && (res[q].status_fwd & BATOTP_ST_CAPACITY) &&
+                                  !(res[q].status_fwd & BATOTP_ST_NONFINITE);
+         if ((st & BATOTP_ST_CAPACITY) && !(st & BATOTP_ST_MAX_INTEG_TIME) && !(res[q].status_rev & BATOTP_ST_NONFINITE) &&
+             (res[q].n_rev == 0 || res[q].n_fwd == 0) && (res[q].steps_rev + 1 >= cap || res[q].steps_fwd + 1 >= cap || inPlaceFull))
          {
-            if (outOfRoom == 0) firstOut = k;
+            if (outOfRoom == 0) firstOut = q;
             ++outOfRoom;
          }
       }
@@ -884,192 +1032,80 @@ int BA::optimizeBatchOnDevice(std::vector<Traj> &trajs)
              (long long)capNext);
       cap = capNext;
    }
-   if (rs.r)
-   {
-      batotp_hip_resampled_destroy(rs.r);
-      rs.r = nullptr;
-   }
+   batotp_hip_resampled_destroy(rs.r);
+   rs.r = nullptr;
 
-   // 3) output stage.  On the device when the configuration allows it (batotp_hip_output): only the finished
-   //    trajectories come back, in ranges of paths so that their device copy stays small.
-   batotp_output_params outPrm;
-   if (_deviceOutput && exportOutputParams(&outPrm) == 0)
+   // 3) output stage behind the C-ABI (batotp_hip_output): only the finished trajectories come back, in ranges of paths
+   //    that integrate with the same step (one step for the whole batch unless the automatic integration resolution is
+   //    on) and of at most 1024 paths, so that their device copy stays small
+   const std::chrono::steady_clock::time_point tOut0 = std::chrono::steady_clock::now();
+   double kernelMs = 0;
+   const size_t range = 1024;
+   std::vector<double> flatAll;
+   std::vector<int64_t> nPtsOut;
+   std::vector<double> sresOut;
+   for (size_t k0 = 0; k0 < live.size();)
    {
-      const std::chrono::steady_clock::time_point tOut0 = std::chrono::steady_clock::now();
-      double kernelMs = 0;
-      const size_t range = 1024;
-      std::vector<double> flatAll;
-      std::vector<int64_t> nPtsOut;
-      std::vector<double> sresOut;
-      for (size_t k0 = 0; k0 < live.size(); k0 += range)
+      size_t cnt = 1;
+      while (k0 + cnt < live.size() && cnt < range && integOf[k0 + cnt] == integOf[k0]) ++cnt;
+      const double h = integOf[k0];
+      if (!(h > 0))
       {
-         const size_t cnt = std::min(range, live.size() - k0);
-         OutputGuard og;
-         rc = batotp_hip_output(g.b, &outPrm, (int32_t)k0, (int32_t)cnt, &og.o);
-         if (rc) return fail("output", rc);
-         nPtsOut.assign(cnt, 0);
-         sresOut.assign(cnt, 0.0);
-         rc = batotp_hip_output_info(og.o, nPtsOut.data(), sresOut.data());
-         if (rc) return fail("output_info", rc);
-         float ms = 0;
-         batotp_hip_output_ms(og.o, &ms); // timing only
-         kernelMs += ms;
-         int32_t nTh = 0, nCa = 0, nTq = 0;
-         rc = batotp_hip_output_channels(og.o, &nTh, &nCa, &nTq);
-         if (rc) return fail("output_channels", rc);
-         const size_t rows = (size_t)(nTh + nCa + nTq);
-         size_t rangePts = 0;
-         for (size_t q = 0; q < cnt; ++q) rangePts += (size_t)nPtsOut[q];
-         flatAll.resize(rangePts * rows);
-         rc = batotp_hip_output_download_all(og.o, flatAll.data()); // one copy for the whole range of paths
-         if (rc) return fail("output_download_all", rc);
-         size_t at = 0;
-         for (size_t q = 0; q < cnt; ++q)
-         {
-            const size_t k = k0 + q;
-            Traj &t = trajs[live[k]];
-            const batotp_path_result &r = res[k];
-            if ((r.status_rev | r.status_fwd) & BATOTP_ST_MAX_INTEG_TIME) setErrorOptimization(MAX_INTEGRATION_TIME);
-            const int64_t n = nPtsOut[q];
-            if (n == 0) { ok[live[k]] = 0; continue; }
-            const std::vector<double>::const_iterator flatTh0 = flatAll.begin() + at;
-            at += (size_t)n * rows;
-            t.theta.assign(_nJoints, std::vector<double>());
-            for (unsigned int j = 0; j < _nJoints; ++j) t.theta[j].assign(flatTh0 + (size_t)j * n, flatTh0 + (size_t)(j + 1) * n);
-            t.trq.clear();
-            if (nCa > 0)
-            {
-               // cable robot, robots with forward kinematics, pose paths: Cartesian rows and (torque constraints on) the recomputed
-               // cable tensions / joint torques come with the joints
-               if (_pathType == BOTH && nCa == 6) _nCart = 6;   // q2aaVect (reference ba.cpp:399): axis-angle again
-               t.cart.assign(_nCart, std::vector<double>());
-               for (int j = 0; j < nCa; ++j) t.cart[j].assign(flatTh0 + (size_t)(nTh + j) * n, flatTh0 + (size_t)(nTh + j + 1) * n);
-               if (nTq > 0)
-               {
-                  t.trq.assign(_nJoints, std::vector<double>());
-                  for (int j = 0; j < nTq; ++j)
-                     t.trq[j].assign(flatTh0 + (size_t)(nTh + nCa + j) * n, flatTh0 + (size_t)(nTh + nCa + j + 1) * n);
-               }
-            }
-            else
-            {
-               // no kinematic model: the Cartesian rows are zeros that interpOutputData sizes (ba.cpp:1829-1836),
-               // smooths and down-samples with the joints (ba.cpp:1861-1869) but does not re-interpolate
-               // (ba.cpp:1899); the writer keeps them only if their length ends up equal to the joints'
-               double outResEff = _outRes, smoothEff = _outSmoothFact;
-               if (_outRes < _integRes) { outResEff = _integRes; smoothEff *= std::max(_outRes / outResEff, 1.); }
-               const double tStep = (r.status_fwd & BATOTP_ST_SHORT) ? r.t_total / 3. : _integRes;
-               const double tLast = tStep * (double)(r.n_fwd - 1);
-               int nCartPts = std::max((int)(smoothEff * std::ceil(tLast / outResEff + 1.)), 4);
-               if (smoothEff > 1.5) nCartPts = std::max((int)((nCartPts - 1) / smoothEff) + 1, 4);
-               t.cart.assign(_nCart, std::vector<double>((size_t)nCartPts, 0.0));
-            }
-            t.nPts = (unsigned int)n;
-            t.sres = sresOut[q];
-            t.tTotalTraj = r.t_total;
-            if (is_sdotOut)
-            {
-               int64_t got = 0;
-               t.myMVChist.s.assign(4, std::vector<double>());
-               t.myMVChist.sdot.assign(4, std::vector<double>());
-               t.myMVChist.s[0].resize((size_t)r.n_rev); t.myMVChist.sdot[0].resize((size_t)r.n_rev);
-               t.myMVChist.s[1].resize((size_t)r.n_fwd); t.myMVChist.sdot[1].resize((size_t)r.n_fwd);
-               rc = batotp_hip_download_curve(g.b, (int32_t)k, -1, t.myMVChist.s[0].data(), t.myMVChist.sdot[0].data(), r.n_rev, &got);
-               if (rc || got != r.n_rev) return fail("download_curve(rev)", rc);
-               rc = batotp_hip_download_curve(g.b, (int32_t)k, +1, t.myMVChist.s[1].data(), t.myMVChist.sdot[1].data(), r.n_fwd, &got);
-               if (rc || got != r.n_fwd) return fail("download_curve(fwd)", rc);
-            }
-         }
-      }
-      _lastOutputKernelMs = kernelMs;
-      _lastOutputMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tOut0).count();
-      int failedDev = 0;
-      for (size_t p = 0; p < trajs.size(); ++p) failedDev += ok[p] ? 0 : 1;
-      if (_pathType == BOTH && _nCart == 7) _nCart = 6;   // (no path reached the conversion: leave the object as q2aaVect would)
-      return failedDev;
-   }
-
-   // unmarshal each path and finish it on the host
-   const std::chrono::steady_clock::time_point tHostOut0 = std::chrono::steady_clock::now();
-   const double outRes0 = _outRes, outSmooth0 = _outSmoothFact;
-   std::vector<double> flat, samp;
-   for (size_t k = 0; k < live.size(); ++k)
-   {
-      Traj &t = trajs[live[k]];
-      const batotp_path_result &r = res[k];
-      const int64_t N = nKnots[k];
-      if ((r.status_rev | r.status_fwd) & (BATOTP_ST_MAX_INTEG_TIME | BATOTP_ST_CAPACITY | BATOTP_ST_NONFINITE))
-      {
-         if ((r.status_rev | r.status_fwd) & BATOTP_ST_MAX_INTEG_TIME) setErrorOptimization(MAX_INTEGRATION_TIME);
-         ok[live[k]] = 0;
+         // no integration step, no trajectory (the rule gave NaN: a robot without Cartesian limits)
+         for (size_t q = 0; q < cnt; ++q) ok[live[k0 + q]] = 0;
+         k0 += cnt;
          continue;
       }
-      _nCart = nCartRun; // interpOutputData of the previous path turned quaternions back into axis-angle
-      const double sresIn = t.sres;
-      t.nPtsC = (int)N;
-      t.sC.resize(N);
-      for (int64_t i = 0; i < N; ++i) t.sC[i] = sresIn * (double)i;
-      t.sresC = sresIn;
-      t.vFact = 1 / t.sresC;
-      t.aFact = t.vFact * t.vFact;
-      t.thetaC.resize(_nJoints); t.cartC.resize(_nCart);
-      t.thetaD.resize(_nJoints); t.thetaD2.resize(_nJoints);
-      t.cartD.resize(_nCart); t.cartD2.resize(_nCart); t.cart.resize(_nCart); t.theta.resize(_nJoints);
-      flat.resize(4 * (size_t)N); samp.resize(3 * (size_t)N);
-      for (int ch = 0; ch < nIn; ++ch)
+      outPrm.integ_res = h;
+      OutputGuard og;
+      rc = batotp_hip_output(g.b, &outPrm, (int32_t)k0, (int32_t)cnt, &og.o);
+      if (rc) return fail("output", rc);
+      nPtsOut.assign(cnt, 0);
+      sresOut.assign(cnt, 0.0);
+      rc = batotp_hip_output_info(og.o, nPtsOut.data(), sresOut.data());
+      if (rc) return fail("output_info", rc);
+      float ms = 0;
+      batotp_hip_output_ms(og.o, &ms); // timing only
+      kernelMs += ms;
+      int32_t nTh = 0, nCa = 0, nTq = 0;
+      rc = batotp_hip_output_channels(og.o, &nTh, &nCa, &nTq);
+      if (rc) return fail("output_channels", rc);
+      const size_t rows = (size_t)(nTh + nCa + nTq);
+      size_t rangePts = 0;
+      for (size_t q = 0; q < cnt; ++q) rangePts += (size_t)nPtsOut[q];
+      flatAll.resize(rangePts * rows);
+      rc = batotp_hip_output_download_all(og.o, flatAll.data()); // one copy for the whole range of paths
+      if (rc) return fail("output_download_all", rc);
+      size_t at = 0;
+      for (size_t q = 0; q < cnt; ++q)
       {
-         rc = batotp_hip_download_coeffs(g.b, (int32_t)k, ch, flat.data());
-         if (rc) return fail("download_coeffs", rc);
-         rc = batotp_hip_download_samples(g.b, (int32_t)k, ch, samp.data());
-         if (rc) return fail("download_samples", rc);
-         const bool isTheta = ch < (int)_nJoints;
-         const int j = isTheta ? ch : ch - (int)_nJoints;
-         vectorToCoeffs(flat, (size_t)N, isTheta ? t.thetaC[j] : t.cartC[j]);
-         (isTheta ? t.theta[j] : t.cart[j]).assign(samp.begin(), samp.begin() + N);
-         (isTheta ? t.thetaD[j] : t.cartD[j]).assign(samp.begin() + N, samp.begin() + 2 * N);
-         (isTheta ? t.thetaD2[j] : t.cartD2[j]).assign(samp.begin() + 2 * N, samp.begin() + 3 * N);
-      }
-      if (_isTrqConOn)
-      {
-         const int d = _isParallelMechOrig ? (int)_nCart : (int)_nJoints;
-         t.a1.assign(d, std::vector<double>()); t.a2 = t.a1; t.a3 = t.a1; t.a4 = t.a1;
-         if (_isParallelMechOrig)
+         const size_t k = k0 + q;
+         Traj &t = trajs[live[k]];
+         const batotp_path_result &r = res[k];
+         if ((r.status_rev | r.status_fwd) & BATOTP_ST_MAX_INTEG_TIME) setErrorOptimization(MAX_INTEGRATION_TIME);
+         const int64_t n = nPtsOut[q];
+         if (n == 0) { ok[live[k]] = 0; continue; }
+         _nCart = (rsp.path_type == BATOTP_PATH_BOTH && nCartTaught == 6) ? 7 : nCartTaught;
+         unpackOutputRows(t, flatAll.data() + at, n, nTh, nCa, nTq, sresOut[q], r.n_fwd, r.t_total, (r.status_fwd & BATOTP_ST_SHORT) != 0, h);
+         at += (size_t)n * rows;
+         if (is_sdotOut)
          {
-            t.Apt.resize(_nCart);
-            for (unsigned int q = 0; q < _nCart; ++q) t.Apt[q].resize(_nJoints);
+            int64_t got = 0;
+            t.myMVChist.s.assign(4, std::vector<double>());
+            t.myMVChist.sdot.assign(4, std::vector<double>());
+            t.myMVChist.s[0].resize((size_t)r.n_rev); t.myMVChist.sdot[0].resize((size_t)r.n_rev);
+            t.myMVChist.s[1].resize((size_t)r.n_fwd); t.myMVChist.sdot[1].resize((size_t)r.n_fwd);
+            rc = batotp_hip_download_curve(g.b, (int32_t)k, -1, t.myMVChist.s[0].data(), t.myMVChist.sdot[0].data(), r.n_rev, &got);
+            if (rc || got != r.n_rev) return fail("download_curve(rev)", rc);
+            rc = batotp_hip_download_curve(g.b, (int32_t)k, +1, t.myMVChist.s[1].data(), t.myMVChist.sdot[1].data(), r.n_fwd, &got);
+            if (rc || got != r.n_fwd) return fail("download_curve(fwd)", rc);
          }
       }
-      t.sMVC.resize((size_t)r.n_fwd);
-      t.sdot.resize((size_t)r.n_fwd);
-      int64_t got = 0;
-      rc = batotp_hip_download_curve(g.b, (int32_t)k, +1, t.sMVC.data(), t.sdot.data(), r.n_fwd, &got);
-      if (rc || got != r.n_fwd) return fail("download_curve(fwd)", rc);
-      t.nPts = (unsigned int)r.n_fwd;
-      t.tTotalTraj = r.t_total;
-      t.tMVC.resize((size_t)r.n_fwd);
-      const double tStep = (r.status_fwd & BATOTP_ST_SHORT) ? r.t_total / 3. : _integRes;
-      for (int64_t i = 0; i < r.n_fwd; ++i) t.tMVC[i] = tStep * (double)i;
-      if (is_sdotOut)
-      {
-         t.myMVChist.s.assign(4, std::vector<double>());
-         t.myMVChist.sdot.assign(4, std::vector<double>());
-         t.myMVChist.s[0].resize((size_t)r.n_rev);
-         t.myMVChist.sdot[0].resize((size_t)r.n_rev);
-         rc = batotp_hip_download_curve(g.b, (int32_t)k, -1, t.myMVChist.s[0].data(), t.myMVChist.sdot[0].data(), r.n_rev, &got);
-         if (rc || got != r.n_rev) return fail("download_curve(rev)", rc);
-         t.myMVChist.s[1] = t.sMVC;
-         t.myMVChist.sdot[1] = t.sdot;
-      }
-      _outRes = outRes0;
-      _outSmoothFact = outSmooth0;
-      interpOutputData(t);
+      k0 += cnt;
    }
-   _outRes = outRes0;
-   _outSmoothFact = outSmooth0;
-   if (_isParallelMechOrig && _isPar2Ser && _isTrqConOn) _isParallelMech = false;
-   _lastOutputKernelMs = 0;
-   _lastOutputMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tHostOut0).count();
-
+   _lastOutputKernelMs = kernelMs;
+   _lastOutputMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tOut0).count();
+   if (_isParallelMechOrig && _isPar2Ser && _isTrqConOn) _isParallelMech = false; // reference ba.cpp:937
    int failed = 0;
    for (size_t p = 0; p < trajs.size(); ++p) failed += ok[p] ? 0 : 1;
    return failed;

@@ -42,7 +42,9 @@ int main(int argc, char *argv[])
       mkDirIfNec(planner.getOutputFolder().c_str());
    }
    const std::string configPath = planner.getInputFolder() + configName;
-   planner.setIsAutoIntegRes(false);
+   // the reference's driver switches the automatic integration resolution off (test/main.cpp:53); a second argument
+   // "--auto-integ-res" keeps the class default (reference ba.h:309)
+   planner.setIsAutoIntegRes(argc > 2 && std::string(argv[2]) == "--auto-integ-res");
 
    clock.lap(0);
    if (planner.readConfigData(configPath.c_str()) == -1) return -1;

@@ -558,12 +558,20 @@ def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=
         "stage_evals_per_s": 7.0 * (steps_rev + steps_fwd) / (r2_ms * 1e-3),
         "us_per_integration_step": (1e3 * (kernel_ms[3] + kernel_ms[4]) / max(steps_rev + steps_fwd, 1)) if B == 1 else None,
         "paths_with_error_status": int(np.count_nonzero((res["status_rev"] | res["status_fwd"]) & ~np.uint32(capi.ST_BISECT_FAIL))) if B else 0,
+        # candidate paths the constraints do not admit (cable tensions outside their limits) that were replaced by other seeds
+        # before the timed region -- the reference would grind through such a path and return -1
+        "swapped_seeds": int(inp.skipped),
+        # a launch of one-path wavefronts lasts as long as its slowest path: integration steps of the slowest / the mean path
+        "slowest_over_mean_path": {"rev": float(np.max(sr) / max(np.mean(sr), 1.0)), "fwd": float(np.max(sf) / max(np.mean(sf), 1.0))} if B else None,
         "hbm_bytes_resident": batch.nbytes() if batch is not None else 0,
         "gathered_rows": int(state["gathered"].shape[0]) if state["gathered"] is not None else 0,
         # "bound" names the roofline the path is priced against (north_star: HBM GB/s vs peak); what the counters say limits the
         # kernel is in "limited_by" / "issue": the sweep is an initial-value problem, bound by fp64 instruction issue on two
         # wavefronts per SIMD, not by bytes (SURVEY.md 8d "honest expectation")
-        "roofline": {"bound": "hbm", "limited_by": "valu-issue (fp64 dependent chains, 2 wavefronts per SIMD)", "issue": issue,
+        "roofline": {"bound": "valu-issue" if B > 64 else "latency (one wavefront per path)", "priced_against": "hbm",
+                     "limited_by": ("fp64 vector instruction issue on two wavefronts per SIMD" if B > 64 else
+                                    "instruction issue of a lone wavefront per SIMD") + " (the counters in `issue`; HBM bytes are what the north_star prices)",
+                     "issue": issue,
                      "kernel": f"k_sweep ({2 * launches} launches per step: reverse, forward; per-launch averages)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_src, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
@@ -623,28 +631,34 @@ def load_cpu_checker():
     return capi.Library(os.path.join(ROOT, "oracle", "_build", "libbatotp_oracle_abi.so"))
 
 
-def cpu_baseline(kept, budget_s, out_prm=None, want_output=False):
+def cpu_baseline(kept, budget_s, out_prm=None, want_output=False, max_distinct=16, single_path=False):
+    """the oracle (oracle/_build, the bit-identical C restatement of the reference's path) on the host cores, on a bounded sample
+    of the SAME inputs: (i) one path on one thread, (ii) one path per thread on all host threads.  Both with the
+    regions of test/main.cpp:90-96: sweeps only ("Accel. constraint integ.") and spline / dynamics build + sweeps.  Every sampled
+    path's traversal time and step counts are compared with the GPU's.  single_path: the configuration IS one trajectory
+    (BASELINE configs 2 / 3): the one-thread figure is the baseline, no all-core run."""
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     octx = capi.Context(load_cpu_checker(), 0)
     cores = os.cpu_count() or 1
     inp, prob, cap, K = kept["inp"], kept["prob"], kept["cap"], kept["K"]
-    D = min(K, 16)                                        # distinct paths of the sample (host-resampled copies)
+    D = max(1, min(K, max_distinct))                      # distinct paths of the sample (host-resampled copies)
     with cf.ThreadPoolExecutor(max_workers=min(D, cores)) as ex:
         hosts = list(ex.map(inp.host_knots, range(D)))
 
     def cpu_batch(n_paths, passes=1):
         nk = [hosts[i % D][0].shape[1] for i in range(n_paths)]
         pr = capi.Problem.from_buffer_copy(bytes(prob))
-        pr.flags &= ~capi.F_COMPACT_SPLINES
+        pr.flags &= ~(capi.F_COMPACT_SPLINES | capi.F_CURVES_IN_PLACE | capi.F_MVC_IN_CURVES)
         b = capi.Batch(octx, pr, nk, cap)
         for i in range(n_paths):
             b.upload_knots(i, [hosts[i % D][0]], [hosts[i % D][1]])
         prepare_dynamics(b, pr, n_paths)
-        dt = 0.0
+        dt, sw = 0.0, 0.0
         for _ in range(passes):
             t = time.perf_counter()
             b.precompute(0); b.pointwise_mvc(); b.sweep(-1); b.sweep(+1)
             dt = time.perf_counter() - t
+            sw = 1e-3 * (b.kernel_ms(3) + b.kernel_ms(4))
         rr = b.results()
         th0 = None
         if want_output:
@@ -652,19 +666,40 @@ def cpu_baseline(kept, budget_s, out_prm=None, want_output=False):
             th0 = oo.rows(0)
             oo.close()
         b.close()
-        return dt, sum(nk), rr, th0
+        return dt, sw, sum(nk), rr, th0
 
-    t_one, n_one, _, th0 = cpu_batch(1, passes=2)      # one path = one busy thread
-    n_sample = int(max(cores, min(2 * cores, (budget_s / max(t_one, 1e-3)) * cores)))
-    n_sample = max(cores, (n_sample // cores) * cores)
-    wall, n_wp, rows, _ = cpu_batch(n_sample, passes=2)
-    info = {"value": n_wp / wall, "unit": "waypoints/s", "cores": cores, "kind": "port", "single_thread_value": n_one / t_one,
-            "sample": f"{n_sample} paths of the same workload ({D} distinct, N~{n_one}), OpenMP one path per thread on {cores} host "
-                      f"threads, same regions (K1-K4), oracle/ C restatement at -O3 -ffp-contract=off"}
-    m = min(n_sample, kept["chunk0"], D)
+    t_one, sw_one, n_one, rows, th0 = cpu_batch(1, passes=2)      # one path = one busy thread
+    info = {"unit": "waypoints/s", "kind": "port",
+            "single_thread": {"value": n_one / t_one, "sweeps_only_value": n_one / max(sw_one, 1e-9), "seconds": t_one, "sweep_seconds": sw_one,
+                              "steps_per_s": float(rows["steps_rev"][0] + rows["steps_fwd"][0]) / max(sw_one, 1e-9)}}
+    n_sample = 1
+    if single_path:
+        info.update({"value": n_one / t_one, "cores": 1,
+                     "sample": f"the configuration's one trajectory (N = {n_one}) on one host thread, same regions (K1-K4; sweeps alone "
+                               f"{1e3 * sw_one:.0f} ms), oracle/ C restatement at -O3 -ffp-contract=off"})
+    else:
+        try:
+            import psutil
+            avail = psutil.virtual_memory().available
+        except Exception:
+            avail = 64 << 30
+        pr0 = capi.Problem.from_buffer_copy(bytes(prob)); pr0.flags &= ~(capi.F_COMPACT_SPLINES | capi.F_CURVES_IN_PLACE | capi.F_MVC_IN_CURVES)
+        per_path = 1.5 * bytes_per_path(pr0, WORKLOADS[inp.workload]["C"], float(n_one), cap)     # host copy + the checker's arrays
+        by_mem = max(1, int(0.25 * avail / per_path))
+        n_sample = int(max(1, min(2 * cores, (budget_s / max(t_one, 1e-3)) * cores, by_mem)))
+        if n_sample > cores:
+            n_sample = (n_sample // cores) * cores
+        wall, sw, n_wp, rows, _ = cpu_batch(n_sample, passes=2)
+        used = min(cores, n_sample)
+        info.update({"value": n_wp / wall, "sweeps_only_value": n_wp / max(sw, 1e-9), "cores": used,
+                     "sample": f"{n_sample} paths of the same workload ({D} distinct, N~{n_one}), OpenMP one path per thread on {used} of {cores} "
+                               f"host threads, same regions (K1-K4), oracle/ C restatement at -O3 -ffp-contract=off"})
     res = kept["res"]
-    err = float(np.max(np.abs(res["t_total"][:m] - rows["t_total"][:m])))
-    mism = int(np.count_nonzero(res["steps_fwd"][:m] != rows["steps_fwd"][:m]))
+    idx = np.arange(n_sample) % D                          # GPU path p of a chunk holds distinct path p % K; D <= K
+    ok = idx < res.shape[0]
+    err = float(np.max(np.abs(res["t_total"][idx[ok]] - rows["t_total"][: n_sample][ok]))) if np.any(ok) else 0.0
+    mism = int(np.count_nonzero((res["steps_fwd"][idx[ok]] != rows["steps_fwd"][: n_sample][ok]) | (res["steps_rev"][idx[ok]] != rows["steps_rev"][: n_sample][ok])))
+    info["paths_compared"] = int(np.count_nonzero(ok))
     return info, err, mism, th0
 
 
@@ -803,12 +838,20 @@ def main():
     prob, batch = kept["prob"], kept["batch"]
     vel_acc_only = not (prob.flags & (capi.F_TRQ_ON | capi.F_CART_VEL_ON | capi.F_CART_ACC_ON))
 
-    if not args.no_sides and batch is not None and vel_acc_only and kept["chunk0"] > 6144 and args.group in (0, 8):
+    will_check = 1 if (not args.no_sides and batch is not None and vel_acc_only and kept["chunk0"] > 6144 and args.group in (0, 8)) else 0
+    if dist_ctx is not None:
+        # the check below contains a collective: every rank must take the same decision (a rank with an empty or smaller share
+        # would otherwise skip the all_reduce the others wait in)
+        flag = torch.tensor([will_check], dtype=torch.int64, device=dist_ctx["dev"])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        will_check = int(flag.item())
+    if will_check:
         # the automatic loop form of the reverse sweep (flat stage / bisection loop) against the nested loops on the same
         # batch: the result rows must be identical; untimed.  EVERY rank checks its own batch (nobody waits in a barrier
         # while rank 0 sweeps), the verdict is the AND over the ranks.  (Up to 6144 paths the reverse sweep runs k_sweep1.)
         ref_rows = batch.results().tobytes()
         launch_default = batch.last_sweep_launch(-1)
+        launch_default_fwd = batch.last_sweep_launch(+1)
         hip.set_sweep_hold(-1, -1)
         batch.sweep(-1); batch.sweep(+1)
         nested_rev, nested_fwd = batch.kernel_ms(3), batch.kernel_ms(4)
@@ -820,10 +863,11 @@ def main():
             same = bool(flag.item())
         out["nested_loop_cross_check"] = {"sweep_rev_ms": nested_rev, "sweep_fwd_ms": nested_fwd, "result_rows_identical": bool(same),
                                           "default_reverse_launch_lanes_ppw_hold": list(launch_default),
-                                          "flat_loop_gate": hip.flat_loop_status(),
-                                          "what": "the same batch once more with the nested stage / bisection loops in both sweeps (the default "
-                                                  "runs the flat loop in the reverse sweep when its gate -- validated toolchain + on-device "
-                                                  "canary -- is open: flat_loop_gate 1); every rank checks its own batch; untimed"}
+                                          "default_forward_launch_lanes_ppw_hold": list(launch_default_fwd),
+                                          "flat_loop_gate": hip.flat_loop_status(), "toolchain": list(hip.library.toolchain()),
+                                          "what": "the same batch once more through the general kernel k_sweep with the nested stage / bisection loops "
+                                                  "in both sweeps (the default runs k_sweep8 -- flat loop, hold 4 reverse / 8 forward -- when its gate, "
+                                                  "validated toolchain + on-device canary, is open: flat_loop_gate 1); every rank checks its own batch; untimed"}
     if rank == 0 and not args.no_sides and batch is not None:
         # SURVEY.md 8f-2 beside the hot path: the output stage of the first paths of the batch on the device
         wcfg = WORKLOADS[workload]["cfg"]
@@ -856,15 +900,23 @@ def main():
         out["resample"] = measure_resampler(hip, workload, CONFIGS[args.config]["knots"], 1024)
 
     # the BASELINE configs as worded, beside the headline (every rank takes part: cfg4 / cfg5 shard their batch over the ranks)
+    worded_host = {}
     if default_run and not args.no_as_worded:
         worded = {}
         for name in ("cfg2", "cfg3", "cfg4", "cfg5"):
             try:
-                w, _ = measure(hip, name, rank, world, AS_WORDED_STEPS, 1, dist_ctx)
+                w, wk = measure(hip, name, rank, world, AS_WORDED_STEPS, 1, dist_ctx, keep=True)
+                if wk is not None and wk.get("batch") is not None:
+                    wk["batch"].close()
+                if rank == 0 and wk is not None and wk.get("chunk0"):
+                    worded_host[name] = {k: wk[k] for k in ("inp", "prob", "cap", "K", "res", "chunk0")}
+                wk = None
                 worded[name] = {k: w.get(k) for k in ("value", "unit", "steps", "warmup", "ms_per_step", "ms_per_step_median", "ms_per_step_min_max",
                                                        "scaling", "data", "config", "kernel_ms", "steps_per_knot", "steps_per_path",
-                                                       "us_per_integration_step", "gathered_rows", "curve_gather", "launch")}
+                                                       "us_per_integration_step", "gathered_rows", "curve_gather", "launch",
+                                                       "paths_with_error_status", "swapped_seeds", "slowest_over_mean_path")}
                 worded[name]["roofline_frac"] = w["roofline"]["frac"]
+                worded[name]["roofline_bound"] = w["roofline"]["bound"]
             except Exception as e:  # the main line must not depend on a side measurement
                 if world > 1:
                     raise          # ... but ranks must not drift apart in the collectives
@@ -885,6 +937,20 @@ def main():
         out["step_count_mismatches"] = mism
         if th0 is not None and "output_stage" in out:
             out["output_stage"]["identical_to_oracle"] = bool(th0.tobytes() == hip_out0.tobytes())
+    # ... and beside every BASELINE configuration as worded (north_star: each number "next to the reference CPU BA timed on the
+    # same box's host cores"): one trajectory on one thread for cfg 2 / 3, one path per thread on all host threads for cfg 4 / 5
+    if rank == 0 and not args.no_cpu_baseline:
+        for name, kh in worded_host.items():
+            try:
+                single = CONFIGS[name]["paths"] == 1
+                info, err, mism, _ = cpu_baseline(kh, max(2.0, 0.5 * args.cpu_seconds), max_distinct=(1 if single else 32), single_path=single)
+                w = out["as_worded"][name]
+                w["cpu_baseline"] = info
+                w["vs_cpu_baseline"] = w["value"] / info["value"]
+                w["traversal_time_err_s"] = err
+                w["step_count_mismatches"] = mism
+            except Exception as e:
+                out["as_worded"][name]["cpu_baseline"] = {"error": f"{type(e).__name__}: {str(e)[-300:]}"}
     if rank == 0:
         # RCCL writes a version banner through C stdio on rank 0: push it out first, so that the JSON line is the last line
         import ctypes
@@ -893,6 +959,11 @@ def main():
         except Exception:
             pass
         sys.stdout.flush()
+        try:     # an untruncated copy for profiles/ (the driver keeps only the tail of long lines)
+            if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+                open(os.path.join(ROOT, "gpurun_out", "bench_line_full.json"), "w").write(json.dumps(out, indent=1))
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
 
 

@@ -220,6 +220,17 @@ int  batotp_hip_upload_coeffs(batotp_batch *batch, int32_t path, int32_t channel
 /* the curve published by the reverse sweep (traj.sMVC / traj.sdot, n = traj.nPts) */
 int  batotp_hip_upload_curve(batotp_batch *batch, int32_t path, const double *s, const double *sdot,
                              int64_t n);
+/* the curve published by the FORWARD sweep (traj.sMVC / traj.sdot after sweep(+1), n = traj.nPts) with its traversal
+ * time traj.tTotalTraj: what the output stage (batotp_hip_output) needs of a path whose sweeps ran elsewhere -- the
+ * step-by-step host API BA::sweep / BA::interpOutputData (reference ba.cpp:979-1195, 1661-1931) moves one Traj at a time
+ * through batches of one path.  Marks both sweeps of the path as done. */
+int  batotp_hip_upload_forward_curve(batotp_batch *batch, int32_t path, const double *s, const double *sdot,
+                                     int64_t n, double t_total);
+/* the integration step _integRes of paths [path0, path0 + n) (default: batotp_problem.integ_res for every path).  The
+ * automatic integration resolution of the reference (ba.cpp:493-556, the class default ba.h:309) derives it from each path;
+ * the sweeps, the pointwise evaluation and the output stage read it per path.  Call before batotp_hip_precompute /
+ * batotp_hip_sweep; integ_res[k] must be positive or NaN (the rule's own result for a robot without Cartesian limits). */
+int  batotp_hip_set_path_integ_res(batotp_batch *batch, int32_t path0, int32_t n, const double *integ_res);
 
 /* ---- the hot path ----------------------------------------------------------------------- */
 /* stage 1 = theta/cart spline coefficients + knot samples (evalSplineFullTraj);
@@ -378,7 +389,17 @@ typedef struct batotp_resample_params {
     double   pmat[9];                /* cable exit points (CSPR3DOF), row-major 3x3            */
     int32_t  input_decim_fact;       /* _inputDecimFact (values < 2: no decimation)            */
     int32_t  smooth_window;          /* _smoothWindow                                          */
+    /* Automatic integration resolution (BATOTP_RS_AUTO_INTEG_RES in `flags`; the class default of the reference,
+     * ba.h:309): both adjust_s passes derive the integration step, the s weights, the scale type and the Cartesian
+     * resolution of the pass from the path itself (ba.cpp:462-470, 493-556) -- PER PATH; what they leave is reported by
+     * batotp_hip_resampled_auto and goes into the batch with batotp_hip_set_path_integ_res.  Inputs of the rule: */
+    double   jnt_vel_max[BATOTP_MAX_JOINTS], jnt_acc_max[BATOTP_MAX_JOINTS]; /* _JntVelMax, _JntAccMax */
+    double   cart_vel_max, cart_acc_max;  /* _CartVelMax, _CartAccMax                           */
+    double   quad_rad_thresh;        /* _quadraticRadThresh (= cartThresh^2, ba.cpp:2048)       */
+    int32_t  degrees;                /* _areJointAnglesDegrees                                  */
+    int32_t  reserved;
 } batotp_resample_params;
+#define BATOTP_RS_AUTO_INTEG_RES (1u<<16)  /* batotp_resample_params.flags: run the automatic integration resolution */
 
 typedef struct batotp_resampled batotp_resampled;
 
@@ -392,6 +413,10 @@ int  batotp_hip_resample(batotp_ctx *ctx, const batotp_resample_params *prm, int
 int  batotp_hip_resampled_destroy(batotp_resampled *r);
 /* knots per path, traj.sres per path, status bits per path (any pointer may be NULL) */
 int  batotp_hip_resampled_info(batotp_resampled *r, int64_t *n_knots, double *sres, uint32_t *status);
+/* automatic integration resolution (BATOTP_RS_AUTO_INTEG_RES): what the two adjust_s passes left per path -- _integRes,
+ * _sWeights (3 per path) and _scaleType (reference ba.cpp:493-556).  Without the flag: the caller's values.  Any pointer
+ * may be NULL. */
+int  batotp_hip_resampled_auto(batotp_resampled *r, double *integ_res, double *s_weights, int32_t *scale_type);
 /* device pointer of the knots, laid out as batotp_hip_upload_knots_device expects them (paths
  * with a non-zero status hold 4 zero knots).  The knots live in a workspace the context keeps
  * between calls (allocating tens of GB per call costs more than the kernels): they stay valid until

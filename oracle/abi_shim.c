@@ -30,6 +30,7 @@ struct batotp_batch {
     batotp_path_result *res;
     batotp_serial_model serial;
     int has_serial;
+    double *integ_res;   /* per path (batotp_hip_set_path_integ_res); default prob.integ_res */
     int kin_done;
     int mvc_stale;       /* BATOTP_F_MVC_IN_CURVES: a sweep has run since the last pointwise evaluation (state rule of the product) */
     int rev_stale, fwd_stale; /* BATOTP_F_MVC_IN_CURVES: a pointwise evaluation has overwritten that curve since its sweep (state rule of the product) */
@@ -119,6 +120,8 @@ int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *prob, int32_t
     b->fwd_s = (double **)calloc((size_t)n_paths, sizeof(void *));
     b->fwd_sd = (double **)calloc((size_t)n_paths, sizeof(void *));
     b->res = (batotp_path_result *)calloc((size_t)n_paths, sizeof(batotp_path_result));
+    b->integ_res = (double *)calloc((size_t)n_paths, sizeof(double));
+    for (p = 0; p < n_paths; p++) b->integ_res[p] = prob->integ_res;
     for (p = 0; p < n_paths; p++) {
         if (n_knots[p] < 2) return BATOTP_ERR_ARG;
         b->path[p] = bo_path_new(prob, n_knots[p]);
@@ -138,8 +141,27 @@ int batotp_hip_batch_destroy(batotp_batch *b)
         free(b->rev_s[p]); free(b->rev_sd[p]); free(b->fwd_s[p]); free(b->fwd_sd[p]);
     }
     free(b->path); free(b->in_y); free(b->in_sres); free(b->trig);
-    free(b->rev_s); free(b->rev_sd); free(b->fwd_s); free(b->fwd_sd); free(b->res);
+    free(b->rev_s); free(b->rev_sd); free(b->fwd_s); free(b->fwd_sd); free(b->res); free(b->integ_res);
     free(b);
+    return BATOTP_OK;
+}
+
+/* the problem as path p sees it: its own integration step (batotp_hip_set_path_integ_res) */
+static batotp_problem path_prob(const batotp_batch *b, int32_t p)
+{
+    batotp_problem q = b->prob;
+    q.integ_res = b->integ_res[p];
+    return q;
+}
+
+int batotp_hip_set_path_integ_res(batotp_batch *b, int32_t path0, int32_t n, const double *integ_res)
+{
+    int32_t k;
+    if (!b || !integ_res || path0 < 0 || n < 0 || path0 + n > b->n_paths) return BATOTP_ERR_ARG;
+    for (k = 0; k < n; k++) {
+        if (!(integ_res[k] > 0) && integ_res[k] == integ_res[k]) return BATOTP_ERR_ARG; /* positive or NaN */
+        b->integ_res[path0 + k] = integ_res[k];
+    }
     return BATOTP_OK;
 }
 
@@ -235,6 +257,18 @@ int batotp_hip_upload_curve(batotp_batch *b, int32_t path, const double *s, cons
     return BATOTP_OK;
 }
 
+int batotp_hip_upload_forward_curve(batotp_batch *b, int32_t path, const double *s, const double *sdot, int64_t n, double t_total)
+{
+    if (!b || path < 0 || path >= b->n_paths || n < 2 || !s || !sdot) return BATOTP_ERR_ARG;
+    set_curve(b->fwd_s, b->fwd_sd, path, s, sdot, n);
+    b->res[path].n_fwd = n;
+    b->res[path].steps_fwd = n - 1;
+    b->res[path].t_total = t_total;
+    b->res[path].status_fwd = 0;
+    b->fwd_stale = 0;
+    return BATOTP_OK;
+}
+
 int batotp_hip_precompute(batotp_batch *b, int32_t stage)
 {
     int32_t p;
@@ -265,7 +299,7 @@ int batotp_hip_pointwise_mvc(batotp_batch *b)
     double t0 = now_ms();
     if (!b || !b->kin_done) return BATOTP_ERR_STATE;
     #pragma omp parallel for schedule(dynamic, 1)
-    for (p = 0; p < b->n_paths; p++) bo_pointwise_mvc(&b->prob, b->path[p]);
+    for (p = 0; p < b->n_paths; p++) { const batotp_problem q = path_prob(b, p); bo_pointwise_mvc(&q, b->path[p]); }
     b->ms[2] = (float)(now_ms() - t0);
     b->mvc_stale = 0;
     if (b->prob.flags & BATOTP_F_MVC_IN_CURVES) { b->rev_stale = 1; b->fwd_stale = 1; }
@@ -296,7 +330,8 @@ int batotp_hip_sweep(batotp_batch *b, int32_t dir)
             r->n_fwd = 0; r->steps_fwd = 0; r->t_total = 0; r->status_fwd = r->status_rev | BATOTP_ST_CAPACITY; r->n_bisect_fail_fwd = 0;
             continue;
         }
-        bo_sweep_ex(&b->prob, b->path[p], dir, b->rev_s[p], b->rev_sd[p], r->n_rev, s, sd, b->cap, &n, &steps, &T, &st, &nf,
+        const batotp_problem q = path_prob(b, p);
+        bo_sweep_ex(&q, b->path[p], dir, b->rev_s[p], b->rev_sd[p], r->n_rev, s, sd, b->cap, &n, &steps, &T, &st, &nf,
                     (b->prob.flags & BATOTP_F_CURVES_IN_PLACE) != 0);
         if (dir == -1) {
             free(b->rev_s[p]); free(b->rev_sd[p]);
@@ -434,6 +469,7 @@ struct batotp_resampled {
     double *sres;
     uint32_t *status;
     double *y; /* concatenated knots, the layout batotp_hip_upload_knots expects */
+    double *au; /* per path: integ_res, s_weights[3], scale_type (automatic integration resolution) */
     float ms;
 };
 
@@ -443,7 +479,7 @@ int batotp_hip_ctx_trim(batotp_ctx *ctx) { return ctx ? BATOTP_OK : BATOTP_ERR_A
 int batotp_hip_resampled_destroy(batotp_resampled *r)
 {
     if (!r) return BATOTP_OK;
-    free(r->n); free(r->off); free(r->sres); free(r->status); free(r->y);
+    free(r->n); free(r->off); free(r->sres); free(r->status); free(r->y); free(r->au);
     free(r);
     return BATOTP_OK;
 }
@@ -468,13 +504,14 @@ int batotp_hip_resample(batotp_ctx *ctx, const batotp_resample_params *prm, int3
     r->off = (int64_t *)calloc((size_t)n_paths, sizeof(int64_t));
     r->sres = (double *)calloc((size_t)n_paths, sizeof(double));
     r->status = (uint32_t *)calloc((size_t)n_paths, sizeof(uint32_t));
+    r->au = (double *)calloc((size_t)n_paths * 5, sizeof(double));
     ys = (double **)calloc((size_t)n_paths, sizeof(double *));
     xoff = (int64_t *)calloc((size_t)n_paths, sizeof(int64_t));
     for (p = 1; p < n_paths; ++p) xoff[p] = xoff[p - 1] + n_in[p - 1] * Cin;
     clock_gettime(CLOCK_MONOTONIC, &t0);
 #pragma omp parallel for schedule(dynamic, 1)
     for (p = 0; p < n_paths; ++p)
-        if (bo_resample(prm, n_in[p], x + xoff[p], sres_in[p], &ys[p], &r->n[p], &r->sres[p], &r->status[p]) != 0) {
+        if (bo_resample_auto(prm, n_in[p], x + xoff[p], sres_in[p], &ys[p], &r->n[p], &r->sres[p], &r->status[p], r->au + 5 * (size_t)p) != 0) {
 #pragma omp atomic write
             bad = 1;
         }
@@ -494,6 +531,18 @@ int batotp_hip_resample(batotp_ctx *ctx, const batotp_resample_params *prm, int3
     }
     free(ys); free(xoff);
     *out = r;
+    return BATOTP_OK;
+}
+
+int batotp_hip_resampled_auto(batotp_resampled *r, double *integ_res, double *s_weights, int32_t *scale_type)
+{
+    int p, k;
+    if (!r) return BATOTP_ERR_ARG;
+    for (p = 0; p < r->n_paths; ++p) {
+        if (integ_res) integ_res[p] = r->au[5 * p];
+        if (s_weights) for (k = 0; k < 3; ++k) s_weights[3 * p + k] = r->au[5 * p + 1 + k];
+        if (scale_type) scale_type[p] = (int32_t)r->au[5 * p + 4];
+    }
     return BATOTP_OK;
 }
 
@@ -561,6 +610,8 @@ int batotp_hip_output(batotp_batch *b, const batotp_output_params *prm, int32_t 
     *out = NULL;
     if (prm->n_joints != b->prob.n_joints || !(prm->out_res > 0) || !(prm->integ_res > 0) || !(prm->out_smooth_fact >= 1))
         return BATOTP_ERR_ARG;
+    for (k = 0; k < n_paths; ++k)
+        if (b->integ_res[path0 + k] != prm->integ_res) return BATOTP_ERR_ARG; /* one call per integration step (batotp_hip_set_path_integ_res) */
     {
         const int cable = prm->path_type == BATOTP_PATH_CART && b->prob.robot_type == BATOTP_ROBOT_CSPR3DOF && prm->n_joints == 3 &&
                           b->prob.n_cart == 3 && (b->prob.flags & BATOTP_F_TRQ_ON) && (b->prob.flags & BATOTP_F_PARALLEL);

@@ -118,6 +118,8 @@ void bo_kat_sdot_lim(const batotp_problem *prob, const bo_path *p, int dir, doub
 typedef batotp_resample_params bo_resample_params;
 int  bo_resample(const bo_resample_params *prm, int64_t n_in, const double *x, double sres_in,
                  double **y_out, int64_t *n_out, double *sres_out, uint32_t *status);
+int  bo_resample_auto(const bo_resample_params *prm, int64_t n_in, const double *x, double sres_in, double **y_out, int64_t *n_out,
+                      double *sres_out, uint32_t *status, double auto_out[5]);
 
 /* Output stage behind the hot path: BA::interpOutputData (ba.cpp:1661-1931) for JOINT paths
  * without kinematic model and without torque constraints.  p: the path as precomputed for the sweep;

@@ -58,6 +58,30 @@ static void rs_rem_close(rs_traj *t, int c0, int cN, double thresh)
     }
 }
 
+/* BA::interpTrajLinear (ba.cpp:2768-2794) for a stage of 2 or 3 points: every row onto 4 evenly spaced nodes by linear
+ * interpolation (findInterpSegs, spline.cpp:56-99; interp1linear, spline.cpp:108-120), the spacing stretched accordingly */
+static void rs_stretch_to_four(rs_traj *t)
+{
+    const int64_t nOld = t->n, nNew = 4;
+    double gOld[3], gNew[4], *y = (double *)calloc((size_t)t->C * (size_t)nNew, sizeof(double));
+    const double cOld = 1.0 / (double)(nOld - 1), cNew = 1.0 / (double)(nNew - 1);
+    for (int64_t k = 0; k < nOld; ++k) gOld[k] = cOld * (double)k;
+    for (int64_t k = 0; k < nNew; ++k) gNew[k] = cNew * (double)k;
+    int64_t cur = 0;
+    for (int64_t i = 0; i < nNew; ++i) {
+        while (!(gNew[i] < gOld[cur + 1] || cur == nOld - 2)) ++cur;
+        const double tau = (gNew[i] - gOld[cur]) / (gOld[cur + 1] - gOld[cur]);
+        for (int c = 0; c < t->C; ++c) {
+            const double a = t->x[c * nOld + cur], b = t->x[c * nOld + cur + 1];
+            y[c * nNew + i] = a + (b - a) * tau;
+        }
+    }
+    free(t->x);
+    t->x = y;
+    t->sres = t->sres * (double)(nOld - 1) / (double)(nNew - 1);
+    t->n = nNew;
+}
+
 /* smooth (util.cpp:263-290): centred moving average, shrinking windows at both ends */
 static void rs_smooth(double *x, int64_t n, int w)
 {
@@ -131,13 +155,55 @@ static void rs_fwdkin(rs_traj *t, int robot_type)
 
 typedef struct rs_scale { double sLast, sResNew, teach, thetaF, cartF, sResi; } rs_scale;
 
+/* what the automatic integration resolution rewrites per path and carries from the first adjust_s pass into the second
+ * (BA::_integRes, _sWeights[1..2], _scaleType are members of the BA object; the Cartesian resolution of a pass is a local) */
+typedef struct rs_auto { int on; double integRes, sw1, sw2; int scaleType; } rs_auto;
+
+static double rs_min(double a, double b) { return (b < a) ? b : a; } /* std::min / std::max of libstdc++ (NaN behaviour included) */
+static double rs_max(double a, double b) { return (a < b) ? b : a; }
+
+/* ba.cpp:493-556 after the arc lengths are known: path-resolution integration step, s weights, scale type, Cartesian resolution */
+static void rs_auto_rule(const bo_resample_params *prm, rs_auto *au, double thetaLast, double cartLast, double minCartPerTheta, double *cartRes)
+{
+    const double kDeg = 180.0 / 3.14159265358979323846; /* _RAD2DEG, config.h:29 */
+    if (cartLast < *cartRes && au->scaleType == 2) { /* no Cartesian motion to speak of: s follows the joints */
+        au->sw1 = au->sw1 + au->sw2;
+        au->sw2 = 0;
+        au->scaleType = 1;
+    }
+    const double weightIn = au->sw1 + au->sw2;
+    double cartRat = 500.0 * cartLast;
+    double thetaRat = thetaLast;
+    if (!prm->degrees) thetaRat *= kDeg;
+    const double lo = 0.004, hi = 0.2, K = 0.0003;
+    double step = K * prm->cart_acc_max / prm->cart_vel_max;
+    for (int j = 0; j < prm->n_joints; ++j) step = rs_max(step, K * prm->jnt_acc_max[j] / prm->jnt_vel_max[j]);
+    step = rs_min(step, hi);
+    const double ratio = cartRat / thetaRat;
+    double byJoints = hi * ratio * ratio;
+    double byWindow = hi * minCartPerTheta * minCartPerTheta;
+    byWindow = rs_max(byWindow, 0.016);
+    byJoints = rs_min(byJoints, byWindow);
+    if (byJoints < step) step = byJoints; /* orientation movement dominates */
+    step = rs_max(step, lo);
+    au->integRes = step;
+    const double rescale = weightIn / (cartRat + thetaRat);
+    cartRat *= rescale;
+    thetaRat *= rescale;
+    if (thetaRat > au->sw1) { au->sw1 = thetaRat; au->sw2 = cartRat; }
+    if (au->sw2 > 0) *cartRes = rs_min(*cartRes, *cartRes * au->sw2 / au->sw1);
+}
+
 /* first half of adjust_s (ba.cpp:430-590): arc lengths, factors, sC.  0 ok / status bit */
-static unsigned rs_arclen(const bo_resample_params *prm, const rs_traj *t, int special, double *sC, rs_scale *sc)
+static unsigned rs_arclen(const bo_resample_params *prm, const rs_traj *t, int special, double *sC, rs_scale *sc, rs_auto *au)
 {
     const int64_t n = t->n;
-    const double cartRes = special ? prm->cart_norm_res : prm->cart_norm_res2;
+    double cartRes = special ? prm->cart_norm_res : prm->cart_norm_res2;
     const double thetaRes = special ? prm->theta_norm_res : prm->theta_norm_res2;
     double *th = (double *)calloc((size_t)n, sizeof(double)), *ca = (double *)calloc((size_t)n, sizeof(double));
+    /* ba.cpp:441-446, 462-470: the smallest Cartesian advance per joint-space advance over windows of 5 degrees */
+    double minCartPerTheta = 1.0 / prm->quad_rad_thresh, window = 5.0, thMark = 0, caMark = 0;
+    if (!prm->degrees) window *= 3.14159265358979323846 / 180.0;
     for (int64_t i = 0; i < n - 1; ++i) {
         double sq = 0;
         for (int j = 0; j < t->nJ; ++j) {
@@ -151,21 +217,30 @@ static unsigned rs_arclen(const bo_resample_params *prm, const rs_traj *t, int s
             sq += d * d;
         }
         ca[i + 1] = ca[i] + sqrt(sq);
+        if (au->on) {
+            const double dTh = th[i + 1] - thMark, dCa = ca[i + 1] - caMark;
+            if (dTh > window) {
+                minCartPerTheta = rs_min(minCartPerTheta, 3.0 * dCa / dTh);
+                thMark = th[i + 1];
+                caMark = ca[i + 1];
+            }
+        }
     }
     unsigned st = 0;
     if (th[n - 1] < thetaRes) st = BATOTP_RS_IDENTICAL; /* ba.cpp:484-488 */
     if (!st) {
         const double sResi = t->sres, last = (double)(n - 1);
         double sLast = 0, sResNew = 0;
-        switch (prm->scale_type) { /* ba.cpp:558-572 */
+        if (au->on) rs_auto_rule(prm, au, th[n - 1], ca[n - 1], minCartPerTheta, &cartRes);
+        switch (au->scaleType) { /* ba.cpp:558-572 */
         case 0: sLast = sResi * last; sResNew = sResi; break;
         case 1: sLast = th[n - 1]; sResNew = thetaRes; break;
         default: sLast = ca[n - 1]; sResNew = cartRes; break;
         }
         double cartF = 0;
-        if (ca[n - 1] >= cartRes) cartF = prm->s_weights[2] * sLast / ca[n - 1];
+        if (ca[n - 1] >= cartRes) cartF = au->sw2 * sLast / ca[n - 1];
         const double teach = prm->s_weights[0] * sLast / (sResi * last);
-        const double thetaF = prm->s_weights[1] * sLast / th[n - 1];
+        const double thetaF = au->sw1 * sLast / th[n - 1];
         for (int64_t i = 0; i < n; ++i) sC[i] = teach * sResi * (double)i + thetaF * th[i] + cartF * ca[i];
         sc->sLast = sLast; sc->sResNew = sResNew; sc->teach = teach; sc->thetaF = thetaF; sc->cartF = cartF; sc->sResi = sResi;
     }
@@ -262,7 +337,8 @@ static unsigned rs_special(const bo_resample_params *prm, rs_traj *t, const doub
     free(out);
     t->n = nNew;
     t->sres = sc->sResNew;
-    return nNew < 4 ? BATOTP_RS_TOO_SHORT : 0;
+    if (nNew < 4) rs_stretch_to_four(t); /* ba.cpp:773-774 */
+    return 0;
 }
 
 /* second half of adjust_s "regularInterp" + evalSplineFullTraj (ba.cpp:601-613, 790-863) */
@@ -301,6 +377,15 @@ static unsigned rs_regular(rs_traj *t, const double *sC, const rs_scale *sc)
 int bo_resample(const bo_resample_params *prm, int64_t n_in, const double *x, double sres_in, double **y_out, int64_t *n_out,
                 double *sres_out, uint32_t *status)
 {
+    double au[5];
+    return bo_resample_auto(prm, n_in, x, sres_in, y_out, n_out, sres_out, status, au);
+}
+
+/* the same, also reporting what the automatic integration resolution left: auto_out = integ_res (NaN-able; 0 when the rule
+ * is off), s_weights[0..2], scale_type */
+int bo_resample_auto(const bo_resample_params *prm, int64_t n_in, const double *x, double sres_in, double **y_out, int64_t *n_out,
+                     double *sres_out, uint32_t *status, double auto_out[5])
+{
     const int joint = prm->path_type == BATOTP_PATH_JOINT && prm->robot_type == BATOTP_ROBOT_GENJNT;
     const int cable = prm->path_type == BATOTP_PATH_CART && prm->robot_type == BATOTP_ROBOT_CSPR3DOF && prm->n_joints == 3;
     /* JOINT path of a robot with forward kinematics (KUKA, RR): SURVEY.md 8 f-3 */
@@ -318,7 +403,8 @@ int bo_resample(const bo_resample_params *prm, int64_t n_in, const double *x, do
     unsigned st = 0;
     if (cable) rs_rem_close(&t, t.nJ, t.nC, prm->cart_thresh); /* ba.cpp:166-175 */
     else rs_rem_close(&t, 0, t.nJ, prm->jnt_thresh);
-    if (t.n < 4) st |= BATOTP_RS_TOO_SHORT;
+    if (t.n < 2) st |= BATOTP_RS_TOO_SHORT; /* "less than one site after remClosePts", ba.cpp:176-181 */
+    else if (t.n < 4) rs_stretch_to_four(&t); /* ba.cpp:182-183 */
     if (!st && both) bo_aa2q_rows(t.x + (size_t)(t.nJ + 3) * t.n, t.n, t.n); /* ba.cpp:186-193 */
     if (!st && (prm->input_decim_fact > 1 || prm->smooth_window > 1)) {
         /* driving rows: joints (JOINT), Cartesian rows (CART), both sets (BOTH), ba.cpp:197-241 */
@@ -327,15 +413,19 @@ int bo_resample(const bo_resample_params *prm, int64_t n_in, const double *x, do
     }
     if (!st && cable) rs_invkin_cspr(&t, prm->pmat);
     if (!st && kin && cartOn) rs_fwdkin(&t, prm->robot_type); /* ba.cpp:247-256; otherwise the Cartesian rows stay as loaded */
+    rs_auto au;
+    au.on = (prm->flags & BATOTP_RS_AUTO_INTEG_RES) != 0;
+    au.integRes = 0; au.sw1 = prm->s_weights[1]; au.sw2 = prm->s_weights[2]; au.scaleType = prm->scale_type;
     for (int pass = 0; pass < 2 && !st; ++pass) {
         double *sC = (double *)malloc(sizeof(double) * (size_t)t.n);
         rs_scale sc;
-        st |= rs_arclen(prm, &t, pass == 0, sC, &sc);
+        st |= rs_arclen(prm, &t, pass == 0, sC, &sc, &au);
         if (!st) st |= pass == 0 ? rs_special(prm, &t, sC, &sc) : rs_regular(&t, sC, &sc);
         free(sC);
         if (!st && cable) rs_invkin_cspr(&t, prm->pmat); /* ba.cpp:630 */
         if (!st && kin) rs_fwdkin(&t, prm->robot_type);   /* ba.cpp:626-628: after either pass, whatever the constraints */
     }
+    auto_out[0] = au.integRes; auto_out[1] = prm->s_weights[0]; auto_out[2] = au.sw1; auto_out[3] = au.sw2; auto_out[4] = (double)au.scaleType;
     *status = st;
     if (st) {
         free(t.x);

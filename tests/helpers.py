@@ -95,7 +95,7 @@ class ResampleCase:
         self.name = name
         d = os.path.join(GOLD, name)
         z = np.load(os.path.join(d, "resample.npz"))
-        self.params = capi.ResampleParams.from_buffer_copy(z["params"].tobytes())
+        self.params = capi.ResampleParams.from_bytes(z["params"].tobytes())
         self.sres_in = float(z["sres_in"])
         nJ, nC = self.params.n_joints, self.params.n_cart
         n = int(z["n_in"])

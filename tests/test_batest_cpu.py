@@ -30,16 +30,14 @@ def _stage(src, dst):
             shutil.copy(os.path.join(src, f), dst / f)
 
 
-@pytest.mark.parametrize("mode", ["device-resample", "host-resample", "host-output"])
-@pytest.mark.parametrize("name", ["synth_cspr_s3", "synth_gen7dof_s1_vel", "synth_ur_s2", "GEN7DOF", "UR5", "RR", "RR_acc", "KUKA-LWR-IV", "KUKA_cartacc"])
-def test_batch_driver_files_equal_reference(tmp_path, oracle_lib, name, mode):
-    """BA::optimizeBatch (the many-path extension) writes, for every copy of the path, the files the
-    reference binary wrote for the single path -- with the resampling done behind the C-ABI
-    (batotp_hip_resample, configurations it covers) and by the host resampler, the output stage behind the C-ABI
-    (batotp_hip_output, configurations it covers) and by the host code"""
+@pytest.mark.parametrize("name", ["synth_cspr_s3", "synth_gen7dof_s1_vel", "synth_ur_s2", "GEN7DOF", "UR5", "RR", "RR_acc", "KUKA-LWR-IV", "KUKA_cartacc",
+                                  "CSPR3DOF", "CSPR3DOF_svd", "synth_gen7dof_s10_decim", "synth_cspr_s9_dup"])
+def test_batch_driver_files_equal_reference(tmp_path, oracle_lib, name):
+    """BA::optimizeBatch (the many-path extension) writes, for every copy of the path, the files the reference binary wrote for
+    the single path -- resampling (batotp_hip_resample) and output stage (batotp_hip_output) behind the C-ABI"""
     src = os.path.join(helpers.GOLD, name)
     _stage(src, tmp_path)
-    cmd = [os.path.join(helpers.BUILD, "batest_batch_oracle"), "config.dat", "3"] + (["--" + mode] if mode.startswith("host-") else [])
+    cmd = [os.path.join(helpers.BUILD, "batest_batch_oracle"), "config.dat", "3"]
     r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
     for d in ("out_first", "out_last"):
@@ -138,3 +136,36 @@ def test_batch_driver_over_several_devices(tmp_path, oracle_lib, name, mode):
     for d in ("out_first", "out_last"):
         assert filecmp.cmp(tmp_path / d / "s-sdot.dat", os.path.join(src, "ref_s-sdot.dat"), shallow=False)
         assert filecmp.cmp(tmp_path / d / "traj_out.dat", os.path.join(src, "ref_traj_out.dat"), shallow=False)
+
+
+AUTORES = sorted(d for d in os.listdir(helpers.GOLD) if os.path.exists(os.path.join(helpers.GOLD, d, "autores.npz")))
+
+
+@pytest.mark.parametrize("name", AUTORES)
+def test_default_ba_with_automatic_integration_resolution(tmp_path, oracle_lib, name):
+    """A BA object with _isAutoIntegRes left at the class default (reference ba.h:309; ba.cpp:493-556): the step-by-step API
+    (interpInputData -> sweep x2 -> interpOutputData, one path) and optimizeBatch (three copies as one batch, every path with the
+    integration step the rule derives from it) write the same files, and the step is the one of tests/golden/<case>/autores.npz"""
+    import re
+    import numpy as np
+    src = os.path.join(helpers.GOLD, name)
+    want = float(np.load(os.path.join(src, "autores.npz"))["integ_res"])
+    one, many = tmp_path / "one", tmp_path / "many"
+    one.mkdir(); many.mkdir()
+    _stage(src, one); _stage(src, many)
+    r1 = subprocess.run([os.path.join(helpers.BUILD, "batest_oracle"), "config.dat", "--auto-integ-res"], cwd=one, capture_output=True, text=True)
+    m = re.findall(r"Final integ\. res is ([-0-9.naif]+) s", r1.stdout)
+    assert m, r1.stdout[-2000:]
+    if want != want:
+        # a robot without Cartesian limits: the rule divides 0 by 0 and the reference would integrate with a NaN step
+        assert "nan" in m[-1] and r1.returncode != 0
+        rb = subprocess.run([os.path.join(helpers.BUILD, "batest_batch_oracle"), "config.dat", "3", "--auto-integ-res"], cwd=many, capture_output=True, text=True)
+        assert rb.returncode != 0 and "3 failed" in rb.stdout
+        return
+    assert r1.returncode == 0, r1.stdout[-3000:]
+    assert abs(float(m[-1]) - want) < 5.1e-7
+    rb = subprocess.run([os.path.join(helpers.BUILD, "batest_batch_oracle"), "config.dat", "3", "--auto-integ-res"], cwd=many, capture_output=True, text=True)
+    assert rb.returncode == 0, rb.stdout[-3000:]
+    for d in ("out_first", "out_last"):
+        assert filecmp.cmp(many / d / "s-sdot.dat", one / "s-sdot.dat", shallow=False)
+        assert filecmp.cmp(many / d / "traj_out.dat", one / "traj_out.dat", shallow=False)

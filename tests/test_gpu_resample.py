@@ -253,3 +253,48 @@ def test_knots_of_an_older_resample_call_are_refused(hip_lib):
         second.knots(0)
     third = capi.Resampled(ctx, c.params, [c.x], [c.sres_in])   # the workspaces are allocated again on demand
     assert_bit_equal(third.knots(0), c.y, "after trim")
+
+
+import os
+from test_oracle_resample import AUTORES_CASES, autores_params
+
+
+@pytest.mark.parametrize("name", AUTORES_CASES)
+def test_device_resampler_automatic_integration_resolution(hip_ctx, oracle_ctx, name):
+    """the automatic integration resolution (reference ba.cpp:462-470, 493-556; class default ba.h:309) in the device
+    resampler, per path: a ragged batch (the case's path, its first half, the path reversed) against the oracle, and the
+    case's own path against tests/golden/<case>/autores.npz (knots, integration step, s weights, scale type)"""
+    c = ResampleCase(name)
+    z = np.load(os.path.join(helpers.GOLD, name, "autores.npz"))
+    p = autores_params(c, Case(name).problem)
+    n = c.x.shape[1]
+    xs = [c.x, c.x[:, :max(8, n // 2)].copy(), c.x[:, ::-1].copy()]
+    sr = [c.sres_in] * len(xs)
+    h = capi.Resampled(hip_ctx, p, xs, sr)
+    o = capi.Resampled(oracle_ctx, p, xs, sr)
+    _same(h, o, f"{name}: automatic integration resolution")
+    hi, hw, hs = h.auto()
+    oi, ow, os_ = o.auto()
+    assert hi.tobytes() == oi.tobytes() and hw.tobytes() == ow.tobytes() and np.array_equal(hs, os_), (hi, oi, hw, ow, hs, os_)
+    assert np.array_equal(np.array([hi[0]]).view(np.uint64), np.array([float(z["integ_res"])]).view(np.uint64))
+    assert hw[0].tobytes() == np.asarray(z["s_weights"], dtype=np.float64).tobytes() and int(hs[0]) == int(z["scale_type"])
+    assert_bit_equal(h.knots(0), np.ascontiguousarray(z["y"]), f"{name}: knots under the automatic integration resolution")
+    h.close(); o.close()
+
+
+def test_short_paths_are_stretched_to_four_points(hip_ctx, oracle_ctx):
+    """BA::interpTrajLinear (reference ba.cpp:182-183, 773-774, 2768-2794): a path that remClosePts leaves with two or three points,
+    and a path so short that interpSpecial emits fewer than four, are stretched onto four points and go on"""
+    c = ResampleCase("synth_gen7dof_s0")
+    a = np.repeat(c.x[:, :3], 4, axis=1)                       # 12 taught points, 3 distinct
+    b = np.repeat(c.x[:, :2], 5, axis=1)                       # 10 taught points, 2 distinct
+    tiny = c.x[:, :6].copy()
+    tiny[:, 1:] = tiny[:, :1] + (tiny[:, 1:] - tiny[:, :1]) * 0.02   # six points within a fraction of one resolution step
+    one = np.repeat(c.x[:, :1], 8, axis=1)                     # a single distinct point: nothing to optimise
+    xs, sr = [a, b, tiny, one, c.x], [c.sres_in] * 5
+    h = capi.Resampled(hip_ctx, c.params, xs, sr)
+    o = capi.Resampled(oracle_ctx, c.params, xs, sr)
+    _same(h, o, "short paths")
+    assert int(h.status[3]) != 0 and int(h.status[4]) == 0
+    assert_bit_equal(h.knots(4), c.y, "the full path beside them is untouched")
+    h.close(); o.close()

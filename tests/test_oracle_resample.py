@@ -1,6 +1,8 @@
 """Pins the oracle's restatement of the path resampling to the golden knots: the knots
 it produces from the taught points must be byte-identical to knots.npz -- the knots behind the
 s-sdot / trajectory outputs that match the reference binary byte for byte."""
+import os
+
 import numpy as np
 import pytest
 
@@ -58,3 +60,38 @@ def test_unsupported_kind_is_refused(octx):
     p.robot_type = capi.ROBOT_UR
     with pytest.raises(capi.BatotpError):
         capi.Resampled(octx, p, [c.x], [c.sres_in])
+
+
+AUTORES_CASES = sorted(d for d in os.listdir(helpers.GOLD) if os.path.exists(os.path.join(helpers.GOLD, d, "autores.npz")))
+
+
+def autores_params(c, problem):
+    """the resampling parameters of a golden case with the automatic integration resolution switched on (the reference's
+    class default, ba.h:309) and the inputs its rule reads (ba.cpp:493-556)"""
+    p = capi.ResampleParams.from_buffer_copy(bytes(c.params))
+    p.flags |= capi.RS_AUTO_INTEG_RES
+    for j in range(p.n_joints):
+        p.jnt_vel_max[j], p.jnt_acc_max[j] = problem.jnt_vel_max[j], problem.jnt_acc_max[j]
+    p.cart_vel_max, p.cart_acc_max, p.quad_rad_thresh = problem.cart_vel_max, problem.cart_acc_max, problem.quad_rad_thresh
+    cfg = open(os.path.join(helpers.GOLD, c.name, "config.dat")).read().splitlines()
+    p.degrees = int([l for l in cfg if "areJntAnglesDegrees" in l or "areJointAnglesDegrees" in l][0].split()[0])
+    return p
+
+
+@pytest.mark.parametrize("name", AUTORES_CASES)
+def test_automatic_integration_resolution(octx, name):
+    """reference ba.cpp:462-470, 493-556 (class default ba.h:309; batest switches it off, so the reference binary cannot pin it):
+    knots, integration step, s weights and scale type against tests/golden/<case>/autores.npz, written once by the round-3
+    statement-level host restatement of adjust_s (oracle/make_autores_fixtures.py)"""
+    c = ResampleCase(name)
+    z = np.load(os.path.join(helpers.GOLD, name, "autores.npz"))
+    p = autores_params(c, helpers.Case(name).problem)
+    r = capi.Resampled(octx, p, [c.x], [c.sres_in])
+    assert int(r.status[0]) == 0
+    integ, sw, st = r.auto()
+    assert np.array_equal(np.array([integ[0]]).view(np.uint64), np.array([float(z["integ_res"])]).view(np.uint64)), (integ[0], float(z["integ_res"]))
+    assert sw[0].tobytes() == np.asarray(z["s_weights"], dtype=np.float64).tobytes(), (sw[0], z["s_weights"])
+    assert int(st[0]) == int(z["scale_type"])
+    assert float(r.sres[0]) == float(z["sres"]) and int(r.n_knots[0]) == z["y"].shape[1]
+    assert r.knots(0).tobytes() == np.ascontiguousarray(z["y"]).tobytes()
+    r.close()

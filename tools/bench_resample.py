@@ -67,7 +67,7 @@ def main():
     pmat = None
     if args.workload == "cspr":
         z = np.load(os.path.join(ROOT, "tests", "golden", "synth_cspr_s3", "resample.npz"))
-        pmat = list(capi.ResampleParams.from_buffer_copy(z["params"].tobytes()).pmat)
+        pmat = list(capi.ResampleParams.from_bytes(z["params"].tobytes()).pmat)
     prm = params(args.workload, pmat)
     K = min(args.distinct, args.paths)
     base = [taught(args.workload, 2000 + k, args.knots) for k in range(K)]
