@@ -66,6 +66,10 @@ __global__ void __launch_bounds__(ST_BLOCK) k_spline_tile(TileArgs a)
    __shared__ double S[ST_CH][ST_T + 3];     // second derivatives sol[t0 .. t1]
    __shared__ double warmF[ST_CH][(ST_T + ST_K) / ST_L + 3], warmB[ST_CH][ST_T / ST_L + 3];
    __shared__ int bad;
+   // ~69 KB of static LDS: this translation unit is for gfx950 (160 KB of LDS per CU: two tiles per CU) and does not fit an
+   // architecture with 64 KB per workgroup
+   static_assert(sizeof(double) * (2 * ST_CH * ST_SPANP + ST_CH * (ST_T + 3) + ST_CH * ((ST_T + ST_K) / ST_L + 3) + ST_CH * (ST_T / ST_L + 3)) <= 96 * 1024,
+                 "k_spline_tile: LDS budget of gfx950");
 
    // which tile
    int lo = 0, hi = a.B - 1;
@@ -251,6 +255,9 @@ __global__ void __launch_bounds__(ST_BLOCK) k_spline_tile(TileArgs a)
       for (int x = tid; x < cnt; x += ST_BLOCK)
       {
          const int kk = x / a.C, c = x - kk * a.C;
+         // In place: a neighbouring block of this launch may still be LOADING the .x of these knots as its halo while this
+         // store runs.  Invariant that makes that harmless: the stored .x is bit-identical to the value loaded (Y is never
+         // modified), so a reader sees the same 8 bytes before, during and after the store; .y is only read by later kernels.
          if (c >= e0 && c < e0 + nc) g[(int64_t)(t0 + kk) * a.C + c] = make_double2(Y[c - e0][t0 + kk - k0], S[c - e0][kk]);
       }
    }

@@ -587,6 +587,10 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
             const int sv = __shfl((int)useT, src);
             if (j >= 4) { au = su; al = sl; mj = sm; ej = se; valid = sv != 0; }
          }
+         // a line with a non-finite coefficient (theta' = 0 with a zero threshold gives rcp(0) here) must stop the fast-forward:
+         // the min / max reductions below would silently drop its NaN
+         const bool lineFinite = !valid || ((au == au) & (mj == mj) & (ej == ej) & (fabs(au) < kInf) & (fabs(mj) < kInf) & (ej < kInf));
+         const bool allFinite = __ballot(!lineFinite) == 0;
          au = valid ? au : kInf;
          al = valid ? al : -kInf;
          mj = valid ? mj : 0.0;
@@ -626,7 +630,9 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
          const double xThr = forceFirst ? xForce : xstar;
          const double bandThr = forceFirst ? -1.0 : band;
          // magnitudes far inside the normal range (no overflow, no gradual underflow in the check or here); NaNs fail every test
-         const bool sane = (R < 0x1p30) & (sMin2 > 1e-100) & (eMax < 1e100) & (xTop > 1e-100) & (xTop < 1e100) & (xstar > 1e-100) &
+         // (every quantity of the certificate must be a finite number: a NaN operand can be dropped by the min / max reductions that
+         //  formed eMax / xstar, so the comparisons below are made on values that are tested for finiteness explicitly)
+         const bool sane = allFinite & (eMax == eMax) & (xstar == xstar) & (R == R) & (R < 0x1p30) & (sMin2 > 1e-100) & (eMax < 1e100) & (xTop > 1e-100) & (xTop < 1e100) & (xstar > 1e-100) &
                            (forceFirst | (xForce > xstar + band));
          BK_TICK(tq1);
          BK_ACC(cyP1, tp2, tq1);
@@ -738,13 +744,18 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
          double eq = useA ? aa + fabs(ma) * xTop : 0.0;
          const double eT = (fabs(tmaxj) + fabs(tminj) + 2.0 * fabs(a4pt) + fabs(a3pt) * cTop + fabs(a2pt) * xTop) * fabs(r1);
          eq = useT ? dmax(eq, eT) : eq;
+         // a bound with a non-finite coefficient (a divisor of exactly 0 under a zero threshold) must stop the fast-forward: the
+         // max reduction below would drop its NaN
+         const bool finA = !useA || ((aa == aa) & (ma == ma) & (aa < kInf) & (fabs(ma) < kInf));
+         const bool finT = !useT || ((tu == tu) & (tl == tl) & (tb == tb) & (tm == tm) & (fabs(tu) < kInf) & (fabs(tl) < kInf) & (fabs(tb) < kInf) & (fabs(tm) < kInf));
+         const bool allFinite = __ballot(!(finA & finT & (eq == eq))) == 0;
          const double eMax = grp_max<8>(eq);
          const double bandG = eMax * 0x1p-44;
          const bool standing = accOn && jv && !useA && !(fabs(thD2) < thrA);
          double xForce = kInf;
          if (__ballot(standing)) xForce = grp_min<8>(standing ? amaxj / fabs(thD2) : kInf);
          // magnitudes far inside the normal range; NaNs fail every test
-         const bool sane = (eMax > 1e-100) & (eMax < 1e100) & (cTop > 1e-100) & (cTop < 1e50);
+         const bool sane = allFinite & (eMax == eMax) & (cTop == cTop) & (eMax > 1e-100) & (eMax < 1e100) & (cTop > 1e-100) & (cTop < 1e50);
          // d(c) > 0 <=> violated, |d(c)| > bandG <=> certain: -g(c) of the approximate check, +inf where a standing joint forbids c
          auto dOf = [&](double c) __attribute__((always_inline)) -> double {
             const double x = c * c;
