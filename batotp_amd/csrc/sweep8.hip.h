@@ -29,6 +29,12 @@ constexpr int S8_BLOCK = 256;
 #ifndef S8_TAB_FAST
 #define S8_TAB_FAST 1   // tableau combination without selects while every stage value is finite
 #endif
+#ifndef S8_LDS_STAGES
+#define S8_LDS_STAGES 0 // 1: the stage values (v_k, w_k), k = 1..5, of a path live in LDS instead of registers + 20 selects per stage
+#endif
+#ifndef S8_WALK_PRECHECK
+#define S8_WALK_PRECHECK 1 // skip the knot-cursor walk when every path is still inside its segment
+#endif
 #ifndef S8_KINDS
 #define S8_KINDS 0      // 1: bisection update in blocks by situation -- measured 5 % SLOWER than one block of selects (the guards of four blocks cost more than the selects they save: profiles/r04_b_*)
 #endif
@@ -94,6 +100,9 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
    __shared__ double lim[6][8];
    __shared__ double rk[7][6];                 // rk[st][k] = weight of stage value k in stage st (column st-1 of ba.cpp:58-63), 0 for k >= st
    __shared__ double2 pts[S8_BLOCK / G][4];    // curve points of a path waiting for their 64-byte store
+#if S8_LDS_STAGES
+   __shared__ double2 vw[S8_BLOCK / G][8];     // (v_k, w_k) of stage k = 1..5 of every path; slot 0 and 7: writes that must not land
+#endif
    if (threadIdx.x < 42)
    {
       const double tab[42] = {0, 0, 0, 0, 0, 0,
@@ -118,6 +127,10 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
    const int n = (int)pi.n;
    const int64_t cap = a.cap;
    double2 *mypts = pts[threadIdx.x / G];
+#if S8_LDS_STAGES
+   double2 *myvw = vw[threadIdx.x / G];
+   for (int k = j; k < 8; k += G) myvw[k] = make_double2(0.0, 0.0);
+#endif
 
    // bootstrap (ba.cpp:1021-1041) through the general kernel's device functions; the loop below carries its own state
    Pt<G, FEAT, true> t;
@@ -262,12 +275,23 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                phase = PH_FIRST;
                const double vN = sdotCur;
                wild |= !(fabs(vN) < kInf) | !(fabs(wN) < kInf);
+#if S8_LDS_STAGES
+               // slot st keeps (vN, wN); a failed bisection leaves sddotArr[st] as it was (the w half goes to the spare slot 7);
+               // stage 6 is kept in registers by the step end below (its writes go to the spare slot 7 as well)
+               {
+                  double *slotV = reinterpret_cast<double *>(myvw + (st < 6 ? st : 7));
+                  double *slotW = reinterpret_cast<double *>(myvw + ((st < 6 && !stageFailed) ? st : 7)) + 1;
+                  *slotV = vN;
+                  *slotW = wN;
+               }
+#else
                const int stW = stageFailed ? 0 : st; // a failed bisection leaves sddotArr[st] as it was
                v1 = (st == 1) ? vN : v1; w1 = (stW == 1) ? wN : w1;
                v2 = (st == 2) ? vN : v2; w2 = (stW == 2) ? wN : w2;
                v3 = (st == 3) ? vN : v3; w3 = (stW == 3) ? wN : w3;
                v4 = (st == 4) ? vN : v4; w4 = (stW == 4) ? wN : w4;
                v5 = (st == 5) ? vN : v5; w5 = (stW == 5) ? wN : w5;
+#endif
                const bool stepEnd = (st == 6);
                st = stepEnd ? st : st + 1;
                if (__ballot(stepEnd) != 0)
@@ -325,6 +349,12 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                // ---- tableau combination, ba.cpp:1073-1085 ---------------------------------------------
                const double *bc = rk[st];
                double sdotT = 0, sddotT = 0;
+#if S8_LDS_STAGES
+               {
+                  const double2 q1 = myvw[1], q2 = myvw[2], q3 = myvw[3], q4 = myvw[4], q5 = myvw[5];
+                  v1 = q1.x; w1 = q1.y; v2 = q2.x; w2 = q2.y; v3 = q3.x; w3 = q3.y; v4 = q4.x; w4 = q4.y; v5 = q5.x; w5 = q5.y;
+               }
+#endif
                // Stage st adds the terms k < st only.  The weights of the others are +0 in the table, and adding their products
                // changes nothing as long as every stage value is finite (x + (+-0) = x: a partial sum starts as 0 + b0 v0 and
                // is therefore never -0); a path that ever kept a non-finite stage value (0 * inf = NaN) takes the literal form.
@@ -392,7 +422,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                lowFact = .01; sdotGood = 0; nGood = 0; sdotL = 0; sdotH = vN; sdotTry = vN; nIter = 0; stageFailed = false;
 
                // ---- evalSplinePartials, ba.cpp:1341-1413: updateCurSeg (ba.cpp:1617-1652) on the sites sres*k ----
-               if (__ballot(!((sCur >= sSeg) & (sCur <= sNext))) != 0)
+               if (!S8_WALK_PRECHECK || __ballot(!((sCur >= sSeg) & (sCur <= sNext))) != 0)
                {
                   for (;;)
                   {
