@@ -30,7 +30,7 @@ constexpr int S8_BLOCK = 256;
 #define S8_TAB_FAST 1   // tableau combination without selects while every stage value is finite
 #endif
 #ifndef S8_LDS_STAGES
-#define S8_LDS_STAGES 0 // 1: the stage values (v_k, w_k), k = 1..5, of a path live in LDS instead of registers + 20 selects per stage
+#define S8_LDS_STAGES 1 // the stage values (v_k, w_k), k = 1..5, of a path live in LDS instead of registers + 20 selects per stage
 #endif
 #ifndef S8_WALK_PRECHECK
 #define S8_WALK_PRECHECK 1 // skip the knot-cursor walk when every path is still inside its segment
