@@ -127,6 +127,39 @@ __device__ __forceinline__ void grp_min_max(double &h, double &l)
    }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Division by a value that stays the same for several quotients (theta' of the evaluation point divides the two bounds of
+// every constraint check of a stage and the velocity limit of the next stage).  hipcc lowers an fp64 `a / b` to
+//    ds = v_div_scale(b, b, a); ns = v_div_scale(a, b, a); r = v_rcp(ds); two Newton steps on r (four FMAs);
+//    q = ns * r; rem = fma(-ds, q, ns); v_div_fmas(rem, r, q); v_div_fixup(., b, a)
+// where both v_div_scale return their operand unchanged, v_div_fmas is a plain FMA and v_div_fixup returns its first
+// operand unless an operand is zero / infinite / NaN, the quotient leaves the normal range or the exponents are extreme
+// (ISA: scaling when the numerator's biased exponent is <= 53, the denominator or its reciprocal is denormal, the
+// exponents differ by >= 768, or the quotient is denormal).  For |a|, |b| in [2^-350, 2^350] none of that applies, the
+// refined reciprocal depends on b alone, and a quotient is the last three operations of the SAME sequence: the same bits
+// as `a / b` by construction (checked on the device against `/` for 2^22 operand pairs incl. the edges of the window:
+// batotp_hip_fp64_kat, tests/test_gpu_parity.py::test_shared_reciprocal_division...).  Outside the window the callers use `/`.
+// Used by k_sweep8 (sweep8.hip.h) and k_sweep1 (sweep1.hip.h) for the quotients by theta' (ba.cpp:1223, 1526-1531) and by a1 (ba.cpp:1495-1509).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr double SDIV_LO = 0x1p-350, SDIV_HI = 0x1p350;
+__device__ __forceinline__ bool sdiv_window(double x) { return (fabs(x) >= SDIV_LO) & (fabs(x) <= SDIV_HI); }
+__device__ __forceinline__ double sdiv_rcp(double den)
+{
+   double r = __builtin_amdgcn_rcp(den);
+   double e = __builtin_fma(-den, r, 1.0);
+   r = __builtin_fma(r, e, r);
+   e = __builtin_fma(-den, r, 1.0);
+   r = __builtin_fma(r, e, r);
+   return r;
+}
+__device__ __forceinline__ double sdiv_by(double num, double den, double r)
+{
+   const double q = num * r;
+   const double rem = __builtin_fma(-den, q, num);
+   return __builtin_fma(rem, r, q);
+}
+
+
 template <int G>
 __device__ __forceinline__ int grp_or(int v)
 {

@@ -35,6 +35,14 @@ constexpr int S8_BLOCK = 256;
 #ifndef S8_WALK_PRECHECK
 #define S8_WALK_PRECHECK 1 // skip the knot-cursor walk when every path is still inside its segment
 #endif
+#ifndef S8_PREFETCH
+#define S8_PREFETCH 1   // the knot the cursor will need next is loaded one segment change ahead (compact pairs).  (The same for the next
+                        // point of the reverse curve in the forward sweep measured 5 % slower -- 440 against 419 ms -- and is not done.)
+#endif
+#ifndef S8_REORDER
+#define S8_REORDER 0    // 1: the knot-cursor walk runs before the velocity limit, so that the division for tau and the velocity limit's
+                        // quotient + reduction share one basic block (two independent dependent chains for the scheduler to interleave)
+#endif
 #ifndef S8_KINDS
 #define S8_KINDS 0      // 1: bisection update in blocks by situation -- measured 5 % SLOWER than one block of selects (the guards of four blocks cost more than the selects they save: profiles/r04_b_*)
 #endif
@@ -49,36 +57,13 @@ __device__ __forceinline__ bool s8_ratio_lt_fast(double num, double den, double 
    return lt;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Division by a value that stays the same for several quotients (theta' of the evaluation point divides the two bounds of
-// every constraint check of a stage and the velocity limit of the next stage).  hipcc lowers an fp64 `a / b` to
-//    ds = v_div_scale(b, b, a); ns = v_div_scale(a, b, a); r = v_rcp(ds); two Newton steps on r (four FMAs);
-//    q = ns * r; rem = fma(-ds, q, ns); v_div_fmas(rem, r, q); v_div_fixup(., b, a)
-// where both v_div_scale return their operand unchanged, v_div_fmas is a plain FMA and v_div_fixup returns its first
-// operand unless an operand is zero / infinite / NaN, the quotient leaves the normal range or the exponents are extreme
-// (ISA: scaling when the numerator's biased exponent is <= 53, the denominator or its reciprocal is denormal, the
-// exponents differ by >= 768, or the quotient is denormal).  For |a|, |b| in [2^-350, 2^350] none of that applies, the
-// refined reciprocal depends on b alone, and a quotient is the last three operations of the SAME sequence: the same bits
-// as `a / b` by construction (checked on the device against `/` for 2^22 operand pairs incl. the edges of the window:
-// batotp_hip_fp64_kat, tests/test_gpu_parity.py::test_shared_reciprocal_division...).  Outside the window the callers use `/`.
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr double S8_DIV_LO = 0x1p-350, S8_DIV_HI = 0x1p350;
-__device__ __forceinline__ bool s8_div_window(double x) { return (fabs(x) >= S8_DIV_LO) & (fabs(x) <= S8_DIV_HI); }
-__device__ __forceinline__ double s8_rcp_refined(double den)
-{
-   double r = __builtin_amdgcn_rcp(den);
-   double e = __builtin_fma(-den, r, 1.0);
-   r = __builtin_fma(r, e, r);
-   e = __builtin_fma(-den, r, 1.0);
-   r = __builtin_fma(r, e, r);
-   return r;
-}
-__device__ __forceinline__ double s8_div_by(double num, double den, double r)
-{
-   const double q = num * r;
-   const double rem = __builtin_fma(-den, q, num);
-   return __builtin_fma(rem, r, q);
-}
+// (the shared refined reciprocal of theta' -- sdiv_window / sdiv_rcp / sdiv_by -- lives in device_math.h.  In k_sweep1, the
+// one-path-per-wavefront kernel, the same technique measured 3-10 % SLOWER -- cfg 4: 961 against 874 ms -- and is not used there:
+// its window tests and ballot guards cost a lone wavefront more than the shorter quotients save; profiles/r04_b_*)
+constexpr double S8_DIV_LO = SDIV_LO, S8_DIV_HI = SDIV_HI;
+__device__ __forceinline__ bool s8_div_window(double x) { return sdiv_window(x); }
+__device__ __forceinline__ double s8_rcp_refined(double den) { return sdiv_rcp(den); }
+__device__ __forceinline__ double s8_div_by(double num, double den, double r) { return sdiv_by(num, den, r); }
 
 // known-answer test of the shared-reciprocal division against `/` (batotp_hip_fp64_kat)
 __global__ void k_kat_sdiv(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ q, int *__restrict__ inWindow)
@@ -212,6 +197,13 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
    const double *__restrict__ coef = t.coef;
    const int rowStride = t.C * 4;
    int seg = t.segC, rowSeg = t.rowSeg;
+   // S8_PREFETCH (compact pairs): the knot on the side the cursor moves to (reverse: knot rowSeg, forward: knot rowSeg + 1)
+   // and the one beyond it, loaded when the cursor entered the current segment -- a segment change one step further then
+   // forms its coefficients from registers and issues the load for the change after it
+   double2 kEdge[PER], kPre[PER];
+   int preIdx = -(1 << 20); // knot index kPre holds (and kEdge holds preIdx - DIR): none yet
+#pragma unroll
+   for (int q = 0; q < PER; ++q) { kEdge[q] = make_double2(0, 0); kPre[q] = make_double2(0, 0); }
    double sSeg = sres * (double)seg, sNext = sres * (double)(seg + 1); // sites of the cursor's segment
    // reverse-curve cursor (forward sweep): segment and its two points
    int segM = 0;
@@ -381,6 +373,64 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                vN = dmax(vN, floorV); // ba.cpp:1085
                sCur = sN;
 
+#if S8_REORDER
+               // ---- evalSplinePartials, ba.cpp:1341-1413: updateCurSeg (ba.cpp:1617-1652) on the sites sres*k ----
+               if (!S8_WALK_PRECHECK || __ballot(!((sCur >= sSeg) & (sCur <= sNext))) != 0)
+               {
+                  for (;;)
+                  {
+                     sSeg = sres * (double)seg;
+                     sNext = sres * (double)(seg + 1);
+                     const bool inside = (sCur >= sSeg) & (sCur <= sNext);
+                     const bool up = !inside & (sCur > sSeg), down = !inside & (sCur < sSeg);
+                     status |= (!inside & !up & !down) ? (unsigned)BATOTP_ST_NONFINITE : 0u;
+                     const bool mvUp = up & (seg < lastSeg), mvDn = down & (seg > 0);
+                     seg = mvUp ? seg + 1 : (mvDn ? seg - 1 : seg);
+                     if (__ballot(mvUp | mvDn) == 0) break;
+                  }
+               }
+               // ---- sdotLim, ba.cpp:1204-1236 (theta' of the PREVIOUS evaluation point) -----------------
+               if (DIR == 1)
+               {
+                  // evalsdot, ba.cpp:1590-1607
+#include "sweep8_mvcwalk.inc"
+                  const double tauM = (sCur - mS0) / (mS1 - mS0);
+                  const double sdotMVC = dmax(mD0 + tauM * (mD1 - mD0), sdotMin);
+                  vN = (vN > sdotMVC) ? sdotMVC : vN;
+               }
+               vN = dmin(vN, sdotCap);
+               vN = dmax(vN, sdotMin);
+               {
+                  double lim1 = kInf;
+                  bool slowDiv = false; // a quotient outside the window of the shared reciprocal
+#pragma unroll
+                  for (int q = 0; q < PER; ++q) slowDiv |= jOn[q] && fabs(thD[q]) > thrV && !(rOk[q] & s8_div_window(vmax[q]));
+                  if (__ballot(slowDiv) != 0)
+                  {
+#pragma unroll
+                     for (int q = 0; q < PER; ++q)
+                     {
+                        const bool on = jOn[q] && fabs(thD[q]) > thrV;
+                        const bool fast = rOk[q] & s8_div_window(vmax[q]);
+                        if (on && !fast) lim1 = dmin(lim1, fabs(vmax[q] / thD[q]));
+                     }
+                  }
+#pragma unroll
+                  for (int q = 0; q < PER; ++q)
+                  {
+                     const bool on = jOn[q] && fabs(thD[q]) > thrV;
+                     const bool fast = rOk[q] & s8_div_window(vmax[q]);
+                     const double qv = fabs(s8_div_by(vmax[q], thD[q], rD[q]));
+                     lim1 = (on & fast) ? dmin(lim1, qv) : lim1;
+                  }
+                  lim1 = grp_min<G>(lim1);
+                  vN = dmin(vN, lim1);
+               }
+               sdotCur = vN;
+               // applyAccelConstraintsBisectionPt, ba.cpp:1250-1265
+               lowFact = .01; sdotGood = 0; nGood = 0; sdotL = 0; sdotH = vN; sdotTry = vN; nIter = 0; stageFailed = false;
+
+#else
                // ---- sdotLim, ba.cpp:1204-1236 (theta' of the PREVIOUS evaluation point) -----------------
                if (DIR == 1)
                {
@@ -436,6 +486,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                      if (__ballot(mvUp | mvDn) == 0) break;
                   }
                }
+#endif
                const double tau = (sCur - sSeg) / (sNext - sSeg);
                const bool chg = (seg != rowSeg);
                if (__ballot(chg) != 0)
@@ -448,7 +499,28 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                         if (FEAT < 0)
                         {
                            const unsigned at = (unsigned)(seg * nIn + jAt[q]);
-                           const double2 kl = km[at], kr = km[at + nIn]; // knots seg and seg + 1 of this joint
+                           double2 kl, kr; // knots seg and seg + 1 of this joint
+                           if (S8_PREFETCH)
+                           {
+                              // one segment further in the direction of the sweep: both knots are in registers
+                              const bool hit = (DIR == 1) ? (preIdx == seg + 1) : (preIdx == seg);
+                              if (__ballot(!hit) != 0)
+                              {
+                                 const double2 dl = km[at], dr = km[at + nIn];
+                                 kl = hit ? ((DIR == 1) ? kEdge[q] : kPre[q]) : dl;
+                                 kr = hit ? ((DIR == 1) ? kPre[q] : kEdge[q]) : dr;
+                              }
+                              else
+                              {
+                                 kl = (DIR == 1) ? kEdge[q] : kPre[q];
+                                 kr = (DIR == 1) ? kPre[q] : kEdge[q];
+                              }
+                              kEdge[q] = (DIR == 1) ? kr : kl;
+                              int nxt = (DIR == 1) ? seg + 2 : seg - 1;
+                              nxt = nxt < 0 ? 0 : (nxt > lastSeg + 1 ? lastSeg + 1 : nxt);
+                              kPre[q] = km[(unsigned)(nxt * nIn + jAt[q])];
+                           }
+                           else { kl = km[at]; kr = km[at + nIn]; }
                            const double solL = kl.y, solR = kr.y, yL = kl.x, yR = kr.x;
                            // emit_segment's formulas (spline.cpp:203-209)
                            const double c3 = div6(solR - solL);
@@ -461,6 +533,11 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                            const Coef4 k = *reinterpret_cast<const Coef4 *>(coef + (unsigned)(seg * rowStride) + jAt[q] * 4);
                            c1[q] = k.c1; c2x2[q] = 2 * k.c2; c3x3[q] = 3 * k.c3; c3x6[q] = 6 * k.c3;
                         }
+                     }
+                     if (S8_PREFETCH && FEAT < 0)
+                     {
+                        const int nxt = (DIR == 1) ? seg + 2 : seg - 1;
+                        preIdx = nxt < 0 ? (-(1 << 20)) : (nxt > lastSeg + 1 ? (-(1 << 20)) : nxt); // a clamped prefetch holds no usable knot
                      }
                      rowSeg = seg;
                   }
