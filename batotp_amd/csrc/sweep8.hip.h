@@ -26,6 +26,8 @@ namespace bk
 {
 
 constexpr int S8_BLOCK = 256;
+// "does any active lane ...": the i1 ballot intrinsic (HIP's __ballot goes through an integer compare: a v_cndmask + v_cmp per use)
+#define S8_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0)
 #ifndef S8_TAB_FAST
 #define S8_TAB_FAST 1   // tableau combination without selects while every stage value is finite
 #endif
@@ -39,10 +41,6 @@ constexpr int S8_BLOCK = 256;
 #define S8_PREFETCH 1   // the knot the cursor will need next is loaded one segment change ahead (compact pairs).  (The same for the next
                         // point of the reverse curve in the forward sweep measured 5 % slower -- 440 against 419 ms -- and is not done.)
 #endif
-#ifndef S8_REORDER
-#define S8_REORDER 0    // 1: the knot-cursor walk runs before the velocity limit, so that the division for tau and the velocity limit's
-                        // quotient + reduction share one basic block (two independent dependent chains for the scheduler to interleave)
-#endif
 #ifndef S8_KINDS
 #define S8_KINDS 0      // 1: bisection update in blocks by situation -- measured 5 % SLOWER than one block of selects (the guards of four blocks cost more than the selects they save: profiles/r04_b_*)
 #endif
@@ -51,7 +49,8 @@ constexpr int S8_BLOCK = 256;
 __device__ __forceinline__ bool s8_ratio_lt_fast(double num, double den, double thr, bool &decided)
 {
    const double p = thr * den;
-   const bool ok = (den > 0.0) & (num >= 0.0) & (p > 1e-290) & (p < 1e290);
+   // thr > 0: p > 1e-290 implies den > 0, and for a positive divisor the product form is right for a numerator of either sign
+   const bool ok = (p > 1e-290) & (p < 1e290);
    const bool lt = num < p * (1.0 - 1e-14), gt = num > p * (1.0 + 1e-14);
    decided = ok & (lt | gt);
    return lt;
@@ -286,7 +285,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
 #endif
                const bool stepEnd = (st == 6);
                st = stepEnd ? st : st + 1;
-               if (__ballot(stepEnd) != 0)
+               if (S8_ANY(stepEnd))
                {
                   if (stepEnd)
                   {
@@ -308,7 +307,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                      // a complete group of four points: one 64-byte store (not for the step that ends the path: its last
                      // point is still to be snapped onto the path end)
                      const bool chunk = !fin && ((DIR == 1) ? ((idx & 3) == 3) : ((idx & 3) == 0));
-                     if (__ballot(chunk) != 0)
+                     if (S8_ANY(chunk))
                      {
                         if (chunk)
                         {
@@ -328,7 +327,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                {
                   // forward predictor (ba.cpp:1055-1065): only the move of the reverse-curve cursor survives
                   const bool pred = (st == 0);
-                  if (__ballot(pred) != 0)
+                  if (S8_ANY(pred))
                   {
                      if (pred)
                      {
@@ -350,7 +349,14 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                // Stage st adds the terms k < st only.  The weights of the others are +0 in the table, and adding their products
                // changes nothing as long as every stage value is finite (x + (+-0) = x: a partial sum starts as 0 + b0 v0 and
                // is therefore never -0); a path that ever kept a non-finite stage value (0 * inf = NaN) takes the literal form.
-               if (S8_TAB_FAST && __ballot(wild) == 0)
+               // Two rare situations share ONE wavefront-uniform guard (a ballot costs three vector instructions and a branch that
+               // waits for it): a non-finite stage value (below), and a velocity-limit quotient outside the window of the shared
+               // reciprocal (further down: `odd` is then a scalar condition)
+               bool slowDiv = false;
+#pragma unroll
+               for (int q = 0; q < PER; ++q) slowDiv |= jOn[q] && fabs(thD[q]) > thrV && !(rOk[q] & s8_div_window(vmax[q]));
+               const bool odd = S8_ANY(wild | slowDiv);
+               if (S8_TAB_FAST && !odd)
                {
                   sdotT += bc[0] * v0; sddotT += bc[0] * w0;
                   sdotT += bc[1] * v1; sddotT += bc[1] * w1;
@@ -373,22 +379,6 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                vN = dmax(vN, floorV); // ba.cpp:1085
                sCur = sN;
 
-#if S8_REORDER
-               // ---- evalSplinePartials, ba.cpp:1341-1413: updateCurSeg (ba.cpp:1617-1652) on the sites sres*k ----
-               if (!S8_WALK_PRECHECK || __ballot(!((sCur >= sSeg) & (sCur <= sNext))) != 0)
-               {
-                  for (;;)
-                  {
-                     sSeg = sres * (double)seg;
-                     sNext = sres * (double)(seg + 1);
-                     const bool inside = (sCur >= sSeg) & (sCur <= sNext);
-                     const bool up = !inside & (sCur > sSeg), down = !inside & (sCur < sSeg);
-                     status |= (!inside & !up & !down) ? (unsigned)BATOTP_ST_NONFINITE : 0u;
-                     const bool mvUp = up & (seg < lastSeg), mvDn = down & (seg > 0);
-                     seg = mvUp ? seg + 1 : (mvDn ? seg - 1 : seg);
-                     if (__ballot(mvUp | mvDn) == 0) break;
-                  }
-               }
                // ---- sdotLim, ba.cpp:1204-1236 (theta' of the PREVIOUS evaluation point) -----------------
                if (DIR == 1)
                {
@@ -402,19 +392,6 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                vN = dmax(vN, sdotMin);
                {
                   double lim1 = kInf;
-                  bool slowDiv = false; // a quotient outside the window of the shared reciprocal
-#pragma unroll
-                  for (int q = 0; q < PER; ++q) slowDiv |= jOn[q] && fabs(thD[q]) > thrV && !(rOk[q] & s8_div_window(vmax[q]));
-                  if (__ballot(slowDiv) != 0)
-                  {
-#pragma unroll
-                     for (int q = 0; q < PER; ++q)
-                     {
-                        const bool on = jOn[q] && fabs(thD[q]) > thrV;
-                        const bool fast = rOk[q] & s8_div_window(vmax[q]);
-                        if (on && !fast) lim1 = dmin(lim1, fabs(vmax[q] / thD[q]));
-                     }
-                  }
 #pragma unroll
                   for (int q = 0; q < PER; ++q)
                   {
@@ -423,38 +400,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                      const double qv = fabs(s8_div_by(vmax[q], thD[q], rD[q]));
                      lim1 = (on & fast) ? dmin(lim1, qv) : lim1;
                   }
-                  lim1 = grp_min<G>(lim1);
-                  vN = dmin(vN, lim1);
-               }
-               sdotCur = vN;
-               // applyAccelConstraintsBisectionPt, ba.cpp:1250-1265
-               lowFact = .01; sdotGood = 0; nGood = 0; sdotL = 0; sdotH = vN; sdotTry = vN; nIter = 0; stageFailed = false;
-
-#else
-               // ---- sdotLim, ba.cpp:1204-1236 (theta' of the PREVIOUS evaluation point) -----------------
-               if (DIR == 1)
-               {
-                  // evalsdot, ba.cpp:1590-1607
-#include "sweep8_mvcwalk.inc"
-                  const double tauM = (sCur - mS0) / (mS1 - mS0);
-                  const double sdotMVC = dmax(mD0 + tauM * (mD1 - mD0), sdotMin);
-                  vN = (vN > sdotMVC) ? sdotMVC : vN;
-               }
-               vN = dmin(vN, sdotCap);
-               vN = dmax(vN, sdotMin);
-               {
-                  double lim1 = kInf;
-                  bool slowDiv = false; // a quotient outside the window of the shared reciprocal
-#pragma unroll
-                  for (int q = 0; q < PER; ++q)
-                  {
-                     const bool on = jOn[q] && fabs(thD[q]) > thrV;
-                     const bool fast = rOk[q] & s8_div_window(vmax[q]);
-                     const double qv = fabs(s8_div_by(vmax[q], thD[q], rD[q]));
-                     lim1 = (on & fast) ? dmin(lim1, qv) : lim1;
-                     slowDiv |= on & !fast;
-                  }
-                  if (__ballot(slowDiv) != 0)
+                  if (odd)
                   {
 #pragma unroll
                      for (int q = 0; q < PER; ++q)
@@ -472,7 +418,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                lowFact = .01; sdotGood = 0; nGood = 0; sdotL = 0; sdotH = vN; sdotTry = vN; nIter = 0; stageFailed = false;
 
                // ---- evalSplinePartials, ba.cpp:1341-1413: updateCurSeg (ba.cpp:1617-1652) on the sites sres*k ----
-               if (!S8_WALK_PRECHECK || __ballot(!((sCur >= sSeg) & (sCur <= sNext))) != 0)
+               if (!S8_WALK_PRECHECK || S8_ANY(!((sCur >= sSeg) & (sCur <= sNext))))
                {
                   for (;;)
                   {
@@ -483,13 +429,12 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                      status |= (!inside & !up & !down) ? (unsigned)BATOTP_ST_NONFINITE : 0u;
                      const bool mvUp = up & (seg < lastSeg), mvDn = down & (seg > 0);
                      seg = mvUp ? seg + 1 : (mvDn ? seg - 1 : seg);
-                     if (__ballot(mvUp | mvDn) == 0) break;
+                     if (!S8_ANY(mvUp | mvDn)) break;
                   }
                }
-#endif
                const double tau = (sCur - sSeg) / (sNext - sSeg);
                const bool chg = (seg != rowSeg);
-               if (__ballot(chg) != 0)
+               if (S8_ANY(chg))
                {
                   if (chg)
                   {
@@ -504,7 +449,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                            {
                               // one segment further in the direction of the sweep: both knots are in registers
                               const bool hit = (DIR == 1) ? (preIdx == seg + 1) : (preIdx == seg);
-                              if (__ballot(!hit) != 0)
+                              if (S8_ANY(!hit))
                               {
                                  const double2 dl = km[at], dr = km[at + nIn];
                                  kl = hit ? ((DIR == 1) ? kEdge[q] : kPre[q]) : dl;
@@ -581,7 +526,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                L = use ? dmax(L, qL) : L;
                rare |= jOn[q] & (slow | !fast);
             }
-            if (__ballot(rare) != 0)
+            if (S8_ANY(rare))
             {
 #pragma unroll
                for (int q = 0; q < PER; ++q)
@@ -617,7 +562,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
          const bool fin0 = !isViol && first;
          const bool search = isViol && nGood == 0, upper = isViol && nGood != 0, good = !isViol && !first;
          bool fin = fin0, failed = false;
-         if (__ballot(search) != 0)
+         if (S8_ANY(search))
          {
             if (search)
             {
@@ -628,11 +573,11 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                bool dec2;
                const double num2 = sdotH - sdotL;
                bool tiny = s8_ratio_lt_fast(num2, sdotH, 1e-20, dec2);
-               if (__ballot(!dec2) != 0) tiny = dec2 ? tiny : (num2 / sdotH < 1e-20);
+               if (S8_ANY(!dec2)) tiny = dec2 ? tiny : (num2 / sdotH < 1e-20);
                failed = (nIter + 1 > 100) || (sdotTry < 0.0) || tiny;
             }
          }
-         if (__ballot(upper) != 0)
+         if (S8_ANY(upper))
          {
             if (upper)
             {
@@ -640,7 +585,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                failed = (nIter + 1 > 100) || (sdotTry < 0.0);
             }
          }
-         if (__ballot(good) != 0)
+         if (S8_ANY(good))
          {
             if (good)
             {
@@ -648,7 +593,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                bool dec1;
                const double num1 = fabs(sdotTry - sdotGood);
                bool close = s8_ratio_lt_fast(num1, sdotTry, .001, dec1);
-               if (__ballot(!dec1) != 0) close = dec1 ? close : (num1 / sdotTry < .001);
+               if (S8_ANY(!dec1)) close = dec1 ? close : (num1 / sdotTry < .001);
                const bool conv = close || sdotTry < 0.0;
                sdotGood = sdotTry;
                nGood += 1;
@@ -658,7 +603,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                failed = !conv && ((nIter + 1 > 100) || (sdotTry < 0.0));
             }
          }
-         if (__ballot(!fin0) != 0)
+         if (S8_ANY(!fin0))
          {
             const bool on = !fin && !failed;
             nIter += fin ? 0 : 1;
@@ -670,19 +615,29 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
 #else
          // ---- one pass of the loop of ba.cpp:1267-1321, as selects -----------------------------------------
          const bool first = (nIter == 0);
-         const bool fin0 = !isViol && first; // the common case: the first check passes, nothing else happens
+         const bool fin0 = !isViol && first; // the first check passes: the stage is done, nothing else happens
          bool fin = fin0, failed = false;
-         if (__ballot(!fin0) != 0)
+         // forward sweep: 99 % of the checks end here and the block is skipped; reverse sweep: three quarters of the time a
+         // path is inside a bisection, the guard would nearly always be taken and only cost its ballot
+         if (DIR == -1 || S8_ANY(!fin0))
          {
             const bool good = !isViol && !first;      // a feasible point after at least one violated one
             const bool shrink = isViol && nGood == 0; // ba.cpp:1281-1285: no feasible point known yet
             const double lowFact2 = lowFact * 2.0;
             const double sdotLShrunk = dmax(.999 * 0.0, (1.0 - lowFact2) * sdotTry);
-            // ba.cpp:1294-1303: two successive feasible points closer than 1e-3 (relative), or a negative one
-            bool dec1;
-            const double num1 = fabs(sdotTry - sdotGood);
+            // the two threshold tests of the loop, both up front and behind ONE guard for the quotients they may need:
+            //   ba.cpp:1294-1303: two successive feasible points closer than 1e-3 (relative)   -- matters for `good` paths
+            //   ba.cpp:1313: the bracket [sdotL, sdotH] has collapsed                          -- matters while no feasible point is
+            //   known, i.e. for `shrink` paths, whose bracket after this pass is [sdotLShrunk, sdotTry] whatever the other test says
+            bool dec1, dec2;
+            const double num1 = fabs(sdotTry - sdotGood), num2 = sdotTry - sdotLShrunk;
             bool close = s8_ratio_lt_fast(num1, sdotTry, .001, dec1);
-            if (__ballot(good & !dec1) != 0) close = dec1 ? close : (num1 / sdotTry < .001);
+            bool tiny = s8_ratio_lt_fast(num2, sdotTry, 1e-20, dec2);
+            if (S8_ANY((good & !dec1) | (shrink & !dec2)))
+            {
+               close = dec1 ? close : (num1 / sdotTry < .001);
+               tiny = dec2 ? tiny : (num2 / sdotTry < 1e-20);
+            }
             const bool conv = good && (close || sdotTry < 0.0);
             fin = fin0 || conv;
             lowFact = shrink ? lowFact2 : lowFact;
@@ -692,11 +647,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
             nGood += good ? 1 : 0;
             sdotCur = conv ? sdotTry : sdotCur;
             // ba.cpp:1305-1320
-            bool dec2;
-            const double num2 = sdotH - sdotL;
-            bool tiny = s8_ratio_lt_fast(num2, sdotH, 1e-20, dec2);
-            if (__ballot((nGood == 0) & !fin & !dec2) != 0) tiny = dec2 ? tiny : (num2 / sdotH < 1e-20);
-            const bool collapsed = (nGood == 0) && tiny;
+            const bool collapsed = shrink && tiny;
             failed = !fin && (nIter + 1 > 100 || sdotTry < 0.0 || collapsed);
             nIter += fin ? 0 : 1;
             sdotTry = (fin || failed) ? sdotTry : .5 * (sdotH + sdotL);
