@@ -28,6 +28,7 @@ namespace bk
 constexpr int S8_BLOCK = 256;
 // "does any active lane ...": the i1 ballot intrinsic (HIP's __ballot goes through an integer compare: a v_cndmask + v_cmp per use)
 #define S8_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0)
+#define S8_RARE(x) __builtin_expect(S8_ANY(x), 0) // a guard whose block is off the straight-line code
 #ifndef S8_TAB_FAST
 #define S8_TAB_FAST 1   // tableau combination without selects while every stage value is finite
 #endif
@@ -239,9 +240,11 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
    const double floorV = 0.0 / absh; // ba.cpp:1050-1051,1085
    int nPts = 0, i = 1;
    unsigned endStatus = 0;
-   int st = (DIR == 1) ? 0 : 1;
+   // A path starts as if the stage before its first one had just ended (st one lower, PH_ENDED): the stores of that stage
+   // go to slots nothing reads, and the loop needs no separate state for the first stage.
+   int st = (DIR == 1) ? -1 : 0;
    constexpr int PH_FIRST = 0, PH_ENDED = 1, PH_CHECK = 2, PH_DEAD = 3;
-   int phase = PH_FIRST;
+   int phase = PH_ENDED;
    if (S8_CURVE_FULL(i)) { endStatus = BATOTP_ST_CAPACITY; phase = PH_DEAD; }
    double sN = 0, wN = 0;
    double lowFact = .01, sdotGood = 0, sdotL = 0, sdotH = 0, sdotTry = 0;
@@ -261,7 +264,6 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
          if (phase < PH_CHECK)
          {
             // ---- the stage that ended: keep its values --------------------------------------------
-            if (phase == PH_ENDED)
             {
                phase = PH_FIRST;
                const double vN = sdotCur;
@@ -270,8 +272,8 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                // slot st keeps (vN, wN); a failed bisection leaves sddotArr[st] as it was (the w half goes to the spare slot 7);
                // stage 6 is kept in registers by the step end below (its writes go to the spare slot 7 as well)
                {
-                  double *slotV = reinterpret_cast<double *>(myvw + (st < 6 ? st : 7));
-                  double *slotW = reinterpret_cast<double *>(myvw + ((st < 6 && !stageFailed) ? st : 7)) + 1;
+                  double *slotV = reinterpret_cast<double *>(myvw + ((unsigned)st < 6u ? st : 7));
+                  double *slotW = reinterpret_cast<double *>(myvw + (((unsigned)st < 6u && !stageFailed) ? st : 7)) + 1;
                   *slotV = vN;
                   *slotW = wN;
                }
@@ -355,7 +357,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                bool slowDiv = false;
 #pragma unroll
                for (int q = 0; q < PER; ++q) slowDiv |= jOn[q] && fabs(thD[q]) > thrV && !(rOk[q] & s8_div_window(vmax[q]));
-               const bool odd = S8_ANY(wild | slowDiv);
+               const bool odd = S8_RARE(wild | slowDiv);
                if (S8_TAB_FAST && !odd)
                {
                   sdotT += bc[0] * v0; sddotT += bc[0] * w0;
@@ -445,32 +447,49 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                         {
                            const unsigned at = (unsigned)(seg * nIn + jAt[q]);
                            double2 kl, kr; // knots seg and seg + 1 of this joint
+                           bool literal = false; // the knots are not the prefetched ones, or a sixth lies outside div6's window
                            if (S8_PREFETCH)
                            {
                               // one segment further in the direction of the sweep: both knots are in registers
                               const bool hit = (DIR == 1) ? (preIdx == seg + 1) : (preIdx == seg);
-                              if (S8_ANY(!hit))
+                              kl = (DIR == 1) ? kEdge[q] : kPre[q];
+                              kr = (DIR == 1) ? kPre[q] : kEdge[q];
+                              literal = !hit;
+                           }
+                           else { kl = km[at]; kr = km[at + nIn]; }
+                           // emit_segment's formulas (spline.cpp:203-209); x / 6 as div6 computes it inside its window, and ONE
+                           // wavefront-uniform guard for everything that is rare here (a missed prefetch, a sixth outside the window)
+                           double solL = kl.y, solR = kr.y, yL = kl.x, yR = kr.x;
+                           double xa = solR - solL, xb = solR + 2 * solL;
+                           literal |= !((fabs(xa) > 1e-280) & (fabs(xa) < 1e280) & (fabs(xb) > 1e-280) & (fabs(xb) < 1e280));
+                           double c3, sixthB;
+                           {
+                              const double qa = xa * (1.0 / 6.0), qb = xb * (1.0 / 6.0);
+                              c3 = __builtin_fma(__builtin_fma(-6.0, qa, xa), 1.0 / 6.0, qa);
+                              sixthB = __builtin_fma(__builtin_fma(-6.0, qb, xb), 1.0 / 6.0, qb);
+                           }
+                           if (S8_RARE(literal))
+                           {
+                              if (S8_PREFETCH)
                               {
+                                 const bool hit = (DIR == 1) ? (preIdx == seg + 1) : (preIdx == seg);
                                  const double2 dl = km[at], dr = km[at + nIn];
-                                 kl = hit ? ((DIR == 1) ? kEdge[q] : kPre[q]) : dl;
-                                 kr = hit ? ((DIR == 1) ? kPre[q] : kEdge[q]) : dr;
+                                 kl = hit ? kl : dl;
+                                 kr = hit ? kr : dr;
                               }
-                              else
-                              {
-                                 kl = (DIR == 1) ? kEdge[q] : kPre[q];
-                                 kr = (DIR == 1) ? kPre[q] : kEdge[q];
-                              }
+                              solL = kl.y; solR = kr.y; yL = kl.x; yR = kr.x;
+                              c3 = div6(solR - solL);
+                              sixthB = div6(solR + 2 * solL);
+                           }
+                           if (S8_PREFETCH)
+                           {
                               kEdge[q] = (DIR == 1) ? kr : kl;
                               int nxt = (DIR == 1) ? seg + 2 : seg - 1;
                               nxt = nxt < 0 ? 0 : (nxt > lastSeg + 1 ? lastSeg + 1 : nxt);
                               kPre[q] = km[(unsigned)(nxt * nIn + jAt[q])];
                            }
-                           else { kl = km[at]; kr = km[at + nIn]; }
-                           const double solL = kl.y, solR = kr.y, yL = kl.x, yR = kr.x;
-                           // emit_segment's formulas (spline.cpp:203-209)
-                           const double c3 = div6(solR - solL);
                            const double c2 = solL / 2.0;
-                           c1[q] = yR - yL - div6(solR + 2 * solL);
+                           c1[q] = yR - yL - sixthB;
                            c2x2[q] = 2 * c2; c3x3[q] = 3 * c3; c3x6[q] = 6 * c3;
                         }
                         else
@@ -505,6 +524,14 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
       }
       if (phase == PH_CHECK)
       {
+         // (what the bisection update below needs and the constraint check does not produce is computed first: it fills the
+         //  wait of the check's wavefront-uniform guard for its ballot)
+         const double lowFact2 = lowFact * 2.0;
+         const double sdotLShrunk = dmax(.999 * 0.0, (1.0 - lowFact2) * sdotTry);
+         bool dec1, dec2;
+         const double num1 = fabs(sdotTry - sdotGood), num2 = sdotTry - sdotLShrunk;
+         bool close = s8_ratio_lt_fast(num1, sdotTry, .001, dec1);
+         bool tiny = s8_ratio_lt_fast(num2, sdotTry, 1e-20, dec2);
          // ---- verifySecondOrderConstraints, ba.cpp:1514-1534, at sdotTry ---------------------------------
          const double sdotSQ = sdotTry * sdotTry;
          double H = sddotMax, L = -sddotMax;
@@ -526,7 +553,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                L = use ? dmax(L, qL) : L;
                rare |= jOn[q] & (slow | !fast);
             }
-            if (S8_ANY(rare))
+            if (S8_RARE(rare))
             {
 #pragma unroll
                for (int q = 0; q < PER; ++q)
@@ -623,17 +650,11 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
          {
             const bool good = !isViol && !first;      // a feasible point after at least one violated one
             const bool shrink = isViol && nGood == 0; // ba.cpp:1281-1285: no feasible point known yet
-            const double lowFact2 = lowFact * 2.0;
-            const double sdotLShrunk = dmax(.999 * 0.0, (1.0 - lowFact2) * sdotTry);
-            // the two threshold tests of the loop, both up front and behind ONE guard for the quotients they may need:
+            // the two threshold tests of the loop (computed above), behind ONE guard for the quotients they may need:
             //   ba.cpp:1294-1303: two successive feasible points closer than 1e-3 (relative)   -- matters for `good` paths
             //   ba.cpp:1313: the bracket [sdotL, sdotH] has collapsed                          -- matters while no feasible point is
             //   known, i.e. for `shrink` paths, whose bracket after this pass is [sdotLShrunk, sdotTry] whatever the other test says
-            bool dec1, dec2;
-            const double num1 = fabs(sdotTry - sdotGood), num2 = sdotTry - sdotLShrunk;
-            bool close = s8_ratio_lt_fast(num1, sdotTry, .001, dec1);
-            bool tiny = s8_ratio_lt_fast(num2, sdotTry, 1e-20, dec2);
-            if (S8_ANY((good & !dec1) | (shrink & !dec2)))
+            if (S8_RARE((good & !dec1) | (shrink & !dec2)))
             {
                close = dec1 ? close : (num1 / sdotTry < .001);
                tiny = dec2 ? tiny : (num2 / sdotTry < 1e-20);
