@@ -56,6 +56,20 @@ __device__ __forceinline__ bool s8_ratio_lt_fast(double num, double den, double 
    decided = ok & (lt | gt);
    return lt;
 }
+// The two threshold tests of one bisection pass divide by the same den: num1 / den < THR1 and num2 / den < THR2 with the
+// thresholds of ba.cpp:1294 and 1313 (1e-3, 1e-20).  A test is decided when the numerator lies outside the band
+// den * thr * (1 -+ 1e-14): the quotient's rounding error (2^-53) cannot carry it across thr from there.  (The bounds of the band
+// are single products with constants; where exactly the band ends is immaterial, inside it the literal quotient decides.)
+// den in (1e-260, 1e260): positive, and every product is a normal number.
+__device__ __forceinline__ void s8_ratio_lt_pair(double num1, double num2, double den, bool &lt1, bool &dec1, bool &lt2, bool &dec2)
+{
+   constexpr double T1 = .001, T2 = 1e-20;
+   const bool ok = (den > 1e-260) & (den < 1e260);
+   lt1 = num1 < den * (T1 * (1.0 - 1e-14));
+   lt2 = num2 < den * (T2 * (1.0 - 1e-14));
+   dec1 = ok & (lt1 | (num1 > den * (T1 * (1.0 + 1e-14))));
+   dec2 = ok & (lt2 | (num2 > den * (T2 * (1.0 + 1e-14))));
+}
 
 // (the shared refined reciprocal of theta' -- sdiv_window / sdiv_rcp / sdiv_by -- lives in device_math.h.  In k_sweep1, the
 // one-path-per-wavefront kernel, the same technique measured 3-10 % SLOWER -- cfg 4: 961 against 874 ms -- and is not used there:
@@ -191,6 +205,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
    const bool accOn = (t.flags & BATOTP_F_JNT_ACC_ON) != 0;
    const double thrV = t.thrV, thrA = t.thrA, vfact = t.vfact, afact = t.afact;
    const double sdotCap = t.sdotCap, sddotMax = t.sddotMax, sdotMin = t.sdotMin;
+   const bool capOk = (sddotMax == sddotMax); // the acceleration cap is not a NaN (otherwise every bound takes the literal form)
    const int lastSeg = n - 2;
    const int nIn = t.nIn;
    const double2 *__restrict__ km = t.km;
@@ -530,8 +545,8 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
          const double sdotLShrunk = dmax(.999 * 0.0, (1.0 - lowFact2) * sdotTry);
          bool dec1, dec2;
          const double num1 = fabs(sdotTry - sdotGood), num2 = sdotTry - sdotLShrunk;
-         bool close = s8_ratio_lt_fast(num1, sdotTry, .001, dec1);
-         bool tiny = s8_ratio_lt_fast(num2, sdotTry, 1e-20, dec2);
+         bool close, tiny;
+         s8_ratio_lt_pair(num1, num2, sdotTry, close, dec1, tiny, dec2);
          // ---- verifySecondOrderConstraints, ba.cpp:1514-1534, at sdotTry ---------------------------------
          const double sdotSQ = sdotTry * sdotTry;
          double H = sddotMax, L = -sddotMax;
@@ -545,12 +560,15 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                const bool slow = fabs(thD[q]) < thrV;
                const double vTerm = thD2[q] * sdotSQ;
                const double nH = sa[q] - vTerm, nL = -sa[q] - vTerm; // (theta' = 0 lies outside the window: the literal form below)
-               const bool fast = rOk[q] & s8_div_window(nH) & s8_div_window(nL);
+               const bool fast = capOk & rOk[q] & s8_div_window(nH) & s8_div_window(nL);
                const double qH = s8_div_by(nH, thD[q], rD[q]);
                const double qL = s8_div_by(nL, thD[q], rD[q]);
                const bool use = jOn[q] & !slow & fast;
-               H = use ? dmin(H, qH) : H;
-               L = use ? dmax(L, qL) : L;
+               // inside the window both quotients are finite and the bound is not a NaN (capOk): the one-instruction min / max
+               // returns what the compare-and-select form returns (device_math.h: up to the sign of a zero that nothing reads)
+               const double Hm = vmin_f64(H, qH), Lm = vmax_f64(L, qL);
+               H = use ? Hm : H;
+               L = use ? Lm : L;
                rare |= jOn[q] & (slow | !fast);
             }
             if (S8_RARE(rare))
@@ -562,7 +580,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                   const int svpt = sgn(thD[q]);
                   const double vTerm = thD2[q] * sdotSQ;
                   const double nH = svpt * amax[q] - vTerm, nL = -svpt * amax[q] - vTerm;
-                  const bool fast = rOk[q] & s8_div_window(sa[q] - vTerm) & s8_div_window(-sa[q] - vTerm);
+                  const bool fast = capOk & rOk[q] & s8_div_window(sa[q] - vTerm) & s8_div_window(-sa[q] - vTerm);
                   if (jOn[q] && !slow && !fast)
                   {
                      H = dmin(H, nH / thD[q]);
@@ -574,6 +592,9 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
             }
          }
          double Hred = force ? -kInf : H;
+         // (Reducing only the side the stage keeps and reading the other side's verdict off the ballot of "my bound is crossed"
+         //  saves six instructions and measured 4 % SLOWER -- 716 against 690 ms: the ballot's way through the scalar registers
+         //  sits on the critical path of the pass.)
          grp_min_max<G>(Hred, L);
          sddotH = Hred; sddotL = L;
          const bool isViol = L > Hred;
@@ -671,6 +692,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
             const bool collapsed = shrink && tiny;
             failed = !fin && (nIter + 1 > 100 || sdotTry < 0.0 || collapsed);
             nIter += fin ? 0 : 1;
+            // (the next candidate computed for both verdicts ahead of the reduction, then one select: 1.5 % SLOWER, 691 against 681 ms)
             sdotTry = (fin || failed) ? sdotTry : .5 * (sdotH + sdotL);
             status |= failed ? (unsigned)BATOTP_ST_BISECT_FAIL : 0u;
             nfail += failed ? 1 : 0;
