@@ -960,7 +960,7 @@ def main():
             pass
         sys.stdout.flush()
         try:     # an untruncated copy for profiles/ (the driver keeps only the tail of long lines)
-            if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+            if os.path.isdir(os.path.join(ROOT, "gpurun_out")) and default_run and not args.no_as_worded:   # (not the profiling passes)
                 open(os.path.join(ROOT, "gpurun_out", "bench_line_full.json"), "w").write(json.dumps(out, indent=1))
         except Exception:
             pass
