@@ -111,7 +111,10 @@ struct batotp_batch
    bool needPar = false;        // some path may run the parallel-mechanism torque branch
    bool k3Pending = false;      // an overlapped per-knot evaluation may still be running on ctx->stream2
    bool lastForm8[2] = {false, false}; // the most recent sweep per direction ran k_sweep8
-   bool compact = false;        // BATOTP_F_COMPACT_SPLINES: dElim holds the second derivatives, there is no dCoef
+   bool compact = false;        // BATOTP_F_COMPACT_SPLINES: (value, second derivative) pairs in dKM, there is no dCoef
+   bool pairsAll = false;       // ... of a problem with Cartesian / dynamics channels: ALL C channels are pairs (kmC = C), the kernels of the
+                                // coefficient-row layouts (FEAT >= 0) form their rows from them, no sample and no dynamics array exists
+   int kmC = 0;                 // channels per knot in dKM (Cin, or C with pairsAll)
    bool kinDone = false, dynDone = false, sitesSet = false, revDone = false, trigSet = false;
    bool inPlace = false;   // BATOTP_F_CURVES_IN_PLACE: dFwd aliases dRev
    bool revGone = false;   // ... and the forward sweep has overwritten the reverse curve
@@ -557,12 +560,14 @@ extern "C" int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *pr
    }
 
    b->compact = (prob->flags & BATOTP_F_COMPACT_SPLINES) != 0;
-   if (b->compact && (d != 0 || !(prob->flags & BATOTP_F_NO_SAMPLES) || (prob->flags & (BATOTP_F_CART_VEL_ON | BATOTP_F_CART_ACC_ON))))
+   if (b->compact && (!(prob->flags & BATOTP_F_NO_SAMPLES) || b->needPar))
    {
-      snprintf(g_err, sizeof(g_err), "compact splines need a joint velocity/acceleration-only problem with BATOTP_F_NO_SAMPLES");
+      snprintf(g_err, sizeof(g_err), "compact splines need BATOTP_F_NO_SAMPLES and constraints in serial form (no parallel-mechanism torque branch)");
       batotp_hip_batch_destroy(b);
       return BATOTP_ERR_ARG;
    }
+   b->pairsAll = b->compact && (d != 0 || (prob->flags & (BATOTP_F_CART_VEL_ON | BATOTP_F_CART_ACC_ON)));
+   b->kmC = b->compact ? (b->pairsAll ? P.C : P.Cin) : 0;
 
 #define ALLOC(ptr, count, type)                                                        \
    rc = devAlloc(b, (void **)&(ptr), sizeof(type) * (size_t)(count));                   \
@@ -574,9 +579,9 @@ extern "C" int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *pr
    // the array only when a path's sites are uploaded (batotp_hip_upload_path_sites)
    if (!b->compact) { ALLOC(b->dSC, off, double) }   // (devAlloc turns a zero-size request into 8 bytes: the pointer must stay null here)
    ALLOC(b->dCoef, b->compact ? 0 : off * P.C * 4, double)
-   if ((prob->flags & BATOTP_F_NO_SAMPLES) && d != 0) { batotp_hip_batch_destroy(b); return BATOTP_ERR_ARG; }
+   if ((prob->flags & BATOTP_F_NO_SAMPLES) && d != 0 && !b->pairsAll) { batotp_hip_batch_destroy(b); return BATOTP_ERR_ARG; } // K2 reads the samples
    ALLOC(b->dSamp, (prob->flags & BATOTP_F_NO_SAMPLES) ? 0 : off * P.Cin * 3, double)
-   ALLOC(b->dDyn, off * 4 * (d ? d : 0), double)
+   ALLOC(b->dDyn, b->pairsAll ? 0 : off * 4 * (d ? d : 0), double)
    ALLOC(b->dTrig, (prob->robot_type == BATOTP_ROBOT_RR && d) ? off * 4 : 0, double)
    b->mvcInCurves = (prob->flags & BATOTP_F_MVC_IN_CURVES) != 0;
    if (b->mvcInCurves && 2 * max_steps < 3 * b->maxN)
@@ -594,7 +599,7 @@ extern "C" int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *pr
    ALLOC(b->dStage, 4 * b->maxN, double)
    ALLOC(b->dSink, n_paths, int)
    ALLOC(b->dElim, b->compact ? 0 : off * (P.Cin > 4 * d ? P.Cin : 4 * d), double)
-   ALLOC(b->dKM, b->compact ? off * P.Cin * 2 : 0, double)
+   ALLOC(b->dKM, b->compact ? off * b->kmC * 2 : 0, double)
    std::vector<int> tileOff((size_t)n_paths + 1, 0);
    {
       b->nchMax = std::max(P.Cin, 4 * d);
@@ -662,7 +667,7 @@ static int uploadKnotsImpl(batotp_batch *b, int32_t path0, int32_t n, const doub
    {
       // compact splines: the values go straight from the caller's device buffer into the pair array
       const int64_t total = last - first;
-      hipLaunchKernelGGL(k_pairs_from_rows, dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, st, b->dPinfo, path0, n, Cin, y, b->dKM, total);
+      hipLaunchKernelGGL(k_pairs_from_rows, dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, st, b->dPinfo, path0, n, Cin, b->kmC, y, b->dKM, total);
       HIP_TRY(hipGetLastError());
    }
    else
@@ -685,7 +690,7 @@ static int uploadKnotsImpl(batotp_batch *b, int32_t path0, int32_t n, const doub
          if (q == p) return BATOTP_ERR_STATE;
          const int64_t off = b->pinfo[p].koff - first;
          HIP_TRY(hipMemcpyAsync(b->dUp, y + off * Cin, sizeof(double) * (size_t)(knots * Cin), hipMemcpyHostToDevice, st));
-         hipLaunchKernelGGL(k_pairs_from_rows, dim3((unsigned)((knots + bs - 1) / bs)), dim3(bs), 0, st, b->dPinfo, p, q - p, Cin, b->dUp, b->dKM, knots);
+         hipLaunchKernelGGL(k_pairs_from_rows, dim3((unsigned)((knots + bs - 1) / bs)), dim3(bs), 0, st, b->dPinfo, p, q - p, Cin, b->kmC, b->dUp, b->dKM, knots);
          HIP_TRY(hipGetLastError());
          HIP_TRY(hipStreamSynchronize(st)); // the staging buffer is reused by the next run
          p = q;
@@ -880,7 +885,8 @@ static void evStop(batotp_batch *b, int which) { hipEventRecord(b->ev[which][1],
 // K1 of nch series per path: the tiled kernel (spline_tile.hip.h) for every path of at least ST_MIN_KNOTS knots, then the
 // sequential kernel for what is left (short paths; a series whose boundary comparison failed -- never observed).
 // pairs: the compact layout (in place in dKM); else channel-major rows `src` in, coefficient rows out.
-static int launchSpline(batotp_batch *b, int nch, int mode, const double *src, int64_t srcStridePerKnot, bool pairs = false)
+// pairs: series c0 .. c0 + nch - 1 of the kmC channels a knot holds.
+static int launchSpline(batotp_batch *b, int nch, int mode, const double *src, int64_t srcStridePerKnot, bool pairs = false, int c0 = 0)
 {
    hipStream_t st = b->ctx->stream;
    const int threads = b->B * nch;
@@ -900,7 +906,7 @@ static int launchSpline(batotp_batch *b, int nch, int mode, const double *src, i
    {
       TileArgs a;
       a.pinfo = b->dPinfo; a.tileOff = b->dTileOff; a.B = b->B; a.mode = mode; a.pairs = pairs ? 1 : 0; a.nch = nch;
-      a.C = b->P.C; a.Cin = b->P.Cin; a.d = b->P.d > 0 ? b->P.d : 1;
+      a.C = pairs ? b->kmC : b->P.C; a.Cin = b->P.Cin; a.d = b->P.d > 0 ? b->P.d : 1; a.c0 = pairs ? c0 : 0;
       a.src = src; a.srcStride = srcStridePerKnot; a.km = b->dKM; a.coef = b->dCoef; a.edge = b->dEdge; a.dirty = b->dDirty;
       hipLaunchKernelGGL(k_tile_dirty_init, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, b->dPinfo, b->B, nch, b->dDirty);
       hipLaunchKernelGGL(k_spline_tile, dim3((unsigned)b->totalTiles, (unsigned)((nch + ST_CH - 1) / ST_CH)), dim3(ST_BLOCK), 0, st, a);
@@ -909,7 +915,7 @@ static int launchSpline(batotp_batch *b, int nch, int mode, const double *src, i
       only = b->dDirty;
       b->lastTileNch = nch;
    }
-   if (pairs) hipLaunchKernelGGL(k_spline_pairs, dim3((unsigned)((threads + bs - 1) / bs)), dim3(bs), 0, st, b->dPinfo, b->B, nch, b->dKM, only);
+   if (pairs) hipLaunchKernelGGL(k_spline_pairs, dim3((unsigned)((threads + bs - 1) / bs)), dim3(bs), 0, st, b->dPinfo, b->B, nch, c0, b->kmC, b->dKM, only);
    else
       hipLaunchKernelGGL(k_spline, dim3((unsigned)((threads + bs - 1) / bs)), dim3(bs), 0, st, b->dPinfo, b->B, nch, mode,
                          b->P.C, b->P.Cin, b->P.d > 0 ? b->P.d : 1, src, srcStridePerKnot, b->dElim, b->dCoef, only);
@@ -965,17 +971,21 @@ extern "C" int batotp_hip_precompute(batotp_batch *b, int32_t stage)
          const bool hostTrig = (b->prob.flags & BATOTP_F_HOST_TRIG) != 0;
          if (hostTrig && !b->jtrigSet) return BATOTP_ERR_STATE;
          hipLaunchKernelGGL(k_dyn_serial, dim3((unsigned)((b->totalKnots + KDS_BLOCK - 1) / KDS_BLOCK)), dim3(KDS_BLOCK), 0, st, b->dModel,
-                            b->P.Cin, b->dPinfo, b->B, b->dSamp, hostTrig ? b->dJTrig : (const double *)nullptr, b->dDyn, b->totalKnots);
+                            b->P.Cin, b->dPinfo, b->B, b->dSamp, hostTrig ? b->dJTrig : (const double *)nullptr, b->dDyn, b->totalKnots,
+                            b->pairsAll ? b->dKM : (double *)nullptr, b->kmC, b->dRes);
       }
       else
       {
          const bool hostTrig = (b->prob.flags & BATOTP_F_HOST_TRIG) && b->prob.robot_type == BATOTP_ROBOT_RR;
          if (hostTrig && !b->trigSet) return BATOTP_ERR_STATE;
          hipLaunchKernelGGL(k_dynamics, dim3(gridKnots), dim3(bs), 0, st, b->P, b->dP, b->dPinfo, b->B, b->dSamp,
-                            hostTrig ? b->dTrig : (const double *)nullptr, b->dDyn, b->totalKnots);
+                            hostTrig ? b->dTrig : (const double *)nullptr, b->dDyn, b->totalKnots, b->pairsAll ? b->dKM : (double *)nullptr, b->kmC,
+                            b->dRes);
       }
       HIP_TRY(hipGetLastError());
-      rc = launchSpline(b, 4 * b->P.d, 1, b->dDyn, 4 * b->P.d);
+      // (pairs for all channels: the values are already in their slots, device channel Cin + 4 r + k; solved in place)
+      if (b->pairsAll) rc = launchSpline(b, 4 * b->P.d, 0, nullptr, 0, true, b->P.Cin); // (mode 0: series e IS channel c0 + e)
+      else rc = launchSpline(b, 4 * b->P.d, 1, b->dDyn, 4 * b->P.d);
       if (rc) return rc;
       if ((b->prob.flags & BATOTP_F_PARALLEL) && (b->prob.flags & BATOTP_F_PAR2SER))
       {
@@ -996,7 +1006,7 @@ static int featureLevel(const batotp_batch *b)
    if (b->needPar) return 3;
    if (b->prob.flags & BATOTP_F_TRQ_ON) return 2;
    if (b->prob.flags & (BATOTP_F_CART_VEL_ON | BATOTP_F_CART_ACC_ON)) return 1;
-   return b->compact ? -1 : 0;
+   return (b->compact && !b->pairsAll) ? -1 : 0;
 }
 
 static int readyForSweep(const batotp_batch *b)
@@ -1015,7 +1025,7 @@ extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
    // a lane per knot, or (when a lane grouping is selected explicitly) a lane group per knot as in the sweep.
    // Measured on UR6, 16384 paths: lane per knot 366 ms, lane group per knot 461 ms (2 of 8 lanes idle, the
    // scalar work of a knot replicated over its 8 lanes) -- the lane-per-knot form is the default.
-   const bool grouped = b->ctx->sweepGroup > 1;
+   const bool grouped = b->ctx->sweepGroup > 1 && !b->pairsAll; // (pairs for all channels: the lane-per-knot kernel forms its row from them)
    const int bs = grouped ? K3G_BLOCK : K3_BLOCK;
    const int64_t knotsPerBlock = grouped ? K3G_BLOCK / 8 : K3_BLOCK;
    const int64_t sliceKnots = (int64_t)1 << 27; // x 8 lanes = 2^30 threads per launch
@@ -1396,6 +1406,12 @@ extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
       // 6144 paths 1784 vs 2024, 8192 paths 2328 vs 2137; forward: 3072 paths 923 vs 981, 4096 paths 1118 vs 1031; UR6 alike)
       if (sweep1Applies(b) && b->B <= (a.dir == -1 ? 6144 : 3072)) lanes = 64;
    }
+   if (b->pairsAll)
+   {
+      // rows exist in the LDS windows of the one-path-per-wavefront kernel only
+      if (!sweep1Applies(b)) { snprintf(g_err, sizeof(g_err), "pairs for all channels need uniform knot sites and constraints in serial form"); return BATOTP_ERR_STATE; }
+      lanes = 64;
+   }
    if (lanes == 64 && !sweep1Applies(b)) lanes = 32; // a parallel mechanism's torque limits, uploaded sites: the general kernel
    // the gate of the flat loop (its canary launches sweeps of its own) is settled before this sweep's timed region starts
    if (b->ctx->sweepHold[dir == -1 ? 0 : 1] == -2 && (lanes == 8 || lanes == 4 || lanes == 2) && featureLevel(b) <= 0) (void)flatLoopStatus(b->ctx);
@@ -1482,7 +1498,7 @@ extern "C" int batotp_hip_download_coeffs(batotp_batch *b, int32_t path, int32_t
    const int bs = 256;
    if (b->compact)
       hipLaunchKernelGGL(k_coef_from_sol, dim3((unsigned)((pi.n + bs - 1) / bs)), dim3(bs), 0, b->ctx->stream,
-                         b->dKM + pi.koff * b->P.Cin * 2, b->P.Cin, dc, pi.n, b->dStage);
+                         b->dKM + pi.koff * b->kmC * 2, b->kmC, dc, pi.n, b->dStage);
    else
       hipLaunchKernelGGL(k_coef_gather, dim3((unsigned)((pi.n + bs - 1) / bs)), dim3(bs), 0, b->ctx->stream,
                          b->dCoef + pi.koff * b->P.C * 4, b->P.C, dc, pi.n, b->dStage);
@@ -1507,6 +1523,7 @@ extern "C" int batotp_hip_download_samples(batotp_batch *b, int32_t path, int32_
 extern "C" int batotp_hip_download_dyn(batotp_batch *b, int32_t path, int32_t k, int32_t row, double *out)
 {
    if (!b || !out || path < 0 || path >= b->B || k < 1 || k > 4 || row < 0 || row >= b->P.d) return BATOTP_ERR_ARG;
+   if (b->pairsAll) return BATOTP_ERR_STATE; // no dynamics array: the values are c0 of the channel's rows (batotp_hip_download_coeffs)
    int rc = bind(b->ctx);
    if (rc) return rc;
    const PathInfo &pi = b->pinfo[path];

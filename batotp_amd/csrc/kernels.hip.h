@@ -245,7 +245,8 @@ __device__ __forceinline__ void spline_channel(const PathInfo *__restrict__ pinf
    const int N = (int)pi.n;
    // PAIRS (compact splines): src = scratch = the knot-major array of (value, second derivative) pairs,
    // [N][C][2]; the value of knot i of channel c is element (i*C + c)*2, its scratch slot the next one
-   const int64_t streamOff = PAIRS ? pi.koff * C * 2 + (int64_t)c * 2 : pi.koff * src_stride_per_knot + (int64_t)c * N;
+   // (PAIRS: Cin carries the first channel of the nch series inside the C channels of a knot)
+   const int64_t streamOff = PAIRS ? pi.koff * C * 2 + (int64_t)(Cin + c) * 2 : pi.koff * src_stride_per_knot + (int64_t)c * N;
    const double *__restrict__ y = src + streamOff;
    double *__restrict__ dpark = scratch + streamOff + (PAIRS ? 1 : 0); // eliminated right-hand sides d[i]
    double *__restrict__ cf = coef + pi.koff * C * 4;
@@ -267,9 +268,12 @@ __global__ void __launch_bounds__(64) k_spline_sol(const PathInfo *__restrict__ 
 }
 
 // compact splines of the hot path: km = [N][C][2] (value, second derivative) pairs per path, solved in place
-__global__ void __launch_bounds__(64) k_spline_pairs(const PathInfo *__restrict__ pinfo, int B, int C, double *__restrict__ km, const int *__restrict__ only)
+// (series c0 .. c0 + nch - 1 of the C channels a knot holds: the input channels of a velocity / acceleration-only batch, or -- all
+// channels as pairs -- the input channels and, in a second launch, the dynamics channels behind them)
+__global__ void __launch_bounds__(64) k_spline_pairs(const PathInfo *__restrict__ pinfo, int B, int nch, int c0, int C, double *__restrict__ km,
+                                                     const int *__restrict__ only)
 {
-   spline_channel<true, true>(pinfo, B, C, 0, C, C, 1, km, (int64_t)C, km, nullptr, only);
+   spline_channel<true, true>(pinfo, B, nch, 0, C, c0, 1, km, (int64_t)C, km, nullptr, only);
 }
 
 // natural-spline second derivatives of arbitrary series: series k has n[k] values y[yOff[k] + i*ys] and leaves its
@@ -549,11 +553,51 @@ __device__ __forceinline__ void cspr_setA(const double *pmat, const double *th, 
       for (int j = 0; j < 3; ++j) A[i * 3 + j] = (ca[i] - pmat[i * 3 + j]) / th[j];
 }
 
+// All channels as (value, second derivative) pairs (uniform sites): there is no sample array.  What k_samples would have stored
+// for site i of a path is formed from the pairs of the site's segment -- the same search, the same row (coeffs_from_sol =
+// emit_segment's formulas), the same three expressions.
+struct PairSite
+{
+   const double2 *kmP; // the path's pairs, kmC channels per knot
+   int kmC;
+   int64_t seg;
+   double tau, tau2, tau3, vf, af;
+   __device__ __forceinline__ void init(const PathInfo &pi, int64_t i, const double *km, int kmC_)
+   {
+      kmP = reinterpret_cast<const double2 *>(km) + pi.koff * kmC_;
+      kmC = kmC_;
+      const int64_t N = pi.n;
+      const double sScale = (pi.sres_c * (double)(N - 1)) / (double)(N - 1);
+      const double site = sScale * (double)i;
+      seg = (i < N - 1) ? i : N - 2;
+      while (seg > 0 && site < pi.sres_c * (double)seg) --seg;
+      while (seg < N - 2 && !(site < pi.sres_c * (double)(seg + 1))) ++seg;
+      tau = (site - pi.sres_c * (double)seg) / (pi.sres_c * (double)(seg + 1) - pi.sres_c * (double)seg);
+      tau2 = tau * tau; tau3 = tau2 * tau;
+      vf = 1.0 / pi.sres_c; af = vf * vf;
+   }
+   // findInterpSegs aborts when two knots coincide (spline.cpp:81-89)
+   __device__ __forceinline__ static bool coincide(const PathInfo &pi, int64_t i)
+   {
+      return i < pi.n - 1 && (pi.sres_c * (double)(i + 1) - pi.sres_c * (double)i) < 1e-20;
+   }
+   // sample `ord` (0 value, 1 d/ds, 2 d2/ds2) of input channel c
+   __device__ __forceinline__ double sample(int c, int ord) const
+   {
+      const double2 a = kmP[seg * kmC + c], b = kmP[(seg + 1) * kmC + c];
+      const Coef4 k = coeffs_from_sol(a.y, b.y, a.x, b.x);
+      if (ord == 0) return k.c3 * tau3 + k.c2 * tau2 + k.c1 * tau + k.c0;
+      if (ord == 1) return (3 * k.c3 * tau2 + 2 * k.c2 * tau + k.c1) * vf;
+      return (6 * k.c3 * tau + 2 * k.c2) * af;
+   }
+};
+
 // ---------------------------------------------------------------------------------------------
 // K2b: dynamics coefficients a1..a4 at the knots (ba.cpp:873-938).  One thread per knot.
 // ---------------------------------------------------------------------------------------------
 __global__ void k_dynamics(DevProblem P, const DevProblem *__restrict__ dP, const PathInfo *__restrict__ pinfo, int B, const double *__restrict__ samp,
-                           const double *__restrict__ trig, double *__restrict__ dyn, int64_t total)
+                           const double *__restrict__ trig, double *__restrict__ dyn, int64_t total, double *km = nullptr, int kmC = 0,
+                           batotp_path_result *__restrict__ res = nullptr)
 {
    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
    if (g >= total) return;
@@ -568,17 +612,31 @@ __global__ void k_dynamics(DevProblem P, const DevProblem *__restrict__ dP, cons
    const double *__restrict__ sp = samp + pi.koff * P.Cin * 3;
    double *__restrict__ dy = dyn + pi.koff * 4 * P.d;
    const int d = P.d;
+   // All channels as pairs (km != nullptr): samples through PairSite, and a1..a4 go straight into the value slots of their
+   // channels (device channel Cin + 4 r + k), where K1 then solves them in place -- no sample array, no dynamics array.
+   const bool fused = km != nullptr;
+   PairSite ps;
+   if (fused)
+   {
+      ps.init(pi, i, km, kmC);
+      if (PairSite::coincide(pi, i) && res) atomicOr(&res[lo].status_rev, (unsigned)BATOTP_ST_SEG_ERROR);
+   }
+   auto S = [&](int c, int ord) -> double { return fused ? ps.sample(c, ord) : sp[((int64_t)c * 3 + ord) * N + i]; };
+   // a_k of dynamics row r
+   auto D = [&](int k, int r, double v) {
+      if (fused) km[((pi.koff + i) * kmC + P.Cin + r * 4 + k) * 2] = v;
+      else dy[((int64_t)k * d + r) * N + i] = v;
+   };
 
    if (P.flags & BATOTP_F_PARALLEL)
    {
       // Robot::dynCSPR3DOF (robot.cpp:487-517)
       double a1[3], a2[3], a3[3], a4[3];
-      const double *__restrict__ cs = sp + (int64_t)P.nJ * 3 * N;
 #pragma unroll
       for (int j = 0; j < 3; ++j)
       {
-         a1[j] = -cs[((int64_t)j * 3 + 1) * N + i];
-         a2[j] = -cs[((int64_t)j * 3 + 2) * N + i];
+         a1[j] = -S(P.nJ + j, 1);
+         a2[j] = -S(P.nJ + j, 2);
          a3[j] = 0.0;
          a4[j] = 0.0;
       }
@@ -590,8 +648,8 @@ __global__ void k_dynamics(DevProblem P, const DevProblem *__restrict__ dP, cons
 #pragma unroll
          for (int j = 0; j < 3; ++j)
          {
-            ca[j] = cs[((int64_t)j * 3) * N + i];
-            th[j] = sp[((int64_t)j * 3) * N + i];
+            ca[j] = S(P.nJ + j, 0);
+            th[j] = S(j, 0);
          }
          cspr_setA(dP->pmat, th, ca, A);
          solve3(P.flags, A, a1, xs); a1[0] = xs[0]; a1[1] = xs[1]; a1[2] = xs[2];
@@ -602,10 +660,10 @@ __global__ void k_dynamics(DevProblem P, const DevProblem *__restrict__ dP, cons
 #pragma unroll
       for (int j = 0; j < 3; ++j)
       {
-         dy[((int64_t)0 * d + j) * N + i] = a1[j];
-         dy[((int64_t)1 * d + j) * N + i] = a2[j];
-         dy[((int64_t)2 * d + j) * N + i] = a3[j];
-         dy[((int64_t)3 * d + j) * N + i] = a4[j];
+         D(0, j, a1[j]);
+         D(1, j, a2[j]);
+         D(2, j, a3[j]);
+         D(3, j, a4[j]);
       }
       return;
    }
@@ -614,12 +672,12 @@ __global__ void k_dynamics(DevProblem P, const DevProblem *__restrict__ dP, cons
    const double kDeg2Rad = 3.14159265358979323846 / 180.0;
    const double kG = 9.81;
    double A1 = .4, A2 = .6, m1 = 4, m2 = 8;
-   const double th1 = kDeg2Rad * sp[(0 * 3 + 0) * N + i];
-   const double th2 = kDeg2Rad * sp[((int64_t)1 * 3 + 0) * N + i];
-   const double dth1 = kDeg2Rad * sp[(0 * 3 + 1) * N + i];
-   const double dth2 = kDeg2Rad * sp[((int64_t)1 * 3 + 1) * N + i];
-   const double ddth1 = kDeg2Rad * sp[(0 * 3 + 2) * N + i];
-   const double ddth2 = kDeg2Rad * sp[((int64_t)1 * 3 + 2) * N + i];
+   const double th1 = kDeg2Rad * S(0, 0);
+   const double th2 = kDeg2Rad * S(1, 0);
+   const double dth1 = kDeg2Rad * S(0, 1);
+   const double dth2 = kDeg2Rad * S(1, 1);
+   const double ddth1 = kDeg2Rad * S(0, 2);
+   const double ddth2 = kDeg2Rad * S(1, 2);
    double c1, c2, c12, s2;
    if (trig != nullptr)
    {
@@ -635,14 +693,14 @@ __global__ void k_dynamics(DevProblem P, const DevProblem *__restrict__ dP, cons
    const double A12 = .5 * m2 * (.5 * A2 * A2 + A1 * A2 * c2);
    const double A22 = .25 * m2 * A2 * A2;
    const double ccFact = m2 * A1 * A2 * s2;
-   dy[((int64_t)0 * d + 0) * N + i] = A11 * dth1 + A12 * dth2;
-   dy[((int64_t)0 * d + 1) * N + i] = A12 * dth1 + A22 * dth2;
-   dy[((int64_t)1 * d + 0) * N + i] = A11 * ddth1 + A12 * ddth2 - ccFact * dth2 * (dth1 + .5 * dth2);
-   dy[((int64_t)1 * d + 1) * N + i] = A12 * ddth1 + A22 * ddth2 - .5 * ccFact * dth1 * dth1;
-   dy[((int64_t)2 * d + 0) * N + i] = 10 * dth1;
-   dy[((int64_t)2 * d + 1) * N + i] = 10 * dth2;
-   dy[((int64_t)3 * d + 0) * N + i] = .5 * kG * (m1 * A1 * c1 + m2 * (2.0 * A1 * c1 + A2 * c12));
-   dy[((int64_t)3 * d + 1) * N + i] = .5 * kG * m2 * A2 * c12;
+   D(0, 0, A11 * dth1 + A12 * dth2);
+   D(0, 1, A12 * dth1 + A22 * dth2);
+   D(1, 0, A11 * ddth1 + A12 * ddth2 - ccFact * dth2 * (dth1 + .5 * dth2));
+   D(1, 1, A12 * ddth1 + A22 * ddth2 - .5 * ccFact * dth1 * dth1);
+   D(2, 0, 10 * dth1);
+   D(2, 1, 10 * dth2);
+   D(3, 0, .5 * kG * (m1 * A1 * c1 + m2 * (2.0 * A1 * c1 + A2 * c12)));
+   D(3, 1, .5 * kG * m2 * A2 * c12);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -779,7 +837,8 @@ __device__ __forceinline__ void rnea_pass(const batotp_serial_model &m, const do
 constexpr int KDS_BLOCK = 128;
 __global__ void __launch_bounds__(KDS_BLOCK) k_dyn_serial(const batotp_serial_model *__restrict__ model, int Cin,
                                                           const PathInfo *__restrict__ pinfo, int B, const double *__restrict__ samp,
-                                                          const double *__restrict__ trig, double *__restrict__ dyn, int64_t total)
+                                                          const double *__restrict__ trig, double *__restrict__ dyn, int64_t total,
+                                                          double *km = nullptr, int kmC = 0, batotp_path_result *__restrict__ res = nullptr)
 {
    __shared__ batotp_serial_model sm;
    {
@@ -805,6 +864,19 @@ __global__ void __launch_bounds__(KDS_BLOCK) k_dyn_serial(const batotp_serial_mo
    double *__restrict__ dy = dyn + pi.koff * 4 * nl;
    const double kDeg2Rad = 3.14159265358979323846 / 180.0;
    const double unit = sm.degrees ? kDeg2Rad : 1.0;
+   // all channels as pairs (km != nullptr): as in k_dynamics
+   const bool fused = km != nullptr;
+   PairSite ps;
+   if (fused)
+   {
+      ps.init(pi, i, km, kmC);
+      if (PairSite::coincide(pi, i) && res) atomicOr(&res[lo].status_rev, (unsigned)BATOTP_ST_SEG_ERROR);
+   }
+   auto S = [&](int c, int ord) -> double { return fused ? ps.sample(c, ord) : sp[((int64_t)c * 3 + ord) * N + i]; };
+   auto D = [&](int k, int r, double v) {
+      if (fused) km[((pi.koff + i) * kmC + Cin + r * 4 + k) * 2] = v;
+      else dy[((int64_t)k * nl + r) * N + i] = v;
+   };
 
    double cq[BATOTP_MAX_LINKS], sq[BATOTP_MAX_LINKS], q1[BATOTP_MAX_LINKS], q2[BATOTP_MAX_LINKS], z[BATOTP_MAX_LINKS];
 #pragma unroll
@@ -813,9 +885,9 @@ __global__ void __launch_bounds__(KDS_BLOCK) k_dyn_serial(const batotp_serial_mo
       cq[j] = 1; sq[j] = 0; q1[j] = 0; q2[j] = 0; z[j] = 0;
       if (j < nl)
       {
-         const double q = unit * sp[((int64_t)j * 3 + 0) * N + i];
-         q1[j] = unit * sp[((int64_t)j * 3 + 1) * N + i];
-         q2[j] = unit * sp[((int64_t)j * 3 + 2) * N + i];
+         const double q = unit * S(j, 0);
+         q1[j] = unit * S(j, 1);
+         q2[j] = unit * S(j, 2);
          if (tg) { cq[j] = tg[(int64_t)j * N + i]; sq[j] = tg[(int64_t)(nl + j) * N + i]; }
          else { cq[j] = cos(q); sq[j] = sin(q); } // device libm: not bit-identical to glibc (BATOTP_F_HOST_TRIG)
       }
@@ -831,10 +903,10 @@ __global__ void __launch_bounds__(KDS_BLOCK) k_dyn_serial(const batotp_serial_mo
    {
       if (j < nl)
       {
-         dy[((int64_t)0 * nl + j) * N + i] = t1[j];
-         dy[((int64_t)1 * nl + j) * N + i] = t2[j];
-         dy[((int64_t)2 * nl + j) * N + i] = sm.link[j].fv * q1[j];
-         dy[((int64_t)3 * nl + j) * N + i] = t4[j];
+         D(0, j, t1[j]);
+         D(1, j, t2[j]);
+         D(2, j, sm.link[j].fv * q1[j]);
+         D(3, j, t4[j]);
       }
    }
 }
@@ -1640,8 +1712,24 @@ __global__ void __launch_bounds__(K3_BLOCK) k_pointwise(DevProblem P, const Path
    else
    {
       const int rowLocal = (int)threadIdx.x - (i - t.segC); // the last knot of a path uses the previous row
-      const double *row = (useTile && rowLocal >= 0) ? (tile + rowLocal * rowPad) : (t.coef + (unsigned)(t.segC * rowD));
-      eval_partials_row(t, 0, row);
+      if (km != nullptr)
+      {
+         // all channels as pairs: the row of the knot's segment is formed here (emit_segment's formulas)
+         alignas(32) double rowLoc[(BATOTP_MAX_JOINTS + BATOTP_MAX_CART + 4 * BATOTP_MAX_JOINTS) * 4];
+         const double2 *__restrict__ kp = reinterpret_cast<const double2 *>(km) + (pi.koff + t.segC) * P.C;
+         for (int c = 0; c < P.C; ++c)
+         {
+            const double2 a = kp[c], bq = kp[P.C + c];
+            const Coef4 k = coeffs_from_sol(a.y, bq.y, a.x, bq.x);
+            rowLoc[c * 4 + 0] = k.c0; rowLoc[c * 4 + 1] = k.c1; rowLoc[c * 4 + 2] = k.c2; rowLoc[c * 4 + 3] = k.c3;
+         }
+         eval_partials_row(t, 0, rowLoc);
+      }
+      else
+      {
+         const double *row = (useTile && rowLocal >= 0) ? (tile + rowLocal * rowPad) : (t.coef + (unsigned)(t.segC * rowD));
+         eval_partials_row(t, 0, row);
+      }
    }
    double sdot = t.sdotCap;
    sdot_lim(t, 0, sdot);
@@ -2235,7 +2323,7 @@ __global__ void k_coef_from_sol(const double *__restrict__ kmPath, int C, int dc
 }
 // knot values of paths [path0, path0+n) from the C-ABI layout (path after path, [C][N] each) into the value
 // slots of the pair array; one lane per knot
-__global__ void k_pairs_from_rows(const PathInfo *__restrict__ pinfo, int path0, int nPaths, int C, const double *__restrict__ rows,
+__global__ void k_pairs_from_rows(const PathInfo *__restrict__ pinfo, int path0, int nPaths, int C, int kmC, const double *__restrict__ rows,
                                   double *__restrict__ km, int64_t total)
 {
    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2249,7 +2337,7 @@ __global__ void k_pairs_from_rows(const PathInfo *__restrict__ pinfo, int path0,
    }
    const int64_t off = pinfo[lo].koff - base, N = pinfo[lo].n, i = g - off;
    const double *src = rows + off * C + i;
-   double *dst = km + ((pinfo[lo].koff + i) * C) * 2;
+   double *dst = km + ((pinfo[lo].koff + i) * kmC) * 2; // kmC channels per knot in the pair array (C of them are input channels)
    for (int c = 0; c < C; ++c) dst[2 * c] = src[(int64_t)c * N];
 }
 __global__ void k_coef_scatter(double *__restrict__ coefPath, int C, int dc, int64_t N, const double *__restrict__ in)

@@ -34,6 +34,7 @@ struct OutParams
    int window;      // (int)_outSmoothFact when smoothing, else 0
    int reinterp;
    int compact;     // the batch keeps (value, second derivative) pairs instead of coefficient rows
+   int kmC;         // ... channels per knot in the pair array (Cin, or C when all channels are pairs)
    int svd;         // BATOTP_F_SVD: the cable tensions through the Jacobi SVD instead of the LU
    int C, Cin;
    double outRes;
@@ -173,7 +174,7 @@ __global__ void k_out_eval(OutParams P, const OutPath *__restrict__ paths, int K
       Coef4 k;
       if (P.compact)
       {
-         const double *a = km + ((pi.koff + seg) * P.Cin + c) * 2, *b = a + 2 * P.Cin;
+         const double *a = km + ((pi.koff + seg) * P.kmC + c) * 2, *b = a + 2 * P.kmC;
          k = coeffs_from_sol(a[1], b[1], a[0], b[0]);
       }
       else k = *reinterpret_cast<const Coef4 *>(coef + ((pi.koff + seg) * P.C + c) * 4);

@@ -47,6 +47,7 @@ struct TileArgs
    int pairs;               // 1: compact layout (km in place), 0: channel-major rows in, coefficient rows out
    int nch;                 // series per path in this launch
    int C, Cin, d;
+   int c0;                  // pairs: first of the launch's nch series among the C channels of a knot
    const double *src;       // rows: channel-major values, path at koff*srcStride
    int64_t srcStride;
    double *km;              // pairs: [N][C][2] per path at koff*C*2
@@ -99,7 +100,7 @@ __global__ void __launch_bounds__(ST_BLOCK) k_spline_tile(TileArgs a)
       for (int x = tid; x < cnt; x += ST_BLOCK)
       {
          const int kk = x / a.C, c = x - kk * a.C;
-         if (c >= e0 && c < e0 + nc) Y[c - e0][kk] = g[(int64_t)(k0 + kk) * a.C + c].x;
+         if (c >= a.c0 + e0 && c < a.c0 + e0 + nc) Y[c - a.c0 - e0][kk] = g[(int64_t)(k0 + kk) * a.C + c].x;
       }
    }
    else
@@ -258,7 +259,7 @@ __global__ void __launch_bounds__(ST_BLOCK) k_spline_tile(TileArgs a)
          // In place: a neighbouring block of this launch may still be LOADING the .x of these knots as its halo while this
          // store runs.  Invariant that makes that harmless: the stored .x is bit-identical to the value loaded (Y is never
          // modified), so a reader sees the same 8 bytes before, during and after the store; .y is only read by later kernels.
-         if (c >= e0 && c < e0 + nc) g[(int64_t)(t0 + kk) * a.C + c] = make_double2(Y[c - e0][t0 + kk - k0], S[c - e0][kk]);
+         if (c >= a.c0 + e0 && c < a.c0 + e0 + nc) g[(int64_t)(t0 + kk) * a.C + c] = make_double2(Y[c - a.c0 - e0][t0 + kk - k0], S[c - a.c0 - e0][kk]);
       }
    }
    else

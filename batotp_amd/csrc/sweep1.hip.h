@@ -67,6 +67,11 @@ __constant__ double c_s1B[36] = {BK_B00, BK_B01, BK_B02, BK_B03, BK_B04, BK_B05,
 constexpr int S1_BLOCK = 256;
 constexpr int S1_WK = 64;   // knots per spline window (compact splines: 64 knots x 8 joint slots x 16 B = 8 KB per path)
 constexpr int S1_WM = 256;  // points per reverse-curve window (4 KB per path)
+#ifndef S1_WR_BYTES
+#define S1_WR_BYTES 12288   // coefficient rows (FEAT >= 0): LDS bytes per path for the window of consecutive rows (C x 32 B each: 21 rows of the
+                            // cable robot's 18 channels, 10 of the 7-DOF arm's 38).  With the reverse-curve window of the forward sweep a
+                            // block of four paths takes 64.4 KB: two blocks per CU (two wavefronts per SIMD) still fit the 160 KB
+#endif
 
 // FEAT: -1 = compact splines ((value, second derivative) pairs), 0 = coefficient rows, 1 = coefficient rows + the Cartesian
 // speed / acceleration limits (ba.cpp:1225-1229, 1423-1439, 1535-1579), 2 = those + torque limits of a
@@ -85,6 +90,8 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    // wavefront were s_waitcnt without the windows: profiles/r02_e_*).
    __shared__ double2 winKAll[(FEAT < 0) ? S1_BLOCK / 64 : 1][(FEAT < 0) ? S1_WK * BATOTP_MAX_JOINTS : 1];
    __shared__ double2 winMAll[(DIR == 1) ? S1_BLOCK / 64 : 1][(DIR == 1) ? S1_WM : 1];
+   constexpr bool ROWWIN = FEAT >= 0 && S1_WR_BYTES > 0;
+   __shared__ double2 winRAll[ROWWIN ? S1_BLOCK / 64 : 1][ROWWIN ? S1_WR_BYTES / 16 : 1];
    stage_limits(a.dP, lim);
    const int lane = threadIdx.x & 63;
    const int p = blockIdx.x * (S1_BLOCK / 64) + (threadIdx.x >> 6);
@@ -112,6 +119,8 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
 
    const double2 *__restrict__ km = (FEAT < 0) ? reinterpret_cast<const double2 *>(a.km) + pi.koff * nIn : nullptr;
    const double *__restrict__ coef = (FEAT < 0) ? nullptr : a.coef + pi.koff * C * 4;
+   // FEAT >= 0 on a batch that keeps ALL channels as pairs (a.km set, C channels per knot): rows exist in the LDS window only
+   const double2 *__restrict__ kmAll = (FEAT >= 0 && a.km != nullptr) ? reinterpret_cast<const double2 *>(a.km) + pi.koff * C : nullptr;
    double2 *out = (DIR == 1 ? a.fwd : a.rev) + (int64_t)p * cap; // forward, curves in place: the same buffer as mvc (no __restrict__)
    batotp_path_result *__restrict__ r = a.res + p;
 
@@ -164,6 +173,9 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
    double2 *winM = winMAll[(DIR == 1) ? (threadIdx.x >> 6) : 0];
    int wK0 = 0, wKn = 0; // knots [wK0, wK0 + wKn) are in winK, layout [knot][8 joint slots]
    int wM0 = 0, wMn = 0; // curve points [wM0, wM0 + wMn) are in winM
+   double2 *winR = winRAll[ROWWIN ? (threadIdx.x >> 6) : 0];
+   const bool rowWin = ROWWIN && (kmAll != nullptr || (FEAT == 2 && FF == 0));
+   int wR0 = 0, wRn = 0; // coefficient rows [wR0, wR0 + wRn) are in winR, C x 4 doubles each
 
    // make knots seg and seg + 1 available in winK: a coalesced copy of the window that extends from seg in the direction of
    // travel (two knots of slack behind it).  Fixed stride of 8 slots per knot: Cartesian channels the batch may carry are not
@@ -196,6 +208,74 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
 #undef S1_LD
 #undef S1_ST
       wK0 = w; wKn = cntK;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+   };
+   // The same for coefficient rows (FEAT >= 0): a segment change then reads LDS instead of waiting for a dependent HBM access (the
+   // cable robot changes segment at nearly every stage -- 0.4 steps per knot -- and every change cost the lone wavefront a memory
+   // round trip).  Rows are knot-major and contiguous: the window is ONE contiguous block of HBM.
+   auto needR = [&](int seg) __attribute__((always_inline)) {
+      if (S1_UNI(seg >= wR0 && seg < wR0 + wRn)) return;
+      const int rowD2 = C * 2;                        // 16-byte units per row
+      const int WR = (S1_WR_BYTES / 16) / rowD2;      // rows per window (C <= 8 + 3 + 32 channels: at least 11)
+      const int nRows = n - 1;                        // rows 0 .. n - 2, one per segment
+      int w = (DIR == 1) ? seg - 1 : seg + 2 - WR;    // a row of slack behind the direction of travel
+      const int wmax = nRows - WR;
+      w = w > wmax ? wmax : w;
+      w = w < 0 ? 0 : w;
+      const int cntR = (nRows - w) < WR ? (nRows - w) : WR;
+      const int total = cntR * rowD2;
+      if (kmAll != nullptr)
+      {
+         // all channels as (value, second derivative) pairs: the rows of the window are FORMED here, one (row, channel) per lane
+         // and round -- emit_segment's formulas (spline.cpp:203-209) with x / 6 through div6 --, and nothing but the pairs
+         // (half the bytes of the rows) is resident in HBM
+         const int cells = cntR * C;
+         const double2 *__restrict__ kp = kmAll + (int64_t)w * C;
+#pragma unroll 1
+         for (int e0 = 0; e0 < cells; e0 += 128)
+         {
+            double2 la[4], lb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+            {
+               int e = e0 + lane + 32 * u;
+               e = e < cells ? e : cells - 1;
+               la[u] = kp[e];
+               lb[u] = kp[e + C];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+            {
+               const int e = e0 + lane + 32 * u;
+               const double solL = la[u].y, solR = lb[u].y, yL = la[u].x, yR = lb[u].x;
+               const double k3 = div6(solR - solL);
+               const double k2 = solL / 2.0;
+               const double k1 = yR - yL - div6(solR + 2 * solL);
+               if (e < cells) { winR[2 * e] = make_double2(yL, k1); winR[2 * e + 1] = make_double2(k2, k3); }
+            }
+         }
+         wR0 = w; wRn = cntR;
+         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+         __builtin_amdgcn_wave_barrier();
+         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+         return;
+      }
+      const double2 *__restrict__ src = reinterpret_cast<const double2 *>(coef + (int64_t)w * C * 4);
+#define S1_LD(T, I) { const int e = e0 + lane + 32 * I; T = src[e < total ? e : total - 1]; }
+#define S1_ST(T, I) { const int e = e0 + lane + 32 * I; if (e < total) winR[e] = T; }
+#pragma unroll 1
+      for (int e0 = 0; e0 < total; e0 += 256)
+      {
+         double2 t0, t1, t2, t3, t4, t5, t6, t7;
+         S1_LD(t0, 0) S1_LD(t1, 1) S1_LD(t2, 2) S1_LD(t3, 3) S1_LD(t4, 4) S1_LD(t5, 5) S1_LD(t6, 6) S1_LD(t7, 7)
+         __builtin_amdgcn_sched_barrier(0);
+         S1_ST(t0, 0) S1_ST(t1, 1) S1_ST(t2, 2) S1_ST(t3, 3) S1_ST(t4, 4) S1_ST(t5, 5) S1_ST(t6, 6) S1_ST(t7, 7)
+      }
+#undef S1_LD
+#undef S1_ST
+      wR0 = w; wRn = cntR;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -268,25 +348,34 @@ __global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
          }
          else
          {
-            const double *__restrict__ row = coef + (unsigned)(segC * C * 4);
-            const Coef4 k = *reinterpret_cast<const Coef4 *>(row + jr * 4);
-            k3 = k.c3; k2 = k.c2; k1 = k.c1;
-            if (FEAT >= 1 && cartAny)
-            {
-#pragma unroll
-               for (int q = 0; q < ((FEAT >= 1) ? 3 : 1); ++q)
+            auto readRow = [&](auto row) __attribute__((always_inline)) {
+               const Coef4 k = *reinterpret_cast<const Coef4 *>(row + jr * 4);
+               k3 = k.c3; k2 = k.c2; k1 = k.c1;
+               if (FEAT >= 1 && cartAny)
                {
-                  const Coef4 kc = *reinterpret_cast<const Coef4 *>(row + (nJ + q) * 4);
-                  cA3[q] = 3 * kc.c3; cB2[q] = 2 * kc.c2; cA6[q] = 6 * kc.c3; cC1[q] = kc.c1;
-               }
-            }
-            if (FEAT == 2)
-            {
-               // device channel order: theta[nJ], cart[nC], then per dynamics row r the four channels (a1_r, a2_r, a3_r, a4_r)
-               const Coef4 *kd = reinterpret_cast<const Coef4 *>(row + (nIn + jr * 4) * 4);
 #pragma unroll
-               for (int q = 0; q < 4; ++q) dynK[(FEAT == 2) ? q : 0] = kd[q];
+                  for (int q = 0; q < ((FEAT >= 1) ? 3 : 1); ++q)
+                  {
+                     const Coef4 kc = *reinterpret_cast<const Coef4 *>(row + (nJ + q) * 4);
+                     cA3[q] = 3 * kc.c3; cB2[q] = 2 * kc.c2; cA6[q] = 6 * kc.c3; cC1[q] = kc.c1;
+                  }
+               }
+               if (FEAT == 2)
+               {
+                  // device channel order: theta[nJ], cart[nC], then per dynamics row r the four channels (a1_r, a2_r, a3_r, a4_r)
+                  const Coef4 *kd = reinterpret_cast<const Coef4 *>(row + (nIn + jr * 4) * 4);
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) dynK[(FEAT == 2) ? q : 0] = kd[q];
+               }
+            };
+            // rows through the LDS window (always when the batch keeps pairs only; for rows in HBM where it measured faster:
+            // the cable robot's sweeps 4-6 %, not the 7-DOF arm's, whose cursor needs a new row every other step), or from HBM
+            if (ROWWIN && rowWin)
+            {
+               needR(segC);
+               readRow(reinterpret_cast<const double *>(winR) + (unsigned)((segC - wR0) * C * 4));
             }
+            else readRow(coef + (unsigned)(segC * C * 4));
          }
          // lanes beyond the last joint carry joint 0's numbers; every use of thD / thD2 is behind `jv`
          A3 = 3 * k3;

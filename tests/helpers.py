@@ -155,10 +155,13 @@ def run_to_output(ctx, cases, extra_flags=0):
     return capi.Output(b, output_params(cases[0].name), 0, len(cases)), b
 
 
-def precompute_with_trig(ctx, b, prob, n_paths, serial_model=None):
+def precompute_with_trig(ctx, b, prob, n_paths, serial_model=None, samples_from=None):
     """both precompute stages of a batch whose knots are uploaded, with the model table and the host trig tables the
     dynamics of a serial robot need in between (what the host layer does in ba_device.cpp)"""
     b.precompute(1)
+    # (a batch without a sample array -- pairs for all channels -- takes the joint samples of the host trig tables from a run of the
+    #  same cases that kept them: samples_from[k]["samp"])
+    samples = (lambda k, j: samples_from[k]["samp"][j]) if samples_from is not None else (lambda k, j: b.samples(k, j))
     if prob.flags & capi.F_TRQ_ON:
         if serial_model is None and needs_serial_model(prob):
             serial_model = ctx.library.builtin_serial_model(prob.robot_type)
@@ -166,10 +169,10 @@ def precompute_with_trig(ctx, b, prob, n_paths, serial_model=None):
             b.set_serial_model(serial_model)
             if prob.flags & capi.F_HOST_TRIG:
                 for k in range(n_paths):
-                    b.upload_joint_trig(k, joint_trig(serial_model, [b.samples(k, j)[0] for j in range(prob.n_joints)]))
+                    b.upload_joint_trig(k, joint_trig(serial_model, [samples(k, j)[0] for j in range(prob.n_joints)]))
         elif prob.robot_type == capi.ROBOT_RR and (prob.flags & capi.F_HOST_TRIG):
             for k in range(n_paths):
-                b.upload_rr_trig(k, rr_trig(b.samples(k, 0)[0], b.samples(k, 1)[0]))
+                b.upload_rr_trig(k, rr_trig(samples(k, 0)[0], samples(k, 1)[0]))
         b.precompute(2)
 
 
@@ -213,7 +216,7 @@ def needs_serial_model(prob):
     return bool(prob.flags & capi.F_TRQ_ON) and not (prob.flags & capi.F_PARALLEL) and prob.robot_type != capi.ROBOT_RR
 
 
-def run_pipeline(ctx, cases, max_steps=None, mvc=True, details=True, extra_flags=0, serial_model=None):
+def run_pipeline(ctx, cases, max_steps=None, mvc=True, details=True, extra_flags=0, serial_model=None, samples_from=None):
     """knots -> precompute -> (pointwise) -> sweeps on the library behind `ctx`, as one batch.
 
     All cases must share one problem description.  Returns a list of dicts, one per case."""
@@ -227,7 +230,7 @@ def run_pipeline(ctx, cases, max_steps=None, mvc=True, details=True, extra_flags
     b = capi.Batch(ctx, prob, [c.n for c in cases], cap)
     for k, c in enumerate(cases):
         b.upload_knots(k, [c.y], [c.sres])
-    precompute_with_trig(ctx, b, prob, len(cases), serial_model)
+    precompute_with_trig(ctx, b, prob, len(cases), serial_model, samples_from)
     mvc_early = None
     if mvc:
         b.pointwise_mvc()
@@ -249,7 +252,8 @@ def run_pipeline(ctx, cases, max_steps=None, mvc=True, details=True, extra_flags
             d["coef"] = np.stack([b.coeffs(k, ch) for ch in range(nch)])
             if not (prob.flags & capi.F_NO_SAMPLES):
                 d["samp"] = np.stack([b.samples(k, ch) for ch in range(prob.n_joints + prob.n_cart)])
-            if prob.dyn_dim:
+            pairs_all = bool(prob.flags & capi.F_COMPACT_SPLINES) and (prob.dyn_dim or prob.flags & (capi.F_CART_VEL_ON | capi.F_CART_ACC_ON))
+            if prob.dyn_dim and not pairs_all:   # (pairs for all channels: no dynamics array, the values are c0 of the channels' rows)
                 d["dyn"] = np.stack([np.stack([b.dyn(k, kk, r) for r in range(prob.dyn_dim)]) for kk in (1, 2, 3, 4)])
         if mvc:
             d["mvc"] = mvc_early[k] if mvc_early is not None else np.stack(b.mvc(k))

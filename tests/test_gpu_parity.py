@@ -193,6 +193,36 @@ def test_compact_splines_give_identical_results(hip_lib, oracle_ctx, lanes):
         assert_matches_reference(case, ho)
 
 
+def _cart_or_torque(name):
+    p = Case(name).problem
+    par_branch = (p.flags & capi.F_TRQ_ON) and (p.flags & capi.F_PARALLEL) and not (p.flags & capi.F_PAR2SER)
+    return bool(p.flags & (capi.F_TRQ_ON | capi.F_CART_VEL_ON | capi.F_CART_ACC_ON)) and not par_branch
+
+
+def test_pairs_for_all_channels_give_identical_results(hip_lib, oracle_ctx):
+    """BATOTP_F_COMPACT_SPLINES on problems WITH Cartesian limits / torque limits (round 4): every channel -- joints, Cartesian,
+    a1..a4 of every dynamics row -- is kept as (value, second derivative) pairs, the samples are formed inside K2, the rows inside
+    K3 and in the LDS windows of the sweep kernel.  Every published quantity (the coefficient rows of ALL channels included) is
+    bit-identical to the oracle's rows, and the curves to the reference binary's"""
+    names = [n for n in helpers.FULL_CASES if _cart_or_torque(n)] + list(helpers.SELF_CASES)
+    assert len(names) >= 8, names
+    ctx = capi.Context(hip_lib, 0)
+    for name in names:
+        case = Case(name)
+        oo = run_pipeline(oracle_ctx, [case])[0]
+        ho = run_pipeline(ctx, [case], extra_flags=capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES, samples_from=[oo])[0]
+        oo.pop("samp", None)
+        dyn = oo.pop("dyn", None)
+        _compare(case, ho, oo)
+        if dyn is not None:   # the dynamics values are c0 of their channels' rows (C-ABI channel Cin + (k-1) d + r)
+            cin, d = case.problem.n_joints + case.problem.n_cart, case.problem.dyn_dim
+            for k in range(4):
+                for r in range(d):
+                    helpers.assert_bit_equal(ho["coef"][cin + k * d + r][0][:-1], dyn[k][r][:-1], f"{name}: a{k + 1} of row {r}")
+        assert_matches_reference(case, ho)
+    ctx.close()
+
+
 @pytest.mark.parametrize("name", helpers.DIGEST_CASES)
 def test_hip_baseline_size_paths(hip_ctx, oracle_ctx, name):
     case = Case(name)
