@@ -1056,11 +1056,11 @@ extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
          {                                                                                                                               \
             const int64_t cnt = (b->totalKnots - first) < sliceKnots ? (b->totalKnots - first) : sliceKnots;                            \
             hipLaunchKernelGGL(k_pointwise_grp<F>, dim3((unsigned)((cnt + knotsPerBlock - 1) / knotsPerBlock)), dim3(bs), 0,           \
-                               k3s, b->P, b->dPinfo, b->B, b->dP, b->dSC, b->dCoef, b->dKM, mvcOut, first,         \
+                               k3s, b->P, b->dPinfo, b->B, b->dP, b->dSC, b->dCoef, b->compact ? b->dKM : (double *)nullptr, mvcOut, first,         \
                                first + cnt, mvcSlot);                                                                                             \
          }                                                                                                                               \
       else hipLaunchKernelGGL(k_pointwise<F>, dim3(grid), dim3(bs), ldsBytes, k3s, b->P, b->dPinfo, b->B, b->dP, b->dSC,      \
-                              b->dCoef, b->dKM, mvcOut, b->totalKnots, useTile ? 1 : 0, mvcSlot);                                      \
+                              b->dCoef, b->compact ? b->dKM : (double *)nullptr, mvcOut, b->totalKnots, useTile ? 1 : 0, mvcSlot);                                      \
    } while (0)
    switch (featureLevel(b))
    {
@@ -1388,7 +1388,7 @@ extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
    if (rc) return rc;
    b->mvcValid = false; // BATOTP_F_MVC_IN_CURVES: the sweep writes over the pointwise values
    SweepArgs a;
-   a.P = b->P; a.dP = b->dP; a.pinfo = b->dPinfo; a.sC = b->dSC; a.coef = b->dCoef; a.km = b->dKM;
+   a.P = b->P; a.dP = b->dP; a.pinfo = b->dPinfo; a.sC = b->dSC; a.coef = b->dCoef; a.km = b->compact ? b->dKM : nullptr; // (a zero-size allocation is not a null pointer: the kernels of the row layouts take a non-null km for "all channels as pairs")
    a.rev = b->dRev; a.fwd = b->dFwd; a.res = b->dRes; a.sink = b->dSink; a.prof = b->dMvc; a.cap = b->cap; a.B = b->B; a.dir = dir; a.ppw = 1;
    const int which = dir == -1 ? 3 : 4;
    int lanes = b->ctx->sweepGroup;

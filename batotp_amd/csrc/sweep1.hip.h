@@ -80,7 +80,9 @@ constexpr int S1_WM = 256;  // points per reverse-curve window (4 KB per path)
 // lines in sdot^2 (the cable robot in serial form, whose a3 vanishes), 1: the general form for serial chains (a3 != 0).  One form
 // per kernel: with both in one instantiation the cable robot's sweeps were 2 % slower for code they never run.
 template <int FEAT, int DIR, int FF = 0>
-__global__ void __launch_bounds__(S1_BLOCK, 1) k_sweep1(SweepArgs a)
+// (the cable robot's instantiation is held to 256 registers: with its channels as pairs a chunk holds two paths per SIMD, and the
+//  forward kernel's 279 registers would leave the second one waiting)
+__global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0) ? 2 : 1) k_sweep1(SweepArgs a)
 {
    __shared__ double lim[6][8];
    // Sliding windows in LDS, one per wavefront (= per path): the (value, second derivative) pairs of S1_WK consecutive knots

@@ -325,7 +325,8 @@ def bytes_per_path(prob, C, n_mean, cap):
     cin, d = prob.n_joints + prob.n_cart, prob.dyn_dim
     mvc = 0 if (prob.flags & capi.F_MVC_IN_CURVES) else 24
     if prob.flags & capi.F_COMPACT_SPLINES:
-        per_knot = 16.0 * cin + mvc        # no site array for compact batches
+        pairs_all = d or (prob.flags & (capi.F_CART_VEL_ON | capi.F_CART_ACC_ON))   # every channel as a pair, nothing else per knot
+        per_knot = 16.0 * (C if pairs_all else cin) + mvc        # no site array for compact batches
     else:
         per_knot = 8.0 * cin + 8 + 32.0 * C + (0 if (prob.flags & capi.F_NO_SAMPLES) else 24.0 * cin) + 32.0 * d + mvc + 8.0 * max(cin, 4 * d)
         if d and not (prob.flags & capi.F_PARALLEL):
@@ -367,6 +368,10 @@ def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=
     prob = capi.Problem.from_buffer_copy(bytes(inp.prob))
     if (prob.flags & capi.F_NO_SAMPLES) and not coefficient_rows:
         prob.flags |= capi.F_COMPACT_SPLINES  # same results, half the spline bytes per knot: room for more paths per GPU
+    elif (prob.flags & capi.F_PARALLEL) and (prob.flags & capi.F_PAR2SER) and not coefficient_rows:
+        # the cable robot in serial form: every channel (cables, platform position, a1..a4 of every row) as (value, second
+        # derivative) pairs -- same results, 288 instead of 992 bytes per knot: twice the paths per chunk, two wavefronts per SIMD
+        prob.flags |= capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES
     if c.get("lean"):
         prob.flags |= capi.F_CURVES_IN_PLACE | capi.F_MVC_IN_CURVES   # same results, one curve buffer per path and nothing else per knot
     C = WORKLOADS[workload]["C"]
