@@ -899,6 +899,9 @@ int BA::optimizeBatchOnDevice(std::vector<Traj> &trajs)
    // nothing on the host reads knot samples or coefficient rows: joint velocity/acceleration-only problems keep their
    // splines as (value, second derivative) pairs (same results, less than half the memory per path)
    if (!_isTrqConOn && !_isCartVelConOn && !_isCartAccConOn) prob.flags |= BATOTP_F_NO_SAMPLES | BATOTP_F_COMPACT_SPLINES;
+   // ... and so does the cable robot in serial form, whose dynamics the device evaluates itself: every channel (cable lengths,
+   // platform position, a1..a4 of every row) as pairs -- 288 instead of 992 bytes per knot, twice the paths per chunk of a large batch
+   else if (_isTrqConOn && _isParallelMechOrig && _isPar2Ser) prob.flags |= BATOTP_F_NO_SAMPLES | BATOTP_F_COMPACT_SPLINES;
    // the reverse curves are only read back for s-sdot.dat: without it one curve buffer per path is enough (the forward curve
    // replaces the reverse curve, as traj.sMVC / traj.sdot do in the reference)
    if (!is_sdotOut) prob.flags |= BATOTP_F_CURVES_IN_PLACE;
