@@ -1015,8 +1015,25 @@ __device__ __forceinline__ void update_cur_seg(const double *__restrict__ s, dou
 }
 
 // BA::evalSplinePartials + evalCartQuadCoeffs (ba.cpp:1341-1439)
-template <int G, int FEAT, bool UNI>
-__device__ __forceinline__ void eval_partials_row(Pt<G, FEAT, UNI> &t, int j, const double *__restrict__ row)
+// SRC: where the coefficient row of the cursor's segment comes from -- src(c) returns c0..c3 of device channel c (a row in
+// memory: RowAt; formed on the fly from (value, second derivative) pairs: PairRowAt)
+struct RowAt
+{
+   const double *__restrict__ row;
+   __device__ __forceinline__ Coef4 operator()(int c) const { return *reinterpret_cast<const Coef4 *>(row + c * 4); }
+};
+struct PairRowAt
+{
+   const double2 *__restrict__ kp; // knot of the segment's left end, C channels per knot
+   int C;
+   __device__ __forceinline__ Coef4 operator()(int c) const
+   {
+      const double2 a = kp[c], b = kp[C + c];
+      return coeffs_from_sol(a.y, b.y, a.x, b.x);
+   }
+};
+template <int G, int FEAT, bool UNI, typename SRC>
+__device__ __forceinline__ void eval_partials_src(Pt<G, FEAT, UNI> &t, int j, const SRC &src)
 {
    constexpr bool PAR = (FEAT == 3);
    const double tau = t.tauC, tau2 = tau * tau, tau3 = tau2 * tau;
@@ -1027,7 +1044,7 @@ __device__ __forceinline__ void eval_partials_row(Pt<G, FEAT, UNI> &t, int j, co
       const int jj = j + q * G;
       if (jj < t.nJ)
       {
-         const Coef4 k = *reinterpret_cast<const Coef4 *>(row + jj * 4);
+         const Coef4 k = src(jj);
          t.thD[q] = (3 * k.c3 * tau2 + 2 * k.c2 * tau + k.c1) * t.vfact;
          t.thD2[q] = (6 * k.c3 * tau + 2 * k.c2) * t.afact;
       }
@@ -1038,7 +1055,7 @@ __device__ __forceinline__ void eval_partials_row(Pt<G, FEAT, UNI> &t, int j, co
 #pragma unroll
       for (int i = 0; i < 3; ++i)
       {
-         const Coef4 k = *reinterpret_cast<const Coef4 *>(row + (t.nJ + i) * 4);
+         const Coef4 k = src(t.nJ + i);
          if (PAR) t.cap[PAR ? i : 0] = k.c3 * tau3 + k.c2 * tau2 + k.c1 * tau + k.c0;
          v[i] = (3 * k.c3 * tau2 + 2 * k.c2 * tau + k.c1) * t.vfact;
          a[i] = (6 * k.c3 * tau + 2 * k.c2) * t.afact;
@@ -1054,9 +1071,9 @@ __device__ __forceinline__ void eval_partials_row(Pt<G, FEAT, UNI> &t, int j, co
 #pragma unroll
          for (int r = 0; r < 3; ++r)
          {
-            const Coef4 kt = *reinterpret_cast<const Coef4 *>(row + r * 4);
+            const Coef4 kt = src(r);
             t.thp[PAR ? r : 0] = kt.c3 * tau3 + kt.c2 * tau2 + kt.c1 * tau + kt.c0;
-            const Coef4 *kd = reinterpret_cast<const Coef4 *>(row + (t.nIn + r * 4) * 4);
+            const Coef4 kd[4] = {src(t.nIn + r * 4), src(t.nIn + r * 4 + 1), src(t.nIn + r * 4 + 2), src(t.nIn + r * 4 + 3)};
             t.pa1[PAR ? r : 0] = kd[0].c3 * tau3 + kd[0].c2 * tau2 + kd[0].c1 * tau + kd[0].c0;
             t.pa2[PAR ? r : 0] = kd[1].c3 * tau3 + kd[1].c2 * tau2 + kd[1].c1 * tau + kd[1].c0;
             t.pa3[PAR ? r : 0] = kd[2].c3 * tau3 + kd[2].c2 * tau2 + kd[2].c1 * tau + kd[2].c0;
@@ -1072,8 +1089,7 @@ __device__ __forceinline__ void eval_partials_row(Pt<G, FEAT, UNI> &t, int j, co
             const int jj = j + q * G;
             if (jj < t.nJ)
             {
-               const Coef4 *kd = reinterpret_cast<const Coef4 *>(row + (t.nIn + jj * 4) * 4);
-               const Coef4 k1 = kd[0], k2 = kd[1], k3 = kd[2], k4 = kd[3];
+               const Coef4 k1 = src(t.nIn + jj * 4), k2 = src(t.nIn + jj * 4 + 1), k3 = src(t.nIn + jj * 4 + 2), k4 = src(t.nIn + jj * 4 + 3);
                t.a1[q] = k1.c3 * tau3 + k1.c2 * tau2 + k1.c1 * tau + k1.c0;
                t.a2[q] = k2.c3 * tau3 + k2.c2 * tau2 + k2.c1 * tau + k2.c0;
                t.a3[q] = k3.c3 * tau3 + k3.c2 * tau2 + k3.c1 * tau + k3.c0;
@@ -1082,6 +1098,12 @@ __device__ __forceinline__ void eval_partials_row(Pt<G, FEAT, UNI> &t, int j, co
          }
       }
    }
+}
+
+template <int G, int FEAT, bool UNI>
+__device__ __forceinline__ void eval_partials_row(Pt<G, FEAT, UNI> &t, int j, const double *__restrict__ row)
+{
+   eval_partials_src(t, j, RowAt{row});
 }
 
 // (x / 6.0) correctly rounded through the reciprocal (see div_by_const): the compact spline form
@@ -1714,16 +1736,8 @@ __global__ void __launch_bounds__(K3_BLOCK) k_pointwise(DevProblem P, const Path
       const int rowLocal = (int)threadIdx.x - (i - t.segC); // the last knot of a path uses the previous row
       if (km != nullptr)
       {
-         // all channels as pairs: the row of the knot's segment is formed here (emit_segment's formulas)
-         alignas(32) double rowLoc[(BATOTP_MAX_JOINTS + BATOTP_MAX_CART + 4 * BATOTP_MAX_JOINTS) * 4];
-         const double2 *__restrict__ kp = reinterpret_cast<const double2 *>(km) + (pi.koff + t.segC) * P.C;
-         for (int c = 0; c < P.C; ++c)
-         {
-            const double2 a = kp[c], bq = kp[P.C + c];
-            const Coef4 k = coeffs_from_sol(a.y, bq.y, a.x, bq.x);
-            rowLoc[c * 4 + 0] = k.c0; rowLoc[c * 4 + 1] = k.c1; rowLoc[c * 4 + 2] = k.c2; rowLoc[c * 4 + 3] = k.c3;
-         }
-         eval_partials_row(t, 0, rowLoc);
+         // all channels as pairs: the row of the knot's segment is formed channel by channel where it is read (emit_segment's formulas)
+         eval_partials_src(t, 0, PairRowAt{reinterpret_cast<const double2 *>(km) + (pi.koff + t.segC) * P.C, P.C});
       }
       else
       {

@@ -10,9 +10,9 @@ from batotp_amd import capi
 
 B, knots = int(sys.argv[1]), int(sys.argv[2])
 rows = len(sys.argv) > 3 and sys.argv[3] == "rows"
-lib = capi.load_hip()
+lib = capi.Library(os.environ['REPRO_LIB']) if os.environ.get('REPRO_LIB') else capi.load_hip()
 hip = capi.Context(lib, 0)
-K = 32
+K = int(os.environ.get('REPRO_K', '128'))
 inp = bench.Inputs(hip, "cspr", knots, [1000 + k for k in range(K)])
 prob = capi.Problem.from_buffer_copy(bytes(inp.prob))
 if not rows:
