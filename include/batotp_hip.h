@@ -62,12 +62,23 @@ extern "C" {
 #define BATOTP_F_PAR2SER        (1u<<5)  /* _isPar2Ser: convert a1..a4 with A^-1 per knot (ba.cpp:916-938) */
 #define BATOTP_F_HOST_TRIG      (1u<<6)  /* RR dynamics use host-supplied cos/sin (bit parity with glibc) */
 #define BATOTP_F_NO_SAMPLES     (1u<<7)  /* do not keep traj.theta/thetaD/thetaD2-style knot samples (saves 24 B/knot/channel;
-                                            only valid without torque constraints; download_samples then fails) */
+                                            without torque constraints, or together with BATOTP_F_COMPACT_SPLINES;
+                                            download_samples then fails) */
 #define BATOTP_F_COMPACT_SPLINES (1u<<8) /* keep every spline as (knot value, second derivative) instead of the four
                                             coefficients per segment: 16 instead of 32 bytes per knot and channel, the
                                             coefficients are formed where they are used (same arithmetic, same results).
-                                            Joint velocity/acceleration-only problems with BATOTP_F_NO_SAMPLES;
-                                            upload_coeffs then fails, download_coeffs still works */
+                                            Needs BATOTP_F_NO_SAMPLES.  Joint velocity/acceleration-only problems keep their
+                                            n_joints + n_cart input channels that way; problems with Cartesian or torque limits
+                                            (constraints in serial form: not the parallel-mechanism torque branch) keep ALL
+                                            channels that way, a1..a4 of every dynamics row included (round 4): the dynamics
+                                            stage forms the samples it needs from the pairs and writes its values into their
+                                            channels' slots, the per-knot evaluation and the one-path-per-wavefront sweep kernel
+                                            form their coefficient rows from the pairs (the sweep in an LDS window); there is no
+                                            sample, dynamics or coefficient array -- for the cable robot 288 instead of 992
+                                            bytes per knot.  Uniform knot sites only (a sweep after batotp_hip_upload_path_sites
+                                            with other sites fails with BATOTP_ERR_STATE); host trig tables of a serial model
+                                            need samples from elsewhere.  upload_coeffs and download_dynamics then fail,
+                                            download_coeffs still works for every channel (a_k of row r is c0 of its rows) */
 #define BATOTP_F_CURVES_IN_PLACE (1u<<9) /* the forward sweep writes its curve over the reverse curve, as the reference does
                                             with traj.sMVC / traj.sdot (ba.cpp:1143-1160): one curve buffer of max_steps points
                                             per path instead of two.  The forward curve has at least as many points up to any
