@@ -1345,37 +1345,36 @@ static void launchSweep1(batotp_batch *b, SweepArgs &a)
    b->lastLanes[a.dir == -1 ? 0 : 1] = 64; b->lastPpw[a.dir == -1 ? 0 : 1] = 1; b->lastHold[a.dir == -1 ? 0 : 1] = -1;
    const unsigned grid = (unsigned)((b->B + (S1_BLOCK / 64) - 1) / (S1_BLOCK / 64));
    hipStream_t st = b->ctx->stream;
+   // (the last template argument: the batch keeps all its channels as pairs)
+#define LAUNCH_S1(F, FFORM)                                                                                              \
+   do {                                                                                                                 \
+      if (b->pairsAll)                                                                                                  \
+      {                                                                                                                 \
+         if (a.dir == 1) hipLaunchKernelGGL((k_sweep1<F, 1, FFORM, true>), dim3(grid), dim3(S1_BLOCK), 0, st, a);       \
+         else hipLaunchKernelGGL((k_sweep1<F, -1, FFORM, true>), dim3(grid), dim3(S1_BLOCK), 0, st, a);                 \
+      }                                                                                                                 \
+      else                                                                                                              \
+      {                                                                                                                 \
+         if (a.dir == 1) hipLaunchKernelGGL((k_sweep1<F, 1, FFORM, false>), dim3(grid), dim3(S1_BLOCK), 0, st, a);      \
+         else hipLaunchKernelGGL((k_sweep1<F, -1, FFORM, false>), dim3(grid), dim3(S1_BLOCK), 0, st, a);                \
+      }                                                                                                                 \
+   } while (0)
    if (featureLevel(b) == 2)
    {
       // the fast-forward of the bisection in the form that fits the mechanism: a parallel robot converted to serial form has
       // a3 = 0 (tension bounds are lines in sdot^2), a serial chain has friction (bounds quadratic in sdot)
       const bool lines = (b->P.flags & BATOTP_F_PARALLEL) != 0;
-      if (lines)
-      {
-         if (a.dir == 1) hipLaunchKernelGGL((k_sweep1<2, 1, 0>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
-         else hipLaunchKernelGGL((k_sweep1<2, -1, 0>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
-      }
-      else
-      {
-         if (a.dir == 1) hipLaunchKernelGGL((k_sweep1<2, 1, 1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
-         else hipLaunchKernelGGL((k_sweep1<2, -1, 1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
-      }
+      if (lines) LAUNCH_S1(2, 0);
+      else LAUNCH_S1(2, 1);
    }
-   else if (featureLevel(b) == 1)
-   {
-      if (a.dir == 1) hipLaunchKernelGGL((k_sweep1<1, 1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
-      else hipLaunchKernelGGL((k_sweep1<1, -1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
-   }
-   else if (b->compact)
+   else if (featureLevel(b) == 1) LAUNCH_S1(1, 0);
+   else if (b->compact && !b->pairsAll)
    {
       if (a.dir == 1) hipLaunchKernelGGL((k_sweep1<-1, 1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
       else hipLaunchKernelGGL((k_sweep1<-1, -1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
    }
-   else
-   {
-      if (a.dir == 1) hipLaunchKernelGGL((k_sweep1<0, 1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
-      else hipLaunchKernelGGL((k_sweep1<0, -1>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
-   }
+   else LAUNCH_S1(0, 0);
+#undef LAUNCH_S1
 }
 
 extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)

@@ -79,10 +79,13 @@ constexpr int S1_WM = 256;  // points per reverse-curve window (4 KB per path)
 // FF (FEAT == 2 only): which form of the certified fast-forward of the bisection the instantiation carries -- 0: constraints that are
 // lines in sdot^2 (the cable robot in serial form, whose a3 vanishes), 1: the general form for serial chains (a3 != 0).  One form
 // per kernel: with both in one instantiation the cable robot's sweeps were 2 % slower for code they never run.
-template <int FEAT, int DIR, int FF = 0>
+// PAIRS (FEAT >= 0 only): the batch keeps ALL its channels as (value, second derivative) pairs and coefficient rows exist in this
+// kernel's LDS window only.  A template parameter, not a run-time test: the window's code and registers cost the lone wavefront of a
+// single trajectory 10 % when they are merely present (BASELINE config 3: 1129 against 1018 ms).
+template <int FEAT, int DIR, int FF = 0, bool PAIRS = false>
 // (the cable robot's instantiation is held to 256 registers: with its channels as pairs a chunk holds two paths per SIMD, and the
 //  forward kernel's 279 registers would leave the second one waiting)
-__global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0) ? 2 : 1) k_sweep1(SweepArgs a)
+__global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 : 1) k_sweep1(SweepArgs a)
 {
    __shared__ double lim[6][8];
    // Sliding windows in LDS, one per wavefront (= per path): the (value, second derivative) pairs of S1_WK consecutive knots
@@ -92,7 +95,10 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0) ? 2 : 1) k_sw
    // wavefront were s_waitcnt without the windows: profiles/r02_e_*).
    __shared__ double2 winKAll[(FEAT < 0) ? S1_BLOCK / 64 : 1][(FEAT < 0) ? S1_WK * BATOTP_MAX_JOINTS : 1];
    __shared__ double2 winMAll[(DIR == 1) ? S1_BLOCK / 64 : 1][(DIR == 1) ? S1_WM : 1];
-   constexpr bool ROWWIN = FEAT >= 0 && S1_WR_BYTES > 0;
+   static_assert(!PAIRS || FEAT >= 0, "FEAT -1 reads its joint pairs through winK");
+   // rows through an LDS window: always when the batch keeps pairs only; for rows in HBM where it measured faster (the cable robot's
+   // sweeps 4-6 %, not the 7-DOF arm's, whose cursor needs a new row every other step)
+   constexpr bool ROWWIN = FEAT >= 0 && S1_WR_BYTES > 0 && (PAIRS || (FEAT == 2 && FF == 0));
    __shared__ double2 winRAll[ROWWIN ? S1_BLOCK / 64 : 1][ROWWIN ? S1_WR_BYTES / 16 : 1];
    stage_limits(a.dP, lim);
    const int lane = threadIdx.x & 63;
@@ -122,7 +128,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0) ? 2 : 1) k_sw
    const double2 *__restrict__ km = (FEAT < 0) ? reinterpret_cast<const double2 *>(a.km) + pi.koff * nIn : nullptr;
    const double *__restrict__ coef = (FEAT < 0) ? nullptr : a.coef + pi.koff * C * 4;
    // FEAT >= 0 on a batch that keeps ALL channels as pairs (a.km set, C channels per knot): rows exist in the LDS window only
-   const double2 *__restrict__ kmAll = (FEAT >= 0 && a.km != nullptr) ? reinterpret_cast<const double2 *>(a.km) + pi.koff * C : nullptr;
+   const double2 *__restrict__ kmAll = PAIRS ? reinterpret_cast<const double2 *>(a.km) + pi.koff * C : nullptr;
    double2 *out = (DIR == 1 ? a.fwd : a.rev) + (int64_t)p * cap; // forward, curves in place: the same buffer as mvc (no __restrict__)
    batotp_path_result *__restrict__ r = a.res + p;
 
@@ -176,7 +182,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0) ? 2 : 1) k_sw
    int wK0 = 0, wKn = 0; // knots [wK0, wK0 + wKn) are in winK, layout [knot][8 joint slots]
    int wM0 = 0, wMn = 0; // curve points [wM0, wM0 + wMn) are in winM
    double2 *winR = winRAll[ROWWIN ? (threadIdx.x >> 6) : 0];
-   const bool rowWin = ROWWIN && (kmAll != nullptr || (FEAT == 2 && FF == 0));
+   constexpr bool rowWin = ROWWIN;
    int wR0 = 0, wRn = 0; // coefficient rows [wR0, wR0 + wRn) are in winR, C x 4 doubles each
 
    // make knots seg and seg + 1 available in winK: a coalesced copy of the window that extends from seg in the direction of
@@ -228,7 +234,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0) ? 2 : 1) k_sw
       w = w < 0 ? 0 : w;
       const int cntR = (nRows - w) < WR ? (nRows - w) : WR;
       const int total = cntR * rowD2;
-      if (kmAll != nullptr)
+      if (PAIRS)
       {
          // all channels as (value, second derivative) pairs: the rows of the window are FORMED here, one (row, channel) per lane
          // and round -- emit_segment's formulas (spline.cpp:203-209) with x / 6 through div6 --, and nothing but the pairs
@@ -370,8 +376,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0) ? 2 : 1) k_sw
                   for (int q = 0; q < 4; ++q) dynK[(FEAT == 2) ? q : 0] = kd[q];
                }
             };
-            // rows through the LDS window (always when the batch keeps pairs only; for rows in HBM where it measured faster:
-            // the cable robot's sweeps 4-6 %, not the 7-DOF arm's, whose cursor needs a new row every other step), or from HBM
+            // rows through the LDS window, or from HBM
             if (ROWWIN && rowWin)
             {
                needR(segC);
