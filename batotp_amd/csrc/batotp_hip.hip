@@ -1403,7 +1403,9 @@ extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
       // wins for a while beyond that, with its wavefronts queueing for the two slots per SIMD its registers leave: the 8-lane
       // layout at 2-4 paths per wavefront is latency-bound and slower (GEN7DOF, N = 5e4, reverse: 3072 paths 944 vs 1882 ms,
       // 6144 paths 1784 vs 2024, 8192 paths 2328 vs 2137; forward: 3072 paths 923 vs 981, 4096 paths 1118 vs 1031; UR6 alike)
-      if (sweep1Applies(b) && b->B <= (a.dir == -1 ? 6144 : 3072)) lanes = 64;
+      // (round 4, against k_sweep8 instead of k_sweep -- N = 5e4, reverse / forward ms: 2048 paths 594 / 516 vs 1117 / 687, 4096 paths
+      //  1051 / 1008 vs 1231 / 738: the reverse crossover moved from ~6000 to ~4900 paths, the forward one stays near 3000)
+      if (sweep1Applies(b) && b->B <= (a.dir == -1 ? 4608 : 3072)) lanes = 64;
    }
    if (b->pairsAll)
    {
