@@ -258,6 +258,26 @@ def test_ragged_batch_equals_single_paths(hip_ctx, oracle_ctx):
         _compare(c, many[k], ref[c.name])
 
 
+def test_ragged_batch_with_pairs_for_all_channels(hip_lib, oracle_ctx):
+    """a batch of cable-robot paths of different length with every channel as pairs (several blocks of the one-path-per-wavefront
+    kernel, paths at different offsets of the pair array): every path -- per-knot bounds, both curves, the result row -- equals its
+    single-path oracle run"""
+    names = ["synth_cspr_s3", "CSPR3DOF", "synth_cspr_s5", "synth_cspr_s3", "synth_cspr_s9_dup", "CSPR3DOF", "synth_cspr_s5"]
+    cases = [Case(n) for n in names]
+    for c in cases:
+        c.problem = cases[0].problem
+    ctx = capi.Context(hip_lib, 0)
+    cap = 2 * max(c.max_steps() for c in cases)
+    many = run_pipeline(ctx, cases * 3, max_steps=cap, mvc=True, details=False, extra_flags=capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES)
+    ref = {}
+    for c in cases:
+        if c.name not in ref:
+            ref[c.name] = run_pipeline(oracle_ctx, [c], max_steps=cap, mvc=True, details=False)[0]
+    for k, c in enumerate(cases * 3):
+        _compare(c, many[k], ref[c.name])
+    ctx.close()
+
+
 @pytest.mark.parametrize("hold", [(0, 0), (3, 5), (4, -1), (5, 3), (8, 8), (-1, 6), (-1, -1), (-2, -2)])
 @pytest.mark.parametrize("compact", [False, True])
 def test_flat_sweep_loop_with_paths_drifting_apart(hip_lib, oracle_ctx, hold, compact):
