@@ -622,9 +622,15 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
       // (robot.cpp:487-517: a3 = 0 at every knot, so its spline is 0 and tmp1 of ba.cpp:1497 is a4 exactly); no Cartesian
       // acceleration limit (a quadratic in sddot, ba.cpp:1535-1579).  The torque lines take the joint lanes 4..7 of a slot:
       // at most 4 joints.
-      bool ffApplies = FF == 0 && a.ff && !over && !cartAccOn && (FEAT == 2 || accOn);
+      // (not in the forward kernel of a pair batch: it is held to 256 registers -- two paths per SIMD --, the forward sweep bisects in
+      //  0.6 % of its stages, and without the block 22 instead of 35 registers spill: cfg 5 forward 3194 -> 3021 ms)
+#ifndef S1_FWD_PAIRS_FF
+#define S1_FWD_PAIRS_FF 0
+#endif
+      constexpr bool FF0 = FF == 0 && (S1_FWD_PAIRS_FF || !(PAIRS && DIR == 1));
+      bool ffApplies = FF0 && a.ff && !over && !cartAccOn && (FEAT == 2 || accOn);
       if (FEAT == 2) ffApplies = ffApplies && nJ <= 4 && !__ballot(jv && !(a3pt == 0.0));
-      if (FF == 0 && ffApplies)
+      if (FF0 && ffApplies)
       {
          // CERTIFIED FAST-FORWARD.  In x = sdot^2 every constraint of the check is an interval [l_q(x), u_q(x)] for sddot with
          //      u_q = au_q - m_q x,   l_q = al_q - m_q x:
