@@ -315,7 +315,7 @@ class Context:
 
     def set_fast_forward(self, on):
         """certified fast-forward of the bisection (include/batotp_hip.h); never changes a result"""
-        self.library.check(self.library.lib.batotp_hip_set_fast_forward(self.handle, 1 if on else 0), "set_fast_forward")
+        self.library.check(self.library.lib.batotp_hip_set_fast_forward(self.handle, int(on)), "set_fast_forward")
 
     def set_spline_tiles(self, on):
         """True / False, or -1 for the automatic choice (tiles for small batches)"""

@@ -376,7 +376,7 @@ extern "C" int batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on)
 extern "C" int batotp_hip_set_fast_forward(batotp_ctx *ctx, int32_t on)
 {
    if (!ctx) return BATOTP_ERR_ARG;
-   ctx->fastForward = on ? 1 : 0;
+   ctx->fastForward = on < 0 ? 0 : (on > 3 ? 3 : on);   // (k_sweep8: bit 0 forward sweep, bit 1 reverse sweep; the other kernels: non-zero)
    return BATOTP_OK;
 }
 

@@ -42,6 +42,9 @@ constexpr int S8_BLOCK = 256;
 #define S8_PREFETCH 1   // the knot the cursor will need next is loaded one segment change ahead (compact pairs).  (The same for the next
                         // point of the reverse curve in the forward sweep measured 5 % slower -- 440 against 419 ms -- and is not done.)
 #endif
+#ifndef S8_FF
+#define S8_FF 1      // the certified fast-forward of the bisection (see the block in the loop), forward sweep by default
+#endif
 #ifndef S8_KINDS
 #define S8_KINDS 0      // 1: bisection update in blocks by situation -- measured 5 % SLOWER than one block of selects (the guards of four blocks cost more than the selects they save: profiles/r04_b_*)
 #endif
@@ -697,6 +700,123 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
             status |= failed ? (unsigned)BATOTP_ST_BISECT_FAIL : 0u;
             nfail += failed ? 1 : 0;
             stageFailed = failed;
+#if S8_FF
+            // ---- CERTIFIED FAST-FORWARD of the bisection (the block of k_sweep1, sweep1.hip.h: its derivation and error analysis
+            // are there; this is the same certificate on the 8 lanes of a path) ------------------------------------------------
+            // The first check of the stage was violated and the loop goes on.  In x = sdot^2 every bound of the check is a line:
+            // joint q allows sddot in [-au_q - m_q x, au_q - m_q x] with au = amax_q / |theta'_q|, m = theta''_q / theta'_q, and
+            // [-sddotMax, sddotMax] is the line au = sddotMax, m = 0.  They stop intersecting at
+            //    x* = min over pairs (upper line i, lower line j, m_i > m_j) of (au_i + au_j) / (m_i - m_j),
+            // and a candidate c of the loop is violated iff c^2 > x* -- for certain when |c^2 - x*| exceeds the band 2^-40 R x*
+            // (R = 2 E / Smin: the rounding errors of the check against the width of the interval at x = 0).  The loop of
+            // ba.cpp:1267-1321 is advanced with its own update statements through every iteration whose outcome is certain and that
+            // neither ends it nor can take a failure exit; it stops in front of the first candidate inside the band, or the one
+            // that would end the loop: that one gets the real check in the next pass.  Anything unusual (a standing joint's
+            // threshold inside the band, non-finite or extreme values) leaves the state as it is.
+            // Where it pays: the forward sweep runs its 8 paths in lockstep and 0.6 % of its stages bisect -- a dozen passes in which
+            // seven paths wait for one.  In the reverse sweep (22 % of the stages bisect, the passes are shared by several paths) the
+            // block costs what it saves (profiles/r03_g_*, r04_j_*): it runs there only when asked for (a.ff & 2).
+            if ((DIR == 1 || S8_FF > 1) && PER == 1 && accOn)   // (compiled into the reverse kernel it costs 5 % switched off: -DS8_FF=2 for that A/B)
+            {
+               const bool ffWant = (((DIR == 1) ? (a.ff & 1) : (a.ff & 2)) != 0) && first && isViol && !failed;
+               if (S8_ANY(ffWant))
+               {
+                  if (ffWant)
+                  {
+                     auto fastRcp = [](double d) {
+                        double r = __builtin_amdgcn_rcp(d);
+                        r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+                        return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+                     };
+                     const double xTop = sdotH * sdotH;                 // the first candidate: no later one is larger
+                     const bool use = jOn[0] && !(fabs(thD[0]) < thrV);
+                     const double rv = fastRcp(use ? thD[0] : 1.0);
+                     double au = amax[0] * fabs(rv);
+                     double mj = thD2[0] * rv;
+                     double ej = au + fabs(mj) * xTop;
+                     // a line with a non-finite coefficient must stop the fast-forward: the min / max reductions would drop its NaN
+                     const bool lineFinite = !use || ((au == au) & (mj == mj) & (ej == ej) & (fabs(au) < kInf) & (fabs(mj) < kInf) & (ej < kInf));
+                     const unsigned long long mBad = __builtin_amdgcn_ballot_w64(!lineFinite);
+                     const bool allFinite = ((unsigned)(mBad >> (lane & ~7)) & 0xffu) == 0u;
+                     au = use ? au : kInf;
+                     mj = use ? mj : 0.0;
+                     ej = use ? ej : 0.0;
+                     double uMin = au, lMax = -au;
+                     grp_min_max<8>(uMin, lMax);
+                     const double eMax = grp_max<8>(ej);
+                     const double sMin2 = .5 * (dmin(uMin, sddotMax) - dmax(lMax, -sddotMax));
+                     const bool standing = jOn[0] && !use && !(fabs(thD2[0]) < thrA);
+                     const double xForce = grp_min<8>(standing ? amax[0] / fabs(thD2[0]) : kInf);
+                     // this lane's line against [-sddotMax, sddotMax]: as the upper line when m > 0, as the lower line when m < 0
+                     double xs = kInf;
+                     if (use && mj > 0.0) xs = (au + sddotMax) * fastRcp(mj);
+                     if (use && mj < 0.0) xs = (sddotMax + au) * fastRcp(-mj);
+                     // ... and as the upper line against every other joint's lower line (the partner computes the other orientation)
+#pragma unroll
+                     for (int k = 1; k < 8; ++k)
+                     {
+                        const double aui = __shfl_xor(au, k), mi = __shfl_xor(mj, k);
+                        const double dm = mj - mi;
+                        const double bnd = (au + aui) * fastRcp(dm > 0.0 ? dm : 1.0);
+                        xs = dmin(xs, (dm > 0.0 && use && aui < kInf) ? bnd : kInf);
+                     }
+                     xs = grp_min<8>(xs);
+                     const double xstar = dmin(xs, 4.0 * xTop);          // beyond 4 xTop: "never violated by the lines" just as well
+                     const double R = eMax * fastRcp(sMin2 > 0.0 ? sMin2 : 1.0);
+                     const double band = (R * 0x1p-40) * xstar;
+                     // a standing joint's threshold below the band around x* decides alone, and exactly; one above the band never
+                     // matters; one inside the band: no fast-forward
+                     const bool forceFirst = xForce < xstar - band;
+                     const double xThr = forceFirst ? xForce : xstar;
+                     const double bandThr = forceFirst ? -1.0 : band;
+                     const bool sane = allFinite & (eMax == eMax) & (xstar == xstar) & (R == R) & (R < 0x1p30) & (sMin2 > 1e-100) & (eMax < 1e100) &
+                                       (xTop > 1e-100) & (xTop < 1e100) & (xstar > 1e-100) & (forceFirst | (xForce > xstar + band));
+                     if (sane)
+                     {
+                        int it = nIter;
+                        bool inBand = false;
+                        // the search for a first feasible speed (ba.cpp:1281-1285): the bracket shrinks below every violated candidate
+#pragma unroll 1
+                        for (; it < 90; ++it)
+                        {
+                           const double c = sdotTry, d = c * c - xThr;   // c * c: sdotSQ of the check
+                           inBand = !((fabs(d) > bandThr) & (c > 1e-100));
+                           if (inBand | !(d > 0.0)) break;
+                           lowFact *= 2.0;
+                           sdotH = c;
+                           sdotL = dmax(.999 * 0.0, (1.0 - lowFact) * c);
+                           sdotTry = .5 * (sdotH + sdotL);
+                        }
+                        if (!inBand && it < 90)
+                        {
+                           // sdotTry is feasible for certain and the first such speed: ba.cpp:1294 compares it with sdotGood = 0 and
+                           // goes on.  From here the plain bisection (ba.cpp:1286-1303): sdotGood == sdotL throughout
+                           sdotGood = sdotTry; nGood = 1; sdotL = sdotTry;
+                           ++it;
+                           sdotTry = .5 * (sdotH + sdotL);
+                           // ba.cpp:1294 is false for certain when |c - sdotGood| > 1e-3 c (1 + 3e-14); otherwise this candidate is, or
+                           // may be, the last one and gets the real check and the real test
+                           const double convThr = 1e-3 * (1.0 + 3e-14);
+#pragma unroll 1
+                           for (; it < 90; ++it)
+                           {
+                              const double c = sdotTry, d = c * c - xThr;
+                              const bool viol = d > 0.0;
+                              inBand = !(fabs(d) > bandThr);
+                              const bool goesOn = viol | (fabs(c - sdotL) > convThr * c);
+                              if (inBand | !goesOn) break;
+                              sdotH = viol ? c : sdotH;
+                              sdotL = viol ? sdotL : c;
+                              sdotTry = .5 * (sdotH + sdotL);
+                           }
+                           sdotGood = sdotL;
+                        }
+                        nIter = it;
+                     }
+                  }
+               }
+            }
+#endif
          }
 #endif
          wN = fin ? ((DIR == 1) ? sddotH : sddotL) : wN;

@@ -15,6 +15,7 @@ ap.add_argument("--coefficient-rows", action="store_true")
 ap.add_argument("--lib", default=None, help="alternative build of the library (experiments)")
 ap.add_argument("--hold", type=int, nargs=2, default=None, help="sweep loop form, reverse forward (batotp_hip_set_sweep_hold)")
 ap.add_argument("--flat-form", type=int, default=None, help="0 = flat instantiation of k_sweep, 1 = k_sweep8 (batotp_hip_set_flat_form)")
+ap.add_argument("--fast-forward", type=int, default=None, help="batotp_hip_set_fast_forward: 0 off, 1 default (k_sweep8: forward), 3 (k_sweep8: both sweeps)")
 ap.add_argument("--tag", default="", help="label printed in front of every line")
 ap.add_argument("--variants", default=None, help="A/B of sweep forms on ONE resident batch: comma-separated form:holdRev:holdFwd[:ppw] "
                 "(form 0 = k_sweep's flat instantiation, 1 = k_sweep8; hold -1 = nested loops); prints kernel times and digests of rows / curves")
@@ -37,6 +38,8 @@ if a.hold:
     hip.set_sweep_hold(*a.hold)
 if a.flat_form is not None:
     hip.set_flat_form(a.flat_form)
+if a.fast_forward is not None:
+    hip.set_fast_forward(a.fast_forward)
 import hashlib
 for _ in range(a.reps):
     t = time.perf_counter(); b.precompute(0); b.pointwise_mvc(); b.sweep(-1); b.sweep(1); dt = time.perf_counter() - t
