@@ -349,7 +349,10 @@ int  batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on);
  * otherwise), and takes every iteration of the loop whose outcome is CERTAIN given the rounding-error bounds of the check without
  * running the check;
  * candidates within the error band, and the last one (whose sddot bounds are the result), get the real check.  Results are
- * identical with it on (default) and off (the parity tests run both).  on: 1 / 0. */
+ * identical with it on (default) and off (the parity tests run both).  on: 1 / 0.  Round 4: the batch kernel of the 8-lane layout
+ * (batotp_amd/csrc/sweep8.hip.h) carries the same certificate in its forward sweep, where the eight paths of a wavefront run in
+ * lockstep and wait for a path that bisects (bit 0 of `on`; bit 1 is reserved for the reverse sweep, where the block measured
+ * slower and is not compiled in: profiles/r04_j_*). */
 int  batotp_hip_set_fast_forward(batotp_ctx *ctx, int32_t on);
 /* diagnostic: series of the most recent tiled spline build of this batch whose boundary comparison failed and that the
  * sequential kernel therefore recomputed (paths too short for tiles are not counted).  Expected: 0. */
