@@ -45,9 +45,6 @@ constexpr int S8_BLOCK = 256;
 #ifndef S8_FF
 #define S8_FF 1      // the certified fast-forward of the bisection (see the block in the loop), forward sweep by default
 #endif
-#ifndef S8_KINDS
-#define S8_KINDS 0      // 1: bisection update in blocks by situation -- measured 5 % SLOWER than one block of selects (the guards of four blocks cost more than the selects they save: profiles/r04_b_*)
-#endif
 
 // (num / den) < thr as ratio_lt (kernels.hip.h) decides it, in two parts: the product form, and whether it was decisive
 __device__ __forceinline__ bool s8_ratio_lt_fast(double num, double den, double thr, bool &decided)
@@ -602,68 +599,9 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
          sddotH = Hred; sddotL = L;
          const bool isViol = L > Hred;
 
-#if S8_KINDS
-         // ---- one pass of the loop of ba.cpp:1267-1321.  A path is in one of four situations; each block runs under the
-         // lanes in it and is skipped when there are none (the common pass holds one or two kinds):
-         //   first check passed (fin0)                      -> the stage is done, nothing else happens
-         //   violated, no feasible point known yet (search) -> ba.cpp:1276-1285: shrink the lower end geometrically
-         //   violated, a feasible point is known (upper)    -> ba.cpp:1278: the candidate becomes the upper end
-         //   feasible after a violation (good)              -> ba.cpp:1288-1303: convergence test, else new lower end
-         const bool first = (nIter == 0);
-         const bool fin0 = !isViol && first;
-         const bool search = isViol && nGood == 0, upper = isViol && nGood != 0, good = !isViol && !first;
-         bool fin = fin0, failed = false;
-         if (S8_ANY(search))
-         {
-            if (search)
-            {
-               lowFact *= 2.0;
-               sdotH = sdotTry;
-               sdotL = dmax(.999 * 0.0, (1.0 - lowFact) * sdotH);
-               // ba.cpp:1305-1319
-               bool dec2;
-               const double num2 = sdotH - sdotL;
-               bool tiny = s8_ratio_lt_fast(num2, sdotH, 1e-20, dec2);
-               if (S8_ANY(!dec2)) tiny = dec2 ? tiny : (num2 / sdotH < 1e-20);
-               failed = (nIter + 1 > 100) || (sdotTry < 0.0) || tiny;
-            }
-         }
-         if (S8_ANY(upper))
-         {
-            if (upper)
-            {
-               sdotH = sdotTry;
-               failed = (nIter + 1 > 100) || (sdotTry < 0.0);
-            }
-         }
-         if (S8_ANY(good))
-         {
-            if (good)
-            {
-               // ba.cpp:1294-1303: two successive feasible points closer than 1e-3 (relative), or a negative one
-               bool dec1;
-               const double num1 = fabs(sdotTry - sdotGood);
-               bool close = s8_ratio_lt_fast(num1, sdotTry, .001, dec1);
-               if (S8_ANY(!dec1)) close = dec1 ? close : (num1 / sdotTry < .001);
-               const bool conv = close || sdotTry < 0.0;
-               sdotGood = sdotTry;
-               nGood += 1;
-               sdotCur = conv ? sdotTry : sdotCur;
-               sdotL = conv ? sdotL : sdotTry;
-               fin = conv;
-               failed = !conv && ((nIter + 1 > 100) || (sdotTry < 0.0));
-            }
-         }
-         if (S8_ANY(!fin0))
-         {
-            const bool on = !fin && !failed;
-            nIter += fin ? 0 : 1;
-            sdotTry = on ? .5 * (sdotH + sdotL) : sdotTry;
-            status |= failed ? (unsigned)BATOTP_ST_BISECT_FAIL : 0u;
-            nfail += failed ? 1 : 0;
-            stageFailed = failed;
-         }
-#else
+         // (The same pass as four exec-masked blocks by situation -- first check passed / violated without a feasible point / violated with
+         //  one / feasible after a violation -- measured 5 % SLOWER than this one block of selects: the guards of four blocks cost more than
+         //  the selects they save, profiles/r04_b_*; that variant is not kept in the source.)
          // ---- one pass of the loop of ba.cpp:1267-1321, as selects -----------------------------------------
          const bool first = (nIter == 0);
          const bool fin0 = !isViol && first; // the first check passes: the stage is done, nothing else happens
@@ -818,7 +756,6 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
             }
 #endif
          }
-#endif
          wN = fin ? ((DIR == 1) ? sddotH : sddotL) : wN;
          phase = (fin || failed) ? PH_ENDED : phase;
       }
