@@ -319,7 +319,7 @@ class Context:
 
     def set_spline_tiles(self, on):
         """True / False, or -1 for the automatic choice (tiles for small batches)"""
-        self.library.check(self.library.lib.batotp_hip_set_spline_tiles(self.handle, -1 if on == -1 else (1 if on else 0)), "set_spline_tiles")
+        self.library.check(self.library.lib.batotp_hip_set_spline_tiles(self.handle, -1 if on == -1 else int(on)), "set_spline_tiles")   # (2: the single-pass kernel for pairs)
 
     def flat_loop_status(self) -> int:
         """1 = the automatic loop choice uses the flat loop; negative: why not (include/batotp_hip.h)"""

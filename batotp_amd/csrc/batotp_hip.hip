@@ -18,6 +18,7 @@
 #include "kernels.hip.h"
 #include "sweep1.hip.h"
 #include "sweep8.hip.h"
+#include "spline_stream.hip.h"
 #include "spline_tile.hip.h"
 #include "resample.hip.h"
 #include "output.hip.h"
@@ -369,7 +370,7 @@ extern "C" int batotp_hip_set_sweep_prefetch(batotp_ctx *ctx, int32_t reverse, i
 extern "C" int batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on)
 {
    if (!ctx) return BATOTP_ERR_ARG;
-   ctx->splineTiles = on < 0 ? -1 : (on ? 1 : 0);
+   ctx->splineTiles = on < 0 ? -1 : (on > 2 ? 2 : on);   // (2: the single-pass kernel for pairs whatever the batch size)
    return BATOTP_OK;
 }
 
@@ -912,6 +913,18 @@ static int launchSpline(batotp_batch *b, int nch, int mode, const double *src, i
       hipLaunchKernelGGL(k_spline_tile, dim3((unsigned)b->totalTiles, (unsigned)((nch + ST_CH - 1) / ST_CH)), dim3(ST_BLOCK), 0, st, a);
       const int64_t slots = (int64_t)b->totalTiles * nch;
       hipLaunchKernelGGL(k_spline_tile_check, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, a, b->totalTiles);
+      only = b->dDirty;
+      b->lastTileNch = nch;
+   }
+   // Large batches of pairs (no tiles): the single-pass kernel (spline_stream.hip.h) for every series of at least ST_MIN_KNOTS knots,
+   // then the sequential kernel for what is left (short paths; a series whose boundary comparison failed -- never observed).
+   // splineTiles: 2 = this kernel whatever the batch size (tests), 0 = never
+   const bool stream = pairs && !tiled && b->totalTiles > 0 &&
+                       (b->ctx->splineTiles == 2 || (b->ctx->splineTiles < 0 && (int64_t)b->B * nch > tileLimit));
+   if (stream)
+   {
+      hipLaunchKernelGGL(k_tile_dirty_init, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, b->dPinfo, b->B, nch, b->dDirty);
+      hipLaunchKernelGGL(k_spline_pairs_stream, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, b->dPinfo, b->B, nch, c0, b->kmC, b->dKM, b->dDirty);
       only = b->dDirty;
       b->lastTileNch = nch;
    }

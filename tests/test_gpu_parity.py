@@ -373,6 +373,13 @@ def test_spline_build_in_tiles_equals_the_sequential_kernel(hip_lib, oracle_ctx,
         oc = np.stack([ob.coeffs(k, ch) for ch in range(C_in)])
         assert_bit_equal(tiled[k], oc, f"{layout}: path {k} (N = {lengths[k]}): tiles against the oracle")
     ob.close()
+    if layout == "pairs":
+        # the single-pass kernel of large pair batches (spline_stream.hip.h: forward elimination through an LDS ring, back substitution
+        # in blocks that start 48 knots ahead and are checked against their neighbours), forced here on a small batch
+        streamed, fb2 = run(ys, 2)
+        assert fb2 == 0, f"{fb2} series of smooth paths fell back to the sequential kernel (single-pass kernel)"
+        for k in range(len(ys)):
+            assert_bit_equal(streamed[k], seq[k], f"pairs: path {k} (N = {lengths[k]}): single-pass kernel against the sequential kernel")
     # kinks and exactly straight stretches
     n = 5000
     t = np.linspace(0, 1, n)
@@ -382,6 +389,9 @@ def test_spline_build_in_tiles_equals_the_sequential_kernel(hip_lib, oracle_ctx,
     a, fb = run([kinky], True)
     c, _ = run([kinky], False)
     assert_bit_equal(a[0], c[0], f"{layout}: piecewise-linear path: tiles (with {fb} series through the fallback) against the sequential kernel")
+    if layout == "pairs":
+        a2, fb2 = run([kinky], 2)
+        assert_bit_equal(a2[0], c[0], f"pairs: piecewise-linear path: single-pass kernel (with {fb2} series through the fallback) against the sequential kernel")
 
 
 def test_flat_sweep_loop_is_gated_by_toolchain_and_canary(hip_lib, oracle_ctx, monkeypatch):
