@@ -339,8 +339,11 @@ int  batotp_hip_set_sweep_prefetch(batotp_ctx *ctx, int32_t reverse, int32_t for
  * bit for bit with the neighbouring chunk's, and a series with a disagreement is redone by the sequential kernel, so the
  * result IS the sequential kernel's (batotp_amd/csrc/spline_tile.hip.h).  on: -1 (default) automatic -- tiles for batches of
  * up to 4096 series (paths x channels; 16 384 where coefficient rows are written), where the lane-per-series kernel is a dependent chain of N steps with most of the GPU
- * idle (one 6-joint trajectory of 1e5 knots: 0.05 ms instead of 9.5 ms), the lane-per-series kernel beyond --, 1 always,
- * 0 never (the parity tests run both). */
+ * idle (one 6-joint trajectory of 1e5 knots: 0.05 ms instead of 9.5 ms), the lane-per-series kernels beyond --, 1 always,
+ * 0 never (the parity tests run both).  Round 4: beyond that size, batches that keep their splines as pairs take the lane-per-series
+ * kernel in its single-pass form (batotp_amd/csrc/spline_stream.hip.h: the forward elimination of reference batotp/spline.cpp:257-268
+ * keeps its last 64 values in LDS, the back substitution of spline.cpp:269-274 runs in blocks that start 48 knots ahead and are
+ * checked against their neighbours the same way; half the HBM traffic of the two-sweep kernel); 2 = that kernel whatever the size. */
 int  batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on);
 /* the bisection of BA::applyAccelConstraintsBisectionPt (reference batotp/ba.cpp:1248-1332) in the one-path-per-wavefront sweep
  * kernel (batotp_amd/csrc/sweep1.hip.h), problems with joint velocity / acceleration limits and / or serial torque limits (no
