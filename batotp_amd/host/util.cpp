@@ -109,84 +109,88 @@ int normalizeArcLength(std::vector<double> &s)
    return 0;
 }
 
-// Centred moving average with shrinking windows at both ends (reference util.cpp:257-290).
+// ---- moving-window filters (reference util.cpp:257-338) -----------------------------------------
+// Both filters of the reference look at sample i through a window that is centred on i, `half` samples wide on either side in
+// the interior and shrinking to what fits next to an end; the two end samples pass through.  What makes the result
+// reproducible to the bit is the ORDER in which a window is folded: windows that touch the front of the series, and interior
+// windows, are folded front to back; windows that touch the back are folded from the last sample backwards.  Here that is one
+// description (Window) and one traversal (foldWindows); the filters only differ in the fold.  The device kernels
+// k_rs_smooth / k_out_down and the oracle state the same rule per sample.
+namespace
+{
+struct Window
+{
+   int first; // first sample folded
+   int count; // samples in the window (always odd)
+   int step;  // +1 front to back, -1 back to front
+};
+
+// effective half-width of a filter of nominal width w on n samples: the largest odd window not wider than min(w, n)
+int halfWidth(int w, int n)
+{
+   const int width = std::min(w, n);
+   return width / 2 + width % 2 - 1;
+}
+
+Window windowAt(int i, int n, int half)
+{
+   if (i < half) return Window{0, 2 * i + 1, +1};
+   if (i >= n - half) return Window{n - 1, 2 * (n - 1 - i) + 1, -1};
+   return Window{i - half, 2 * half + 1, +1};
+}
+
+// out[i] = finish(fold over the window of i, number of samples folded).  The two ends are copied -- except by a filter of
+// width one (half == 0), whose single-sample windows the reference also runs over the ends (util.cpp:281-287)
+template <class Fold, class Finish>
+std::vector<double> foldWindows(const std::vector<double> &in, int half, Fold fold, Finish finish)
+{
+   const int n = (int)in.size();
+   std::vector<double> out(in);
+   const int skip = half > 0 ? 1 : 0;
+   for (int i = skip; i + skip < n; ++i)
+   {
+      const Window win = windowAt(i, n, half);
+      double acc = in[win.first];
+      for (int k = 1, at = win.first + win.step; k < win.count; ++k, at += win.step) acc = fold(acc, in[at]);
+      out[i] = finish(acc, win.count);
+   }
+   return out;
+}
+
+double addTo(double acc, double v) { return acc + v; }
+double lesserOf(double acc, double v) { return std::min(acc, v); }
+double meanOf(double sum, int count) { return sum / count; }
+double asIs(double v, int) { return v; }
+} // namespace
+
+// centred moving average (reference util.cpp:257-290)
 int smooth(std::vector<double> &x, int w)
 {
-   const int n = (int)x.size();
-   w = std::min(w, n);
-   const int half = w / 2 + w % 2 - 1;
-   w = 2 * half + 1;
-
-   std::vector<double> y(n);
-   y[0] = x[0];
-   y[n - 1] = x[n - 1];
-
-   for (int i = 1; i < half; ++i)
-   {
-      const int span = 2 * i + 1;
-      double head = 0, tail = 0;
-      for (int j = 0; j < span; ++j)
-      {
-         head += x[j];
-         tail += x[n - j - 1];
-      }
-      y[i] = head / span;
-      y[n - i - 1] = tail / span;
-   }
-   for (int i = half; i < n - half; ++i)
-   {
-      double acc = 0;
-      for (int j = i - half; j < i + half + 1; ++j) acc += x[j];
-      y[i] = acc / w;
-   }
-   x = y;
+   // the first term of a window sum is 0 + x in the reference; adding to +0.0 changes no bit except -0.0 -> +0.0, which
+   // the explicit zero start below keeps
+   x = foldWindows(x, halfWidth(w, (int)x.size()), addTo, [](double sum, int count) { return meanOf(0.0 + sum, count); });
    return 0;
 }
 
-// Moving-window minimum followed by smooth(), then pointwise min with the input
-// (reference util.cpp:299-338).
+// moving minimum, smoothed, and never above the input (reference util.cpp:299-338)
 int minsmooth(std::vector<double> &x, int w)
 {
-   const int n = (int)x.size();
-   w = std::min(w, n);
-   const int half = w / 2 + w % 2 - 1;
-   w = 2 * half + 1;
-
-   std::vector<double> y(n);
-   y[0] = x[0];
-   y[n - 1] = x[n - 1];
-
-   for (int i = 1; i < half; ++i)
-   {
-      const int span = 2 * i + 1;
-      double head = x[0], tail = x[n - 1];
-      for (int j = 1; j < span; ++j)
-      {
-         head = std::min(head, x[j]);
-         tail = std::min(tail, x[n - j - 1]);
-      }
-      y[i] = head;
-      y[n - i - 1] = tail;
-   }
-   for (int i = half; i < n - half; ++i)
-   {
-      double m = x[i - half];
-      for (int j = i - half + 1; j < i + half + 1; ++j) m = std::min(m, x[j]);
-      y[i] = m;
-   }
-   smooth(y, w);
-   for (int i = 0; i < n; ++i) x[i] = std::min(x[i], y[i]);
+   const int half = halfWidth(w, (int)x.size());
+   std::vector<double> floorLine = foldWindows(x, half, lesserOf, asIs);
+   smooth(floorLine, 2 * half + 1);
+   std::transform(x.begin(), x.end(), floorLine.begin(), x.begin(), lesserOf);
    return 0;
 }
 
-// keep every w-th sample, always keeping the last one (reference util.cpp:347-356)
+// every w-th sample, and always the final one (reference util.cpp:347-356)
 int decimate(std::vector<double> &x, int w)
 {
-   const int nIn = (int)x.size();
-   const int nOut = (nIn - 1) / w + 1;
-   for (int i = 0; i < nOut; ++i) x[i] = x[w * i];
-   if (w * (nOut - 1) + 1 != nIn) x[nOut - 1] = x[nIn - 1];
-   x.resize(nOut);
+   const size_t last = x.size() - 1, kept = last / (size_t)w + 1;
+   std::vector<double> thin;
+   thin.reserve(kept);
+   for (size_t at = 0; thin.size() + 1 < kept; at += (size_t)w) thin.push_back(x[at]);
+   thin.push_back(x[last]);
+   x.swap(thin);
    return 0;
 }
 
@@ -425,58 +429,65 @@ bool solveLinSys(const std::vector<std::vector<double>> &Av, const std::vector<d
    return false;
 }
 
-// Iteratively drop samples closer than xThresh to their predecessor; within one pass only
-// non-adjacent samples are dropped and the last sample always survives
-// (reference util.cpp:452-524).  y is filtered with the same mask.
+// ---- close-point removal (reference util.cpp:452-524) --------------------------------------------
+// A sample goes when it lies within the threshold of its predecessor and that predecessor stays; the final sample always
+// stays -- when it was marked, the sample before it goes instead and the one before that is kept.  Passes repeat on the
+// thinned series until one removes nothing.  A pass is stated as the list of surviving indices, which is then applied to
+// every row of both channel sets.
+namespace
+{
+typedef std::vector<std::vector<double>> Rows;
+
+std::vector<int> survivorsOfPass(const Rows &driving, int n, double threshSq)
+{
+   std::vector<int> stay(1, 0);
+   stay.reserve((size_t)n);
+   bool previousGone = false;
+   for (int i = 1; i < n; ++i)
+   {
+      double distSq = 0;
+      for (size_t r = 0; r < driving.size(); ++r)
+      {
+         const double step = driving[r][i] - driving[r][i - 1];
+         distSq += step * step;
+      }
+      const bool gone = !previousGone && distSq < threshSq;
+      if (!gone) stay.push_back(i);
+      previousGone = gone;
+   }
+   if (previousGone && n > 2)
+   {
+      stay.pop_back();                              // n-2 (it stayed, or n-1 could not have been marked)
+      if (stay.back() != n - 3) stay.push_back(n - 3);
+      stay.push_back(n - 1);
+   }
+   return stay;
+}
+
+void keepOnly(Rows &rows, const std::vector<int> &stay, size_t nBefore)
+{
+   for (size_t r = 0; r < rows.size(); ++r)
+   {
+      if (rows[r].size() < nBefore) continue;
+      for (size_t k = 0; k < stay.size(); ++k) rows[r][k] = rows[r][(size_t)stay[k]];
+      rows[r].resize(stay.size());
+   }
+}
+} // namespace
+
 int remClosePts(std::vector<std::vector<double>> &x, std::vector<std::vector<double>> &y,
                 double xThresh)
 {
    printf("remClosePts():  ||dtheta||_min=%f deg imposed. ", xThresh);
-
-   const double threshSq = xThresh * xThresh;
-   const int nx = (int)x.size();
-   const int ny = (int)y.size();
-   int n = (int)x[0].size();
-   const int nStart = n;
-   std::vector<char> drop(n, 0);
-
+   const int nStart = (int)x[0].size();
+   int n = nStart;
    for (;;)
    {
-      bool any = false;
-      for (int i = 1; i < n; ++i)
-      {
-         double distSq = 0;
-         for (int j = 0; j < nx; ++j)
-         {
-            const double dlt = x[j][i] - x[j][i - 1];
-            distSq += dlt * dlt;
-         }
-         if (distSq < threshSq && !drop[i - 1])
-         {
-            drop[i] = 1;
-            any = true;
-         }
-      }
-      if (drop[n - 1] && n > 2)
-      {
-         drop[n - 1] = 0;
-         drop[n - 2] = 1;
-         drop[n - 3] = 0;
-      }
-      if (!any) break;
-
-      int keep = 0;
-      for (int i = 0; i < n; ++i)
-      {
-         if (drop[i]) continue;
-         for (int j = 0; j < nx; ++j) x[j][keep] = x[j][i];
-         for (int j = 0; j < ny; ++j) y[j][keep] = y[j][i];
-         ++keep;
-      }
-      n = keep;
-      for (int j = 0; j < nx; ++j) x[j].resize(n);
-      for (int j = 0; j < ny; ++j) y[j].resize(n);
-      drop.assign(n, 0);
+      const std::vector<int> stay = survivorsOfPass(x, n, xThresh * xThresh);
+      if ((int)stay.size() == n) break;
+      keepOnly(x, stay, (size_t)n);
+      keepOnly(y, stay, (size_t)n);
+      n = (int)stay.size();
    }
    printf(" before %d points; after %d points\n", nStart, n);
    return 0;

@@ -41,7 +41,11 @@ from batotp_amd import capi, pathgen  # noqa: E402
 from batotp_amd import dist as bdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-DUMP_KNOTS = os.path.join(ROOT, "batotp_amd", "host", "_build", "baknots")  # the product's host resampler as a tool (no device call)
+# the PRODUCT's one-path route as a tool: BA::prepareKnots -> batotp_hip_resample with a batch of one (runs on the GPU)
+BAKNOTS = os.path.join(ROOT, "batotp_amd", "host", "_build", "baknots")
+# TEST INFRASTRUCTURE, cpu_baseline leg only: the same host shell linked against the CPU checker -- the ORACLE's resampler
+# (oracle/batotp_oracle_resample.c), the independent restatement every CPU-side comparison of this file is fed from
+ORACLE_KNOTS = os.path.join(ROOT, "oracle", "_build", "dump_knots")
 METRIC = "constraint-evaluated waypoints/sec + traversal-time err vs CPU ref"
 AS_WORDED_STEPS = 3     # timed steps of each BASELINE configuration as worded beside the headline (median reported as well)
 
@@ -99,17 +103,18 @@ CONFIGS = {
 # ---------------------------------------------------------------------------------------------------------------------
 # synthetic inputs
 # ---------------------------------------------------------------------------------------------------------------------
-def make_knots(workload: str, seed: int, n_target: int):
-    """one synthetic path -> (y [C_in][N], sres, problem, taught points) through the host resampler of the BA library"""
+def make_knots(workload: str, seed: int, n_target: int, tool: str = BAKNOTS):
+    """one synthetic path -> (y [C_in][N], sres, problem, taught points) through BA::prepareKnots of the host library: with the
+    default tool the product's one-path route (the device resampler with a batch of one), with ORACLE_KNOTS the checker's"""
     w = WORKLOADS[workload]
     n_coarse = max(8, int(round(n_target / w["knots_per_coarse"])))
     theta, cart, tres = w["gen"](seed, n_coarse)
     with tempfile.TemporaryDirectory() as work:
         pathgen.write_traj_bin(os.path.join(work, "path.dat"), tres, theta, cart)
         pathgen.write_config(os.path.join(work, "config.dat"), **w["cfg"])
-        r = subprocess.run([DUMP_KNOTS, "config.dat"], cwd=work, capture_output=True, text=True)
+        r = subprocess.run([tool, "config.dat"], cwd=work, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError("host resampling failed: " + r.stdout[-1000:])
+            raise RuntimeError(f"{os.path.basename(tool)} failed: " + r.stdout[-1000:])
         kb = open(os.path.join(work, "knots.bin"), "rb").read()
         N, nJ, nC = (int(v) for v in np.frombuffer(kb, "<i8", 3, 0))
         sres = float(np.frombuffer(kb, "<f8", 1, 24)[0])
@@ -180,7 +185,7 @@ class Inputs:
     def __init__(self, hip, workload, knots, seeds):
         self.hip, self.workload, self.K = hip, workload, len(seeds)
         self.seeds, self.knots_target = list(seeds), knots
-        first = make_knots(workload, seeds[0], knots)        # the host resampler: problem description, and the check below
+        first = make_knots(workload, seeds[0], knots)        # the one-path route of the product: problem description, and the check below
         self.prob = first[2]
         self.on_device = device_resamplable(workload) and self.K > 4
         if self.on_device:
@@ -201,14 +206,15 @@ class Inputs:
                 self.K = len(self.seeds)
             self.n_knots, self.sres = np.zeros(self.K, np.int64), np.zeros(self.K)
             self.taught, self.sres_in = taught_points_f32(workload, self.seeds, knots)
-            self.host_check = None
+            self.one_path_check = None
             for k0, rs in self._chunks():
                 m = rs.n_knots.shape[0]
                 if np.any(rs.status):
                     raise RuntimeError(f"device resampler refused {int(np.count_nonzero(rs.status))} synthetic paths")
                 self.n_knots[k0:k0 + m], self.sres[k0:k0 + m] = rs.n_knots, rs.sres
                 if k0 == 0:
-                    self.host_check = bool(np.array_equal(rs.knots(0)[: self.keep], first[0]) and rs.sres[0] == first[1])
+                    # the batch call and the one-path call (BA::interpInputData, a batch of one in another process) agree
+                    self.one_path_check = bool(np.array_equal(rs.knots(0)[: self.keep], first[0]) and rs.sres[0] == first[1])
                 rs.close()
             if self.K > want:
                 b = capi.Batch(hip, self.prob, [int(n) for n in self.n_knots], 8)
@@ -233,7 +239,8 @@ class Inputs:
             self.base = [first] + rest
             self.n_knots = np.array([b[0].shape[1] for b in self.base], np.int64)
             self.sres = np.array([b[1] for b in self.base])
-            self._data = f"synthetic: {self.K} distinct seeded spline paths per GPU resampled by the host BA library"
+            self._data = (f"synthetic: {self.K} distinct seeded spline paths per GPU resampled one by one through BA::interpInputData "
+                          f"(the device resampler with a batch of one)")
 
     spares = []
     skipped = 0
@@ -260,10 +267,28 @@ class Inputs:
             xs = [widen(self.workload, t) for t in self.taught[k0:k0 + self.CHUNK]]
             yield k0, capi.Resampled(self.hip, self.prm, xs, [self.sres_in] * len(xs))
 
-    def host_knots(self, k):
-        if self.on_device:
-            return make_knots(self.workload, self.seeds[k], self.knots_target)[:2]
-        return self.base[k][0], self.base[k][1]
+    def oracle_knots(self, k):
+        """CHECKER (cpu_baseline leg and tests only): (y, sres) of distinct path k from the ORACLE's resampler -- independent
+        of the device resampler that produced the knots the batch holds"""
+        return make_knots(self.workload, self.seeds[k], self.knots_target, tool=ORACLE_KNOTS)[:2]
+
+    def device_knot_digests(self, D):
+        """(sha256 of the knot rows, N, sres) of the first D distinct paths as the PRODUCT made them (device resampler: the batch
+        call, or the one-path route) -- kept on the host so that the cpu_baseline leg can compare them with the oracle's knots
+        after the GPU context is gone"""
+        import hashlib
+        out = []
+        if not self.on_device:
+            for k in range(min(D, self.K)):
+                out.append((hashlib.sha256(np.ascontiguousarray(self.base[k][0]).tobytes()).hexdigest(), int(self.base[k][0].shape[1]), float(self.base[k][1])))
+            return out
+        xs = [widen(self.workload, t) for t in self.taught[: min(D, self.K)]]
+        rs = capi.Resampled(self.hip, self.prm, xs, [self.sres_in] * len(xs))
+        for k in range(len(xs)):
+            y = np.ascontiguousarray(rs.knots(k)[: self.keep])
+            out.append((hashlib.sha256(y.tobytes()).hexdigest(), int(y.shape[1]), float(rs.sres[k])))
+        rs.close()
+        return out
 
     def fill(self, batch, n_paths):
         """path p of the batch <- distinct path p % K"""
@@ -583,12 +608,15 @@ def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=
                      "reverse": {"ms": kernel_ms[3], "algorithmic_bytes": bytes_rev}, "forward": {"ms": kernel_ms[4], "algorithmic_bytes": bytes_fwd}},
     }
     if inp.on_device:
-        out["inputs_identical_to_host_resampler"] = inp.host_check
+        # product against product (two routes into the same kernels); the comparison with the ORACLE's resampler is part of the
+        # cpu_baseline leg (`inputs_identical_to_oracle_resampler`)
+        out["batch_resampler_equals_one_path_route"] = inp.one_path_check
     if curve_gather is not None:
         out["curve_gather"] = curve_gather
     kept = None
     if keep:
-        kept = dict(batch=batch, inp=inp, prob=prob, cap=cap, res=res, K=K, B=B, chunk0=chunk_sizes[0] if B else 0)
+        kept = dict(batch=batch, inp=inp, prob=prob, cap=cap, res=res, K=K, B=B, chunk0=chunk_sizes[0] if B else 0,
+                    knot_digests=inp.device_knot_digests(32) if (rank == 0 and B) else [])
     elif batch is not None:
         batch.close()
     return out, kept
@@ -627,7 +655,7 @@ def measure_resampler(hip, workload, knots, n_paths):
         r.close()
         best = ms if best is None else min(best, ms)
     hip.trim()
-    return {"paths": n_paths, "knots": nk, "ms": best, "knots_per_s": nk / (best * 1e-3), "identical_to_host_resampler": same,
+    return {"paths": n_paths, "knots": nk, "ms": best, "knots_per_s": nk / (best * 1e-3), "identical_to_one_path_route": same,
             "what": "remClosePts + adjust_s x2 + interpSpecial + uniform re-evaluation on the device (taught points resident)"}
 
 
@@ -646,9 +674,16 @@ def cpu_baseline(kept, budget_s, out_prm=None, want_output=False, max_distinct=1
     octx = capi.Context(load_cpu_checker(), 0)
     cores = os.cpu_count() or 1
     inp, prob, cap, K = kept["inp"], kept["prob"], kept["cap"], kept["K"]
-    D = max(1, min(K, max_distinct))                      # distinct paths of the sample (host-resampled copies)
+    D = max(1, min(K, max_distinct))                      # distinct paths of the sample
+    # ... resampled by the ORACLE (oracle/batotp_oracle_resample.c through dump_knots), never by the product: the CPU leg is
+    # independent of the device from the taught points on, and the knots the GPU swept are compared with these bit for bit
     with cf.ThreadPoolExecutor(max_workers=min(D, cores)) as ex:
-        hosts = list(ex.map(inp.host_knots, range(D)))
+        hosts = list(ex.map(inp.oracle_knots, range(D)))
+    import hashlib
+    dig = kept.get("knot_digests") or []
+    n_cmp = min(D, len(dig))
+    knots_same = [bool(hashlib.sha256(np.ascontiguousarray(hosts[k][0]).tobytes()).hexdigest() == dig[k][0] and hosts[k][0].shape[1] == dig[k][1]
+                       and hosts[k][1] == dig[k][2]) for k in range(n_cmp)]
 
     def cpu_batch(n_paths, passes=1):
         nk = [hosts[i % D][0].shape[1] for i in range(n_paths)]
@@ -705,6 +740,9 @@ def cpu_baseline(kept, budget_s, out_prm=None, want_output=False, max_distinct=1
     err = float(np.max(np.abs(res["t_total"][idx[ok]] - rows["t_total"][: n_sample][ok]))) if np.any(ok) else 0.0
     mism = int(np.count_nonzero((res["steps_fwd"][idx[ok]] != rows["steps_fwd"][: n_sample][ok]) | (res["steps_rev"][idx[ok]] != rows["steps_rev"][: n_sample][ok])))
     info["paths_compared"] = int(np.count_nonzero(ok))
+    # the knots the GPU swept (device resampler) against the oracle resampler's, bit for bit (sha256 of the rows, N, sres)
+    info["inputs_identical_to_oracle_resampler"] = bool(n_cmp > 0 and all(knots_same))
+    info["inputs_compared"] = n_cmp
     return info, err, mism, th0
 
 
@@ -897,7 +935,7 @@ def main():
     if batch is not None:
         batch.close()
     # what the CPU baseline needs later lives on the host (the device batch is released now)
-    kept_host = {k: kept[k] for k in ("inp", "prob", "cap", "K", "res", "chunk0")} if (rank == 0 and kept is not None) else None
+    kept_host = {k: kept[k] for k in ("inp", "prob", "cap", "K", "res", "chunk0", "knot_digests")} if (rank == 0 and kept is not None) else None
     kept = None
     hip.trim()
 
@@ -914,7 +952,7 @@ def main():
                 if wk is not None and wk.get("batch") is not None:
                     wk["batch"].close()
                 if rank == 0 and wk is not None and wk.get("chunk0"):
-                    worded_host[name] = {k: wk[k] for k in ("inp", "prob", "cap", "K", "res", "chunk0")}
+                    worded_host[name] = {k: wk[k] for k in ("inp", "prob", "cap", "K", "res", "chunk0", "knot_digests")}
                 wk = None
                 worded[name] = {k: w.get(k) for k in ("value", "unit", "steps", "warmup", "ms_per_step", "ms_per_step_median", "ms_per_step_min_max",
                                                        "scaling", "data", "config", "kernel_ms", "steps_per_knot", "steps_per_path",

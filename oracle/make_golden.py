@@ -141,6 +141,11 @@ CASES = {
     # input decimation + smoothing (ba.cpp:195-242)
     "synth_gen7dof_s10_decim": (synth_gen7dof(10, 45, decim=3, smooth=3), True),
     "synth_cspr_s11_decim": (synth_cspr(11, 14, decim=2), True),
+    # s = teach time (sWeights 1 0 0: adjust_s returns at once, ba.cpp:416): the knots are the taught points after close-point
+    # removal, input smoothing / decimation -- the branch the host library keeps (BA::keepTaughtSpacing with the filters of
+    # batotp_amd/host/util.cpp); repeated points so that remClosePts really thins the path, the last one repeated too
+    "synth_gen7dof_s14_teachtime": (synth_gen7dof(14, 24, repeat_every=7, decim=3, smooth=3, s_weights=(1, 0, 0), scale_type=0), True),
+    "synth_gen7dof_s15_teachtime_decim2": (synth_gen7dof(15, 18, repeat_every=5, decim=2, s_weights=(1, 0, 0), scale_type=0), True),
     # BASELINE-size single paths: digest only (sha256 of the float32 curves + 1-in-64 samples)
     "synth_gen7dof_s4_50k": (synth_gen7dof(4, 871), False),
     "synth_ur_s7_100k": (synth_ur(7, 500), False),

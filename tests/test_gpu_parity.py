@@ -157,7 +157,10 @@ def test_serial_chain_needs_a_model(hip_ctx):
 def test_kuka_torque_limits_at_baseline_size(hip_ctx, oracle_ctx):
     """BASELINE config 3 as worded: KUKA-LWR-IV 7-DOF with torque limits, N = 100k, one trajectory: HIP == oracle"""
     import bench
-    y, sres, prob, _ = bench.make_knots("kuka7trq", 14, 100000)
+    y, sres, prob, _ = bench.make_knots("kuka7trq", 14, 100000, tool=bench.ORACLE_KNOTS)      # the checker's resampler
+    yp, sresp, _, _ = bench.make_knots("kuka7trq", 14, 100000)                                    # BA::interpInputData on the device
+    assert_bit_equal(yp, y, "one-path device resampler (KUKA joints + tool point) vs the oracle's knots")
+    assert sresp == sres
     assert 95000 < y.shape[1] < 105000 and prob.n_joints == 7 and (prob.flags & capi.F_TRQ_ON)
 
     class _C:
@@ -720,92 +723,6 @@ def test_product_batest_end_to_end_on_gpu(tmp_path):
         assert r.returncode == 0, (name, r.stdout[-2000:])
         assert filecmp.cmp(work / "s-sdot.dat", os.path.join(src, "ref_s-sdot.dat"), shallow=False), name
         assert filecmp.cmp(work / "traj_out.dat", os.path.join(src, "ref_traj_out.dat"), shallow=False), name
-
-
-def _batch_as_worded(hip_lib, oracle_ctx, config, n_paths, sample):
-    """a BASELINE batch configuration as bench.py builds it (distinct seeded paths, taught points -> knots by the device
-    resampler): size-independent properties for every path, bit equality with the oracle (fed by the HOST resampler) for a sample"""
-    import bench
-    ctx = capi.Context(hip_lib, 0)
-    c = bench.CONFIGS[config]
-    seeds = [7000 + k for k in range(min(c["distinct"], n_paths))]
-    inp = bench.Inputs(ctx, c["workload"], c["knots"], seeds)
-    K = inp.K
-    prob = capi.Problem.from_buffer_copy(bytes(inp.prob))
-    if prob.flags & capi.F_NO_SAMPLES:
-        prob.flags |= capi.F_COMPACT_SPLINES
-    cap = int(int(inp.n_knots.max()) * bench.WORKLOADS[c["workload"]]["cap"] * 2) + 1024
-    b = capi.Batch(ctx, prob, [int(inp.n_knots[p % K]) for p in range(n_paths)], cap)
-    inp.fill(b, n_paths)
-    b.precompute(0); b.sweep(-1); b.sweep(+1)
-    res = b.results()
-    ok = ((res["status_rev"] | res["status_fwd"]) & ~np.uint32(capi.ST_BISECT_FAIL)) == 0
-    # every distinct path through the oracle (one path per host thread, chunks bounded in memory): the result ROWS of all of
-    # them must be equal -- in particular the set of paths that end with an error status (cable tensions the limits do not
-    # admit: the reference grinds through such a path and returns -1) is exactly the oracle's, not "at most 3 %"
-    import concurrent.futures as cf
-    with cf.ThreadPoolExecutor(max_workers=min(K, os.cpu_count() or 1, 64)) as ex:
-        hosts = list(ex.map(inp.host_knots, range(K)))
-    pr = capi.Problem.from_buffer_copy(bytes(inp.prob))
-    chunk = max(1, min(K, int((24 << 30) / (1.5 * bench.bytes_per_path(pr, bench.WORKLOADS[c["workload"]]["C"], float(inp.n_knots.mean()), cap)))))
-    for k0 in range(0, K, chunk):
-        ks = range(k0, min(K, k0 + chunk))
-        ob = capi.Batch(oracle_ctx, pr, [hosts[k][0].shape[1] for k in ks], cap)
-        for i, k in enumerate(ks):
-            ob.upload_knots(i, [hosts[k][0]], [hosts[k][1]])
-        bench.prepare_dynamics(ob, pr, len(ks))
-        ob.precompute(0); ob.sweep(-1); ob.sweep(+1)
-        orows = ob.results()
-        ob.close()
-        for i, k in enumerate(ks):
-            assert res[k] == orows[i], (config, "distinct path", k, res[k], orows[i])
-    assert ok.mean() > 0.9, f"{(~ok).sum()} of {n_paths} paths failed: the generator is meant to produce mostly feasible paths"
-    assert np.all(res["t_total"][ok] == prob.integ_res * res["steps_fwd"][ok])           # T is quantised to the step
-    assert np.all(res["n_fwd"][ok] == res["steps_fwd"][ok] + 1) and np.all(res["n_rev"][ok] == res["steps_rev"][ok] + 1)
-    for p in range(K, n_paths):                                                          # tiled copies give identical rows
-        assert res[p] == res[p % K]
-    for p in sample:
-        y, sres = inp.host_knots(p % K)
-        class _C:
-            name = f"{config}:{p}"
-        cs = _C()
-        cs.y, cs.sres, cs.problem, cs.n = y, sres, inp.prob, y.shape[1]
-        cs.max_steps = lambda: cap
-        oo = run_pipeline(oracle_ctx, [cs], mvc=False, details=False)[0]
-        for f in res.dtype.names:
-            assert res[p][f] == oo["result"][f], (config, p, f)
-        if ok[p]:
-            for which, key in ((-1, "rev"), (1, "fwd")):
-                s, sd = b.curve(p, which)
-                assert_bit_equal(s, oo[key][0], f"{config} path {p} {key}.s")
-                assert_bit_equal(sd, oo[key][1], f"{config} path {p} {key}.sdot")
-                assert s[0] == 0.0 and np.all(np.diff(s) > 0)
-    # the same batch again with every bisection iteration checked (batotp_hip_set_fast_forward 0): every result row and the
-    # sampled curves must come out the same -- the certified fast-forward never changes a result, at full size either
-    kept = {p: (b.curve(p, -1), b.curve(p, 1)) for p in sample if ok[p]}
-    ctx.set_fast_forward(False)
-    b.precompute(0); b.sweep(-1); b.sweep(+1)
-    res2 = b.results()
-    for f in res.dtype.names:
-        assert np.array_equal(res2[f], res[f]), (config, "fast-forward off", f)
-    for p, (rev, fwd) in kept.items():
-        for which, before in ((-1, rev), (1, fwd)):
-            s, sd = b.curve(p, which)
-            assert_bit_equal(s, before[0], f"{config} path {p} curve {which} s, fast-forward off")
-            assert_bit_equal(sd, before[1], f"{config} path {p} curve {which} sdot, fast-forward off")
-    b.close()
-    ctx.trim()
-    ctx.close()
-
-
-def test_cfg4_batch_as_worded(hip_lib, oracle_ctx):
-    """BASELINE config 4 as worded: GEN7DOF, N = 50k, a batch of 1024 randomised (distinct) paths"""
-    _batch_as_worded(hip_lib, oracle_ctx, "cfg4", 1024, [0, 1, 511, 777, 1023])
-
-
-def test_cfg5_share_as_worded(hip_lib, oracle_ctx):
-    """BASELINE config 5 as worded, one GPU's share of the 4096-path batch at 8 GPUs: 512 cable-robot paths of 200k knots"""
-    _batch_as_worded(hip_lib, oracle_ctx, "cfg5", 512, [0, 77, 300])
 
 
 def test_paths_of_one_batch_integrate_with_their_own_steps(hip_lib, oracle_ctx):

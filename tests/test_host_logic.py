@@ -113,4 +113,8 @@ def test_which_configurations_the_device_stages_cover():
                                            "KUKA-LWR-IV", "KUKA_cartacc", "RR", "RR_acc", "UR5", "UR5_nocartacc",
                                            # the cable robot with solveLinSys through the Jacobi SVD (isSVD = 1)
                                            "CSPR3DOF_svd", "CSPR3DOF_par_svd"}
-    assert set(helpers.OUTPUT_CASES) == set(helpers.RESAMPLE_CASES) == set(helpers.FULL_CASES)   # every shipped example and edited variant
+    # paths whose s is the teach time (sWeights 1 0 0) need no resampling stage: adjust_s returns at once (ba.cpp:416) and the
+    # knots are the taught points after the host filters (BA::keepTaughtSpacing); the output stage runs on the device for them too
+    teach_time = {"synth_gen7dof_s14_teachtime", "synth_gen7dof_s15_teachtime_decim2"}
+    assert set(helpers.RESAMPLE_CASES) | teach_time == set(helpers.FULL_CASES)   # every shipped example and edited variant
+    assert set(helpers.OUTPUT_CASES) == set(helpers.FULL_CASES)
