@@ -97,7 +97,7 @@ struct batotp_ctx
    int flatForm = 1;      // flat loop of the 8-lane layout: 1 = k_sweep8 (sweep8.hip.h), 0 = k_sweep's own flat instantiation (A/B, parity)
    int fastForward = 1;   // certified fast-forward of the bisection in the sweep kernels that have it (bisect_fast_forward)
    int flatStatus = 0;
-   char builtWith[192] = "";    // toolchain the gate compares (the real one unless BATOTP_ASSUME_TOOLCHAIN overrides it for a test)
+   char builtWith[192] = "";    // toolchain the gate compares (the real one; only a -DBATOTP_TEST_HOOKS build lets a test override it)
 };
 
 struct batotp_batch
@@ -269,15 +269,20 @@ extern "C" int batotp_hip_ctx_create(int device, batotp_ctx **out)
    batotp_ctx *c = new (std::nothrow) batotp_ctx;
    if (!c) return BATOTP_ERR_ALLOC;
    c->device = device;
+   strncpy(c->builtWith, kBuiltWith, sizeof(c->builtWith) - 1);
+#ifdef BATOTP_TEST_HOOKS
    {
-      // a test can pretend the library came from ANOTHER compiler (tests/test_gpu_parity.py: the automatic choice must then
-      // run the nested loops).  The variable can only close the gate: a value equal to the validated string is ignored, so
-      // nobody opens the gate of a library from an unvalidated compiler through the environment.
+      // TEST BUILD ONLY (csrc/libbatotp_hip_testhooks.so, never the shipped library): a test can pretend the library came from
+      // ANOTHER compiler -- the automatic choice must then run the nested loops (tests/test_gpu_parity.py).  The variable can
+      // only close the gate: a value equal to the validated string is ignored.
       const char *assume = getenv("BATOTP_ASSUME_TOOLCHAIN");
-      const bool closes = assume && assume[0] && strcmp(assume, kFlatValidatedWith) != 0;
-      strncpy(c->builtWith, closes ? assume : kBuiltWith, sizeof(c->builtWith) - 1);
-      // (the C-ABI never prints: batotp_hip_flat_loop_status / batotp_hip_toolchain report a closed gate, bench.py puts both in its line)
+      if (assume && assume[0] && strcmp(assume, kFlatValidatedWith) != 0)
+      {
+         memset(c->builtWith, 0, sizeof(c->builtWith));
+         strncpy(c->builtWith, assume, sizeof(c->builtWith) - 1);
+      }
    }
+#endif
    e = hipSetDevice(device);
    if (e != hipSuccess) { delete c; return hipFail(e, "hipSetDevice"); }
    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -1102,17 +1107,22 @@ extern "C" int batotp_hip_upload_forward_curve(batotp_batch *b, int32_t path, co
 {
    if (!b || !s || !sdot || path < 0 || path >= b->B || n < 2 || n > b->cap) return BATOTP_ERR_ARG;
    if (b->inPlace || b->mvcInCurves) { snprintf(g_err, sizeof(g_err), "upload_forward_curve: not for batches that share curve slots"); return BATOTP_ERR_STATE; }
+   // the batch-wide state flags below (revDone, fwdStale) describe EVERY path: the call is for the batch of one that
+   // BA::interpOutputData builds around a caller's Traj, not for marking one path of many as swept
+   if (b->B != 1) { snprintf(g_err, sizeof(g_err), "upload_forward_curve: only for a batch of one path"); return BATOTP_ERR_STATE; }
    int rc = bind(b->ctx);
    if (rc) return rc;
+   if ((rc = joinK3(b))) return rc; // an overlapped pointwise evaluation may still be running on the second stream
    double *tmp = nullptr;
    rc = xferReserve(b->ctx, sizeof(double) * 2 * (size_t)n, &tmp);
    if (rc) return rc;
-   hipMemcpyAsync(tmp, s, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, b->ctx->stream);
-   hipMemcpyAsync(tmp + n, sdot, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, b->ctx->stream);
+   HIP_TRY(hipMemcpyAsync(tmp, s, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, b->ctx->stream));
+   HIP_TRY(hipMemcpyAsync(tmp + n, sdot, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, b->ctx->stream));
    const int bs = 256;
    hipLaunchKernelGGL(k_curve_pack, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, b->ctx->stream, b->dFwd + (int64_t)path * b->cap, tmp, tmp + n, n);
+   HIP_TRY(hipGetLastError());
    batotp_path_result r;
-   hipMemcpyAsync(&r, b->dRes + path, sizeof(r), hipMemcpyDeviceToHost, b->ctx->stream);
+   HIP_TRY(hipMemcpyAsync(&r, b->dRes + path, sizeof(r), hipMemcpyDeviceToHost, b->ctx->stream));
    hipError_t e = hipStreamSynchronize(b->ctx->stream);
    if (e == hipSuccess)
    {
@@ -1131,7 +1141,10 @@ extern "C" int batotp_hip_set_path_integ_res(batotp_batch *b, int32_t path0, int
 {
    if (!b || !integ_res || path0 < 0 || n < 0 || path0 + n > b->B) return BATOTP_ERR_ARG;
    for (int k = 0; k < n; ++k)
-      if (!(integ_res[k] > 0) && integ_res[k] == integ_res[k]) return BATOTP_ERR_ARG; // positive or NaN (the rule's result without Cartesian limits)
+      // positive and finite, or NaN: what the automatic rule leaves for a robot without Cartesian limits (0/0 kept by std::min /
+      // std::max, ba.cpp:519-533) -- such a path takes no integration step and ends with BATOTP_ST_MAX_INTEG_TIME; an infinite
+      // step is never a result of the rule
+      if ((!(integ_res[k] > 0) && integ_res[k] == integ_res[k]) || std::isinf(integ_res[k])) return BATOTP_ERR_ARG;
    int rc = bind(b->ctx);
    if (rc) return rc;
    for (int k = 0; k < n; ++k) b->pinfo[path0 + k].integ_res = integ_res[k];
@@ -1188,7 +1201,10 @@ static int flatCanaryOnce(batotp_ctx *ctx, bool compact, bool *same)
    std::vector<batotp_path_result> rows[2];
    std::vector<double2> curves[2], curvesF[2];
    const int holdSaved[2] = {ctx->sweepHold[0], ctx->sweepHold[1]}, groupSaved = ctx->sweepGroup, ppwSaved = ctx->pathsPerWave;
-   ctx->sweepGroup = 8; ctx->pathsPerWave = 8;
+   const int formSaved = ctx->flatForm, ffSaved = ctx->fastForward;
+   // the canary compares exactly what the automatic choice launches: 8 lanes per path, k_sweep8, the certified fast-forward on --
+   // whatever the developer switches of this context say at the moment
+   ctx->sweepGroup = 8; ctx->pathsPerWave = 8; ctx->flatForm = 1; ctx->fastForward = 1;
    rc = batotp_hip_upload_knots(b, 0, B, y.data(), sres.data());
    if (!rc) rc = batotp_hip_precompute(b, 0);
    for (int form = 0; form < 2 && !rc; ++form)
@@ -1205,6 +1221,7 @@ static int flatCanaryOnce(batotp_ctx *ctx, bool compact, bool *same)
       if (!rc && hipMemcpy(curvesF[form].data(), b->dFwd, sizeof(double2) * curvesF[form].size(), hipMemcpyDeviceToHost) != hipSuccess) rc = BATOTP_ERR_HIP;
    }
    ctx->sweepHold[0] = holdSaved[0]; ctx->sweepHold[1] = holdSaved[1]; ctx->sweepGroup = groupSaved; ctx->pathsPerWave = ppwSaved;
+   ctx->flatForm = formSaved; ctx->fastForward = ffSaved;
    batotp_hip_batch_destroy(b);
    if (rc) return rc;
    bool eq = memcmp(rows[0].data(), rows[1].data(), sizeof(batotp_path_result) * (size_t)B) == 0;
@@ -1302,10 +1319,12 @@ static void launchSweep(batotp_batch *b, SweepArgs &a)
       // loops' schedule, every path of the wavefront starts its stage together -- because that kernel executes 9 % fewer
       // vector and 37 % fewer scalar instructions than the nested form of k_sweep (round 4: 444 against 560 ms at 16 384
       // paths, profiles/r04_a_*); the general kernel's own flat form does not gain in the forward sweep and keeps the nested loops
-      const bool candidate = (G == 8 || G == 4 || G == 2) && featureLevel(b) <= 0 && uni;
-      const bool fwd8 = G == 8 && b->ctx->flatForm == 1 && b->cap < ((int64_t)1 << 30);
+      // Only the form the canary of flatLoopStatus compares: 8 lanes per path in k_sweep8.  With 2 or 4 lanes per path, or with
+      // k_sweep's own flat instantiation selected (batotp_hip_set_flat_form 0), the automatic choice keeps the nested loops --
+      // an explicit batotp_hip_set_sweep_hold remains the developer's switch for those.
+      const bool candidate = G == 8 && featureLevel(b) <= 0 && uni && b->ctx->flatForm == 1 && b->cap < ((int64_t)1 << 30);
       hold = -1;
-      if (candidate && (a.dir == -1 || fwd8) && flatLoopStatus(b->ctx) == 1) hold = a.dir == -1 ? 4 : 8;
+      if (candidate && flatLoopStatus(b->ctx) == 1) hold = a.dir == -1 ? 4 : 8;
    }
    if (hold > 8) hold = 8;
    a.hold = hold;

@@ -560,6 +560,14 @@ int BA::deviceSweep(Traj &traj)
       return -1;
    }
 
+   if (!(_integRes > 0) || std::isinf(_integRes) || !(_maxIntegTime >= 0))
+   {
+      // (the automatic integration resolution leaves NaN for a robot without Cartesian limits, reference ba.cpp:519-533; the
+      // reference then loops on NaN state until its step budget -- itself a cast of NaN -- runs out)
+      printf("Error in sweep(): the integration step (%g s) is not a positive finite number.\n", _integRes);
+      setErrorOptimization(MAX_INTEGRATION_TIME);
+      return -1;
+   }
    const int64_t maxIntegSteps = (int64_t)std::floor(_maxIntegTime / _integRes) + 1;
    const int64_t cap = maxIntegSteps + 2;
 

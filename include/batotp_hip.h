@@ -234,13 +234,16 @@ int  batotp_hip_upload_curve(batotp_batch *batch, int32_t path, const double *s,
 /* the curve published by the FORWARD sweep (traj.sMVC / traj.sdot after sweep(+1), n = traj.nPts) with its traversal
  * time traj.tTotalTraj: what the output stage (batotp_hip_output) needs of a path whose sweeps ran elsewhere -- the
  * step-by-step host API BA::sweep / BA::interpOutputData (reference ba.cpp:979-1195, 1661-1931) moves one Traj at a time
- * through batches of one path.  Marks both sweeps of the path as done. */
+ * through batches of one path.  Marks both sweeps as done, for the WHOLE batch: the call is only valid on a batch of one path
+ * (BATOTP_ERR_STATE otherwise) that does not share curve slots (no BATOTP_F_CURVES_IN_PLACE / BATOTP_F_MVC_IN_CURVES). */
 int  batotp_hip_upload_forward_curve(batotp_batch *batch, int32_t path, const double *s, const double *sdot,
                                      int64_t n, double t_total);
 /* the integration step _integRes of paths [path0, path0 + n) (default: batotp_problem.integ_res for every path).  The
  * automatic integration resolution of the reference (ba.cpp:493-556, the class default ba.h:309) derives it from each path;
  * the sweeps, the pointwise evaluation and the output stage read it per path.  Call before batotp_hip_precompute /
- * batotp_hip_sweep; integ_res[k] must be positive or NaN (the rule's own result for a robot without Cartesian limits). */
+ * batotp_hip_sweep; integ_res[k] must be positive and finite, or NaN (the rule's own result for a robot without Cartesian
+ * limits: such a path takes no step and ends with BATOTP_ST_MAX_INTEG_TIME); zero, negative and infinite steps are
+ * BATOTP_ERR_ARG. */
 int  batotp_hip_set_path_integ_res(batotp_batch *batch, int32_t path0, int32_t n, const double *integ_res);
 
 /* ---- the hot path ----------------------------------------------------------------------- */
@@ -431,8 +434,9 @@ int  batotp_hip_resampled_destroy(batotp_resampled *r);
 /* knots per path, traj.sres per path, status bits per path (any pointer may be NULL) */
 int  batotp_hip_resampled_info(batotp_resampled *r, int64_t *n_knots, double *sres, uint32_t *status);
 /* automatic integration resolution (BATOTP_RS_AUTO_INTEG_RES): what the two adjust_s passes left per path -- _integRes,
- * _sWeights (3 per path) and _scaleType (reference ba.cpp:493-556).  Without the flag: the caller's values.  Any pointer
- * may be NULL. */
+ * _sWeights (3 per path) and _scaleType (reference ba.cpp:493-556).  Without the flag s_weights / scale_type come back as the
+ * caller passed them and integ_res[] is 0.0 -- batotp_resample_params carries no integration step, and 0.0 is a value
+ * batotp_hip_set_path_integ_res refuses, so it cannot be fed on by accident.  Any pointer may be NULL. */
 int  batotp_hip_resampled_auto(batotp_resampled *r, double *integ_res, double *s_weights, int32_t *scale_type);
 /* device pointer of the knots, laid out as batotp_hip_upload_knots_device expects them (paths
  * with a non-zero status hold 4 zero knots).  The knots live in a workspace the context keeps

@@ -159,7 +159,7 @@ int batotp_hip_set_path_integ_res(batotp_batch *b, int32_t path0, int32_t n, con
     int32_t k;
     if (!b || !integ_res || path0 < 0 || n < 0 || path0 + n > b->n_paths) return BATOTP_ERR_ARG;
     for (k = 0; k < n; k++) {
-        if (!(integ_res[k] > 0) && integ_res[k] == integ_res[k]) return BATOTP_ERR_ARG; /* positive or NaN */
+        if ((!(integ_res[k] > 0) && integ_res[k] == integ_res[k]) || isinf(integ_res[k])) return BATOTP_ERR_ARG; /* positive and finite, or NaN */
         b->integ_res[path0 + k] = integ_res[k];
     }
     return BATOTP_OK;
@@ -260,6 +260,7 @@ int batotp_hip_upload_curve(batotp_batch *b, int32_t path, const double *s, cons
 int batotp_hip_upload_forward_curve(batotp_batch *b, int32_t path, const double *s, const double *sdot, int64_t n, double t_total)
 {
     if (!b || path < 0 || path >= b->n_paths || n < 2 || !s || !sdot) return BATOTP_ERR_ARG;
+    if (b->n_paths != 1) return BATOTP_ERR_STATE; /* state rule of the product: a batch of one */
     set_curve(b->fwd_s, b->fwd_sd, path, s, sdot, n);
     b->res[path].n_fwd = n;
     b->res[path].steps_fwd = n - 1;

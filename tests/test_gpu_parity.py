@@ -400,8 +400,11 @@ def test_spline_build_in_tiles_equals_the_sequential_kernel(hip_lib, oracle_ctx,
 def test_flat_sweep_loop_is_gated_by_toolchain_and_canary(hip_lib, oracle_ctx, monkeypatch):
     """the AUTOMATIC loop choice takes the flat reverse loop only if the library was built by the toolchain the loop was
     validated with and the on-device canary (nested against flat loop on ordinary, crawling and always-failing paths) found
-    no difference; a library from another toolchain -- forced here through BATOTP_ASSUME_TOOLCHAIN -- runs the nested loops.
-    Results are the oracle's either way."""
+    no difference; a library from another toolchain runs the nested loops.  The mismatch is forced through
+    BATOTP_ASSUME_TOOLCHAIN, which only the TEST BUILD of the library reads (csrc/libbatotp_hip_testhooks.so, the same source
+    with -DBATOTP_TEST_HOOKS); the shipped library ignores the variable.  Results are the oracle's either way."""
+    shipped = hip_lib
+    hip_lib = capi.Library(os.path.join(helpers.ROOT, "batotp_amd", "csrc", "libbatotp_hip_testhooks.so"))
     built, validated = hip_lib.toolchain()
     assert built and validated
     case = Case("synth_gen7dof_s0")
@@ -434,6 +437,11 @@ def test_flat_sweep_loop_is_gated_by_toolchain_and_canary(hip_lib, oracle_ctx, m
     # gate open: reverse = flat loop with hold 4, forward = k_sweep8 with hold 8 (the nested loops' schedule in the leaner kernel)
     assert seen["real"][1] == (8, 8, 4 if expect_real == 1 else -1) and seen["real"][2] == (8, 8, 8 if expect_real == 1 else -1), seen
     assert seen["other"][0] == -1 and seen["other"][1] == (8, 8, -1) and seen["other"][2] == (8, 8, -1), seen
+    # the shipped library does not read the environment: the same variable leaves its gate where the real toolchain puts it
+    monkeypatch.setenv("BATOTP_ASSUME_TOOLCHAIN", "clang 99.0 / HIP 99.0")
+    ctx = capi.Context(shipped, 0)
+    assert ctx.flat_loop_status() == expect_real
+    ctx.close()
 
 
 @pytest.mark.parametrize("lanes", [0, 1, 8, 16, 32, 64, "flat4"])

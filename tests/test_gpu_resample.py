@@ -298,3 +298,39 @@ def test_short_paths_are_stretched_to_four_points(hip_ctx, oracle_ctx):
     assert int(h.status[3]) != 0 and int(h.status[4]) == 0
     assert_bit_equal(h.knots(4), c.y, "the full path beside them is untouched")
     h.close(); o.close()
+
+
+@pytest.mark.parametrize("workload,knots,n_seeds", [("gen7", 6000, 192), ("cspr", 8000, 96), ("kuka7trq", 6000, 64)])
+def test_concurrent_one_path_resampling_equals_the_oracle(workload, knots, n_seeds):
+    """Regression for the red driver run of round 4: BA::interpInputData of ONE path goes through batotp_hip_resample with a
+    batch of one -- `baknots`, a process and a HIP context per path, 64 of them at a time on one GPU (what bench.py and the
+    BASELINE-size tests did when one of 1024 such calls came back with different knots and rc 0).  Every knots.bin must be
+    the ORACLE resampler's (oracle/_build/dump_knots: the same host shell over the CPU checker), bit for bit; a call that
+    fails must say so through its exit code."""
+    import concurrent.futures as cf
+    import hashlib
+    import os
+    import subprocess
+    import tempfile
+    import bench
+
+    def digest(tool, seed):
+        w = bench.WORKLOADS[workload]
+        n_coarse = max(8, int(round(knots / w["knots_per_coarse"])))
+        theta, cart, tres = w["gen"](seed, n_coarse)
+        with tempfile.TemporaryDirectory() as work:
+            pathgen.write_traj_bin(os.path.join(work, "path.dat"), tres, theta, cart)
+            pathgen.write_config(os.path.join(work, "config.dat"), **w["cfg"])
+            r = subprocess.run([tool, "config.dat"], cwd=work, capture_output=True, text=True)
+            assert r.returncode == 0, (workload, seed, os.path.basename(tool), r.stdout[-600:])
+            return hashlib.sha256(open(os.path.join(work, "knots.bin"), "rb").read()).hexdigest()
+
+    seeds = [31000 + k for k in range(n_seeds)]
+    jobs = min(64, os.cpu_count() or 1)
+    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+        want = list(ex.map(lambda s: digest(bench.ORACLE_KNOTS, s), seeds))
+    for rnd in range(2):
+        with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+            got = list(ex.map(lambda s: digest(bench.BAKNOTS, s), seeds))
+        bad = [s for s, a, b in zip(seeds, want, got) if a != b]
+        assert not bad, f"{workload}: one-path device resampling differs from the oracle's knots for seeds {bad} (round {rnd}, {jobs} concurrent processes)"

@@ -34,11 +34,13 @@ ORACLE_KNOTS = os.path.join(ROOT, "oracle", "_build", "dump_knots")
 
 
 def prepare(workload, seed, n_target, work):
+    """writes path.dat / config.dat; returns the sha256 of path.dat (the generator runs in the calling thread)"""
     w = bench.WORKLOADS[workload]
     n_coarse = max(8, int(round(n_target / w["knots_per_coarse"])))
     theta, cart, tres = w["gen"](seed, n_coarse)
     pathgen.write_traj_bin(os.path.join(work, "path.dat"), tres, theta, cart)
     pathgen.write_config(os.path.join(work, "config.dat"), **w["cfg"])
+    return hashlib.sha256(open(os.path.join(work, "path.dat"), "rb").read()).hexdigest()
 
 
 def run_tool(tool, work, env=None):
@@ -64,6 +66,7 @@ def main():
     ap.add_argument("--jobs", type=int, default=64)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--resident", type=int, default=1024, help="paths of a resident batch sweeping meanwhile (0: none)")
+    ap.add_argument("--idle", action="store_true", help="the resident batch sweeps once and then sits idle (what the red test had)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "repro"))
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
@@ -75,16 +78,28 @@ def main():
     def oracle_one(seed):
         work = os.path.join(base, f"o{seed}")
         os.makedirs(work)
-        prepare(a.workload, seed, a.knots, work)
+        ph = prepare(a.workload, seed, a.knots, work)
         kb, msg = run_tool(ORACLE_KNOTS, work)
         if kb is None:
             raise RuntimeError(f"oracle resampler failed on seed {seed}: {msg}")
         shutil.rmtree(work)
-        return hashlib.sha256(kb).hexdigest(), len(kb)
+        return hashlib.sha256(kb).hexdigest(), len(kb), ph
+
+    # the synthetic-path generator (numpy / scipy in many threads): serial digests first, so that a wrong INPUT is told
+    # apart from a wrong resampling result
+    serial = {}
+    for seed in seeds:
+        work = os.path.join(base, f"g{seed}")
+        os.makedirs(work)
+        serial[seed] = prepare(a.workload, seed, a.knots, work)
+        shutil.rmtree(work)
+    print(f"serial generation of {len(seeds)} inputs in {time.time() - t0:.1f} s", flush=True)
 
     with cf.ThreadPoolExecutor(max_workers=min(a.jobs, os.cpu_count() or 1)) as ex:
         want = dict(zip(seeds, ex.map(oracle_one, seeds)))
     by_digest = {v[0]: s for s, v in want.items()}
+    gen_bad = [s for s in seeds if want[s][2] != serial[s]]
+    print(f"generator in {a.jobs} threads against serial generation: {len(gen_bad)} different inputs {gen_bad[:8]}", flush=True)
     print(f"oracle knots of {len(seeds)} seeds in {time.time() - t0:.1f} s", flush=True)
 
     # a resident batch that keeps the GPU busy the way the test had it (its own context, sweeping in a loop)
@@ -106,6 +121,9 @@ def main():
             while not stop.is_set():
                 b.precompute(0); b.sweep(-1); b.sweep(+1)
                 busy["steps"] += 1
+                if a.idle:
+                    hip.synchronize()
+                    break
         thr = threading.Thread(target=spin)
         thr.start()
         print(f"resident batch of {a.resident} paths sweeping ({b.nbytes() / 2**30:.1f} GiB)", flush=True)
@@ -116,10 +134,12 @@ def main():
         rnd, seed = args
         work = os.path.join(base, f"d{rnd}_{seed}")
         os.makedirs(work)
-        prepare(a.workload, seed, a.knots, work)
+        ph = prepare(a.workload, seed, a.knots, work)
         kb, msg = run_tool(BAKNOTS, work)
         rec = None
-        if kb is None:
+        if ph != serial[seed]:
+            rec = dict(round=rnd, seed=seed, kind="generator produced a different input in this thread")
+        elif kb is None:
             rec = dict(round=rnd, seed=seed, kind="failed", msg=msg)
         elif hashlib.sha256(kb).hexdigest() != want[seed][0]:
             keep = os.path.join(a.out, f"r{rnd}_s{seed}")
