@@ -228,6 +228,9 @@ class Library:
             "batotp_hip_set_sweep_prefetch": [P, I32, I32],
             "batotp_hip_set_spline_tiles": [P, I32],
             "batotp_hip_set_fast_forward": [P, I32],
+            "batotp_hip_set_k3_form": [P, I32],
+            "batotp_hip_set_path_order": [P, I32],
+            "batotp_hip_set_workspace_budget": [P, C.c_int64, C.c_int64],
             "batotp_hip_spline_tile_fallbacks": [P, C.POINTER(I32)],
             "batotp_hip_flat_loop_status": [P, C.POINTER(I32)],
             "batotp_hip_toolchain": [C.c_char_p, C.c_char_p, I32],
@@ -316,6 +319,18 @@ class Context:
     def set_fast_forward(self, on):
         """certified fast-forward of the bisection (include/batotp_hip.h); never changes a result"""
         self.library.check(self.library.lib.batotp_hip_set_fast_forward(self.handle, int(on)), "set_fast_forward")
+
+    def set_workspace_budget(self, resample_bytes: int = 0, output_bytes: int = 0):
+        """scratch bytes per chunk of paths of the resampler / the output stage (0 = from the free device memory)"""
+        self.library.check(self.library.lib.batotp_hip_set_workspace_budget(self.handle, int(resample_bytes), int(output_bytes)), "set_workspace_budget")
+
+    def set_path_order(self, mode: int):
+        """ragged batches: 1 = the sweeps take the paths longest first (default), 0 = in the order given"""
+        self.library.check(self.library.lib.batotp_hip_set_path_order(self.handle, int(mode)), "set_path_order")
+
+    def set_k3_form(self, form: int):
+        """per-knot evaluation of velocity / acceleration-only problems: 1 = k_pointwise_va (default), 0 = the general kernel"""
+        self.library.check(self.library.lib.batotp_hip_set_k3_form(self.handle, int(form)), "set_k3_form")
 
     def set_spline_tiles(self, on):
         """True / False, or -1 for the automatic choice (tiles for small batches)"""

@@ -18,6 +18,7 @@
 #include "kernels.hip.h"
 #include "sweep1.hip.h"
 #include "sweep8.hip.h"
+#include "pointwise_va.hip.h"
 #include "spline_stream.hip.h"
 #include "spline_tile.hip.h"
 #include "resample.hip.h"
@@ -96,6 +97,9 @@ struct batotp_ctx
    int splineTiles = -1;  // K1 in tiles of knots (spline_tile.hip.h): -1 automatic (small batches), 1 always, 0 never
    int flatForm = 1;      // flat loop of the 8-lane layout: 1 = k_sweep8 (sweep8.hip.h), 0 = k_sweep's own flat instantiation (A/B, parity)
    int fastForward = 1;   // certified fast-forward of the bisection in the sweep kernels that have it (bisect_fast_forward)
+   int64_t rsBudget = 0, outBudget = 0; // scratch bytes a chunk of the resampler / output stage may take; 0 = from the free memory
+   int pathOrder = 1;     // ragged batches: 1 = the sweeps take the paths longest first (SweepArgs::order), 0 = in the order given
+   int k3Form = 1;        // per-knot evaluation of velocity / acceleration-only problems: 1 = k_pointwise_va (pointwise_va.hip.h), 0 = the general kernel
    int flatStatus = 0;
    char builtWith[192] = "";    // toolchain the gate compares (the real one; only a -DBATOTP_TEST_HOOKS build lets a test override it)
 };
@@ -128,6 +132,8 @@ struct batotp_batch
    double *dY = nullptr, *dSC = nullptr, *dCoef = nullptr, *dSamp = nullptr, *dDyn = nullptr, *dTrig = nullptr, *dMvc = nullptr;
    double2 *dRev = nullptr, *dFwd = nullptr;
    batotp_path_result *dRes = nullptr;
+   int *dOrder = nullptr;    // ragged batch: path indices sorted by knot count, longest first (nullptr: all paths equally long)
+   double *dProf = nullptr;  // diagnostic build (-DS8_PROFILE): 16 doubles per wavefront of k_sweep8
    double *dStage = nullptr; // staging for marshalling (4*maxN doubles)
    int *dSink = nullptr;     // consumer of the sweep kernel's prefetch touches
    double *dElim = nullptr;  // Thomas elimination values of k_spline, [max(Cin,4d)][N] per path
@@ -386,6 +392,39 @@ extern "C" int batotp_hip_set_fast_forward(batotp_ctx *ctx, int32_t on)
    return BATOTP_OK;
 }
 
+#ifdef S8_PROFILE
+// diagnostic build only: the counters k_sweep8 left (16 doubles per wavefront, n_waves <= B)
+extern "C" int batotp_hip_debug_sweep8_counters(batotp_batch *b, double *out, int64_t n_doubles)
+{
+   if (!b || !out || n_doubles > (int64_t)b->B * 16 + 16) return BATOTP_ERR_ARG;
+   HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+   HIP_TRY(hipMemcpy(out, b->dProf, sizeof(double) * (size_t)n_doubles, hipMemcpyDeviceToHost));
+   return BATOTP_OK;
+}
+#endif
+
+extern "C" int batotp_hip_set_path_order(batotp_ctx *ctx, int32_t mode)
+{
+   if (!ctx || (mode != 0 && mode != 1)) return BATOTP_ERR_ARG;
+   ctx->pathOrder = mode;
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_set_workspace_budget(batotp_ctx *ctx, int64_t resample_bytes, int64_t output_bytes)
+{
+   if (!ctx || resample_bytes < 0 || output_bytes < 0) return BATOTP_ERR_ARG;
+   ctx->rsBudget = resample_bytes;
+   ctx->outBudget = output_bytes;
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_set_k3_form(batotp_ctx *ctx, int32_t form)
+{
+   if (!ctx || (form != 0 && form != 1)) return BATOTP_ERR_ARG;
+   ctx->k3Form = form;
+   return BATOTP_OK;
+}
+
 extern "C" int batotp_hip_spline_tile_fallbacks(batotp_batch *b, int32_t *series)
 {
    if (!b || !series) return BATOTP_ERR_ARG;
@@ -497,7 +536,7 @@ extern "C" int batotp_hip_batch_destroy(batotp_batch *b)
    if (b->ctx) hipSetDevice(b->ctx->device);
    if (b->ctx && b->k3Pending) hipStreamSynchronize(b->ctx->stream2);
    if (b->dFwd == b->dRev) b->dFwd = nullptr; // BATOTP_F_CURVES_IN_PLACE: one buffer
-   void *ptrs[] = {b->dP, b->dPinfo, b->dY, b->dSC, b->dCoef, b->dSamp, b->dDyn, b->dTrig, b->dMvc, b->dRev, b->dFwd, b->dRes, b->dStage, b->dSink, b->dElim, b->dKM, b->dUp, b->dModel, b->dJTrig, b->dTileOff, b->dDirty, b->dEdge};
+   void *ptrs[] = {b->dP, b->dPinfo, b->dY, b->dSC, b->dCoef, b->dSamp, b->dDyn, b->dTrig, b->dMvc, b->dRev, b->dFwd, b->dRes, b->dStage, b->dSink, b->dElim, b->dKM, b->dUp, b->dModel, b->dJTrig, b->dTileOff, b->dDirty, b->dEdge, b->dProf, b->dOrder};
    for (void *p : ptrs)
       if (p) hipFree(p);
    for (int k = 0; k < 5; ++k)
@@ -597,6 +636,26 @@ extern "C" int batotp_hip_batch_create(batotp_ctx *ctx, const batotp_problem *pr
       return BATOTP_ERR_ARG;
    }
    if (!b->mvcInCurves) { ALLOC(b->dMvc, off * 3, double) }
+   {
+      // ragged batch: the launch order of the sweeps (SweepArgs::order)
+      bool ragged = false;
+      for (int p = 1; p < n_paths; ++p) ragged |= n_knots[p] != n_knots[0];
+      if (ragged)
+      {
+         std::vector<int> order((size_t)n_paths);
+         for (int p = 0; p < n_paths; ++p) order[(size_t)p] = p;
+         std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return n_knots[x] > n_knots[y]; });
+         ALLOC(b->dOrder, n_paths, int)
+         if (hipMemcpy(b->dOrder, order.data(), sizeof(int) * (size_t)n_paths, hipMemcpyHostToDevice) != hipSuccess)
+         {
+            batotp_hip_batch_destroy(b);
+            return BATOTP_ERR_HIP;
+         }
+      }
+   }
+#ifdef S8_PROFILE
+   ALLOC(b->dProf, (int64_t)n_paths * 16 + 16, double)
+#endif
    ALLOC(b->dRev, (int64_t)n_paths * max_steps, double2)
    b->inPlace = (prob->flags & BATOTP_F_CURVES_IN_PLACE) != 0;
    if (b->inPlace) b->dFwd = b->dRev; // one curve buffer: the forward sweep overwrites the reverse points behind its cursor
@@ -1052,7 +1111,9 @@ extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
    // LDS staging of the coefficient rows (coalesced copy, then conflict-free reads) is available but off: measured, it
    // is the occupancy it costs that matters -- UR6 rows (C = 6) 90 ms with the tile, 60 ms reading the rows directly;
    // cable robot (C = 18) 125 vs 53 ms.  BATOTP_K3_TILE=1 switches it on for experiments.
-   const bool useTile = !grouped && !b->compact && getenv("BATOTP_K3_TILE") != nullptr;
+   const bool useTile = false;
+   // velocity / acceleration-only problems: the kernel written for them (same bits; batotp_hip_set_k3_form(ctx, 0) runs the general one)
+   const bool formVA = !grouped && b->ctx->k3Form == 1 && featureLevel(b) <= 0;
    const size_t ldsBytes = useTile ? sizeof(double) * (size_t)bs * (size_t)(b->P.C * 4 + 2) : 0;
    // overlap: K3 reads what the precompute wrote and nothing reads K3's output before the caller downloads it, so it
    // can share the GPU with the sweeps (second stream, joined by get_results / synchronize / the next precompute)
@@ -1077,6 +1138,10 @@ extern "C" int batotp_hip_pointwise_mvc(batotp_batch *b)
                                k3s, b->P, b->dPinfo, b->B, b->dP, b->dSC, b->dCoef, b->compact ? b->dKM : (double *)nullptr, mvcOut, first,         \
                                first + cnt, mvcSlot);                                                                                             \
          }                                                                                                                               \
+      else if (formVA && F <= 0)                                                                                                        \
+         hipLaunchKernelGGL(k_pointwise_va<(F <= 0 ? F : 0)>, dim3((unsigned)((b->totalKnots + K3V_BLOCK - 1) / K3V_BLOCK)), dim3(K3V_BLOCK), 0, k3s, b->P,  \
+                            b->dPinfo, b->B, b->dP, b->dSC, b->dCoef, b->compact ? b->dKM : (double *)nullptr, mvcOut, b->totalKnots, mvcSlot,           \
+                            b->ctx->fastForward);                                                                                         \
       else hipLaunchKernelGGL(k_pointwise<F>, dim3(grid), dim3(bs), ldsBytes, k3s, b->P, b->dPinfo, b->B, b->dP, b->dSC,      \
                               b->dCoef, b->compact ? b->dKM : (double *)nullptr, mvcOut, b->totalKnots, useTile ? 1 : 0, mvcSlot);                                      \
    } while (0)
@@ -1421,6 +1486,11 @@ extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
    SweepArgs a;
    a.P = b->P; a.dP = b->dP; a.pinfo = b->dPinfo; a.sC = b->dSC; a.coef = b->dCoef; a.km = b->compact ? b->dKM : nullptr; // (a zero-size allocation is not a null pointer: the kernels of the row layouts take a non-null km for "all channels as pairs")
    a.rev = b->dRev; a.fwd = b->dFwd; a.res = b->dRes; a.sink = b->dSink; a.prof = b->dMvc; a.cap = b->cap; a.B = b->B; a.dir = dir; a.ppw = 1;
+   a.order = b->ctx->pathOrder ? b->dOrder : nullptr;
+#ifdef S8_PROFILE
+   a.prof = b->dProf;
+   hipMemsetAsync(b->dProf, 0, sizeof(double) * ((size_t)b->B * 16 + 16), b->ctx->stream);
+#endif
    const int which = dir == -1 ? 3 : 4;
    int lanes = b->ctx->sweepGroup;
    if (lanes == 0)

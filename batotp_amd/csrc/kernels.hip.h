@@ -1845,6 +1845,12 @@ struct SweepArgs
    int hold;      // FLAT kernels: a stage is started once hold/8 of the wavefront's live paths wait for one
    int touch;     // software prefetch: bit 0 = spline rows ahead of the cursor, bit 1 = reverse curve ahead of its cursor (forward sweep)
    int ff;        // k_sweep1: certified fast-forward of the bisection (sweep1.hip.h), batotp_hip_set_fast_forward
+   // Ragged batches: launch slot k of the sweep processes path order[k] -- the paths sorted by knot count, longest
+   // first.  The hardware hands workgroups to the SIMDs in launch order as slots free up, so this is longest-processing-time-first
+   // scheduling for the kernels with a wavefront per path, and it puts paths of similar length into the same wavefront of the
+   // kernels that carry several (a wavefront lasts as long as its longest path).  nullptr: paths in the order given (all equally
+   // long, or batotp_hip_set_path_order(ctx, 0)).  Nothing in a path's own arithmetic or memory depends on its slot.
+   const int *order;
 };
 
 // Butcher tableau of ba.cpp:58-63 (_B[k][j]; stage j+1 uses column j)
@@ -1944,8 +1950,9 @@ __global__ void __launch_bounds__(K4_BLOCK, (G > 1 && G < 8) ? 1 : (FEAT <= 1 &&
    constexpr bool SPEC = Pt<G, FEAT, UNI>::SPEC;
    const int j = (SPLIT || SPEC) ? (lane & 7) : lane % G;   // joint owned by this lane
    const int slot = lane / G;
-   const int p = wave * a.ppw + slot;
-   if (slot >= a.ppw || p >= a.B) return; // whole groups leave together; DPP never crosses groups
+   const int pslot = wave * a.ppw + slot;
+   if (slot >= a.ppw || pslot >= a.B) return; // whole groups leave together; DPP never crosses groups
+   const int p = a.order ? a.order[pslot] : pslot;
    const bool writer = (lane % G == 0);
    const int dir = a.dir;
    const PathInfo pi = a.pinfo[p];

@@ -102,8 +102,9 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
    __shared__ double2 winRAll[ROWWIN ? S1_BLOCK / 64 : 1][ROWWIN ? S1_WR_BYTES / 16 : 1];
    stage_limits(a.dP, lim);
    const int lane = threadIdx.x & 63;
-   const int p = blockIdx.x * (S1_BLOCK / 64) + (threadIdx.x >> 6);
-   if (p >= a.B || lane >= 32) return;
+   const int pslot = blockIdx.x * (S1_BLOCK / 64) + (threadIdx.x >> 6);
+   if (pslot >= a.B || lane >= 32) return;
+   const int p = a.order ? a.order[pslot] : pslot;   // ragged batches: longest paths first (SweepArgs::order)
    const int j = lane & 7, cslot = lane >> 3;
    const bool writer = (lane == 0);
    const PathInfo pi = a.pinfo[p];

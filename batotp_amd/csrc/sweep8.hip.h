@@ -22,6 +22,18 @@
 #pragma once
 #include "kernels.hip.h"
 
+// diagnostic build (-DS8_PROFILE): what a wavefront of k_sweep8 spends its passes and cycles on, 16 doubles per wavefront in
+// SweepArgs::prof (tools/sweep8_sections.py); no effect otherwise
+#ifdef S8_PROFILE
+#define S8_CNT(k, v) pc[k] += (double)(v)
+#define S8_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
+#define S8_CYC(k, a, b) pc[k] += (double)((b) - (a))
+#else
+#define S8_CNT(k, v)
+#define S8_TICK(var)
+#define S8_CYC(k, a, b)
+#endif
+
 namespace bk
 {
 
@@ -119,8 +131,9 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
    const int wave = blockIdx.x * (S8_BLOCK / 64) + (threadIdx.x >> 6);
    const int j = lane % G;
    const int slot = lane / G;
-   const int p = wave * a.ppw + slot;
-   if (slot >= a.ppw || p >= a.B) return; // whole groups leave together; DPP never crosses groups
+   const int pslot = wave * a.ppw + slot;
+   if (slot >= a.ppw || pslot >= a.B) return; // whole groups leave together; DPP never crosses groups
+   const int p = a.order ? a.order[pslot] : pslot;   // ragged batches: paths of similar length share a wavefront (SweepArgs::order)
    const bool writer = (j == 0);
    const PathInfo pi = a.pinfo[p];
    const int n = (int)pi.n;
@@ -267,6 +280,14 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
    bool wild = !(fabs(v0) < kInf) | !(fabs(w0) < kInf); // a non-finite stage value has been kept (sticky; see the tableau combination)
    bool stageFailed = false; // the bisection of the stage that ended failed: sddotArr[st] keeps its previous value (ba.cpp:1091 ignores the code)
    const int hold = a.hold;
+#ifdef S8_PROFILE
+   // [0] passes of the loop, [1] prologue blocks, [2] paths they served, [3] check blocks, [4] paths inside them, [5] cycles in
+   // prologue blocks, [6] cycles in check blocks, [7] cycles in the loop, [8] step-end blocks, [9] segment-change blocks,
+   // [10] knot-cursor walks, [11] fast-forward blocks, [12] literal-form (rare) blocks of the check, [13] live paths summed over passes
+   double pc[16];
+   for (int k = 0; k < 16; ++k) pc[k] = 0;
+   const unsigned long long tLoop0 = __builtin_readcyclecounter();
+#endif
 
    for (;;)
    {
@@ -274,8 +295,11 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
       if (mAlive == 0) break;
       const unsigned long long mWait = __ballot(phase < PH_CHECK);
       const bool startNow = (mWait == mAlive) || (__popcll(mWait) * 8 >= __popcll(mAlive) * hold);
+      S8_CNT(0, 1); S8_CNT(13, __popcll(mAlive) / G);
+      S8_TICK(tA);
       if (startNow && mWait != 0)
       {
+         S8_CNT(1, 1); S8_CNT(2, __popcll(mWait) / G);
          if (phase < PH_CHECK)
          {
             // ---- the stage that ended: keep its values --------------------------------------------
@@ -304,6 +328,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                st = stepEnd ? st : st + 1;
                if (S8_ANY(stepEnd))
                {
+                  S8_CNT(8, 1);
                   if (stepEnd)
                   {
                      // FSAL shift and publish, ba.cpp:1096-1100 (stage 6: position sN, values vN, wN or the stale sddotArr[6])
@@ -437,6 +462,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                // ---- evalSplinePartials, ba.cpp:1341-1413: updateCurSeg (ba.cpp:1617-1652) on the sites sres*k ----
                if (!S8_WALK_PRECHECK || S8_ANY(!((sCur >= sSeg) & (sCur <= sNext))))
                {
+                  S8_CNT(10, 1);
                   for (;;)
                   {
                      sSeg = sres * (double)seg;
@@ -453,6 +479,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                const bool chg = (seg != rowSeg);
                if (S8_ANY(chg))
                {
+                  S8_CNT(9, 1);
                   if (chg)
                   {
 #pragma unroll
@@ -537,6 +564,14 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
             }
          }
       }
+      S8_TICK(tB);
+      S8_CYC(5, tA, tB);
+#ifdef S8_PROFILE
+      {
+         const unsigned long long mChk = __ballot(phase == PH_CHECK);
+         S8_CNT(3, mChk != 0 ? 1 : 0); S8_CNT(4, __popcll(mChk) / G);
+      }
+#endif
       if (phase == PH_CHECK)
       {
          // (what the bisection update below needs and the constraint check does not produce is computed first: it fills the
@@ -573,6 +608,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
             }
             if (S8_RARE(rare))
             {
+               S8_CNT(12, 1);
 #pragma unroll
                for (int q = 0; q < PER; ++q)
                {
@@ -659,6 +695,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                const bool ffWant = (((DIR == 1) ? (a.ff & 1) : (a.ff & 2)) != 0) && first && isViol && !failed;
                if (S8_ANY(ffWant))
                {
+                  S8_CNT(11, 1);
                   if (ffWant)
                   {
                      auto fastRcp = [](double d) {
@@ -759,7 +796,14 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
          wN = fin ? ((DIR == 1) ? sddotH : sddotL) : wN;
          phase = (fin || failed) ? PH_ENDED : phase;
       }
+      S8_TICK(tC);
+      S8_CYC(6, tB, tC);
    }
+#ifdef S8_PROFILE
+   pc[7] = (double)(__builtin_readcyclecounter() - tLoop0);
+   if (lane == 0 && a.prof)
+      for (int k = 0; k < 16; ++k) a.prof[(int64_t)wave * 16 + k] = pc[k];
+#endif
 
    status |= endStatus;
    if (endStatus != 0)

@@ -831,6 +831,7 @@ def main():
     ap.add_argument("--hold", type=int, nargs=2, default=None, help="sweep loop form, reverse forward (batotp_hip_set_sweep_hold; -2 automatic)")
     ap.add_argument("--spline-tiles", type=int, default=None, help="A/B: K1 in tiles of knots, 1 always / 0 never / -1 automatic (batotp_hip_set_spline_tiles)")
     ap.add_argument("--no-fast-forward", action="store_true", help="A/B: run every bisection iteration's check (batotp_hip_set_fast_forward 0)")
+    ap.add_argument("--k3-form", type=int, default=None, help="A/B: per-knot evaluation kernel, 1 k_pointwise_va / 0 the general kernel (batotp_hip_set_k3_form)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sides", action="store_true", help="skip the side measurements (resampler, output stage, nested-loop cross-check)")
@@ -870,6 +871,8 @@ def main():
         hip.set_sweep_hold(*args.hold)
     if args.no_fast_forward:
         hip.set_fast_forward(False)
+    if args.k3_form is not None:
+        hip.set_k3_form(args.k3_form)
     if args.spline_tiles is not None:
         hip.set_spline_tiles(args.spline_tiles)
 

@@ -360,6 +360,20 @@ int  batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on);
  * lockstep and wait for a path that bisects (bit 0 of `on`; bit 1 is reserved for the reverse sweep, where the block measured
  * slower and is not compiled in: profiles/r04_j_*). */
 int  batotp_hip_set_fast_forward(batotp_ctx *ctx, int32_t on);
+/* which kernel evaluates the per-knot values (batotp_hip_pointwise_mvc) of velocity / acceleration-only problems: 1 (default)
+ * k_pointwise_va, written for that constraint family (shared reciprocals, select-form passes, the certified fast-forward), 0 the
+ * general kernel that runs the loop of reference ba.cpp:1267-1321 literally.  Same results bit for bit; the switch exists for
+ * A/B measurements and parity tests. */
+int  batotp_hip_set_k3_form(batotp_ctx *ctx, int32_t form);
+/* Scratch memory the resampler (batotp_hip_resample) and the output stage (batotp_hip_output) may take per chunk of paths, in
+ * bytes; 0 (default) = a share of the device memory that is free when the call starts.  A batch that needs more is processed
+ * in several chunks of paths through the same workspace; results do not depend on the chunking. */
+int  batotp_hip_set_workspace_budget(batotp_ctx *ctx, int64_t resample_bytes, int64_t output_bytes);
+/* Ragged batches (paths of different knot counts): 1 (default) the sweeps take the paths sorted by knot count, longest first --
+ * longest-processing-time-first for the kernels with a wavefront per path (workgroups are handed out in launch order as SIMD
+ * slots free up), paths of similar length in one wavefront for the kernels that carry several (a wavefront lasts as long as its
+ * longest path); 0 the order given.  Results, result rows and curve slots are those of the path whatever slot runs it. */
+int  batotp_hip_set_path_order(batotp_ctx *ctx, int32_t mode);
 /* diagnostic: series of the most recent tiled spline build of this batch whose boundary comparison failed and that the
  * sequential kernel therefore recomputed (paths too short for tiles are not counted).  Expected: 0. */
 int  batotp_hip_spline_tile_fallbacks(batotp_batch *batch, int32_t *series);

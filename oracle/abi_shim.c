@@ -8,6 +8,7 @@
  * programs; the product links batotp_amd/csrc/libbatotp_hip.so instead and has no CPU path.
  */
 #define _POSIX_C_SOURCE 200809L
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -81,6 +82,9 @@ int batotp_hip_set_sweep_prefetch(batotp_ctx *ctx, int32_t reverse, int32_t forw
 int batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on) { (void)ctx; (void)on; return BATOTP_OK; }
 int batotp_hip_set_flat_form(batotp_ctx *ctx, int32_t form) { (void)ctx; (void)form; return BATOTP_OK; }
 int batotp_hip_set_fast_forward(batotp_ctx *ctx, int32_t on) { (void)ctx; (void)on; return BATOTP_OK; }
+int batotp_hip_set_path_order(batotp_ctx *ctx, int32_t mode) { (void)ctx; return (mode == 0 || mode == 1) ? BATOTP_OK : BATOTP_ERR_ARG; }
+int batotp_hip_set_workspace_budget(batotp_ctx *ctx, int64_t resample_bytes, int64_t output_bytes) { (void)ctx; return (resample_bytes < 0 || output_bytes < 0) ? BATOTP_ERR_ARG : BATOTP_OK; }
+int batotp_hip_set_k3_form(batotp_ctx *ctx, int32_t form) { (void)ctx; return (form == 0 || form == 1) ? BATOTP_OK : BATOTP_ERR_ARG; }
 int batotp_hip_spline_tile_fallbacks(batotp_batch *b, int32_t *series) { if (!b || !series) return BATOTP_ERR_ARG; *series = 0; return BATOTP_OK; }
 /* the checker has one loop form (the reference's); the introspection calls of the product answer accordingly */
 int batotp_hip_flat_loop_status(batotp_ctx *ctx, int32_t *status) { if (!ctx || !status) return BATOTP_ERR_ARG; *status = -1; return BATOTP_OK; }

@@ -169,3 +169,24 @@ def test_default_ba_with_automatic_integration_resolution(tmp_path, oracle_lib, 
     for d in ("out_first", "out_last"):
         assert filecmp.cmp(many / d / "s-sdot.dat", one / "s-sdot.dat", shallow=False)
         assert filecmp.cmp(many / d / "traj_out.dat", one / "traj_out.dat", shallow=False)
+
+
+@pytest.mark.parametrize("what", ["cable robot without a cable limit", "JOINT path of a robot without forward kinematics", "BOTH path without orientations"])
+def test_configurations_the_device_resampler_refuses(tmp_path, oracle_lib, what):
+    """BA::exportResampleParams covers the path kinds of the shipped examples and the BASELINE configs; the rest is refused with
+    a message and -1 instead of taking another code path (INTEGRATION.md 2 has the table and what the reference does with each:
+    a -1 of its own, undefined behaviour, or a configuration no shipped example uses)"""
+    if what == "cable robot without a cable limit":
+        _stage(os.path.join(helpers.GOLD, "synth_cspr_s3"), tmp_path)
+        _edit_config(tmp_path / "config.dat", {"isJntVelConOn": 0, "isJntAccConOn": 0, "isTrqConOn": 0})
+    elif what == "JOINT path of a robot without forward kinematics":
+        _stage(os.path.join(helpers.GOLD, "synth_ur_s2"), tmp_path)
+        _edit_config(tmp_path / "config.dat", {"robotTypeStr": "UR"})
+    else:
+        _stage(os.path.join(helpers.GOLD, "UR5"), tmp_path)
+        _edit_config(tmp_path / "config.dat", {"nCart": 3})
+    for tool, args in (("batest_oracle", ["config.dat"]), ("batest_batch_oracle", ["config.dat", "2"])):
+        r = subprocess.run([os.path.join(helpers.BUILD, tool)] + args, cwd=tmp_path, capture_output=True, text=True)
+        assert r.returncode != 0, (what, tool, r.stdout[-1500:])
+        assert "not covered by the device resampler" in r.stdout, (what, tool, r.stdout[-1500:])
+        assert not os.path.exists(tmp_path / "traj_out.dat")

@@ -73,12 +73,8 @@ def test_random_velocity_acceleration_problems(hip_lib, oracle_ctx, seed, lanes)
             assert_bit_equal(ho[k][2], oo[k][2], f"seed {seed} path {k} pointwise")
 
 
-@pytest.mark.parametrize("seed", range(16 * _SCALE))
-def test_certified_fast_forward_of_the_bisection_on_hard_problems(hip_lib, oracle_ctx, seed):
-    """k_sweep1 skips the checks of the bisection iterations whose outcome is certain (sweep1.hip.h): problems built to sit
-    near the edges of that certificate -- joints that almost stand still (theta' just above / below jntThresh, huge
-    a_q = amax / |theta'|), limits spread over six decades, joints that share one shape (pairs of constraint lines that are
-    nearly parallel), all eight joints in use -- against the oracle, bit for bit"""
+def _hard_problem(seed):
+    """velocity / acceleration-only problems built to sit near the edges of the fast-forward certificate (see the test below)"""
     rng = np.random.default_rng(7000 + seed)
     nJ = int(rng.integers(2, 9))
     n_paths = int(rng.integers(4, 12))
@@ -103,6 +99,16 @@ def test_certified_fast_forward_of_the_bisection_on_hard_problems(hip_lib, oracl
         ys.append(np.ascontiguousarray(y))
     sres = [float(rng.uniform(0.01, 0.2)) for _ in range(n_paths)]
     cap = 80000
+    return prob, ys, sres, cap, n_paths
+
+
+@pytest.mark.parametrize("seed", range(16 * _SCALE))
+def test_certified_fast_forward_of_the_bisection_on_hard_problems(hip_lib, oracle_ctx, seed):
+    """k_sweep1 skips the checks of the bisection iterations whose outcome is certain (sweep1.hip.h): problems built to sit
+    near the edges of that certificate -- joints that almost stand still (theta' just above / below jntThresh, huge
+    a_q = amax / |theta'|), limits spread over six decades, joints that share one shape (pairs of constraint lines that are
+    nearly parallel), all eight joints in use -- against the oracle, bit for bit"""
+    prob, ys, sres, cap, n_paths = _hard_problem(seed)
     ro, oo = _run(oracle_ctx, prob, ys, sres, cap)
     for layout in (64, "64noff"):
         ctx = capi.Context(hip_lib, 0)
@@ -116,6 +122,40 @@ def test_certified_fast_forward_of_the_bisection_on_hard_problems(hip_lib, oracl
             for which in (0, 1):
                 assert_bit_equal(ho[k][which][0], oo[k][which][0], f"seed {seed} {layout} path {k} curve {which} s")
                 assert_bit_equal(ho[k][which][1], oo[k][which][1], f"seed {seed} {layout} path {k} curve {which} sdot")
+        ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(8 * _SCALE))
+def test_per_knot_evaluation_kernels_agree_on_hard_problems(hip_lib, oracle_ctx, seed):
+    """K3 of velocity / acceleration-only problems has a kernel of its own (pointwise_va.hip.h: shared reciprocals, select-form
+    passes, the certified fast-forward on every lane at once).  On the problems built for the edges of the certificate -- and
+    with the general kernel, with and without the fast-forward, on coefficient rows and on compact pairs -- the three values of
+    every knot (sdot_max, sddot_L, sddot_H; NaN bounds where no speed is admissible) are the oracle's, bit for bit"""
+    prob, ys, sres, cap, n_paths = _hard_problem(seed)
+    if seed % 4 == 3:
+        prob.jnt_acc_max[0] = -1.0     # every bisection of a knot where joint 0 moves fails: NaN bounds
+    def per_knot(ctx, p):
+        b = capi.Batch(ctx, p, [y.shape[1] for y in ys], 64)
+        b.upload_knots(0, ys, sres)
+        b.precompute(0)
+        b.pointwise_mvc()
+        out = [np.stack(b.mvc(k)) for k in range(n_paths)]
+        b.close()
+        return out
+
+    oo = per_knot(oracle_ctx, prob)
+    if seed % 4 == 3:
+        assert any(np.isnan(o[1]).any() for o in oo)
+    for form, ff, compact in ((1, 1, True), (1, 0, True), (0, 1, True), (1, 1, False), (1, 0, False)):
+        ctx = capi.Context(hip_lib, 0)
+        ctx.set_k3_form(form)
+        ctx.set_fast_forward(ff)
+        p2 = capi.Problem.from_buffer_copy(bytes(prob))
+        if compact:
+            p2.flags |= capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES
+        ho = per_knot(ctx, p2)
+        for k in range(n_paths):
+            assert_bit_equal(ho[k], oo[k], f"seed {seed} form {form} ff {ff} compact {compact} path {k}: per-knot values")
         ctx.close()
 
 

@@ -141,11 +141,11 @@ def test_every_branch_and_a_ragged_batch_match_the_oracle(hip_ctx, oracle_ctx):
     hb.close(); ob.close()
 
 
-def test_chunked_output_equals_one_chunk(hip_lib, oracle_ctx, monkeypatch):
+def test_chunked_output_equals_one_chunk(hip_lib, oracle_ctx):
     """a tiny scratch budget forces one chunk per path: the result must not depend on the chunking"""
     case = Case("synth_ur_s2")
-    monkeypatch.setenv("BATOTP_OUTPUT_BUDGET_MB", "1")
     ctx = capi.Context(hip_lib, 0)
+    ctx.set_workspace_budget(output_bytes=1 << 20)
     ho, hb = run_to_output(ctx, [case, case, case])
     oo, ob = run_to_output(oracle_ctx, [case])
     for k in range(3):

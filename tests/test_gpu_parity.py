@@ -733,6 +733,47 @@ def test_product_batest_end_to_end_on_gpu(tmp_path):
         assert filecmp.cmp(work / "traj_out.dat", os.path.join(src, "ref_traj_out.dat"), shallow=False), name
 
 
+@pytest.mark.parametrize("layout", [0, 8, "flat4", 32, 64, 1])
+def test_ragged_batches_are_swept_longest_path_first(hip_lib, oracle_ctx, layout):
+    """a batch whose paths differ in length is swept in the order of decreasing knot count
+    (batotp_hip_set_path_order 1, the default: launch slot k runs path order[k]) -- longest-processing-time-first for the kernels
+    with a wavefront per path, paths of similar length in one wavefront for the others.  Result rows and curves of every path are
+    those of the static order (mode 0) and the oracle's, whatever slot ran it"""
+    case = Case("synth_gen7dof_s0")
+    rng = np.random.default_rng(99)
+    lens = [int(v) for v in rng.integers(40, case.n, 37)] + [case.n, 17, case.n]
+    ys = [np.ascontiguousarray(case.y[:, :n]) for n in lens]
+    want = {}
+    for n in sorted(set(lens)):
+        class _C:
+            name = f"prefix{n}"
+        c = _C()
+        c.y, c.sres, c.problem, c.n = np.ascontiguousarray(case.y[:, :n]), case.sres, case.problem, n
+        c.max_steps = case.max_steps
+        want[n] = run_pipeline(oracle_ctx, [c], mvc=False, details=False)[0]
+    got = {}
+    for mode in (1, 0):
+        ctx = capi.Context(hip_lib, 0)
+        helpers.set_layout(ctx, layout)
+        ctx.set_path_order(mode)
+        prob = capi.Problem.from_buffer_copy(bytes(case.problem))
+        prob.flags |= capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES
+        b = capi.Batch(ctx, prob, lens, case.max_steps())
+        b.upload_knots(0, ys, [case.sres] * len(ys))
+        b.optimize()
+        res = b.results()
+        got[mode] = (res.tobytes(), [(b.curve(k, -1), b.curve(k, +1)) for k in range(len(lens))])
+        for k, n in enumerate(lens):
+            w = want[n]
+            for f in res.dtype.names:
+                assert res[k][f] == w["result"][f], (layout, mode, k, n, f)
+            for which, key in ((0, "rev"), (1, "fwd")):
+                assert_bit_equal(got[mode][1][k][which][0], w[key][0], f"layout {layout} mode {mode} path {k} {key}.s")
+                assert_bit_equal(got[mode][1][k][which][1], w[key][1], f"layout {layout} mode {mode} path {k} {key}.sdot")
+        b.close(); ctx.close()
+    assert got[0][0] == got[1][0]
+
+
 def test_paths_of_one_batch_integrate_with_their_own_steps(hip_lib, oracle_ctx):
     """batotp_hip_set_path_integ_res: the automatic integration resolution of the reference (ba.cpp:493-556, class default
     ba.h:309) gives every path its own _integRes.  A batch whose paths integrate with different steps equals, row for row and

@@ -222,13 +222,13 @@ def test_product_batch_driver_grows_a_shared_curve_buffer(tmp_path):
         assert filecmp.cmp(many / d / "traj_out.dat", one / "traj_out.dat", shallow=False)
 
 
-def test_chunked_resampling_equals_one_chunk(hip_lib, oracle_ctx, monkeypatch):
+def test_chunked_resampling_equals_one_chunk(hip_lib, oracle_ctx):
     """a tiny scratch budget forces several chunks of paths: the result must not depend on the chunking"""
     c = ResampleCase("synth_cspr_s3")
     xs = [c.x, c.x[:, :900].copy(), c.x[:, ::-1].copy(), c.x[:, 500:2500].copy(), c.x]
     sr = [c.sres_in] * len(xs)
-    monkeypatch.setenv("BATOTP_RESAMPLE_BUDGET_MB", "6")
     ctx = capi.Context(hip_lib, 0)
+    ctx.set_workspace_budget(resample_bytes=6 << 20)
     h = capi.Resampled(ctx, c.params, xs, sr)
     o = capi.Resampled(oracle_ctx, c.params, xs, sr)
     _same(h, o, "chunked cspr batch")
