@@ -54,6 +54,12 @@ constexpr int S8_BLOCK = 256;
 #define S8_PREFETCH 1   // the knot the cursor will need next is loaded one segment change ahead (compact pairs).  (The same for the next
                         // point of the reverse curve in the forward sweep measured 5 % slower -- 440 against 419 ms -- and is not done.)
 #endif
+#ifndef S8_TAU_RCP
+#define S8_TAU_RCP 0 // tau = (sCur - sSeg) / (sNext - sSeg) and the reverse-curve tau of the forward sweep through the refined reciprocal of
+                     // their segment's width (device_math.h: sdiv_rcp / sdiv_by, the bits of `/` inside the window), kept while the cursor
+                     // stays on the segment: 3 instead of ~30 instructions per stage on the dependent chain; the literal quotient behind
+                     // a wavefront-uniform guard where an operand leaves the window (a numerator of exactly 0: the cursor on a knot)
+#endif
 #ifndef S8_FF
 #define S8_FF 1      // the certified fast-forward of the bisection (see the block in the loop), forward sweep by default
 #endif
@@ -233,6 +239,12 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
 #pragma unroll
    for (int q = 0; q < PER; ++q) { kEdge[q] = make_double2(0, 0); kPre[q] = make_double2(0, 0); }
    double sSeg = sres * (double)seg, sNext = sres * (double)(seg + 1); // sites of the cursor's segment
+#if S8_TAU_RCP
+   double rSeg = s8_rcp_refined(sNext - sSeg); // refined reciprocal of the segment's width (renewed when the walk ran)
+   bool segOk = s8_div_window(sNext - sSeg);
+   double rM = 0;   // the same for the reverse-curve segment of the forward sweep
+   bool mOk = false;
+#endif
    // reverse-curve cursor (forward sweep): segment and its two points
    int segM = 0;
    double mS0 = 0, mD0 = 0, mS1 = 0, mD1 = 0;
@@ -241,6 +253,9 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
       segM = t.segMVC;
       const double2 qa = mvc[segM], qb = mvc[segM + 1];
       mS0 = qa.x; mD0 = qa.y; mS1 = qb.x; mD1 = qb.y;
+#if S8_TAU_RCP
+      rM = s8_rcp_refined(mS1 - mS0); mOk = s8_div_window(mS1 - mS0);
+#endif
    }
    unsigned status = t.status;
    int nfail = t.nfail;
@@ -426,7 +441,17 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                {
                   // evalsdot, ba.cpp:1590-1607
 #include "sweep8_mvcwalk.inc"
+#if S8_TAU_RCP
+                  double tauM;
+                  {
+                     const double numM = sCur - mS0, denM = mS1 - mS0;
+                     const bool fastM = mOk & s8_div_window(numM);
+                     tauM = s8_div_by(numM, denM, rM);
+                     if (S8_RARE(!fastM)) tauM = fastM ? tauM : numM / denM;
+                  }
+#else
                   const double tauM = (sCur - mS0) / (mS1 - mS0);
+#endif
                   const double sdotMVC = dmax(mD0 + tauM * (mD1 - mD0), sdotMin);
                   vN = (vN > sdotMVC) ? sdotMVC : vN;
                }
@@ -474,8 +499,21 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                      seg = mvUp ? seg + 1 : (mvDn ? seg - 1 : seg);
                      if (!S8_ANY(mvUp | mvDn)) break;
                   }
+#if S8_TAU_RCP
+                  rSeg = s8_rcp_refined(sNext - sSeg); segOk = s8_div_window(sNext - sSeg);
+#endif
                }
+#if S8_TAU_RCP
+               double tau;
+               {
+                  const double numT = sCur - sSeg, denT = sNext - sSeg;
+                  const bool fastT = segOk & s8_div_window(numT);
+                  tau = s8_div_by(numT, denT, rSeg);
+                  if (S8_RARE(!fastT)) tau = fastT ? tau : numT / denT;
+               }
+#else
                const double tau = (sCur - sSeg) / (sNext - sSeg);
+#endif
                const bool chg = (seg != rowSeg);
                if (S8_ANY(chg))
                {

@@ -83,7 +83,11 @@ CONFIGS = {
     # reference's Traj) + BATOTP_F_MVC_IN_CURVES (the pointwise values live in the curve slots until the sweeps start); compact
     # batches keep no site array: 14.6 instead of 21.3 MB per path -> 16 384 instead of 11 264 paths, every lane of 2048
     # wavefronts carries a path
-    "fill7": dict(workload="gen7", knots=100000, paths=16384, scaling="weak", distinct=2048, lean=True,
+    # distinct = paths: EVERY path of the headline batch is its own seeded path.  (Up to round 4 the batch was 2048 distinct paths
+    # tiled x8.  Since round 5 the library sweeps a ragged batch in the order of decreasing knot count -- which would put the
+    # eight identical copies of a path into one wavefront, where they run in perfect lockstep: 3.05e8 instead of 2.92e8
+    # waypoints/s on the tiled batch, an artefact of the tiling and not a property of the kernels.)
+    "fill7": dict(workload="gen7", knots=100000, paths=16384, scaling="weak", distinct=16384, lean=True,
                   what="GEN7DOF 7-DOF vel+acc, N~100k knots/path, batch of independent paths filling the GPU"),
     "fill6": dict(workload="ur6", knots=100000, paths=16384, scaling="weak", distinct=2048,
                   what="cfg2 shape: UR5-like 6-DOF vel+acc, N~100k knots/path, batch of independent paths filling the GPU"),
@@ -94,7 +98,8 @@ CONFIGS = {
                       "(replicas only)"),
     "cfg4": dict(workload="gen7", knots=50000, paths=1024, scaling="strong", distinct=1024,
                  what="cfg4 as worded: GEN7DOF, N=50k, batch of 1024 randomised paths sharded across the GPUs"),
-    "cfg5": dict(workload="cspr", knots=200000, paths=4096, scaling="strong", distinct=128,
+    # distinct = the paths of one chunk (what fits one GPU: 2048): no two paths of a launch are copies of each other
+    "cfg5": dict(workload="cspr", knots=200000, paths=4096, scaling="strong", distinct=2048,
                  what="cfg5 as worded: CSPR3DOF cable robot with cable-tension constraints, N=200k, batch of 4096 sharded "
                       "across the GPUs"),
 }
@@ -180,7 +185,7 @@ class Inputs:
     """K distinct synthetic paths of a workload for one rank: problem description, knot counts / spacing per distinct path
     and a way to put the knots of distinct path k into path p of a batch"""
 
-    CHUNK = 128   # distinct paths per call of the device resampler
+    CHUNK = 256   # distinct paths per call of the device resampler
 
     def __init__(self, hip, workload, knots, seeds):
         self.hip, self.workload, self.K = hip, workload, len(seeds)
@@ -202,11 +207,12 @@ class Inputs:
                 # of such a path crawls at the speed floor with a failing 100-iteration bisection at every stage until it runs
                 # out of capacity (the reference grinds through it the same way and then returns -1).  The benchmark measures
                 # feasible paths: candidates with a knot at which K3 finds no admissible sdot are skipped.
-                self.seeds = self.seeds + [self.seeds[-1] + 1 + k for k in range(max(8, self.K // 4))]
+                self.seeds = self.seeds + [self.seeds[-1] + 1 + k for k in range(max(32, self.K // 16))]
                 self.K = len(self.seeds)
             self.n_knots, self.sres = np.zeros(self.K, np.int64), np.zeros(self.K)
             self.taught, self.sres_in = taught_points_f32(workload, self.seeds, knots)
             self.one_path_check = None
+            feasible = np.ones(self.K, bool)
             for k0, rs in self._chunks():
                 m = rs.n_knots.shape[0]
                 if np.any(rs.status):
@@ -215,15 +221,23 @@ class Inputs:
                 if k0 == 0:
                     # the batch call and the one-path call (BA::interpInputData, a batch of one in another process) agree
                     self.one_path_check = bool(np.array_equal(rs.knots(0)[: self.keep], first[0]) and rs.sres[0] == first[1])
+                if self.K > want:
+                    # cable robot: which candidates have an admissible speed at every knot -- the per-knot evaluation (K3) of this
+                    # chunk of candidates, through a small batch of its own (every channel as pairs: 288 B per knot)
+                    pr = capi.Problem.from_buffer_copy(bytes(self.prob))
+                    if (pr.flags & capi.F_PARALLEL) and (pr.flags & capi.F_PAR2SER):
+                        pr.flags |= capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES
+                    tb = capi.Batch(hip, pr, [int(n) for n in rs.n_knots], 8)
+                    tb.upload_knots_device(0, m, rs.device_ptr(), list(rs.sres))
+                    tb.precompute(0)
+                    tb.pointwise_mvc()
+                    for j in range(m):
+                        feasible[k0 + j] = not np.isnan(tb.mvc(j)[1]).any()
+                    tb.close()
                 rs.close()
+            hip.trim()
             if self.K > want:
-                b = capi.Batch(hip, self.prob, [int(n) for n in self.n_knots], 8)
-                self.fill(b, self.K)
-                b.precompute(0)
-                b.pointwise_mvc()
-                ok = [p for p in range(self.K) if not np.isnan(b.mvc(p)[1]).any()]
-                b.close()
-                hip.trim()
+                ok = [p for p in range(self.K) if feasible[p]]
                 self.skipped = self.K - len(ok)
                 if len(ok) < want:
                     raise RuntimeError(f"only {len(ok)} of {self.K} candidate paths are feasible")

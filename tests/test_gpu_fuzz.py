@@ -243,17 +243,20 @@ def test_random_cable_robot_problems(hip_lib, oracle_ctx, seed, par2ser):
         sres.append(float(rng.uniform(0.005, 0.03)))
     # 64 / "64noff": one path per wavefront with and without the certified fast-forward of the bisection (which covers the
     # serial form's torque lines: a3 = 0)
+    def run(c):
+        b = capi.Batch(c, prob, [y.shape[1] for y in ys], 4000)
+        for k, y in enumerate(ys):
+            b.upload_knots(k, [y], [sres[k]])
+        b.precompute(0); b.pointwise_mvc(); b.sweep(-1); b.sweep(+1)
+        out = (b.results(), [(b.curve(k, -1), b.curve(k, +1), np.stack(b.mvc(k))) for k in range(len(ys))])
+        b.close()
+        return out
+
+    oracle_out = run(oracle_ctx)      # once: the layouts below are all compared with the same oracle run
     for lanes in (0, 8, 64, "64noff"):
         ctx = capi.Context(hip_lib, 0)
         set_layout(ctx, lanes)
-        outs = []
-        for c in (ctx, oracle_ctx):
-            b = capi.Batch(c, prob, [y.shape[1] for y in ys], 4000)
-            for k, y in enumerate(ys):
-                b.upload_knots(k, [y], [sres[k]])
-            b.precompute(0); b.pointwise_mvc(); b.sweep(-1); b.sweep(+1)
-            outs.append((b.results(), [(b.curve(k, -1), b.curve(k, +1), np.stack(b.mvc(k))) for k in range(len(ys))]))
-            b.close()
+        outs = [run(ctx), oracle_out]
         (rh, ho), (ro, oo) = outs
         for f in rh.dtype.names:
             assert np.array_equal(rh[f], ro[f]), (seed, f, rh[f], ro[f])
@@ -320,7 +323,7 @@ def test_random_two_link_arm_with_torque_limits(hip_lib, oracle_ctx, seed):
         if ctx is None:
             ctx = capi.Context(hip_lib, 0)
             set_layout(ctx, lanes)
-        b = capi.Batch(ctx, prob, [y.shape[1] for y in ys], 30000)
+        b = capi.Batch(ctx, prob, [y.shape[1] for y in ys], 12000)
         for k, y in enumerate(ys):
             b.upload_knots(k, [y], [sres[k]])
         b.precompute(1)

@@ -733,7 +733,7 @@ def test_product_batest_end_to_end_on_gpu(tmp_path):
         assert filecmp.cmp(work / "traj_out.dat", os.path.join(src, "ref_traj_out.dat"), shallow=False), name
 
 
-@pytest.mark.parametrize("layout", [0, 8, "flat4", 32, 64, 1])
+@pytest.mark.parametrize("layout", [0, "flat4", 32, 64])
 def test_ragged_batches_are_swept_longest_path_first(hip_lib, oracle_ctx, layout):
     """a batch whose paths differ in length is swept in the order of decreasing knot count
     (batotp_hip_set_path_order 1, the default: launch slot k runs path order[k]) -- longest-processing-time-first for the kernels
@@ -741,7 +741,7 @@ def test_ragged_batches_are_swept_longest_path_first(hip_lib, oracle_ctx, layout
     those of the static order (mode 0) and the oracle's, whatever slot ran it"""
     case = Case("synth_gen7dof_s0")
     rng = np.random.default_rng(99)
-    lens = [int(v) for v in rng.integers(40, case.n, 37)] + [case.n, 17, case.n]
+    lens = [int(v) for v in rng.integers(40, case.n, 11)] + [case.n, 17, case.n]
     ys = [np.ascontiguousarray(case.y[:, :n]) for n in lens]
     want = {}
     for n in sorted(set(lens)):

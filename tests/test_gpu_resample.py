@@ -300,7 +300,7 @@ def test_short_paths_are_stretched_to_four_points(hip_ctx, oracle_ctx):
     h.close(); o.close()
 
 
-@pytest.mark.parametrize("workload,knots,n_seeds", [("gen7", 6000, 192), ("cspr", 8000, 96), ("kuka7trq", 6000, 64)])
+@pytest.mark.parametrize("workload,knots,n_seeds", [("gen7", 6000, 64), ("cspr", 8000, 48), ("kuka7trq", 6000, 32)])
 def test_concurrent_one_path_resampling_equals_the_oracle(workload, knots, n_seeds):
     """Regression for the red driver run of round 4: BA::interpInputData of ONE path goes through batotp_hip_resample with a
     batch of one -- `baknots`, a process and a HIP context per path, 64 of them at a time on one GPU (what bench.py and the
@@ -329,7 +329,7 @@ def test_concurrent_one_path_resampling_equals_the_oracle(workload, knots, n_see
     jobs = min(64, os.cpu_count() or 1)
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
         want = list(ex.map(lambda s: digest(bench.ORACLE_KNOTS, s), seeds))
-    for rnd in range(2):
+    for rnd in range(1):
         with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
             got = list(ex.map(lambda s: digest(bench.BAKNOTS, s), seeds))
         bad = [s for s, a, b in zip(seeds, want, got) if a != b]

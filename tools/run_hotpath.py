@@ -22,6 +22,8 @@ ap.add_argument("--variants", default=None, help="A/B of sweep forms on ONE resi
 a = ap.parse_args()
 hip = capi.Context(capi.Library(a.lib) if a.lib else capi.load_hip(), 0)
 hip.set_sweep_group(a.group)
+if a.paths > a.distinct:
+    hip.set_path_order(0)   # tiled copies of a path must not become neighbours in a wavefront (they would run in lockstep)
 if a.ppw and hasattr(hip, "set_paths_per_wave"):
     hip.set_paths_per_wave(a.ppw)
 base = [bench.make_knots(a.workload, 1000 + k, a.knots) for k in range(a.distinct)]

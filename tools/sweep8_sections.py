@@ -30,6 +30,8 @@ lib = capi.Library(a.lib)
 hip = capi.Context(lib, 0)
 if a.hold:
     hip.set_sweep_hold(*a.hold)
+if a.paths > a.distinct:
+    hip.set_path_order(0)   # tiled copies of a path must not become neighbours in a wavefront (they would run in lockstep)
 inp = bench.Inputs(hip, a.workload, a.knots, [1000 + k for k in range(a.distinct)])
 prob = capi.Problem.from_buffer_copy(bytes(inp.prob))
 prob.flags |= capi.F_COMPACT_SPLINES | capi.F_CURVES_IN_PLACE | capi.F_MVC_IN_CURVES
