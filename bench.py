@@ -381,8 +381,8 @@ def plan_chunks(B, K, limit):
     while (B + n - 1) // n > limit:
         n += 1
     bc = (B + n - 1) // n
-    if n > 1:
-        bc = max(K, (bc // K) * K)
+    if n > 1 and K <= limit:
+        bc = max(K, (bc // K) * K)      # (more distinct paths than fit one chunk: every chunk holds the first bc of them)
     return [min(bc, B - i * bc) for i in range((B + bc - 1) // bc)] if B else []
 
 
@@ -797,7 +797,11 @@ def launch_check(args, rank, world):
     pr = capi.Problem()
     pr.n_joints, pr.n_cart = cfgd["n_joints"], (cfgd["n_cart"] if (cfgd.get("cart_vel_on") or cfgd.get("is_parallel")) else 0)
     pr.flags = (capi.F_TRQ_ON if cfgd.get("trq_on") else 0) | (capi.F_PARALLEL if cfgd.get("is_parallel") else 0)
-    if not (pr.flags & capi.F_TRQ_ON):
+    if cfgd.get("par2ser"):
+        pr.flags |= capi.F_PAR2SER
+    # the layout measure() picks: (value, second derivative) pairs for velocity / acceleration-only problems and for the cable robot
+    # in serial form (every channel as pairs)
+    if not (pr.flags & capi.F_TRQ_ON) or ((pr.flags & capi.F_PARALLEL) and (pr.flags & capi.F_PAR2SER)):
         pr.flags |= capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES
     knots = args.knots or c["knots"]
     cap = int(knots * w["cap"]) + 1024

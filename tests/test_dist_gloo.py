@@ -121,16 +121,17 @@ def test_bench_refuses_a_rank_count_that_is_not_the_one_asked_for():
 
 def test_bench_rehearses_config_5_on_four_ranks():
     """BASELINE config 5 as worded on 4 ranks without GPUs (--launch-check, gloo): 4096 cable-robot paths in contiguous blocks of
-    1024, every block in ONE chunk of its 288 GB GPU (the rows layout takes ~200 MB per path of 2e5 knots), result rows gathered in
-    rank order, and the size exchange of the curve gather: rank 0 would receive ~3/4 of all forward curves"""
+    1024, every block in ONE chunk of its 288 GB GPU (every channel as pairs: ~68 MB per path of 2e5 knots, the layout measure()
+    picks for the cable robot in serial form), result rows gathered in rank order, and the size exchange of the curve gather: rank 0
+    would receive ~3/4 of all forward curves"""
     r, line = _bench_line(["--gpus", "4", "--launch-check", "--config", "cfg5"])
     assert r.returncode == 0, r.stderr[-2000:]
     assert line["n_gpus"] == 4 and line["scaling"] == "strong" and line["paths_total"] == 4096 and line["gathered_rows"] == 4096
     assert line["rows_in_rank_order"] and line["max_over_ranks"] == 4.0
-    assert line["paths_per_rank"] == 1024 and line["chunks_per_rank"] == [1024] and 1024 <= line["paths_that_fit_one_gpu"] < 2048
+    assert line["paths_per_rank"] == 1024 and line["chunks_per_rank"] == [1024] and 2048 <= line["paths_that_fit_one_gpu"] < 4096
     g = line["curve_gather"]
     assert len(g["points_per_rank"]) == 4 and min(g["points_per_rank"]) > 1024 * 0.4 * 200000 * 0.99
     assert 3.5 < g["GB_to_rank0"] < 6.5
-    # one GPU holds the whole batch in four chunks of whole multiples of the distinct paths
+    # one GPU holds the whole batch in two chunks of whole multiples of the distinct paths (2048: no two paths of a launch are copies)
     r, line = _bench_line(["--gpus", "1", "--launch-check", "--config", "cfg5"])
-    assert r.returncode == 0 and line["paths_per_rank"] == 4096 and line["chunks_per_rank"] == [1024] * 4
+    assert r.returncode == 0 and line["paths_per_rank"] == 4096 and line["chunks_per_rank"] == [2048] * 2
