@@ -132,6 +132,6 @@ def test_bench_rehearses_config_5_on_four_ranks():
     g = line["curve_gather"]
     assert len(g["points_per_rank"]) == 4 and min(g["points_per_rank"]) > 1024 * 0.4 * 200000 * 0.99
     assert 3.5 < g["GB_to_rank0"] < 6.5
-    # one GPU holds the whole batch in two chunks of whole multiples of the distinct paths (2048: no two paths of a launch are copies)
+    # one GPU holds the whole batch in two chunks of whole multiples of the distinct paths
     r, line = _bench_line(["--gpus", "1", "--launch-check", "--config", "cfg5"])
     assert r.returncode == 0 and line["paths_per_rank"] == 4096 and line["chunks_per_rank"] == [2048] * 2
