@@ -6,7 +6,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/prof_r05h
 mkdir -p $O
-CMD="python3 bench.py --no-sides --no-as-worded --no-cpu-baseline --steps 2 --warmup 1 --distinct 2048"
+CMD="python3 bench.py --no-sides --no-as-worded --no-cpu-baseline --steps 2 --warmup 1"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fill7_stats -- $CMD > $O/fill7_stats.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fill7_fetch -- $CMD > $O/fill7_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/fill7_write -- $CMD > $O/fill7_write.log 2>&1
