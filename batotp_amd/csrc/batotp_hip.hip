@@ -1439,9 +1439,34 @@ static bool sweep1Applies(const batotp_batch *b)
 static void launchSweep1(batotp_batch *b, SweepArgs &a)
 {
    a.ppw = 1; a.hold = -1; a.touch = 0; a.ff = b->ctx->fastForward;
-   b->lastLanes[a.dir == -1 ? 0 : 1] = 64; b->lastPpw[a.dir == -1 ? 0 : 1] = 1; b->lastHold[a.dir == -1 ? 0 : 1] = -1;
-   const unsigned grid = (unsigned)((b->B + (S1_BLOCK / 64) - 1) / (S1_BLOCK / 64));
    hipStream_t st = b->ctx->stream;
+   const bool cableLines = featureLevel(b) == 2 && (b->P.flags & BATOTP_F_PARALLEL) != 0 && b->pairsAll;
+   // Two paths per wavefront (k_sweep1's NP = 2; the cable robot in serial form with every channel as pairs): where one path per
+   // wavefront would leave wavefronts queueing for the two slots per SIMD the kernel's registers allow, or where the caller asks
+   // for it (batotp_hip_set_paths_per_wave(ctx, 2) with 64 lanes per path).  Measured on BASELINE config 5 (N = 2e5, reverse +
+   // forward ms; profiles/r05_h_*): up to 2048 paths every path has a resident wavefront either way and the sweeps last as long as
+   // the slowest path -- 1147 + 1326 with one path per wavefront, 1238 + 1474 with two (a wavefront that serves two paths is 8-11 %
+   // slower); 3072 paths 1613 + 1496 against 1244 + 1479; 4096 paths 2159 + 2033 against 1228 + 1479.  The crossover is at ~2300.
+   const int want = b->ctx->pathsPerWave;
+   // ... and the compact velocity / acceleration-only layout (round 5; the batch sizes between the one-path kernel and k_sweep8)
+   const bool compactVA = featureLevel(b) == -1;
+   const bool two = (cableLines && (want == 2 || (want <= 0 && b->B > 2304))) || (compactVA && (want == 2 || (want <= 0 && b->B > 2304)));
+   a.ppw = two ? 2 : 1;
+   b->lastLanes[a.dir == -1 ? 0 : 1] = 64; b->lastPpw[a.dir == -1 ? 0 : 1] = a.ppw; b->lastHold[a.dir == -1 ? 0 : 1] = -1;
+   const unsigned perBlock = (unsigned)(S1_BLOCK / 64) * (unsigned)a.ppw;
+   const unsigned grid = ((unsigned)b->B + perBlock - 1) / perBlock;
+   if (two && cableLines)
+   {
+      if (a.dir == 1) hipLaunchKernelGGL((k_sweep1<2, 1, 0, true, 2>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
+      else hipLaunchKernelGGL((k_sweep1<2, -1, 0, true, 2>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
+      return;
+   }
+   if (two)
+   {
+      if (a.dir == 1) hipLaunchKernelGGL((k_sweep1<-1, 1, 0, false, 2>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
+      else hipLaunchKernelGGL((k_sweep1<-1, -1, 0, false, 2>), dim3(grid), dim3(S1_BLOCK), 0, st, a);
+      return;
+   }
    // (the last template argument: the batch keeps all its channels as pairs)
 #define LAUNCH_S1(F, FFORM)                                                                                              \
    do {                                                                                                                 \

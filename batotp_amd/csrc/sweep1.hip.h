@@ -62,7 +62,12 @@ __constant__ double c_s1B[36] = {BK_B00, BK_B01, BK_B02, BK_B03, BK_B04, BK_B05,
 // config 4 (1024 wavefronts, repeatable to 0.1 %): the reverse-curve walk gains most (forward sweep 438 -> 403 ms); the knot-cursor
 // walk walkC is the exception -- its loop leaves at the first test nearly always, and there the ballot's round trip through the
 // scalar unit costs more than the exec-mask form (449 / 403 ms plain against 469 / 420 ms): it keeps plain conditions.
-#define S1_UNI(c) (__ballot(c) != 0)
+#define S1_UNI(c) (NP == 1 ? (__ballot(c) != 0) : (bool)(c))
+// NP == 2 (two paths per wavefront, one per half: see k_sweep1's template parameter): the ballot of a path's own 32 lanes, and
+// "the value of the path's first lane" -- which every lane of the half holds anyway
+#define S1_BALLOT(c) (NP == 1 ? (unsigned long long)__ballot(c) : ((unsigned long long)__ballot(c) >> (lane & 32)) & 0xffffffffull)
+#define S1_FIRST(x) (NP == 1 ? __builtin_amdgcn_readfirstlane(x) : (x))
+#define S1_RATIO_LT(n, d, t) (NP == 1 ? ratio_lt_uniform(n, d, t) : ratio_lt(n, d, t))
 
 constexpr int S1_BLOCK = 256;
 constexpr int S1_WK = 64;   // knots per spline window (compact splines: 64 knots x 8 joint slots x 16 B = 8 KB per path)
@@ -82,31 +87,44 @@ constexpr int S1_WM = 256;  // points per reverse-curve window (4 KB per path)
 // PAIRS (FEAT >= 0 only): the batch keeps ALL its channels as (value, second derivative) pairs and coefficient rows exist in this
 // kernel's LDS window only.  A template parameter, not a run-time test: the window's code and registers cost the lone wavefront of a
 // single trajectory 10 % when they are merely present (BASELINE config 3: 1129 against 1018 ms).
-template <int FEAT, int DIR, int FF = 0, bool PAIRS = false>
+// NP (round 5): paths per wavefront.  1: the path owns lanes 0..31, the other half exits.  2: a second path in lanes 32..63 -- the
+// same code, with every condition on path-level values a per-lane condition (uniform inside a half, not across the wavefront: the
+// compiler's exec-mask branches instead of scalar ones), ballots cut to the path's own half, and LDS windows of half the size so
+// that a CU still holds two workgroups: where the two paths agree on the control flow (three quarters of the stages pass their
+// first check) one instruction stream serves both; where one bisects the other waits.  For batches that put MORE than two paths
+// on a SIMD (BASELINE config 5 on one GPU: 4096 cable-robot paths).
+template <int FEAT, int DIR, int FF = 0, bool PAIRS = false, int NP = 1>
 // (the cable robot's instantiation is held to 256 registers: with its channels as pairs a chunk holds two paths per SIMD, and the
 //  forward kernel's 279 registers would leave the second one waiting)
-__global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 : 1) k_sweep1(SweepArgs a)
+__global__ void __launch_bounds__(S1_BLOCK, ((FEAT == 2 && FF == 0 && PAIRS) || NP == 2) ? 2 : 1) k_sweep1(SweepArgs a)
 {
+   static_assert(NP == 1 || NP == 2, "paths per wavefront");
+   constexpr int NW = (S1_BLOCK / 64) * NP;            // paths (LDS windows) per workgroup
+   constexpr int WM = (NP == 1) ? S1_WM : S1_WM / 2;   // points per reverse-curve window
+   constexpr int WRB = S1_WR_BYTES / NP;               // bytes per coefficient-row window
+   constexpr int WK = (NP == 1) ? S1_WK : S1_WK / 2;   // knots per spline window (compact splines)
    __shared__ double lim[6][8];
    // Sliding windows in LDS, one per wavefront (= per path): the (value, second derivative) pairs of S1_WK consecutive knots
    // and, for the forward sweep, S1_WM consecutive points of the reverse curve.  Both cursors move monotonically (up to small
    // back-steps), so a window is refilled once per ~S1_WK knots by one coalesced copy -- one memory round trip -- and a
    // segment change reads LDS instead of waiting ~1500 cycles for a dependent HBM access (39 % of the cycles of the lone
    // wavefront were s_waitcnt without the windows: profiles/r02_e_*).
-   __shared__ double2 winKAll[(FEAT < 0) ? S1_BLOCK / 64 : 1][(FEAT < 0) ? S1_WK * BATOTP_MAX_JOINTS : 1];
-   __shared__ double2 winMAll[(DIR == 1) ? S1_BLOCK / 64 : 1][(DIR == 1) ? S1_WM : 1];
+   __shared__ double2 winKAll[(FEAT < 0) ? NW : 1][(FEAT < 0) ? WK * BATOTP_MAX_JOINTS : 1];
+   __shared__ double2 winMAll[(DIR == 1) ? NW : 1][(DIR == 1) ? WM : 1];
    static_assert(!PAIRS || FEAT >= 0, "FEAT -1 reads its joint pairs through winK");
    // rows through an LDS window: always when the batch keeps pairs only; for rows in HBM where it measured faster (the cable robot's
    // sweeps 4-6 %, not the 7-DOF arm's, whose cursor needs a new row every other step)
    constexpr bool ROWWIN = FEAT >= 0 && S1_WR_BYTES > 0 && (PAIRS || (FEAT == 2 && FF == 0));
-   __shared__ double2 winRAll[ROWWIN ? S1_BLOCK / 64 : 1][ROWWIN ? S1_WR_BYTES / 16 : 1];
+   __shared__ double2 winRAll[ROWWIN ? NW : 1][ROWWIN ? WRB / 16 : 1];
    stage_limits(a.dP, lim);
    const int lane = threadIdx.x & 63;
-   const int pslot = blockIdx.x * (S1_BLOCK / 64) + (threadIdx.x >> 6);
-   if (pslot >= a.B || lane >= 32) return;
+   const int hl = lane & 31;                                    // lane inside the path's half
+   const int widx = (threadIdx.x >> 6) * NP + (NP == 2 ? (lane >> 5) : 0);   // this path's LDS windows
+   const int pslot = blockIdx.x * NW + widx;
+   if (pslot >= a.B || (NP == 1 && lane >= 32)) return;
    const int p = a.order ? a.order[pslot] : pslot;   // ragged batches: longest paths first (SweepArgs::order)
-   const int j = lane & 7, cslot = lane >> 3;
-   const bool writer = (lane == 0);
+   const int j = lane & 7, cslot = hl >> 3;
+   const bool writer = (hl == 0);
    const PathInfo pi = a.pinfo[p];
    const int n = (int)pi.n;
    const int64_t cap = a.cap;
@@ -178,11 +196,11 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
    unsigned long long cyA = 0, cyB = 0, cyC = 0, cyD = 0, nBis = 0, nPass = 0, nStage = 0, cyP1 = 0, cyP2 = 0, cyP3 = 0, nAcc = 0;
 #endif
 
-   double2 *winK = winKAll[(FEAT < 0) ? (threadIdx.x >> 6) : 0];
-   double2 *winM = winMAll[(DIR == 1) ? (threadIdx.x >> 6) : 0];
+   double2 *winK = winKAll[(FEAT < 0) ? widx : 0];
+   double2 *winM = winMAll[(DIR == 1) ? widx : 0];
    int wK0 = 0, wKn = 0; // knots [wK0, wK0 + wKn) are in winK, layout [knot][8 joint slots]
    int wM0 = 0, wMn = 0; // curve points [wM0, wM0 + wMn) are in winM
-   double2 *winR = winRAll[ROWWIN ? (threadIdx.x >> 6) : 0];
+   double2 *winR = winRAll[ROWWIN ? widx : 0];
    constexpr bool rowWin = ROWWIN;
    int wR0 = 0, wRn = 0; // coefficient rows [wR0, wR0 + wRn) are in winR, C x 4 doubles each
 
@@ -191,13 +209,13 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
    // copied; slots beyond the last joint hold a copy of joint 0.
    auto needK = [&](int seg) __attribute__((always_inline)) {
       if (S1_UNI(seg >= wK0 && seg + 1 < wK0 + wKn)) return;
-      int w = (DIR == 1) ? seg - 2 : seg + 4 - S1_WK;
-      const int wmax = n - S1_WK;
+      int w = (DIR == 1) ? seg - 2 : seg + 4 - WK;
+      const int wmax = n - WK;
       w = w > wmax ? wmax : w;
       w = w < 0 ? 0 : w;
-      const int cntK = (n - w) < S1_WK ? (n - w) : S1_WK;
+      const int cntK = (n - w) < WK ? (n - w) : WK;
       const int groups = (cntK + 3) >> 2;  // 4 knots (32 lanes) per group
-      const int kLane = lane >> 3;         // knot offset of this lane inside a group
+      const int kLane = hl >> 3;           // knot offset of this lane inside a group
       const double2 *__restrict__ src = km + jr;
       // Eight loads in flight per lane and round trip, then eight unconditional LDS writes (slots past the last knot of
       // the window receive a copy of the path's last knot and are never read).  Written with named temporaries and
@@ -205,7 +223,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
       // condition it sank every load into its store's block -- load / s_waitcnt vmcnt(0) / ds_write per group, one
       // memory round trip per 4 knots.
 #define S1_LD(T, I) { int ki = w + 4 * (g0 + I) + kLane; ki = ki < n ? ki : n - 1; T = src[(unsigned)(ki * nIn)]; }
-#define S1_ST(T, I) winK[lane + 32 * (g0 + I)] = T;
+#define S1_ST(T, I) winK[hl + 32 * (g0 + I)] = T;
 #pragma unroll 1
       for (int g0 = 0; g0 < groups; g0 += 8)
       {
@@ -227,7 +245,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
    auto needR = [&](int seg) __attribute__((always_inline)) {
       if (S1_UNI(seg >= wR0 && seg < wR0 + wRn)) return;
       const int rowD2 = C * 2;                        // 16-byte units per row
-      const int WR = (S1_WR_BYTES / 16) / rowD2;      // rows per window (C <= 8 + 3 + 32 channels: at least 11)
+      const int WR = (WRB / 16) / rowD2;              // rows per window (C <= 8 + 3 + 32 channels: at least 11; two paths per wavefront: 5)
       const int nRows = n - 1;                        // rows 0 .. n - 2, one per segment
       int w = (DIR == 1) ? seg - 1 : seg + 2 - WR;    // a row of slack behind the direction of travel
       const int wmax = nRows - WR;
@@ -249,7 +267,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
 #pragma unroll
             for (int u = 0; u < 4; ++u)
             {
-               int e = e0 + lane + 32 * u;
+               int e = e0 + hl + 32 * u;
                e = e < cells ? e : cells - 1;
                la[u] = kp[e];
                lb[u] = kp[e + C];
@@ -257,7 +275,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
 #pragma unroll
             for (int u = 0; u < 4; ++u)
             {
-               const int e = e0 + lane + 32 * u;
+               const int e = e0 + hl + 32 * u;
                const double solL = la[u].y, solR = lb[u].y, yL = la[u].x, yR = lb[u].x;
                const double k3 = div6(solR - solL);
                const double k2 = solL / 2.0;
@@ -272,8 +290,8 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
          return;
       }
       const double2 *__restrict__ src = reinterpret_cast<const double2 *>(coef + (int64_t)w * C * 4);
-#define S1_LD(T, I) { const int e = e0 + lane + 32 * I; T = src[e < total ? e : total - 1]; }
-#define S1_ST(T, I) { const int e = e0 + lane + 32 * I; if (e < total) winR[e] = T; }
+#define S1_LD(T, I) { const int e = e0 + hl + 32 * I; T = src[e < total ? e : total - 1]; }
+#define S1_ST(T, I) { const int e = e0 + hl + 32 * I; if (e < total) winR[e] = T; }
 #pragma unroll 1
       for (int e0 = 0; e0 < total; e0 += 256)
       {
@@ -293,20 +311,22 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
    auto needM = [&](int k) __attribute__((always_inline)) {
       if (S1_UNI(k >= wM0 && k + 1 < wM0 + wMn)) return;
       int w = k - 16;
-      const int wmax = nMvc - S1_WM;
+      const int wmax = nMvc - WM;
       w = w > wmax ? wmax : w;
       w = w < 0 ? 0 : w;
-      const int cnt = (nMvc - w) < S1_WM ? (nMvc - w) : S1_WM;
+      const int cnt = (nMvc - w) < WM ? (nMvc - w) : WM;
       const double2 *src = reinterpret_cast<const double2 *>(mvc) + w;
       {
          // the whole window in one round trip: 8 loads in flight per lane (indices clamped to the last point), 8 LDS writes
-         static_assert(S1_WM == 256, "needM moves 8 groups of 32 points");
-#define S1_LD(T, I) { const int e = lane + 32 * I; T = src[e < cnt ? e : cnt - 1]; }
-#define S1_ST(T, I) winM[lane + 32 * I] = T;
+         static_assert(S1_WM == 256, "needM moves 8 (one path per wavefront) or 4 (two) groups of 32 points");
+#define S1_LD(T, I) { const int e = hl + 32 * I; T = src[e < cnt ? e : cnt - 1]; }
+#define S1_ST(T, I) winM[hl + 32 * I] = T;
          double2 t0, t1, t2, t3, t4, t5, t6, t7;
-         S1_LD(t0, 0) S1_LD(t1, 1) S1_LD(t2, 2) S1_LD(t3, 3) S1_LD(t4, 4) S1_LD(t5, 5) S1_LD(t6, 6) S1_LD(t7, 7)
+         S1_LD(t0, 0) S1_LD(t1, 1) S1_LD(t2, 2) S1_LD(t3, 3)
+         if (NP == 1) { S1_LD(t4, 4) S1_LD(t5, 5) S1_LD(t6, 6) S1_LD(t7, 7) }
          __builtin_amdgcn_sched_barrier(0);
-         S1_ST(t0, 0) S1_ST(t1, 1) S1_ST(t2, 2) S1_ST(t3, 3) S1_ST(t4, 4) S1_ST(t5, 5) S1_ST(t6, 6) S1_ST(t7, 7)
+         S1_ST(t0, 0) S1_ST(t1, 1) S1_ST(t2, 2) S1_ST(t3, 3)
+         if (NP == 1) { S1_ST(t4, 4) S1_ST(t5, 5) S1_ST(t6, 6) S1_ST(t7, 7) }
 #undef S1_LD
 #undef S1_ST
       }
@@ -599,7 +619,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
          const double lowFact2 = lowFact * 2.0;
          const double sdotLShrunk = dmax(.999 * 0.0, (1.0 - lowFact2) * sdotTry);
          // ba.cpp:1294-1303: two successive feasible points closer than 1e-3 (relative), or a negative one
-         const bool conv = good && (ratio_lt_uniform(fabs(sdotTry - sdotGood), sdotTry, sdotErrThresh) || sdotTry < 0.0);
+         const bool conv = good && (S1_RATIO_LT(fabs(sdotTry - sdotGood), sdotTry, sdotErrThresh) || sdotTry < 0.0);
          fin = (!isViol && first) || conv;
          lowFact = shrink ? lowFact2 : lowFact;
          sdotH = isViol ? sdotTry : sdotH;
@@ -608,7 +628,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
          nGood += good ? 1 : 0;
          sdotCur = conv ? sdotTry : sdotCur;
          // ba.cpp:1305-1320
-         const bool collapsed = (nGood == 0) && ratio_lt_uniform(sdotH - sdotL, sdotH, 1e-20);
+         const bool collapsed = (nGood == 0) && S1_RATIO_LT(sdotH - sdotL, sdotH, 1e-20);
          failed = !fin && (nIter + 1 > 100 || sdotTry < 0.0 || collapsed);
          nIter += fin ? 0 : 1;
          const bool stop = fin || failed;
@@ -616,7 +636,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
          return stop;
       };
       // the first check (violated) is the loop's first iteration; the passes below start with its successor
-      bool over = __builtin_amdgcn_readfirstlane((int)iterate(true)) != 0;
+      bool over = S1_FIRST((int)iterate(true)) != 0;
 #if S1_PREDICT
       // where it applies: the check consists of constraints that are LINES in x = sdot^2 -- joint acceleration limits, and
       // the torque limits of a mechanism whose a3 (the term in sdot) vanishes identically, i.e. the cable robot in serial form
@@ -630,7 +650,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
 #endif
       constexpr bool FF0 = FF == 0 && (S1_FWD_PAIRS_FF || !(PAIRS && DIR == 1));
       bool ffApplies = FF0 && a.ff && !over && !cartAccOn && (FEAT == 2 || accOn);
-      if (FEAT == 2) ffApplies = ffApplies && nJ <= 4 && !__ballot(jv && !(a3pt == 0.0));
+      if (FEAT == 2) ffApplies = ffApplies && nJ <= 4 && !S1_BALLOT(jv && !(a3pt == 0.0));
       if (FF0 && ffApplies)
       {
          // CERTIFIED FAST-FORWARD.  In x = sdot^2 every constraint of the check is an interval [l_q(x), u_q(x)] for sddot with
@@ -685,7 +705,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
             const double q0 = (tmaxj - a4pt) * r1, q1 = (tminj - a4pt) * r1;
             const double tu = dmax(q0, q1), tl = dmin(q0, q1), tm = a2pt * r1;
             const double te = (fabs(tmaxj) + fabs(tminj) + 2.0 * fabs(a4pt) + fabs(a2pt) * xTop) * fabs(r1);
-            const int src = (lane & 24) | (j & 3);
+            const int src = (lane & 56) | (j & 3);
             const double su = __shfl(tu, src), sl = __shfl(tl, src), sm = __shfl(tm, src), se = __shfl(te, src);
             const int sv = __shfl((int)useT, src);
             if (j >= 4) { au = su; al = sl; mj = sm; ej = se; valid = sv != 0; }
@@ -693,7 +713,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
          // a line with a non-finite coefficient (theta' = 0 with a zero threshold gives rcp(0) here) must stop the fast-forward:
          // the min / max reductions below would silently drop its NaN
          const bool lineFinite = !valid || ((au == au) & (mj == mj) & (ej == ej) & (fabs(au) < kInf) & (fabs(mj) < kInf) & (ej < kInf));
-         const bool allFinite = __ballot(!lineFinite) == 0;
+         const bool allFinite = S1_BALLOT(!lineFinite) == 0;
          au = valid ? au : kInf;
          al = valid ? al : -kInf;
          mj = valid ? mj : 0.0;
@@ -704,7 +724,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
          const double sMin2 = .5 * (dmin(uMin, sddotMax) - dmax(lMax, -sddotMax));
          const bool standing = accOn && jv && !use && !(fabs(thD2) < thrA);
          double xForce = kInf;
-         if (__ballot(standing)) xForce = grp_min<8>(standing ? amaxj / fabs(thD2) : kInf);
+         if (S1_BALLOT(standing)) xForce = grp_min<8>(standing ? amaxj / fabs(thD2) : kInf);
          // the pairs of this lane's line with (u_0, l_0): as the upper line when m > 0, as the lower line when m < 0
          double xs = kInf;
          if (valid && mj > 0.0) xs = (au + sddotMax) * fastRcp(mj);
@@ -713,7 +733,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
          for (int rr = 0; rr < 2; ++rr)
          {
             // this lane's line as the upper one, line cslot + 4 rr of its own slot as the lower one
-            const int srcLane = (lane & 24) | (cslot + 4 * rr);
+            const int srcLane = (lane & 56) | (cslot + 4 * rr);
             const double ali = __shfl(al, srcLane), mi = __shfl(mj, srcLane);
             const double dm = mj - mi;
             const double bnd = (au - ali) * fastRcp(dm > 0.0 ? dm : 1.0);
@@ -740,11 +760,11 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
          BK_TICK(tq1);
          BK_ACC(cyP1, tp2, tq1);
          bool expectEnd = false;
-         if (__ballot(sane))
+         if (S1_UNI(sane))
          {
             // every value below is the same in all lanes: the loop conditions are scalar branches on ballots
             // (bitwise operators on purpose: '||' and '&&' become exec-mask branches around single compares)
-            int it = __builtin_amdgcn_readfirstlane(nIter);
+            int it = S1_FIRST(nIter);
             bool inBand = false;
             // the search for a first feasible speed (ba.cpp:1281-1285): the bracket shrinks below every violated candidate
 #pragma unroll 1
@@ -752,13 +772,13 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
             {
                const double c = sdotTry, d = c * c - xThr;           // c * c: sdotSQ of the check
                inBand = !((fabs(d) > bandThr) & (c > 1e-100));
-               if (__ballot(inBand | !(d > 0.0))) break;
+               if (S1_UNI(inBand | !(d > 0.0))) break;
                lowFact *= 2.0;
                sdotH = c;
                sdotL = dmax(.999 * 0.0, (1.0 - lowFact) * c);
                sdotTry = .5 * (sdotH + sdotL);
             }
-            if (!__ballot(inBand) && it < 90)
+            if (!S1_UNI(inBand) && it < 90)
             {
                // sdotTry is feasible for certain and the first such speed: ba.cpp:1294 compares it with sdotGood = 0 and goes on
                // (|c - 0| > 1e-3 c).  From here the plain bisection (ba.cpp:1286-1303): sdotGood == sdotL throughout, every
@@ -778,13 +798,13 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
                   const bool viol = d > 0.0;
                   inBand = !(fabs(d) > bandThr);
                   goesOn = viol | (fabs(c - sdotL) > convThr * c);
-                  if (__ballot(inBand | !goesOn)) break;
+                  if (S1_UNI(inBand | !goesOn)) break;
                   sdotH = viol ? c : sdotH;
                   sdotL = viol ? sdotL : c;
                   sdotTry = .5 * (sdotH + sdotL);
                }
                sdotGood = sdotL;
-               expectEnd = !__ballot(inBand | goesOn);
+               expectEnd = !S1_UNI(inBand | goesOn);
             }
             nIter = it;
          }
@@ -798,7 +818,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
             const bool convC = ratio_lt(fabs(c - sdotGood), c, sdotErrThresh);
             BK_TICK(tq3);
             BK_ACC(cyP3, tq2, tq3);
-            if (__ballot(!violC && convC))
+            if (S1_UNI(!violC && convC))
             {
 #ifdef BK_PROFILE_SECTIONS
                ++nAcc;
@@ -851,12 +871,12 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
          // max reduction below would drop its NaN
          const bool finA = !useA || ((aa == aa) & (ma == ma) & (aa < kInf) & (fabs(ma) < kInf));
          const bool finT = !useT || ((tu == tu) & (tl == tl) & (tb == tb) & (tm == tm) & (fabs(tu) < kInf) & (fabs(tl) < kInf) & (fabs(tb) < kInf) & (fabs(tm) < kInf));
-         const bool allFinite = __ballot(!(finA & finT & (eq == eq))) == 0;
+         const bool allFinite = S1_BALLOT(!(finA & finT & (eq == eq))) == 0;
          const double eMax = grp_max<8>(eq);
          const double bandG = eMax * 0x1p-44;
          const bool standing = accOn && jv && !useA && !(fabs(thD2) < thrA);
          double xForce = kInf;
-         if (__ballot(standing)) xForce = grp_min<8>(standing ? amaxj / fabs(thD2) : kInf);
+         if (S1_BALLOT(standing)) xForce = grp_min<8>(standing ? amaxj / fabs(thD2) : kInf);
          // magnitudes far inside the normal range; NaNs fail every test
          const bool sane = allFinite & (eMax == eMax) & (cTop == cTop) & (eMax > 1e-100) & (eMax < 1e100) & (cTop > 1e-100) & (cTop < 1e50);
          // d(c) > 0 <=> violated, |d(c)| > bandG <=> certain: -g(c) of the approximate check, +inf where a standing joint forbids c
@@ -871,9 +891,9 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
          BK_TICK(tq1);
          BK_ACC(cyP1, tp2, tq1);
          bool expectEnd = false;
-         if (__ballot(sane))
+         if (S1_UNI(sane))
          {
-            int it = __builtin_amdgcn_readfirstlane(nIter);
+            int it = S1_FIRST(nIter);
             bool inBand = false;
             // the search for a first feasible speed (ba.cpp:1281-1285)
 #pragma unroll 1
@@ -881,13 +901,13 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
             {
                const double c = sdotTry, d = dOf(c);
                inBand = !((fabs(d) > bandG) & (c > 1e-100));
-               if (__ballot(inBand | !(d > 0.0))) break;
+               if (S1_UNI(inBand | !(d > 0.0))) break;
                lowFact *= 2.0;
                sdotH = c;
                sdotL = dmax(.999 * 0.0, (1.0 - lowFact) * c);
                sdotTry = .5 * (sdotH + sdotL);
             }
-            if (!__ballot(inBand) && it < 90)
+            if (!S1_UNI(inBand) && it < 90)
             {
                // the first feasible speed: ba.cpp:1294 compares it with sdotGood = 0 and goes on; then the plain bisection
                sdotGood = sdotTry; nGood = 1; sdotL = sdotTry;
@@ -902,13 +922,13 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
                   const bool viol = d > 0.0;
                   inBand = !(fabs(d) > bandG);
                   goesOn = viol | (fabs(c - sdotL) > convThr * c);
-                  if (__ballot(inBand | !goesOn)) break;
+                  if (S1_UNI(inBand | !goesOn)) break;
                   sdotH = viol ? c : sdotH;
                   sdotL = viol ? sdotL : c;
                   sdotTry = .5 * (sdotH + sdotL);
                }
                sdotGood = sdotL;
-               expectEnd = !__ballot(inBand | goesOn);
+               expectEnd = !S1_UNI(inBand | goesOn);
             }
             nIter = it;
          }
@@ -921,7 +941,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
             const bool convC = ratio_lt(fabs(c - sdotGood), c, sdotErrThresh);
             BK_TICK(tq3);
             BK_ACC(cyP3, tq2, tq3);
-            if (__ballot(!violC && convC))
+            if (S1_UNI(!violC && convC))
             {
 #ifdef BK_PROFILE_SECTIONS
                ++nAcc;
@@ -941,8 +961,8 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
          ++nPass;
 #endif
          // the loop's counters are the same in every lane: say so, and every branch on them is a scalar branch
-         nGood = __builtin_amdgcn_readfirstlane(nGood);
-         nIter = __builtin_amdgcn_readfirstlane(nIter);
+         nGood = S1_FIRST(nGood);
+         nIter = S1_FIRST(nIter);
          const double c0 = sdotTry;
          double cand1, cand2, cand3;
          if (nGood == 0)
@@ -962,14 +982,14 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
          }
          const double mine = (cslot == 0) ? c0 : (cslot == 1) ? cand1 : (cslot == 2) ? cand2 : cand3;
          const bool violMine = verify(mine); // this slot's sddotL / sddotH stay in its lanes
-         const unsigned ballot = (unsigned)__ballot(violMine);
+         const unsigned ballot = (unsigned)S1_BALLOT(violMine);
 
          // The replay of the reference's loop for this pass as a walk over ballot bits instead of runs of iterate(): whatever an
          // iteration tests about its candidate -- the convergence test of a feasible one (ba.cpp:1294), the collapsed-bracket
          // test of a violated one while no feasible point is known (ba.cpp:1311-1315) -- is evaluated by the candidate's own
          // slot beside the constraint check, all four at once.  Same updates, same order, same values; the generic replay
          // below keeps what can end in a failure exit (iteration count near 100, a negative candidate, a collapsed bracket).
-         if (__builtin_amdgcn_readfirstlane((int)(nIter <= 96 && !(c0 < 0.0) && !(sdotL < 0.0))))
+         if (S1_FIRST((int)(nIter <= 96 && !(c0 < 0.0) && !(sdotL < 0.0))))
          {
             if (nGood != 0)
             {
@@ -977,7 +997,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
                // compared with the last feasible point before it: sdotGood for c0 and cand1, c0 for cand2
                const double prevGood = (cslot == 2) ? c0 : sdotGood;
                const bool convMine = ratio_lt(fabs(mine - prevGood), mine, sdotErrThresh) || mine < 0.0;
-               const unsigned conv = (unsigned)__ballot(convMine);
+               const unsigned conv = (unsigned)S1_BALLOT(convMine);
                int k2;
                if (ballot & 1u) { sdotH = c0; k2 = 1; }                       // c0 violated: ba.cpp:1278-1280
                else
@@ -1007,8 +1027,8 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
             const double shrunkMine = dmax(.999 * 0.0, (1.0 - lfMine) * mine);
             const bool convMine = ratio_lt(fabs(mine - sdotGood), mine, sdotErrThresh) || mine < 0.0;
             const bool badMine = mine < 0.0 || ratio_lt(mine - shrunkMine, mine, 1e-20);  // a failure exit if this one is violated
-            const unsigned conv = (unsigned)__ballot(convMine);
-            if ((((unsigned)__ballot(badMine)) & ballot & 0x01010101u) == 0u)
+            const unsigned conv = (unsigned)S1_BALLOT(convMine);
+            if ((((unsigned)S1_BALLOT(badMine)) & ballot & 0x01010101u) == 0u)
             {
                bool ended = false;
 #pragma unroll
@@ -1047,11 +1067,11 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
             const bool stop = iterate((ballot >> (8 * k)) & 1u);
             // was the next value evaluated in this pass?
             k = (sdotTry == cand1) ? 1 : (sdotTry == cand2) ? 2 : (sdotTry == cand3 && nGood == 0) ? 3 : -1;
-            over = __builtin_amdgcn_readfirstlane((int)stop) != 0;
-            if (over || __builtin_amdgcn_readfirstlane((int)(k < 0))) break;
+            over = S1_FIRST((int)stop) != 0;
+            if (over || S1_FIRST((int)(k < 0))) break;
          }
       }
-      fin = __builtin_amdgcn_readfirstlane((int)fin) != 0;
+      fin = S1_FIRST((int)fin) != 0;
       failed = !fin;
       BK_TICK(tp3);
       BK_ACC(cyD, tp2, tp3);
@@ -1061,7 +1081,7 @@ __global__ void __launch_bounds__(S1_BLOCK, (FEAT == 2 && FF == 0 && PAIRS) ? 2 
          nfail++;
          return;
       }
-      const int src = 8 * lastSlot;
+      const int src = (lane & 32) + 8 * lastSlot;
       sddotH = __shfl(sddotH, src);
       sddotL = __shfl(sddotL, src);
       sddot = (DIR == 1) ? sddotH : sddotL;

@@ -103,7 +103,9 @@ CONFIGS = {
     # integration steps at more than twice the time per step (long bisections) -- and a launch lasts as long
     # as its slowest path: 16.7 s instead of 6.3 s for the same 4096 x 2e5 knots.  The sample of round 4 is kept so
     # that the number stays comparable; candidates that cannot finish are swapped as before (`swapped_seeds`).
-    "cfg5": dict(workload="cspr", knots=200000, paths=4096, scaling="strong", distinct=128,
+    # lean (round 5): one curve buffer per path and the pointwise values in it -- 62.7 instead of 67.6 MB per path, so that one GPU
+    # holds its whole share (4096 paths) as ONE resident batch, which the library then sweeps with two paths per wavefront
+    "cfg5": dict(workload="cspr", knots=200000, paths=4096, scaling="strong", distinct=128, lean=True,
                  what="cfg5 as worded: CSPR3DOF cable robot with cable-tension constraints, N=200k, batch of 4096 sharded "
                       "across the GPUs"),
 }
@@ -391,7 +393,7 @@ def plan_chunks(B, K, limit):
 
 
 def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=0, knots_override=0, group=0, ppw=0,
-            coefficient_rows=False, distinct_override=0, keep=False):
+            coefficient_rows=False, distinct_override=0, keep=False, lean=False):
     """run one configuration on this rank's share; returns (result dict, kept objects or None)"""
     import torch
     c = CONFIGS[cfg_name]
@@ -422,7 +424,7 @@ def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=
         # the cable robot in serial form: every channel (cables, platform position, a1..a4 of every row) as (value, second
         # derivative) pairs -- same results, 288 instead of 992 bytes per knot: twice the paths per chunk, two wavefronts per SIMD
         prob.flags |= capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES
-    if c.get("lean"):
+    if c.get("lean") or lean:
         prob.flags |= capi.F_CURVES_IN_PLACE | capi.F_MVC_IN_CURVES   # same results, one curve buffer per path and nothing else per knot
     C = WORKLOADS[workload]["C"]
     cap = int(int(inp.n_knots.max()) * WORKLOADS[workload]["cap"]) + 1024
@@ -865,6 +867,7 @@ def main():
     ap.add_argument("--hold", type=int, nargs=2, default=None, help="sweep loop form, reverse forward (batotp_hip_set_sweep_hold; -2 automatic)")
     ap.add_argument("--spline-tiles", type=int, default=None, help="A/B: K1 in tiles of knots, 1 always / 0 never / -1 automatic (batotp_hip_set_spline_tiles)")
     ap.add_argument("--no-fast-forward", action="store_true", help="A/B: run every bisection iteration's check (batotp_hip_set_fast_forward 0)")
+    ap.add_argument("--lean", action="store_true", help="one curve buffer per path and the pointwise values in it, whatever the configuration says (experiments)")
     ap.add_argument("--k3-form", type=int, default=None, help="A/B: per-knot evaluation kernel, 1 k_pointwise_va / 0 the general kernel (batotp_hip_set_k3_form)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -913,7 +916,7 @@ def main():
     default_run = args.config == "fill7" and not args.paths and not args.knots
     cpu_job = (None, None)
     out, kept = measure(hip, args.config, rank, world, args.steps, args.warmup, dist_ctx, args.paths, args.knots, args.group, args.ppw,
-                        args.coefficient_rows, args.distinct, keep=True)
+                        args.coefficient_rows, args.distinct, keep=True, lean=args.lean)
     workload = CONFIGS[args.config]["workload"]
     prob, batch = kept["prob"], kept["batch"]
     vel_acc_only = not (prob.flags & (capi.F_TRQ_ON | capi.F_CART_VEL_ON | capi.F_CART_ACC_ON))

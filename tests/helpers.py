@@ -343,6 +343,10 @@ def set_layout(ctx, layout):
         ctx.set_sweep_group(int(g))
         ctx.set_paths_per_wave(64 // int(g))
         ctx.set_sweep_hold(int(k), int(k))
+    elif layout == "64x2":
+        # k_sweep1 with TWO paths per wavefront (one per half): the cable robot in serial form with every channel as pairs
+        ctx.set_sweep_group(64)
+        ctx.set_paths_per_wave(2)
     elif layout == "64noff":
         # one path per wavefront (k_sweep1) with every iteration of the bisection checked (batotp_hip_set_fast_forward 0)
         ctx.set_sweep_group(64)

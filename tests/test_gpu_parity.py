@@ -733,6 +733,45 @@ def test_product_batest_end_to_end_on_gpu(tmp_path):
         assert filecmp.cmp(work / "traj_out.dat", os.path.join(src, "ref_traj_out.dat"), shallow=False), name
 
 
+@pytest.mark.parametrize("ff", [1, 0])
+def test_two_paths_per_wavefront_of_the_one_path_kernel(hip_lib, oracle_ctx, ff):
+    """k_sweep1 with a second path in lanes 32..63 (NP = 2: the cable robot in serial form, every channel as pairs -- what a GPU's
+    whole share of BASELINE config 5 runs through): ragged batches of an odd number of paths (the last wavefront has an empty half),
+    paths that differ in length and in where they bisect, with and without the certified fast-forward -- result rows and both
+    curves of every path equal the oracle's run of that path alone"""
+    for name in ("CSPR3DOF", "synth_cspr_s3", "synth_cspr_s5", "synth_cspr_s9_dup", "synth_cspr_s11_decim"):
+        case = Case(name)
+        n = case.n
+        lens = sorted({n, max(8, int(0.37 * n)), max(8, int(0.6 * n)), max(8, int(0.81 * n))}) + [n]
+        want = {}
+        for m in sorted(set(lens)):
+            class _C:
+                name = f"{case.name}:{m}"
+            c = _C()
+            c.y, c.sres, c.problem, c.n = np.ascontiguousarray(case.y[:, :m]), case.sres, case.problem, m
+            c.max_steps = case.max_steps
+            want[m] = run_pipeline(oracle_ctx, [c], mvc=False, details=False)[0]
+        ctx = capi.Context(hip_lib, 0)
+        helpers.set_layout(ctx, "64x2")
+        ctx.set_fast_forward(ff)
+        prob = capi.Problem.from_buffer_copy(bytes(case.problem))
+        prob.flags |= capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES
+        b = capi.Batch(ctx, prob, lens, case.max_steps())
+        b.upload_knots(0, [np.ascontiguousarray(case.y[:, :m]) for m in lens], [case.sres] * len(lens))
+        b.optimize()
+        assert b.last_sweep_launch(-1)[:2] == (64, 2) and b.last_sweep_launch(+1)[:2] == (64, 2), (name, b.last_sweep_launch(-1))
+        res = b.results()
+        for k, m in enumerate(lens):
+            w = want[m]
+            for f in res.dtype.names:
+                assert res[k][f] == w["result"][f], (name, ff, k, m, f, res[k], w["result"])
+            for which, key in ((-1, "rev"), (1, "fwd")):
+                s_, sd_ = b.curve(k, which)
+                assert_bit_equal(s_, w[key][0], f"{name} ff {ff} path {k} {key}.s")
+                assert_bit_equal(sd_, w[key][1], f"{name} ff {ff} path {k} {key}.sdot")
+        b.close(); ctx.close()
+
+
 @pytest.mark.parametrize("layout", [0, "flat4", 32, 64])
 def test_ragged_batches_are_swept_longest_path_first(hip_lib, oracle_ctx, layout):
     """a batch whose paths differ in length is swept in the order of decreasing knot count

@@ -105,6 +105,25 @@ def _batch_as_worded(hip_lib, oracle_ctx, config, n_paths, sample, distinct):
             assert_bit_equal(s, before[0], f"{config} path {p} curve {which} s, fast-forward off")
             assert_bit_equal(sd, before[1], f"{config} path {p} curve {which} sdot, fast-forward off")
     b.close()
+    if (prob.flags & capi.F_PARALLEL) and (prob.flags & capi.F_PAR2SER):
+        # the layout bench.py runs this configuration in -- every channel as (value, second derivative) pairs, one curve buffer per
+        # path with the pointwise values in it -- through k_sweep1 with ONE and with TWO paths per wavefront (what a GPU's whole
+        # share of 4096 paths gets): the result rows of every path are those of the coefficient-row batch above
+        lean = capi.Problem.from_buffer_copy(bytes(prob))
+        lean.flags |= capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES | capi.F_CURVES_IN_PLACE | capi.F_MVC_IN_CURVES
+        cap2 = max(cap, int(1.5 * int(inp.n_knots.max())) + 64)
+        for ppw in (1, 2):
+            ctx.set_fast_forward(True)
+            ctx.set_sweep_group(64)
+            ctx.set_paths_per_wave(ppw)
+            b2 = capi.Batch(ctx, lean, [int(inp.n_knots[p % K]) for p in range(n_paths)], cap2)
+            inp.fill(b2, n_paths)
+            b2.precompute(0); b2.pointwise_mvc(); b2.sweep(-1); b2.sweep(+1)
+            assert b2.last_sweep_launch(+1)[:2] == (64, ppw)
+            r2 = b2.results()
+            for f in res.dtype.names:
+                assert np.array_equal(r2[f], res[f]), (config, "pairs for all channels", ppw, f)
+            b2.close()
     ctx.trim()
     ctx.close()
 
