@@ -1450,7 +1450,11 @@ static void launchSweep1(batotp_batch *b, SweepArgs &a)
    const int want = b->ctx->pathsPerWave;
    // ... and the compact velocity / acceleration-only layout (round 5; the batch sizes between the one-path kernel and k_sweep8)
    const bool compactVA = featureLevel(b) == -1;
-   const bool two = (cableLines && (want == 2 || (want <= 0 && b->B > 2304))) || (compactVA && (want == 2 || (want <= 0 && b->B > 2304)));
+   // (a two-path wavefront of this family is 20 % slower in the reverse sweep and as fast as a one-path wavefront in the forward
+   //  sweep: 2048 paths 713 / 513 against 596 / 515 ms; one-path wavefronts queue beyond 2048 paths: 3072 paths 775 / 829 ms
+   //  against 901 / 646)
+   const bool two = (cableLines && (want == 2 || (want <= 0 && b->B > 2304))) ||
+                    (compactVA && (want == 2 || (want <= 0 && b->B > (a.dir == -1 ? 3500 : 2304))));
    a.ppw = two ? 2 : 1;
    b->lastLanes[a.dir == -1 ? 0 : 1] = 64; b->lastPpw[a.dir == -1 ? 0 : 1] = a.ppw; b->lastHold[a.dir == -1 ? 0 : 1] = -1;
    const unsigned perBlock = (unsigned)(S1_BLOCK / 64) * (unsigned)a.ppw;
@@ -1533,6 +1537,11 @@ extern "C" int batotp_hip_sweep(batotp_batch *b, int32_t dir)
       // (round 4, against k_sweep8 instead of k_sweep -- N = 5e4, reverse / forward ms: 2048 paths 594 / 516 vs 1117 / 687, 4096 paths
       //  1051 / 1008 vs 1231 / 738: the reverse crossover moved from ~6000 to ~4900 paths, the forward one stays near 3000)
       if (sweep1Applies(b) && b->B <= (a.dir == -1 ? 4608 : 3072)) lanes = 64;
+      // (round 5, compact velocity / acceleration-only batches: with TWO paths per wavefront the one-path kernel keeps its lead over
+      //  the 8-lane layout up to ~7600 paths in the reverse and ~5000 in the forward sweep -- GEN7DOF, N = 5e4, reverse / forward ms,
+      //  one path | two paths | 8 lanes: 4096 paths 1055 / 1004 | 902 / 646 | 1345 / 738; 6144 paths 1460 / 1480 | 1152 / 1050 |
+      //  1460 / 868; 8192 paths 1905 / 1950 | 1588 / 1260 | 1505 / 868: profiles/r05_i_*; launchSweep1 picks one or two)
+      if (sweep1Applies(b) && featureLevel(b) == -1 && b->B <= (a.dir == -1 ? 7600 : 5000)) lanes = 64;
    }
    if (b->pairsAll)
    {

@@ -44,7 +44,7 @@ def _run(ctx, prob, ys, sres, cap):
 
 
 @pytest.mark.parametrize("seed", range(6 * _SCALE))
-@pytest.mark.parametrize("lanes", [0, 8, "flat0", "flat4", 4, 2, "g4flat0", "g4flat8", "g2flat3", 64, "64noff"])
+@pytest.mark.parametrize("lanes", [0, 8, "flat0", "flat4", 4, 2, "g4flat0", "g4flat8", "g2flat3", 64, "64noff", "64x2"])
 def test_random_velocity_acceleration_problems(hip_lib, oracle_ctx, seed, lanes):
     rng = np.random.default_rng(1000 + seed)
     nJ = int(rng.integers(1, 9))
@@ -110,7 +110,7 @@ def test_certified_fast_forward_of_the_bisection_on_hard_problems(hip_lib, oracl
     nearly parallel), all eight joints in use -- against the oracle, bit for bit"""
     prob, ys, sres, cap, n_paths = _hard_problem(seed)
     ro, oo = _run(oracle_ctx, prob, ys, sres, cap)
-    for layout in (64, "64noff"):
+    for layout in (64, "64noff", "64x2"):
         ctx = capi.Context(hip_lib, 0)
         set_layout(ctx, layout)
         p2 = capi.Problem.from_buffer_copy(bytes(prob))

@@ -179,14 +179,14 @@ def _vel_acc_only(name):
     return name in helpers.FULL_CASES and not (f & (capi.F_TRQ_ON | capi.F_CART_VEL_ON | capi.F_CART_ACC_ON))
 
 
-@pytest.mark.parametrize("lanes", [0, 1, 2, 4, 8, 16, 32, 64])
+@pytest.mark.parametrize("lanes", [0, 1, 2, 4, 8, 16, 32, 64, "64x2"])
 def test_compact_splines_give_identical_results(hip_lib, oracle_ctx, lanes):
     """BATOTP_F_COMPACT_SPLINES (value + second derivative per knot instead of four coefficients): every
     published quantity is bit-identical to the oracle's, for every lane grouping of the sweep"""
     names = [n for n in helpers.FULL_CASES if _vel_acc_only(n)]
     assert len(names) >= 3, names
     ctx = capi.Context(hip_lib, 0)
-    ctx.set_sweep_group(lanes)
+    helpers.set_layout(ctx, lanes)
     for name in names:
         case = Case(name)
         ho = run_pipeline(ctx, [case], extra_flags=capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES)[0]
@@ -444,7 +444,7 @@ def test_flat_sweep_loop_is_gated_by_toolchain_and_canary(hip_lib, oracle_ctx, m
     ctx.close()
 
 
-@pytest.mark.parametrize("lanes", [0, 1, 8, 16, 32, 64, "flat4"])
+@pytest.mark.parametrize("lanes", [0, 1, 8, 16, 32, 64, "flat4", "64x2"])
 def test_curves_in_place_give_identical_results(hip_lib, oracle_ctx, lanes):
     """BATOTP_F_CURVES_IN_PLACE: one curve buffer per path, the forward curve written over the reverse points its cursor has left
     behind -- result rows and both curves (the reverse one fetched between the sweeps) equal the oracle's"""
@@ -772,7 +772,7 @@ def test_two_paths_per_wavefront_of_the_one_path_kernel(hip_lib, oracle_ctx, ff)
         b.close(); ctx.close()
 
 
-@pytest.mark.parametrize("layout", [0, "flat4", 32, 64])
+@pytest.mark.parametrize("layout", [0, "flat4", 32, 64, "64x2"])
 def test_ragged_batches_are_swept_longest_path_first(hip_lib, oracle_ctx, layout):
     """a batch whose paths differ in length is swept in the order of decreasing knot count
     (batotp_hip_set_path_order 1, the default: launch slot k runs path order[k]) -- longest-processing-time-first for the kernels
@@ -827,7 +827,7 @@ def test_paths_of_one_batch_integrate_with_their_own_steps(hip_lib, oracle_ctx):
             cs.problem.integ_res = h
             cs.max_steps = lambda: int(case.max_steps() * 0.01 / min(steps)) + 64
             want.append(run_pipeline(oracle_ctx, [cs], mvc=True, details=False)[0])
-        for layout in (0, 8, "flat4", "oldflat4", 64, 32):
+        for layout in (0, 8, "flat4", "oldflat4", 64, 32, "64x2"):
             ctx = capi.Context(hip_lib, 0)
             helpers.set_layout(ctx, layout)
             prob = capi.Problem.from_buffer_copy(bytes(case.problem))
