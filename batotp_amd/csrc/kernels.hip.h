@@ -122,13 +122,20 @@ __device__ __forceinline__ double div_by_const(double num, double den, double rc
    return num / den;
 }
 
+// (x / 6.0) correctly rounded through the reciprocal (div_by_const: RN(1/6) is a compile-time constant, the significand of 6 is
+// not all ones): the bits of the IEEE quotient in 4 dependent operations instead of the ~30 instructions hipcc emits for `/`
+// (checked on the device for 1.4e6 operands incl. neighbours of exact multiples: test_division_by_six_...).  Every coefficient row
+// formed from (value, second derivative) pairs divides by 6 twice -- since round 5 all of them go through this (k_dynamics and the
+// per-knot kernel of the cable robot form 12-36 rows per knot; the resampler one per channel and output site).
+__device__ __forceinline__ double div6(double x) { return div_by_const(x, 6.0, 1.0 / 6.0); }
+
 __device__ __forceinline__ void emit_segment(double *__restrict__ cf, int64_t i, int C, int dc, double solL, double solR,
                                              double yL, double yR)
 {
    Coef4 o;
-   o.c3 = (solR - solL) / 6.0;
+   o.c3 = div6(solR - solL);
    o.c2 = solL / 2.0;
-   o.c1 = yR - yL - (solR + 2 * solL) / 6.0;
+   o.c1 = yR - yL - div6(solR + 2 * solL);
    o.c0 = yL;
    *reinterpret_cast<Coef4 *>(cf + (i * C + dc) * 4) = o;
 }
@@ -292,9 +299,9 @@ __global__ void __launch_bounds__(64) k_spline_series(int count, const int64_t *
 __device__ __forceinline__ Coef4 coeffs_from_sol(double solL, double solR, double yL, double yR)
 {
    Coef4 o;
-   o.c3 = (solR - solL) / 6.0;
+   o.c3 = div6(solR - solL);
    o.c2 = solL / 2.0;
-   o.c1 = yR - yL - (solR + 2 * solL) / 6.0;
+   o.c1 = yR - yL - div6(solR + 2 * solL);
    o.c0 = yL;
    return o;
 }
@@ -1106,9 +1113,6 @@ __device__ __forceinline__ void eval_partials_row(Pt<G, FEAT, UNI> &t, int j, co
    eval_partials_src(t, j, RowAt{row});
 }
 
-// (x / 6.0) correctly rounded through the reciprocal (see div_by_const): the compact spline form
-// divides twice per coefficient row
-__device__ __forceinline__ double div6(double x) { return div_by_const(x, 6.0, 1.0 / 6.0); }
 
 // FEAT <= 0 (joint velocity / acceleration limits only): this lane's coefficients c1..c3 stay in
 // registers while the cursor stays on the segment (group-uniform test).  FEAT == 0 reads them from the

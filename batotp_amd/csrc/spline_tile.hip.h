@@ -274,9 +274,9 @@ __global__ void __launch_bounds__(ST_BLOCK) k_spline_tile(TileArgs a)
          if (k < n)
          {
             const double solL = S[cl][kk], solR = S[cl][kk + 1], yL = Y[cl][k - k0], yR = Y[cl][k + 1 - k0];
-            o.c3 = (solR - solL) / 6.0;          // spline.cpp:203-209
+            o.c3 = div6(solR - solL);            // spline.cpp:203-209 (x / 6 through the exact reciprocal form, kernels.hip.h)
             o.c2 = solL / 2.0;
-            o.c1 = yR - yL - (solR + 2 * solL) / 6.0;
+            o.c1 = yR - yL - div6(solR + 2 * solL);
             o.c0 = yL;
          }
          else { o.c0 = 0; o.c1 = 0; o.c2 = 0; o.c3 = 0; }       // the row of the last knot is never written (stays zero)
