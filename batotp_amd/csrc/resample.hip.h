@@ -324,6 +324,59 @@ __device__ __forceinline__ void rs_auto_rule(const RsParams &P, RsPath &pp, doub
    if (pp.sw2 > 0) cartRes = dmin(cartRes, cartRes * pp.sw2 / pp.sw1);
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+   return __hiloint2double(hi, lo);
+}
+
+// lane L of the own row (16 lanes) in every lane: v_mov_b32_dpp row_newbcast:L on both halves
+template <int L> __device__ __forceinline__ double row_bcast_f64(double v)
+{
+   const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + L, 0xf, 0xf, false);
+   const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + L, 0xf, 0xf, false);
+   return __hiloint2double(hi, lo);
+}
+
+// what adjust_s derives from the two arc lengths of a path (ba.cpp:472-590): the scale factors and the size of the pass' output
+__device__ __forceinline__ void rs_scan_finish(const RsParams &P, RsPath &pp, int n, double tacc, double cacc, double minCartPerTheta, int special)
+{
+   const bool autoOn = P.autoOn != 0;
+   if (tacc < P.thetaRes) { pp.status |= RS_IDENTICAL; return; }
+
+   double cartRes = P.cartRes;
+   if (autoOn) rs_auto_rule(P, pp, tacc, cacc, minCartPerTheta, cartRes);
+   const double sResi = pp.sres;
+   const double ptsLast = (double)(n - 1); // traj.ptsOrig is 0,1,2,.. at both call sites
+   double sLast = 0, sResNew = 0;
+   switch (pp.scaleType)
+   {
+   case 0: sLast = sResi * ptsLast; sResNew = sResi; break;
+   case 1: sLast = tacc; sResNew = P.thetaRes; break;
+   default: sLast = cacc; sResNew = cartRes; break;
+   }
+   double cartFact = 0;
+   if (cacc >= cartRes) cartFact = pp.sw2 * sLast / cacc;
+   const double teachFact = P.sW[0] * sLast / (sResi * ptsLast);
+   const double thetaFact = pp.sw1 * sLast / tacc;
+   pp.sLast = sLast; pp.sResNew = sResNew; pp.tTeachFact = teachFact; pp.thetaFact = thetaFact; pp.cartFact = cartFact;
+   pp.sresNew = sLast / (n - 1); // traj.sres = sLast/(nPts-1), ba.cpp:585
+   if (special)
+   {
+      int nPts2 = (int)ceil(sLast / sResNew) + 1; // ba.cpp:666-667
+      if (nPts2 < 4) nPts2 = 4;
+      pp.nOut = nPts2; // planning figure; the walk reports the real count
+   }
+   else
+   {
+      // evalSplineFullTraj(traj, traj.sres, sResNew): ba.cpp:796-798
+      int nNew = (int)ceil(pp.sresNew / sResNew * (n - 1)) + 1;
+      if (nNew < 4) nNew = 4;
+      pp.nOut = nNew;
+   }
+}
+
 __global__ void k_rs_scan(RsParams P, RsPath *__restrict__ paths, int B, double *__restrict__ thetaArc, double *__restrict__ cartArc, int special)
 {
    const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -368,39 +421,42 @@ __global__ void k_rs_scan(RsParams P, RsPath *__restrict__ paths, int B, double 
          if (dTh > window) { minCartPerTheta = dmin(minCartPerTheta, 3.0 * dCa / dTh); tMark = tacc; cMark = cacc; }
       }
    }
-   if (tacc < P.thetaRes) { pp.status |= RS_IDENTICAL; return; }
-
-   double cartRes = P.cartRes;
-   if (autoOn) rs_auto_rule(P, pp, tacc, cacc, minCartPerTheta, cartRes);
-   const double sResi = pp.sres;
-   const double ptsLast = (double)(n - 1); // traj.ptsOrig is 0,1,2,.. at both call sites
-   double sLast = 0, sResNew = 0;
-   switch (pp.scaleType)
-   {
-   case 0: sLast = sResi * ptsLast; sResNew = sResi; break;
-   case 1: sLast = tacc; sResNew = P.thetaRes; break;
-   default: sLast = cacc; sResNew = cartRes; break;
-   }
-   double cartFact = 0;
-   if (cacc >= cartRes) cartFact = pp.sw2 * sLast / cacc;
-   const double teachFact = P.sW[0] * sLast / (sResi * ptsLast);
-   const double thetaFact = pp.sw1 * sLast / tacc;
-   pp.sLast = sLast; pp.sResNew = sResNew; pp.tTeachFact = teachFact; pp.thetaFact = thetaFact; pp.cartFact = cartFact;
-   pp.sresNew = sLast / (n - 1); // traj.sres = sLast/(nPts-1), ba.cpp:585
-   if (special)
-   {
-      int nPts2 = (int)ceil(sLast / sResNew) + 1; // ba.cpp:666-667
-      if (nPts2 < 4) nPts2 = 4;
-      pp.nOut = nPts2; // planning figure; the walk reports the real count
-   }
-   else
-   {
-      // evalSplineFullTraj(traj, traj.sres, sResNew): ba.cpp:796-798
-      int nNew = (int)ceil(pp.sresNew / sResNew * (n - 1)) + 1;
-      if (nNew < 4) nNew = 4;
-      pp.nOut = nNew;
-   }
+   rs_scan_finish(P, pp, n, tacc, cacc, minCartPerTheta, special);
 }
+
+// The same running sums with a ROW (16 lanes) per chain: a wavefront takes two paths, rows 0 / 1 the joint-space and the
+// Cartesian chain of the first, rows 2 / 3 those of the second.  A row loads 16 consecutive step lengths at once (one 128-byte
+// line), lane k forms "carry + v0 + v1 + ... + vk" in exactly that order -- step j adds lane j's value, by DPP row broadcast,
+// in the lanes >= j and +0 in the others (arc lengths are >= +0: adding +0 leaves no trace) --, lane 15 hands its sum on as
+// the next carry.  Five instructions per step for four chains, against a lone lane per path that waits for its own 16 loads:
+// 36 -> ms of the GEN7DOF call of tools/bench_resample.py.  Without the automatic integration resolution (its window marks are
+// a scan of their own over both sums: k_rs_scan keeps those calls).
+#define RS_SCAN_STEP(J) acc = acc + (rl >= (J) ? row_bcast_f64<(J)>(v) : 0.0)
+__global__ void __launch_bounds__(64) k_rs_scan_rows(RsParams P, RsPath *__restrict__ paths, int B, double *__restrict__ thetaArc,
+                                                    double *__restrict__ cartArc, int special)
+{
+   const int lane = threadIdx.x, row = lane >> 4, rl = lane & 15;
+   const int pA = 2 * blockIdx.x, pB = pA + 1;
+   const int nA = (pA < B && !paths[pA].status) ? paths[pA].n : 0, nB = (pB < B && !paths[pB].status) ? paths[pB].n : 0;
+   const int p = row < 2 ? pA : pB, n = row < 2 ? nA : nB, nMax = max(nA, nB);
+   double *__restrict__ a = ((row & 1) ? cartArc : thetaArc) + (n ? paths[p].off : 0);
+   double acc = 0; // the carry of the row's chain on entry of a block, the lane's own sum on exit
+   double v = 1 + rl < n ? a[1 + rl] : 0.0;
+   for (int i = 1; i < nMax; i += 16)
+   {
+      const int ahead = i + 16 + rl;
+      const double vNext = ahead < n ? a[ahead] : 0.0; // under way while this block adds
+      RS_SCAN_STEP(0); RS_SCAN_STEP(1); RS_SCAN_STEP(2); RS_SCAN_STEP(3); RS_SCAN_STEP(4); RS_SCAN_STEP(5); RS_SCAN_STEP(6); RS_SCAN_STEP(7);
+      RS_SCAN_STEP(8); RS_SCAN_STEP(9); RS_SCAN_STEP(10); RS_SCAN_STEP(11); RS_SCAN_STEP(12); RS_SCAN_STEP(13); RS_SCAN_STEP(14); RS_SCAN_STEP(15);
+      if (i + rl < n) a[i + rl] = acc;
+      acc = row_bcast_f64<15>(acc); // (points past the end added +0: the carry stays the path's total)
+      v = vNext;
+   }
+   // the Cartesian total sits one row up
+   const int hiC = __shfl(__double2hiint(acc), lane + 16), loC = __shfl(__double2loint(acc), lane + 16);
+   if (rl == 0 && !(row & 1) && n) rs_scan_finish(P, paths[p], n, acc, __hiloint2double(hiC, loC), 0.0, special);
+}
+#undef RS_SCAN_STEP
 
 // RsPath::pad collects the spacing findings of the second pass: bit 0 "s-resolution is too small"
 // (ba.cpp:607-611), bit 1 findInterpSegs' zero width (spline.cpp:84-88); the host turns them into
@@ -432,21 +488,17 @@ __global__ void k_rs_sites(RsParams P, RsPath *__restrict__ paths, int B, const 
 // of (weighted) distance from the last emitted one, by evaluating the splines of the original
 // points.  Output rows are point-major [i][C] (the count is only known at the end).
 //
-// One WAVEFRONT per path, lane c = channel c.  The walk is a serial chain (every emitted point
-// depends on the previous one) with data-dependent control flow; with a lane per path the 64 paths
-// of a wavefront drag each other through both branches and through every memory wait.  With a
-// wavefront per path the control flow is uniform (scalar branches), the channel work of one step
-// runs across lanes, loads of a point / of a coefficient row are one coalesced access, and the
-// other wavefronts of the SIMD (other paths) hide the memory latency.  Values that all lanes
-// share (distances, s, tau) are computed redundantly in every lane from lane-broadcast operands, in
-// the reference's order of operations.
+// One WAVEFRONT per path, a lane per channel (each of the four 16-lane rows carries all channels).  The walk is a serial
+// chain (every emitted point depends on the previous one) with data-dependent control flow; with a lane per path the 64
+// paths of a wavefront drag each other through both branches and through every memory wait.  With a wavefront per path
+// the control flow is uniform, the channel work of one step runs across lanes, and what is left is the LATENCY of the
+// chain (at <= 1024 paths a SIMD holds one wavefront: nothing hides anything), so: the taught points come from an LDS
+// window (round 5), the sums of squares take their operands by DPP row broadcast instead of v_readlane round trips through
+// the scalar unit, and values that all lanes share (distances, s, tau) are computed redundantly in every lane, in the
+// reference's order of operations.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double readlane_f64(double v, int lane)
-{
-   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-   return __hiloint2double(hi, lo);
-}
+constexpr int RS_WIN = 64; // taught points per LDS window (one per lane in a refill)
+constexpr int RS_BACK = 4; // points kept behind the one that caused a refill
 
 __global__ void __launch_bounds__(64) k_rs_special(RsParams P, RsPath *__restrict__ paths, int B, const double *__restrict__ x,
                                                    const double *__restrict__ sC, const double *__restrict__ sol, double *__restrict__ rows)
@@ -457,11 +509,18 @@ __global__ void __launch_bounds__(64) k_rs_special(RsParams P, RsPath *__restric
    if (pp.status) return;
    const int lane = threadIdx.x;
    const int n = pp.n, C = P.C, nJ = P.nJ;
-   const int c = lane < C ? lane : C - 1; // spare lanes shadow the last channel (they never store)
-   const bool owner = lane < C;
+   // lanes of a ROW (16 lanes) of the lower half-wave: 0..7 the joints, 8..15 the Cartesian channels (row 0 stores); of the
+   // upper half-wave: 0..7 the Cartesian channels again.  The sum of squares of a step then is ONE chain of eight DPP row
+   // broadcasts -- the joint-space sum in the lower half, the Cartesian one (x, y, z) in the upper half -- and one square
+   // root; lanes whose channel does not enter their half's sum contribute +0 (a partial sum is never -0, so adding +0
+   // leaves no trace), spare lanes shadow the last channel of their kind
+   const int rl = lane & 15, nC = C - nJ;
+   const bool upper = lane >= 32;
+   const int c = (rl < 8 && !upper) ? min(rl, nJ - 1) : nJ + min(rl & 7, nC - 1);
+   const bool owner = lane < 16 && (rl < 8 ? rl < nJ : rl - 8 < nC);
+   const bool inSum = rl < (upper ? 3 : nJ); // (rl < 8 follows: nJ <= 8)
    const double *__restrict__ xc = x + pp.off * C + (int64_t)c * n; // this lane's channel of the taught points
    const double *__restrict__ s = sC + pp.off;
-   const double *__restrict__ mc = sol + pp.off * C + (int64_t)c * n; // second derivatives of this lane's channel (k_spline_sol)
    double *__restrict__ out = rows + pp.offOut * C + c;
    const int cap = pp.cap;
    const double sResNew = pp.sResNew, teach = pp.tTeachFact * pp.sres, thF = pp.thetaFact, caF = pp.cartFact;
@@ -469,29 +528,70 @@ __global__ void __launch_bounds__(64) k_rs_special(RsParams P, RsPath *__restric
    const bool cartCh = c >= nJ;
    const bool evalCh = !cartCh || P.cartEval != 0; // Cartesian channels keep traj.cartpt (zero) unless a Cartesian constraint is on
 
-   double prev = xc[0], xo = xc[1];
-   Coef4 kk = coeffs_from_sol(mc[0], mc[1], prev, xo);
+   // A window of RS_WIN consecutive taught points (values, second derivatives, sites) in LDS: the walk reads a point, a site
+   // or a coefficient row as soon as the previous step has decided which -- from global memory every such read is a full
+   // memory latency on the serial chain (one wavefront per SIMD at <= 1024 paths: nothing hides it).  A refill is 2C+1
+   // coalesced 512-byte loads issued back to back; the walk moves forward (the cursor steps back only after a rounding
+   // surprise), so a window serves ~RS_WIN points.
+   __shared__ double wX[BATOTP_MAX_JOINTS + BATOTP_MAX_CART][RS_WIN], wM[BATOTP_MAX_JOINTS + BATOTP_MAX_CART][RS_WIN], wS[RS_WIN];
+   const double *__restrict__ xp = x + pp.off * C, *__restrict__ mp = sol + pp.off * C;
+   int w0 = 0;
+   auto refill = [&](int first) {
+      w0 = max(0, min(first, n - RS_WIN));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int k = w0 + lane;
+      if (k < n)
+      {
+#pragma unroll 4
+         for (int ch = 0; ch < C; ++ch)
+         {
+            wX[ch][lane] = xp[(int64_t)ch * n + k];
+            wM[ch][lane] = mp[(int64_t)ch * n + k];
+         }
+         wS[lane] = s[k];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+   };
+   // index of point i in the window (i is the same in every lane: the refill is taken by the whole wavefront)
+   auto at = [&](int i) {
+      if (i < w0 || i >= w0 + RS_WIN) refill(i - RS_BACK);
+      return i - w0;
+   };
+   refill(0);
+
+   double prev = wX[c][0], xo = wX[c][1];
+   Coef4 kk = coeffs_from_sol(wM[c][0], wM[c][1], prev, xo);
    double cartpt = 0.0;
    if (owner) out[0] = prev;
    double sPrv = 0, prvDs = 0;
    int newPt = 1, oldPt = 1, seg = 0, xoAt = 1, kAt = 0;
-   double sA = s[0], sB = s[1]; // s[seg], s[seg+1]
+   double sA = wS[0], sB = wS[1]; // s[seg], s[seg+1]
    const int lastSeg = n - 2;
    bool done = false;
    while (!done)
    {
       if (xoAt != oldPt)
       {
-         xo = xc[oldPt];
+         xo = wX[c][at(oldPt)];
          xoAt = oldPt;
       }
       const double d = xo - prev;
       const double d2 = d * d;
-      double thSq = 0, caSq = 0;
-      for (int j = 0; j < nJ; ++j) thSq += readlane_f64(d2, j);
-      for (int j = 0; j < 3; ++j) caSq += readlane_f64(d2, nJ + j);
-      // the two square roots side by side: lanes 0..31 take the joint-space one, lanes 32..63 the Cartesian one
-      const double root = sqrt(lane < 32 ? thSq : caSq);
+      // both sums of squares in the reference's order (0 + d2[0] + d2[1] + ...), joint space in the lower half-wave, x, y, z in the
+      // upper one; then the two square roots side by side
+      const double t2 = inSum ? d2 : 0.0;
+      double sq = row_bcast_f64<0>(t2);
+      sq += row_bcast_f64<1>(t2);
+      sq += row_bcast_f64<2>(t2);
+      sq += row_bcast_f64<3>(t2);
+      sq += row_bcast_f64<4>(t2);
+      sq += row_bcast_f64<5>(t2);
+      sq += row_bcast_f64<6>(t2);
+      sq += row_bcast_f64<7>(t2);
+      const double root = sqrt(sq);
       const double ds = teach * (double)oldPt + thF * readlane_f64(root, 0) + caF * readlane_f64(root, 32);
       if (ds > sResNew)
       {
@@ -509,20 +609,22 @@ __global__ void __launch_bounds__(64) k_rs_special(RsParams P, RsPath *__restric
                if (sNew > sA)
                {
                   if (seg >= lastSeg) break;
-                  ++seg; sA = sB; sB = s[seg + 1];
+                  ++seg; sA = sB; sB = wS[at(seg + 1)];
                   moved = true;
                }
                else if (sNew < sA)
                {
                   if (seg <= 0) break;
-                  --seg; sB = sA; sA = s[seg];
+                  --seg; sB = sA; sA = wS[at(seg)];
                   moved = true;
                }
                if (!moved) break;
             }
             if (kAt != seg)
             {
-               kk = coeffs_from_sol(mc[seg], mc[seg + 1], xc[seg], xc[seg + 1]);
+               at(seg + 1);
+               const int k0 = at(seg), k1 = k0 + 1; // (whichever of the two refilled, RS_BACK / RS_WIN keep the neighbour inside)
+               kk = coeffs_from_sol(wM[c][k0], wM[c][k1], wX[c][k0], wX[c][k1]);
                kAt = seg;
             }
             const double tau = (sNew - sA) / (sB - sA);
@@ -543,7 +645,7 @@ __global__ void __launch_bounds__(64) k_rs_special(RsParams P, RsPath *__restric
       else
       {
          prvDs = ds;
-         sPrv = s[oldPt];
+         sPrv = wS[at(oldPt)];
          ++oldPt;
       }
    }
