@@ -24,6 +24,17 @@
 #include "resample.hip.h"
 #include "output.hip.h"
 
+// Lanes per workgroup of a lane-per-series Thomas solve outside the hot path (resampler, output stage).  Every lane walks its own
+// stream, so a load or store instruction costs its compute unit's address path one cycle per line it touches on top of a fixed ~20
+// (measured on the resampler's 10 240 series of 10^5 knots: 73 cycles per memory instruction of a 64-lane wavefront, 30 of an
+// 8-lane one), and the wavefronts of a compute unit queue for it (eight-lane wavefronts, five per compute unit: 2x SLOWER than full
+// ones).  So: one wavefront per compute unit, as narrow as that allows.
+static inline unsigned seriesBlock(int64_t series)
+{
+   const int64_t lanes = (series + 255) / 256;
+   return (unsigned)(lanes < 4 ? 4 : (lanes > 64 ? 64 : lanes));
+}
+
 using namespace bk;
 
 // ---------------------------------------------------------------------------------------------

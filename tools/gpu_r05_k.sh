@@ -2,7 +2,7 @@
 # LDS window of k_rs_special: resampler parity tests, the three resampler timings, per-kernel breakdown of the GEN7DOF call
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_resample.py tests/test_gpu_fuzz.py -k resampl -q -m gpu -p no:cacheprovider > gpurun_out/r05_k_resample_tests.log 2>&1
+python -m pytest tests/test_gpu_resample.py tests/test_gpu_fuzz.py tests/test_gpu_output.py -k "resampl or output" -q -m gpu -p no:cacheprovider > gpurun_out/r05_k_resample_tests.log 2>&1
 echo "resample tests rc=$?" >> gpurun_out/r05_k_resample_tests.log
 tail -4 gpurun_out/r05_k_resample_tests.log
 for w in ur6 gen7 cspr; do python tools/bench_resample.py --workload $w --paths 1024 --knots 100000 2>&1 | tail -1 | cut -c1-300; done | tee gpurun_out/r05_k_resample_timings.txt
