@@ -44,6 +44,31 @@ def test_ragged_batch_with_failing_and_duplicated_paths(hip_ctx, oracle_ctx):
     assert_bit_equal(h.knots(2), c.y, "duplicated taught points are dropped first")
 
 
+@pytest.mark.parametrize("name", ["synth_gen7dof_s0", "synth_cspr_s3"])
+def test_running_arc_lengths_with_a_row_per_chain(hip_ctx, oracle_ctx, name):
+    """k_rs_scan_rows adds the step lengths of two paths per wavefront, 16 points of a chain per block: taught paths whose
+    lengths sit around the block edges, a failing path as either partner of a wavefront, an odd number of paths"""
+    c = ResampleCase(name)
+    n = c.x.shape[1]
+    dead = np.repeat(c.x[:, :1], 16, axis=1)
+    lens = [4, 5, 16, 17, 18, 31, 32, 33, 34, 47, 48, 49, 50, 64, 65, 66, 129, n // 3, n]
+    assert n > max(lens[:-2])
+    xs = [dead] + [c.x[:, :k].copy() for k in lens] + [dead, c.x[:, n // 2:].copy(), c.x[:, ::-1].copy()]
+    xs.insert(3, dead)                       # ... and as the second path of a wavefront
+    if len(xs) % 2 == 0:
+        xs.append(c.x[:, 7:107].copy())
+    whole = [k for k, x in enumerate(xs) if x.shape[1] == n and np.array_equal(x, c.x)][0]
+    sr = [c.sres_in] * len(xs)
+    h = capi.Resampled(hip_ctx, c.params, xs, sr)
+    o = capi.Resampled(oracle_ctx, c.params, xs, sr)
+    assert int(h.status[0]) != 0 and int(h.status[3]) != 0 and int(h.status[-1]) == 0 and len(xs) % 2 == 1
+    assert np.array_equal(h.status, o.status) and np.array_equal(h.n_knots, o.n_knots) and h.sres.tobytes() == o.sres.tobytes()
+    for k in range(h.n_paths):
+        if not int(h.status[k]):            # (what the rows of a refused path hold is nobody's business)
+            assert_bit_equal(h.knots(k), o.knots(k), f"{name}: block edges of the row scan: path {k}")
+    assert_bit_equal(h.knots(whole), c.y, "the whole golden path inside the batch")
+
+
 @pytest.mark.parametrize("name", ["KUKA-LWR-IV", "RR"])
 def test_forward_kinematics_robots_ragged_batch(hip_ctx, oracle_ctx, name):
     """JOINT paths of the robots with forward kinematics: the tool point is recomputed before the first pass
