@@ -269,9 +269,9 @@ __global__ void __launch_bounds__(64) k_spline(const PathInfo *__restrict__ pinf
 }
 
 __global__ void __launch_bounds__(64) k_spline_sol(const PathInfo *__restrict__ pinfo, int B, int nch, int C, const double *__restrict__ src,
-                                                   double *__restrict__ sol)
+                                                   double *__restrict__ sol, const int *__restrict__ only)
 {
-   spline_channel<true, false>(pinfo, B, nch, 0, C, C, 1, src, (int64_t)C, sol, nullptr);
+   spline_channel<true, false>(pinfo, B, nch, 0, C, C, 1, src, (int64_t)C, sol, nullptr, only);
 }
 
 // compact splines of the hot path: km = [N][C][2] (value, second derivative) pairs per path, solved in place
@@ -284,13 +284,15 @@ __global__ void __launch_bounds__(64) k_spline_pairs(const PathInfo *__restrict_
 }
 
 // natural-spline second derivatives of arbitrary series: series k has n[k] values y[yOff[k] + i*ys] and leaves its
-// second derivatives at sol[solOff[k] + i]; one lane per series (output stage: s(t) of a path, channels to re-sample)
+// second derivatives at sol[solOff[k] + i]; one lane per series (output stage: s(t) of a path, channels to re-sample -- the
+// series the wavefront-per-series kernel of spline_lanes.hip.h leaves: short ones)
 __global__ void __launch_bounds__(64) k_spline_series(int count, const int64_t *__restrict__ yOff, const int64_t *__restrict__ solOff,
                                                       const int *__restrict__ n, const double *__restrict__ y, int ys,
-                                                      double *__restrict__ sol)
+                                                      double *__restrict__ sol, const int *__restrict__ only)
 {
    const int k = blockIdx.x * blockDim.x + threadIdx.x;
    if (k >= count || n[k] < 4) return;
+   if (only && !only[k]) return; // series that k_spline_series_lanes (spline_lanes.hip.h) has solved
    thomas_series<true, true>(n[k], y + yOff[k], ys, sol + solOff[k], 1, nullptr, 1, 0);
 }
 

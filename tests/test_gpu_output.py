@@ -176,3 +176,31 @@ def test_baseline_size_path_and_failed_paths(hip_ctx, oracle_ctx):
     out = capi.Output(b, output_params("synth_gen7dof_s0"), 0, 1)
     assert int(out.n_pts[0]) == 0 and out.theta(0).size == 0
     out.close(); b.close()
+
+
+def test_long_series_on_the_lanes_of_a_wavefront(hip_ctx, oracle_ctx):
+    """series of more than 16 386 values take spline_lanes.hip.h (64 chunks per series, warm-ups compared bit for bit), shorter
+    ones the lane-per-series kernel: a 1e5-knot path, a prefix of it just above and one just below the limit and a short path in
+    one batch, through the branches that build series (s(t) always; every channel with re-interpolation)"""
+    case = Case("synth_ur_s7_100k")
+    ys = [case.y, np.ascontiguousarray(case.y[:, :68000]), np.ascontiguousarray(case.y[:, :66000]), np.ascontiguousarray(case.y[:, :600]), case.y]
+    outs = []
+    for ctx in (hip_ctx, oracle_ctx):
+        b = capi.Batch(ctx, case.problem, [y.shape[1] for y in ys], case.max_steps())
+        for k, y in enumerate(ys):
+            b.upload_knots(k, [y], [case.sres])
+        b.optimize()
+        outs.append(b)
+    hb, ob = outs
+    res = hb.results()
+    fwd = [int(r["n_fwd"]) for r in res]
+    assert fwd[0] > fwd[1] > 16386 > fwd[2] > 15000 > fwd[3], fwd
+    base = capi.OutputParams(case.problem.n_joints, capi.PATH_JOINT, case.problem.integ_res, 0.008, 5.0)
+    for prm in [base] + _variants(base)[2:6]:
+        h, o = capi.Output(hb, prm, 0, len(ys)), capi.Output(ob, prm, 0, len(ys))
+        what = f"out_res={prm.out_res} smooth={prm.out_smooth_fact}"
+        assert np.array_equal(h.n_pts, o.n_pts), what
+        for k in range(len(ys)):
+            assert_bit_equal(h.theta(k), o.theta(k), f"{what}: path {k}")
+        h.close(); o.close()
+    hb.close(); ob.close()
