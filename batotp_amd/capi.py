@@ -193,6 +193,7 @@ class Library:
             "batotp_hip_ctx_trim": [P],
             "batotp_hip_fp64_kat": [P, I64, D, D, D, D, D],
             "batotp_hip_div6_kat": [P, I64, D, D],
+            "batotp_hip_spline_lanes_kat": [P, I64, D, D, D, C.POINTER(I32)],
             "batotp_hip_sdiv_kat": [P, I64, D, D, D, C.POINTER(I32)],
             "batotp_hip_batch_create": [P, C.POINTER(Problem), I32, C.POINTER(C.c_int64), I64, C.POINTER(P)],
             "batotp_hip_batch_destroy": [P],
@@ -478,6 +479,17 @@ def sdiv_kat(ctx: "Context", a: np.ndarray, b: np.ndarray):
     ctx.library.check(ctx.library.lib.batotp_hip_sdiv_kat(ctx.handle, a.size, _dptr(a), _dptr(b), _dptr(q),
                                                           w.ctypes.data_as(C.POINTER(C.c_int32))), "sdiv_kat")
     return q, w.astype(bool)
+
+
+def spline_lanes_kat(ctx: "Context", y: np.ndarray):
+    """second derivatives of one series by the wavefront-per-series solve (+ its fallback) and by the lane-per-series kernel;
+    returns (sol, sol_seq, redone)"""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    sol, seq = np.empty_like(y), np.empty_like(y)
+    redone = C.c_int32(0)
+    ctx.library.check(ctx.library.lib.batotp_hip_spline_lanes_kat(ctx.handle, y.size, _dptr(y), _dptr(sol), _dptr(seq), C.byref(redone)),
+                      "spline_lanes_kat")
+    return sol, seq, int(redone.value)
 
 
 def div6_kat(ctx: "Context", a: np.ndarray) -> np.ndarray:

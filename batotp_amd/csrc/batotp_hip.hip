@@ -505,6 +505,39 @@ extern "C" int batotp_hip_div6_kat(batotp_ctx *ctx, int64_t n, const double *a, 
    return BATOTP_OK;
 }
 
+extern "C" int batotp_hip_spline_lanes_kat(batotp_ctx *ctx, int64_t n, const double *y, double *sol, double *sol_seq, int32_t *redone)
+{
+   if (!ctx || n < 4 || n > (int64_t)1 << 30 || !y || !sol || !sol_seq || !redone) return BATOTP_ERR_ARG;
+   int rc = bind(ctx);
+   if (rc) return rc;
+   double *d = nullptr;
+   const size_t sz = sizeof(double) * (size_t)n;
+   HIP_TRY(hipMalloc((void **)&d, 3 * sz + 64));
+   double *dy = d, *dA = d + n, *dB = d + 2 * n;
+   int64_t *dOff = reinterpret_cast<int64_t *>(d + 3 * n); // one 0: both offsets
+   int *dCnt = reinterpret_cast<int *>(dOff + 1), *dFlag = dCnt + 1;
+   const int64_t zero = 0;
+   const int cnt = (int)n;
+   hipStream_t st = ctx->stream;
+   hipMemcpyAsync(dy, y, sz, hipMemcpyHostToDevice, st);
+   hipMemcpyAsync(dOff, &zero, sizeof(zero), hipMemcpyHostToDevice, st);
+   hipMemcpyAsync(dCnt, &cnt, sizeof(cnt), hipMemcpyHostToDevice, st);
+   hipMemsetAsync(dA, 0xff, sz, st); // what the kernels do not write shows up as NaN
+   hipMemsetAsync(dB, 0xff, sz, st);
+   hipLaunchKernelGGL(k_spline_series_lanes, dim3(1), dim3(64), 0, st, 1, dOff, dOff, dCnt, dy, 1, dA, dFlag);
+   hipLaunchKernelGGL(k_spline_series, dim3(1), dim3(seriesBlock(1)), 0, st, 1, dOff, dOff, dCnt, dy, 1, dA, dFlag);
+   hipLaunchKernelGGL(k_spline_series, dim3(1), dim3(seriesBlock(1)), 0, st, 1, dOff, dOff, dCnt, dy, 1, dB, (const int *)nullptr);
+   hipMemcpyAsync(sol, dA, sz, hipMemcpyDeviceToHost, st);
+   hipMemcpyAsync(sol_seq, dB, sz, hipMemcpyDeviceToHost, st);
+   int flag = 0;
+   hipMemcpyAsync(&flag, dFlag, sizeof(int), hipMemcpyDeviceToHost, st);
+   hipError_t e = hipStreamSynchronize(st);
+   hipFree(d);
+   if (e != hipSuccess) return hipFail(e, "spline_lanes_kat");
+   *redone = flag;
+   return BATOTP_OK;
+}
+
 extern "C" int batotp_hip_sdiv_kat(batotp_ctx *ctx, int64_t n, const double *a, const double *b, double *q, int32_t *in_window)
 {
    if (!ctx || n <= 0 || !a || !b || !q || !in_window) return BATOTP_ERR_ARG;

@@ -183,6 +183,12 @@ int  batotp_hip_fp64_kat(batotp_ctx *ctx, int64_t n, const double *a, const doub
 /* q[i] = a[i] / 6.0 computed the way the compact spline form (BATOTP_F_COMPACT_SPLINES) divides:
  * through the reciprocal with one exact residual correction; must equal the IEEE quotient */
 int  batotp_hip_div6_kat(batotp_ctx *ctx, int64_t n, const double *a, double *q);
+/* known-answer test of the natural-spline solves outside the hot path (reference batotp/spline.cpp:252-276; resampler and output
+ * stage): second derivatives of ONE series of n values (n >= 4), (a) sol: by the wavefront-per-series kernel of
+ * batotp_amd/csrc/spline_lanes.hip.h -- the series in 64 chunks whose warm-ups are compared bit for bit -- followed by the
+ * lane-per-series kernel if it flagged the series (too short, or a comparison failed), exactly as the two stages run them, and
+ * (b) sol_seq: by the lane-per-series kernel alone.  *redone = 1: the series took the sequential kernel in (a). */
+int  batotp_hip_spline_lanes_kat(batotp_ctx *ctx, int64_t n, const double *y, double *sol, double *sol_seq, int32_t *redone);
 /* known-answer test of the division through a shared refined reciprocal (batotp_amd/csrc/sweep8.hip.h: the last three
  * operations of hipcc's own fp64 division sequence, valid for operands in [2^-350, 2^350]; the sweep kernel k_sweep8 uses it
  * for the quotients by theta' of reference batotp/ba.cpp:1223 and :1526-1531): q[i] = the kernel's a[i] / b[i] -- through the

@@ -62,6 +62,14 @@ int batotp_hip_sdiv_kat(batotp_ctx *ctx, int64_t n, const double *a, const doubl
     for (int64_t i = 0; i < n; ++i) { q[i] = a[i] / b[i]; in_window[i] = 0; }
     return BATOTP_OK;
 }
+int batotp_hip_spline_lanes_kat(batotp_ctx *ctx, int64_t n, const double *y, double *sol, double *sol_seq, int32_t *redone)
+{
+    if (!ctx || n < 4 || !y || !sol || !sol_seq || !redone) return BATOTP_ERR_ARG;
+    bo_spline_sol(y, n, sol);
+    memcpy(sol_seq, sol, sizeof(double) * (size_t)n);
+    *redone = 0;
+    return BATOTP_OK;
+}
 int batotp_hip_div6_kat(batotp_ctx *ctx, int64_t n, const double *a, double *q)
 {
     int64_t i;

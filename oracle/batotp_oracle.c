@@ -119,6 +119,15 @@ void bo_spline_coeffs(const double *y, int64_t n, double *c, int clamped)
     free(sol);
 }
 
+/* the second derivatives Spline::getSplineCoeffs forms its rows from (spline.cpp:168-200, "natural"): sol[0 .. n-1] */
+void bo_spline_sol(const double *y, int64_t n, double *sol)
+{
+    int64_t i;
+    for (i = 0; i < n; i++) sol[i] = 0.0;
+    for (i = 1; i < n - 1; i++) sol[i] = 6 * (y[i - 1] - 2 * y[i] + y[i + 1]);
+    tridiag_natural(sol, n);
+}
+
 /* Spline::findInterpSegs, spline.cpp:56-99 */
 int bo_find_interp_segs(const double *a_in, int64_t n_in, const double *a_out, int64_t n_out,
                         int32_t *seg, double *tau)

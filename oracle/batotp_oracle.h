@@ -51,6 +51,8 @@ void     bo_path_free(bo_path *p);
 /* Spline::getSplineCoeffs, "natural" and "clamped" (spline.cpp:168-211,225-243,252-276).
  * c points to [4][n]. */
 void bo_spline_coeffs(const double *y, int64_t n, double *c, int clamped);
+/* the second derivatives those rows are formed from (natural spline): sol[0 .. n-1] */
+void bo_spline_sol(const double *y, int64_t n, double *sol);
 /* Spline::findInterpSegs (spline.cpp:56-99); returns -1 on the division-by-zero error */
 int  bo_find_interp_segs(const double *a_in, int64_t n_in, const double *a_out, int64_t n_out,
                          int32_t *seg, double *tau);

@@ -397,6 +397,59 @@ def test_spline_build_in_tiles_equals_the_sequential_kernel(hip_lib, oracle_ctx,
         assert_bit_equal(a2[0], c[0], f"pairs: piecewise-linear path: single-pass kernel (with {fb2} series through the fallback) against the sequential kernel")
 
 
+def _series(kind, n, seed):
+    rng = np.random.default_rng(seed)
+    t = np.linspace(0.0, 1.0, n)
+    if kind == "smooth":
+        return np.sin(7.0 * t + seed) + 0.3 * np.cos(31.0 * t) + 2.0 * t
+    if kind == "rough":
+        return np.cumsum(rng.normal(0.0, 1e-3, n)) + rng.normal(0.0, 1e-6, n)
+    if kind == "kinks":
+        return np.interp(t, np.linspace(0, 1, 9), rng.integers(-4, 5, 9).astype(float))
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["smooth", "rough", "kinks"])
+def test_spline_series_on_the_lanes_of_a_wavefront(hip_ctx, oracle_ctx, kind):
+    """spline_lanes.hip.h (output stage, resampler): a series in 64 chunks with bit-checked warm-ups must be the sequential Thomas
+    solve exactly -- lengths at the limit of the kernel, with every remainder of the chunking, and long ones; against the
+    lane-per-series kernel AND the oracle's solve"""
+    for n in (4, 5, 63, 1000, 16385, 16386, 16387, 16386 + 63, 16386 + 64, 16386 + 65, 20011, 65536, 100003, 250000):
+        y = _series(kind, n, n % 7)
+        sol, seq, redone = capi.spline_lanes_kat(hip_ctx, y)
+        ref, _, _ = capi.spline_lanes_kat(oracle_ctx, y)
+        assert_bit_equal(seq, ref, f"{kind}, n = {n}: lane-per-series kernel against the oracle")
+        assert_bit_equal(sol, ref, f"{kind}, n = {n}: wavefront-per-series solve (redone = {redone}) against the oracle")
+        if n < 16386:
+            assert redone == 1, (n, "shorter than the kernel takes: the sequential kernel must have run")
+        elif kind == "smooth":
+            assert redone == 0, (n, "a smooth series fell back to the sequential kernel")
+
+
+def test_spline_series_whose_warm_ups_disagree_take_the_fallback(hip_ctx, oracle_ctx):
+    """the chain 'a boundary comparison fails -> the series is flagged -> the lane-per-series kernel solves it again' must run and
+    leave the sequential result.  A warm-up starts from the guess 0 and forgets that guess's error at 0.268 per knot (2.6e-37 after
+    its 64 knots), so it arrives wrong only where the true value at its START is ~1e20 times what it is at the chunk: a spike two or
+    three knots before the start of a forward warm-up (67 knots left of a chunk boundary) or behind the start of a backward one
+    (66 knots right of it); boundaries of the first, a middle and the last chunk"""
+    n = 40000
+    lc = (n - 2) // 64
+    for where in [1 + l * lc + off for l in (1, 3, 31, 63) for off in (-67, 66)]:
+        for amp in (1e30, -1e25):
+            y = _series("smooth", n, 3)
+            y[where] = amp
+            sol, seq, redone = capi.spline_lanes_kat(hip_ctx, y)
+            ref, _, _ = capi.spline_lanes_kat(oracle_ctx, y)
+            assert redone == 1, (where, amp, "a spike the warm-ups cannot have forgotten went unnoticed")
+            assert_bit_equal(seq, ref, f"spike at {where}: lane-per-series kernel against the oracle")
+            assert_bit_equal(sol, ref, f"spike at {where}: after the fallback against the oracle")
+    # non-finite values: flagged as well, and the fallback leaves what the sequential kernel leaves (NaN payloads are the device's)
+    y = _series("smooth", n, 4)
+    y[5 * lc + 3] = np.inf
+    sol, seq, redone = capi.spline_lanes_kat(hip_ctx, y)
+    assert redone == 1 and sol.tobytes() == seq.tobytes()
+
+
 def test_flat_sweep_loop_is_gated_by_toolchain_and_canary(hip_lib, oracle_ctx, monkeypatch):
     """the AUTOMATIC loop choice takes the flat reverse loop only if the library was built by the toolchain the loop was
     validated with and the on-device canary (nested against flat loop on ordinary, crawling and always-failing paths) found
