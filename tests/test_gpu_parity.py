@@ -395,6 +395,20 @@ def test_spline_build_in_tiles_equals_the_sequential_kernel(hip_lib, oracle_ctx,
     if layout == "pairs":
         a2, fb2 = run([kinky], 2)
         assert_bit_equal(a2[0], c[0], f"pairs: piecewise-linear path: single-pass kernel (with {fb2} series through the fallback) against the sequential kernel")
+    # a series that MUST take the fallback: a spike no warm-up can forget (0.268 per knot: 1e30 is still 1e-7 after 64 knots, far
+    # above half an ulp of the values around it) -- the chain 'comparison fails -> series marked -> sequential kernel with the mask'
+    # runs, over second-derivative slots the parallel kernel has already written, and leaves the sequential result
+    spiky = smooth(5000).copy()
+    ch = prob.n_joints if layout == "cable" else 1
+    spiky[ch, 2500] = 1e30
+    a, fb = run([spiky], True)
+    c, _ = run([spiky], False)
+    assert fb > 0, "the tiled kernel did not notice a spike its warm-ups cannot have forgotten"
+    assert_bit_equal(a[0], c[0], f"{layout}: spike: tiles + fallback against the sequential kernel")
+    if layout == "pairs":
+        a2, fb2 = run([spiky], 2)
+        assert fb2 > 0, "the single-pass kernel did not notice a spike its warm-ups cannot have forgotten"
+        assert_bit_equal(a2[0], c[0], "pairs: spike: single-pass kernel + fallback against the sequential kernel")
 
 
 def _series(kind, n, seed):
