@@ -157,3 +157,21 @@ def test_checker_mirrors_the_state_rules_of_pointwise_values_in_the_curve_slots(
         else:
             assert int(r["n_fwd"]) == 0 and (int(r["status_fwd"]) & capi.ST_CAPACITY) and int(r["steps_fwd"]) + 1 < n_fwd + extra
         b.close()
+
+
+def test_second_derivatives_of_the_spline_kat_are_those_of_the_pinned_rows(oracle_ctx):
+    """the checker side of batotp_hip_spline_lanes_kat (oracle: bo_spline_sol) against the coefficient rows the golden cases pin:
+    c2 of a row is sol / 2 exactly, c3 the difference of two neighbours over 6"""
+    from batotp_amd import capi
+    case = Case("synth_gen7dof_s0")
+    b = capi.Batch(oracle_ctx, case.problem, [case.n], 64)
+    b.upload_knots(0, [case.y], [case.sres])
+    b.precompute(1)
+    for ch in range(case.problem.n_joints):
+        rows = b.coeffs(0, ch)
+        sol, seq, redone = capi.spline_lanes_kat(oracle_ctx, np.ascontiguousarray(case.y[ch]))
+        assert redone == 0 and sol.tobytes() == seq.tobytes()
+        assert sol[0] == 0.0
+        assert (sol[:-1] / 2.0).tobytes() == rows[2][:-1].tobytes()
+        assert ((sol[1:] - sol[:-1]) / 6.0).tobytes() == rows[3][:-1].tobytes()
+    b.close()
