@@ -4,7 +4,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/prof_r05h
+O=gpurun_out/prof_r05o
 mkdir -p $O
 CMD="python3 bench.py --no-sides --no-as-worded --no-cpu-baseline --steps 2 --warmup 1"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fill7_stats -- $CMD > $O/fill7_stats.log 2>&1
