@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--knots", type=int, default=100000)
     ap.add_argument("--distinct", type=int, default=16)
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--budget-gb", type=float, default=0.0, help="scratch bytes per chunk of paths (batotp_hip_set_workspace_budget); 0 = the library's rule")
     args = ap.parse_args()
 
     pmat = None
@@ -76,6 +77,8 @@ def main():
     pts = int(sum(x.shape[1] for x in xs))
 
     hip = capi.Context(capi.load_hip(), 0)
+    if args.budget_gb > 0:
+        hip.set_workspace_budget(resample_bytes=int(args.budget_gb * (1 << 30)))
     best, knots, bad = None, 0, 0
     for rep in range(args.reps):
         t0 = time.perf_counter()
