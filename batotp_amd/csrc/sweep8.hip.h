@@ -554,10 +554,8 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                               {
                                  const bool hit = (DIR == 1) ? (preIdx == seg + 1) : (preIdx == seg);
                                  const double2 dl = km[at], dr = km[at + nIn];
-                                 // (component by component: a select between two double2 OBJECTS is compiled through scratch memory,
-                                 // with two scratch stores on the common path in front of it)
-                                 kl.x = hit ? kl.x : dl.x; kl.y = hit ? kl.y : dl.y;
-                                 kr.x = hit ? kr.x : dr.x; kr.y = hit ? kr.y : dr.y;
+                                 kl = hit ? kl : dl;
+                                 kr = hit ? kr : dr;
                               }
                               solL = kl.y; solR = kr.y; yL = kl.x; yR = kr.x;
                               c3 = div6(solR - solL);
