@@ -229,6 +229,7 @@ class Library:
             "batotp_hip_set_sweep_prefetch": [P, I32, I32],
             "batotp_hip_set_spline_tiles": [P, I32],
             "batotp_hip_set_fast_forward": [P, I32],
+            "batotp_hip_set_cert_hold": [P, I32],
             "batotp_hip_set_k3_form": [P, I32],
             "batotp_hip_set_path_order": [P, I32],
             "batotp_hip_set_workspace_budget": [P, C.c_int64, C.c_int64],
@@ -247,6 +248,7 @@ class Library:
             "batotp_hip_resampled_ms": [P, C.POINTER(C.c_float)],
             "batotp_hip_output": [P, C.POINTER(OutputParams), I32, I32, C.POINTER(P)],
             "batotp_hip_output_destroy": [P],
+            "batotp_hip_out_segmax_kat": [P, I32, C.POINTER(I32), C.POINTER(I32)],
             "batotp_hip_output_info": [P, C.POINTER(C.c_int64), D],
             "batotp_hip_output_channels": [P, C.POINTER(I32), C.POINTER(I32), C.POINTER(I32)],
             "batotp_hip_output_download": [P, I32, D],
@@ -316,6 +318,10 @@ class Context:
 
     def set_sweep_prefetch(self, reverse: int, forward: int):
         self.library.check(self.library.lib.batotp_hip_set_sweep_prefetch(self.handle, reverse, forward), "set_sweep_prefetch")
+
+    def set_cert_hold(self, hold: int):
+        """k_sweep8, reverse sweep: hold of the certificate phase (-1 automatic, 0 off, 1..8); include/batotp_hip.h"""
+        self.library.check(self.library.lib.batotp_hip_set_cert_hold(self.handle, int(hold)), "set_cert_hold")
 
     def set_fast_forward(self, on):
         """certified fast-forward of the bisection (include/batotp_hip.h); never changes a result"""
@@ -479,6 +485,15 @@ def sdiv_kat(ctx: "Context", a: np.ndarray, b: np.ndarray):
     ctx.library.check(ctx.library.lib.batotp_hip_sdiv_kat(ctx.handle, a.size, _dptr(a), _dptr(b), _dptr(q),
                                                           w.ctypes.data_as(C.POINTER(C.c_int32))), "sdiv_kat")
     return q, w.astype(bool)
+
+
+def out_segmax_kat(ctx: "Context", segs):
+    """running maxima of the raw segment indices of several paths (findInterpSegs' cursor), through the output stage's launch function"""
+    n1 = np.ascontiguousarray([len(x) for x in segs], dtype=np.int32)
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.int32) for x in segs]), dtype=np.int32)
+    ctx.library.check(ctx.library.lib.batotp_hip_out_segmax_kat(ctx.handle, len(segs), n1.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                                flat.ctypes.data_as(C.POINTER(C.c_int32))), "out_segmax_kat")
+    return np.split(flat, np.cumsum(n1)[:-1])
 
 
 def spline_lanes_kat(ctx: "Context", y: np.ndarray):

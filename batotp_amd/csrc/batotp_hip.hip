@@ -44,6 +44,12 @@ static inline bool seriesLanesPay(int64_t series) { return series <= 4096; }
 
 using namespace bk;
 
+// k_sweep8, reverse sweep: the certificate block runs once this many eighths of a wavefront's live paths wait for it (measured on the
+// headline batch, profiles/r06_a_*; batotp_hip_set_cert_hold overrides)
+#ifndef BATOTP_CERT_HOLD_DEFAULT
+#define BATOTP_CERT_HOLD_DEFAULT 3
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // error bookkeeping
 // ---------------------------------------------------------------------------------------------
@@ -115,6 +121,7 @@ struct batotp_ctx
    int splineTiles = -1;  // K1 in tiles of knots (spline_tile.hip.h): -1 automatic (small batches), 1 always, 0 never
    int flatForm = 1;      // flat loop of the 8-lane layout: 1 = k_sweep8 (sweep8.hip.h), 0 = k_sweep's own flat instantiation (A/B, parity)
    int fastForward = 1;   // certified fast-forward of the bisection in the sweep kernels that have it (bisect_fast_forward)
+   int certHold = -1;     // k_sweep8, reverse sweep: hold of the certificate phase (-1 automatic, 0 = no certificate there, 1..8)
    int64_t rsBudget = 0, outBudget = 0; // scratch bytes a chunk of the resampler / output stage may take; 0 = from the free memory
    int pathOrder = 1;     // ragged batches: 1 = the sweeps take the paths longest first (SweepArgs::order), 0 = in the order given
    int k3Form = 1;        // per-knot evaluation of velocity / acceleration-only problems: 1 = k_pointwise_va (pointwise_va.hip.h), 0 = the general kernel
@@ -406,9 +413,19 @@ extern "C" int batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on)
 extern "C" int batotp_hip_set_fast_forward(batotp_ctx *ctx, int32_t on)
 {
    if (!ctx) return BATOTP_ERR_ARG;
-   ctx->fastForward = on < 0 ? 0 : (on > 3 ? 3 : on);   // (k_sweep8: bit 0 forward sweep, bit 1 reverse sweep; the other kernels: non-zero)
+   ctx->fastForward = on != 0 ? 1 : 0;
    return BATOTP_OK;
 }
+
+extern "C" int batotp_hip_set_cert_hold(batotp_ctx *ctx, int32_t hold)
+{
+   if (!ctx || hold < -1 || hold > 8) return BATOTP_ERR_ARG;
+   ctx->certHold = hold;
+   return BATOTP_OK;
+}
+// the reverse sweep of k_sweep8 gathers the paths whose first check failed and certifies them in batches (sweep8.hip.h): automatic hold
+static int certHoldOf(const batotp_ctx *ctx) { return ctx->certHold < 0 ? BATOTP_CERT_HOLD_DEFAULT : ctx->certHold; }
+static int sweep8FastForward(const batotp_ctx *ctx) { return ctx->fastForward ? (1 | (certHoldOf(ctx) > 0 ? 2 : 0)) : 0; }
 
 #ifdef S8_PROFILE
 // diagnostic build only: the counters k_sweep8 left (16 doubles per wavefront, n_waves <= B)
@@ -519,21 +536,25 @@ extern "C" int batotp_hip_spline_lanes_kat(batotp_ctx *ctx, int64_t n, const dou
    const int64_t zero = 0;
    const int cnt = (int)n;
    hipStream_t st = ctx->stream;
-   hipMemcpyAsync(dy, y, sz, hipMemcpyHostToDevice, st);
-   hipMemcpyAsync(dOff, &zero, sizeof(zero), hipMemcpyHostToDevice, st);
-   hipMemcpyAsync(dCnt, &cnt, sizeof(cnt), hipMemcpyHostToDevice, st);
-   hipMemsetAsync(dA, 0xff, sz, st); // what the kernels do not write shows up as NaN
-   hipMemsetAsync(dB, 0xff, sz, st);
+   // every call and launch is checked where it is made; the device block is released on every way out
+   struct Guard { double *p; ~Guard() { if (p) (void)hipFree(p); } } guard{d};
+   HIP_TRY(hipMemcpyAsync(dy, y, sz, hipMemcpyHostToDevice, st));
+   HIP_TRY(hipMemcpyAsync(dOff, &zero, sizeof(zero), hipMemcpyHostToDevice, st));
+   HIP_TRY(hipMemcpyAsync(dCnt, &cnt, sizeof(cnt), hipMemcpyHostToDevice, st));
+   HIP_TRY(hipMemsetAsync(dA, 0xff, sz, st)); // what the kernels do not write shows up as NaN
+   HIP_TRY(hipMemsetAsync(dB, 0xff, sz, st));
+   HIP_TRY(hipMemsetAsync(dFlag, 0, sizeof(int), st));
    hipLaunchKernelGGL(k_spline_series_lanes, dim3(1), dim3(64), 0, st, 1, dOff, dOff, dCnt, dy, 1, dA, dFlag);
+   HIP_TRY(hipGetLastError());
    hipLaunchKernelGGL(k_spline_series, dim3(1), dim3(seriesBlock(1)), 0, st, 1, dOff, dOff, dCnt, dy, 1, dA, dFlag);
+   HIP_TRY(hipGetLastError());
    hipLaunchKernelGGL(k_spline_series, dim3(1), dim3(seriesBlock(1)), 0, st, 1, dOff, dOff, dCnt, dy, 1, dB, (const int *)nullptr);
-   hipMemcpyAsync(sol, dA, sz, hipMemcpyDeviceToHost, st);
-   hipMemcpyAsync(sol_seq, dB, sz, hipMemcpyDeviceToHost, st);
+   HIP_TRY(hipGetLastError());
+   HIP_TRY(hipMemcpyAsync(sol, dA, sz, hipMemcpyDeviceToHost, st));
+   HIP_TRY(hipMemcpyAsync(sol_seq, dB, sz, hipMemcpyDeviceToHost, st));
    int flag = 0;
-   hipMemcpyAsync(&flag, dFlag, sizeof(int), hipMemcpyDeviceToHost, st);
-   hipError_t e = hipStreamSynchronize(st);
-   hipFree(d);
-   if (e != hipSuccess) return hipFail(e, "spline_lanes_kat");
+   HIP_TRY(hipMemcpyAsync(&flag, dFlag, sizeof(int), hipMemcpyDeviceToHost, st));
+   HIP_TRY(hipStreamSynchronize(st));
    *redone = flag;
    return BATOTP_OK;
 }
@@ -1317,10 +1338,10 @@ static int flatCanaryOnce(batotp_ctx *ctx, bool compact, bool *same)
    std::vector<batotp_path_result> rows[2];
    std::vector<double2> curves[2], curvesF[2];
    const int holdSaved[2] = {ctx->sweepHold[0], ctx->sweepHold[1]}, groupSaved = ctx->sweepGroup, ppwSaved = ctx->pathsPerWave;
-   const int formSaved = ctx->flatForm, ffSaved = ctx->fastForward;
+   const int formSaved = ctx->flatForm, ffSaved = ctx->fastForward, certSaved = ctx->certHold;
    // the canary compares exactly what the automatic choice launches: 8 lanes per path, k_sweep8, the certified fast-forward on --
    // whatever the developer switches of this context say at the moment
-   ctx->sweepGroup = 8; ctx->pathsPerWave = 8; ctx->flatForm = 1; ctx->fastForward = 1;
+   ctx->sweepGroup = 8; ctx->pathsPerWave = 8; ctx->flatForm = 1; ctx->fastForward = 1; ctx->certHold = -1;
    rc = batotp_hip_upload_knots(b, 0, B, y.data(), sres.data());
    if (!rc) rc = batotp_hip_precompute(b, 0);
    for (int form = 0; form < 2 && !rc; ++form)
@@ -1337,7 +1358,7 @@ static int flatCanaryOnce(batotp_ctx *ctx, bool compact, bool *same)
       if (!rc && hipMemcpy(curvesF[form].data(), b->dFwd, sizeof(double2) * curvesF[form].size(), hipMemcpyDeviceToHost) != hipSuccess) rc = BATOTP_ERR_HIP;
    }
    ctx->sweepHold[0] = holdSaved[0]; ctx->sweepHold[1] = holdSaved[1]; ctx->sweepGroup = groupSaved; ctx->pathsPerWave = ppwSaved;
-   ctx->flatForm = formSaved; ctx->fastForward = ffSaved;
+   ctx->flatForm = formSaved; ctx->fastForward = ffSaved; ctx->certHold = certSaved;
    batotp_hip_batch_destroy(b);
    if (rc) return rc;
    bool eq = memcmp(rows[0].data(), rows[1].data(), sizeof(batotp_path_result) * (size_t)B) == 0;
@@ -1418,7 +1439,8 @@ static void launchSweep(batotp_batch *b, SweepArgs &a)
    // the forward sweep only while every path has a wavefront to itself -- there the sweep waits a third of its time for the
    // dependent loads of segment changes (SQ_WAIT_ANY at B = 1, profiles/), with many paths per wavefront it cost +5 %
    a.touch = (a.dir == -1) ? 1 : (ppw == 1 ? 3 : 0);
-   a.ff = b->ctx->fastForward;
+   a.ff = sweep8FastForward(b->ctx);   // (the general kernel k_sweep reads no bit of it)
+   a.holdc = std::max(1, certHoldOf(b->ctx));
    if (b->ctx->sweepTouch[a.dir == -1 ? 0 : 1] >= 0) a.touch = b->ctx->sweepTouch[a.dir == -1 ? 0 : 1];
    const unsigned waves = (unsigned)((b->B + ppw - 1) / ppw);
    const unsigned grid = (waves + (K4_BLOCK / 64) - 1) / (K4_BLOCK / 64);
@@ -1489,7 +1511,7 @@ static bool sweep1Applies(const batotp_batch *b)
 
 static void launchSweep1(batotp_batch *b, SweepArgs &a)
 {
-   a.ppw = 1; a.hold = -1; a.touch = 0; a.ff = b->ctx->fastForward;
+   a.ppw = 1; a.hold = -1; a.touch = 0; a.ff = b->ctx->fastForward; a.holdc = 0;
    hipStream_t st = b->ctx->stream;
    const bool cableLines = featureLevel(b) == 2 && (b->P.flags & BATOTP_F_PARALLEL) != 0 && b->pairsAll;
    // Two paths per wavefront (k_sweep1's NP = 2; the cable robot in serial form with every channel as pairs): where one path per

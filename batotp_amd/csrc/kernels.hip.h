@@ -1850,7 +1850,8 @@ struct SweepArgs
    int ppw;       // paths per wavefront, 1 .. 64/G
    int hold;      // FLAT kernels: a stage is started once hold/8 of the wavefront's live paths wait for one
    int touch;     // software prefetch: bit 0 = spline rows ahead of the cursor, bit 1 = reverse curve ahead of its cursor (forward sweep)
-   int ff;        // k_sweep1: certified fast-forward of the bisection (sweep1.hip.h), batotp_hip_set_fast_forward
+   int ff;        // k_sweep1: certified fast-forward of the bisection (sweep1.hip.h), batotp_hip_set_fast_forward; k_sweep8: bit 0 forward, bit 1 reverse sweep
+   int holdc;     // k_sweep8, reverse sweep: the certificate block serves the paths waiting for it once holdc/8 of the wavefront's live paths do
    // Ragged batches: launch slot k of the sweep processes path order[k] -- the paths sorted by knot count, longest
    // first.  The hardware hands workgroups to the SIMDs in launch order as slots free up, so this is longest-processing-time-first
    // scheduling for the kernels with a wavefront per path, and it puts paths of similar length into the same wavefront of the

@@ -498,6 +498,8 @@ __global__ void k_rs_sites(RsParams P, RsPath *__restrict__ paths, int B, const 
 // reference's order of operations.
 // ---------------------------------------------------------------------------------------------
 constexpr int RS_WIN = 64; // taught points per LDS window (one per lane in a refill)
+// k_rs_special's lane layout: a 16-lane row holds the joints in its lanes 0..7 and the Cartesian channels in 8..15 (x, y, z first)
+static_assert(BATOTP_MAX_JOINTS <= 8 && BATOTP_MAX_CART <= 8, "k_rs_special carries at most 8 joints and 8 Cartesian channels per 16-lane row");
 constexpr int RS_BACK = 4; // points kept behind the one that caused a refill
 
 __global__ void __launch_bounds__(64) k_rs_special(RsParams P, RsPath *__restrict__ paths, int B, const double *__restrict__ x,

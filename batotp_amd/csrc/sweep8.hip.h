@@ -61,7 +61,10 @@ constexpr int S8_BLOCK = 256;
                      // a wavefront-uniform guard where an operand leaves the window (a numerator of exactly 0: the cursor on a knot)
 #endif
 #ifndef S8_FF
-#define S8_FF 1      // the certified fast-forward of the bisection (see the block in the loop), forward sweep by default
+#define S8_FF 1      // the certified fast-forward of the bisection (s8_certify), both directions (batotp_hip_set_fast_forward: bit 0 forward, bit 1 reverse)
+#endif
+#ifndef S8_CERT_PHASE
+#define S8_CERT_PHASE 1 // reverse sweep: the certificate as a phase of its own, served in batches (0: in the check block, per arriving path)
 #endif
 
 // (num / den) < thr as ratio_lt (kernels.hip.h) decides it, in two parts: the product form, and whether it was decisive
@@ -105,6 +108,137 @@ __global__ void k_kat_sdiv(int64_t n, const double *__restrict__ a, const double
    const bool ok = s8_div_window(a[i]) & s8_div_window(b[i]);
    inWindow[i] = ok ? 1 : 0;
    q[i] = ok ? s8_div_by(a[i], b[i], s8_rcp_refined(b[i])) : a[i] / b[i];
+}
+
+// ---- CERTIFIED FAST-FORWARD of the bisection on the 8 lanes of a path (the certificate of k_sweep1, sweep1.hip.h: its derivation
+// and error analysis are there) ---------------------------------------------------------------------------------------------
+// Called for paths whose first check of the stage was violated, after the loop's first update (ba.cpp:1281-1285: nIter = 1,
+// sdotH = the first candidate, sdotTry = the second one).  In x = sdot^2 every bound of the check is a line: joint q allows
+// sddot in [-au_q - m_q x, au_q - m_q x] with au = amax_q / |theta'_q|, m = theta''_q / theta'_q, and [-sddotMax, sddotMax] is the
+// line au = sddotMax, m = 0.  They stop intersecting at
+//    x* = min over the pairs of lines (i, j) of (au_i + au_j) / |m_i - m_j|
+// (of the two orientations of a pair -- i above, j below, or the other way round -- the one with a positive slope difference
+// crosses), and a candidate c of the loop is violated iff c^2 > x* -- for certain when |c^2 - x*| exceeds the band 2^-40 R x*
+// (R = E / Smin: the rounding errors of the check against the width of the interval at x = 0).  The loop of ba.cpp:1267-1321 is
+// advanced with its own update statements through every iteration whose outcome is certain and that neither ends it nor can take
+// a failure exit; it stops in front of the first candidate inside the band, or the one that would end the loop: that one gets
+// the real check in the next pass.  Anything unusual (a standing joint's threshold inside the band, non-finite or extreme values)
+// leaves the state as it is.
+// Round 6: written for the instruction count -- theta' already has its refined reciprocal (rD: two Newton steps, 2 eps, the
+// accuracy the analysis asks for), the partner lines arrive by DPP moves (quad permutations, the half-row mirror and their
+// products reach every lane of the group) instead of LDS-crossbar shuffles, a pair costs one reciprocal whatever its orientation
+// (|m_i - m_j|), lines that do not exist are the line u = 1e300, m = 0 (every quantity stays finite without a select per pair),
+// and the standing joints' true quotient sits behind a guard.  All lanes of a group are active together (the caller's condition
+// is a path-level value), and the permutations never leave the group.
+constexpr int DPP_QUAD_XOR3 = 0x1B; // quad_perm [3,2,1,0]
+__device__ __forceinline__ double s8_rcp2(double d)
+{
+   double r = __builtin_amdgcn_rcp(d);
+   r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+   return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+}
+// max(|x|, floor): one instruction
+__device__ __forceinline__ double s8_absmax(double x, double floorv)
+{
+   double r;
+   asm("v_max_f64 %0, |%1|, %2" : "=v"(r) : "v"(x), "v"(floorv));
+   return r;
+}
+__device__ __forceinline__ void s8_certify(bool jOn, double thD, double thD2, double rD, bool rOk, double amaxq, double thrV, double thrA,
+                                           double sddotMax, double &lowFact, double &sdotH, double &sdotL, double &sdotTry,
+                                           double &sdotGood, int &nGood, int &nIter)
+{
+   constexpr double BIG = 1e300, TINY = 1e-300;
+   const double xTop = sdotH * sdotH;                 // the first candidate: no later one is larger
+   const bool use = jOn && !(fabs(thD) < thrV);       // a moving joint (ba.cpp:1526-1531)
+   const double aur = amaxq * fabs(rD), mr = thD2 * rD;
+   const double er = aur + fabs(mr) * xTop;
+   // a line with a coefficient that is not an ordinary number stops the fast-forward (eMax = inf fails `sane`); NaNs fail every test
+   const bool lineOk = rOk & (aur < 1e100) & (fabs(mr) < 1e100) & (er < 1e100);
+   const bool have = use & lineOk;
+   const double au = have ? aur : BIG;
+   const double mj = have ? mr : 0.0;
+   const double ej = use ? (lineOk ? er : kInf) : 0.0;
+   const double uMin = grp_min<8>(au);
+   const double eMax = grp_max<8>(ej);
+   const double sMin2 = dmin(uMin, sddotMax);         // half the width of the interval at x = 0
+   const bool standing = jOn && !use && !(fabs(thD2) < thrA);
+   double xForce = kInf;
+   if (S8_RARE(standing)) xForce = grp_min<8>(standing ? amaxq / fabs(thD2) : kInf);   // the check's own quotient (ba.cpp:1519-1524)
+   // this lane's line against [-sddotMax, sddotMax] ...
+   double xs = (au + sddotMax) * s8_rcp2(s8_absmax(mj, TINY));
+   // ... and against the line of every other lane of the group
+#define S8_PAIR(AUI, MI) xs = vmin_f64(xs, (au + (AUI)) * s8_rcp2(s8_absmax(mj - (MI), TINY)))
+   {
+      const double a1 = dpp_mov<DPP_QUAD_XOR1>(au), m1 = dpp_mov<DPP_QUAD_XOR1>(mj);
+      S8_PAIR(a1, m1);
+      const double a2 = dpp_mov<DPP_QUAD_XOR2>(au), m2 = dpp_mov<DPP_QUAD_XOR2>(mj);
+      S8_PAIR(a2, m2);
+      const double a3 = dpp_mov<DPP_QUAD_XOR3>(au), m3 = dpp_mov<DPP_QUAD_XOR3>(mj);
+      S8_PAIR(a3, m3);
+      const double a7 = dpp_mov<DPP_ROW_HALF_MIRROR>(au), m7 = dpp_mov<DPP_ROW_HALF_MIRROR>(mj);   // lane ^ 7
+      S8_PAIR(a7, m7);
+      const double a6 = dpp_mov<DPP_QUAD_XOR1>(a7), m6 = dpp_mov<DPP_QUAD_XOR1>(m7);               // lane ^ 6
+      S8_PAIR(a6, m6);
+      const double a5 = dpp_mov<DPP_QUAD_XOR2>(a7), m5 = dpp_mov<DPP_QUAD_XOR2>(m7);               // lane ^ 5
+      S8_PAIR(a5, m5);
+      const double a4 = dpp_mov<DPP_QUAD_XOR3>(a7), m4 = dpp_mov<DPP_QUAD_XOR3>(m7);               // lane ^ 4
+      S8_PAIR(a4, m4);
+   }
+#undef S8_PAIR
+   xs = grp_min<8>(xs);
+   const double xstar = dmin(xs, 4.0 * xTop);          // beyond 4 xTop: "never violated by the lines" just as well
+   const double R = eMax * s8_rcp2(sMin2 > 0.0 ? sMin2 : 1.0);
+   const double band = (R * 0x1p-40) * xstar;
+   // a standing joint's threshold below the band around x* decides alone, and exactly; one above the band never matters; one
+   // inside the band: no fast-forward
+   const bool forceFirst = xForce < xstar - band;
+   const double xThr = forceFirst ? xForce : xstar;
+   const double bandThr = forceFirst ? -1.0 : band;
+   const bool sane = (sddotMax == sddotMax) & (eMax == eMax) & (xstar == xstar) & (R == R) & (R < 0x1p30) & (sMin2 > 1e-100) & (eMax < 1e100) &
+                     (xTop > 1e-100) & (xTop < 1e100) & (xstar > 1e-100) & (forceFirst | (xForce > xstar + band));
+   if (sane)
+   {
+      int it = nIter;
+      bool inBand = false;
+      // the search for a first feasible speed (ba.cpp:1281-1285): the bracket shrinks below every violated candidate
+#pragma unroll 1
+      for (; it < 90; ++it)
+      {
+         const double c = sdotTry, d = c * c - xThr;   // c * c: sdotSQ of the check
+         inBand = !((fabs(d) > bandThr) & (c > 1e-100));
+         if (inBand | !(d > 0.0)) break;
+         lowFact *= 2.0;
+         sdotH = c;
+         sdotL = dmax(.999 * 0.0, (1.0 - lowFact) * c);
+         sdotTry = .5 * (sdotH + sdotL);
+      }
+      if (!inBand && it < 90)
+      {
+         // sdotTry is feasible for certain and the first such speed: ba.cpp:1294 compares it with sdotGood = 0 and
+         // goes on.  From here the plain bisection (ba.cpp:1286-1303): sdotGood == sdotL throughout
+         sdotGood = sdotTry; nGood = 1; sdotL = sdotTry;
+         ++it;
+         sdotTry = .5 * (sdotH + sdotL);
+         // ba.cpp:1294 is false for certain when |c - sdotGood| > 1e-3 c (1 + 3e-14); otherwise this candidate is, or
+         // may be, the last one and gets the real check and the real test
+         const double convThr = 1e-3 * (1.0 + 3e-14);
+#pragma unroll 1
+         for (; it < 90; ++it)
+         {
+            const double c = sdotTry, d = c * c - xThr;
+            const bool viol = d > 0.0;
+            inBand = !(fabs(d) > bandThr);
+            const bool goesOn = viol | (fabs(c - sdotL) > convThr * c);
+            if (inBand | !goesOn) break;
+            sdotH = viol ? c : sdotH;
+            sdotL = viol ? sdotL : c;
+            sdotTry = .5 * (sdotH + sdotL);
+         }
+         sdotGood = sdotL;
+      }
+      nIter = it;
+   }
 }
 
 // G lanes per path (8: one joint per lane, 4: joints j and j + 4 in lane j), up to 64 / G paths per wavefront
@@ -286,7 +420,11 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
    // A path starts as if the stage before its first one had just ended (st one lower, PH_ENDED): the stores of that stage
    // go to slots nothing reads, and the loop needs no separate state for the first stage.
    int st = (DIR == 1) ? -1 : 0;
-   constexpr int PH_FIRST = 0, PH_ENDED = 1, PH_CHECK = 2, PH_DEAD = 3;
+   constexpr int PH_FIRST = 0, PH_ENDED = 1, PH_CHECK = 2, PH_DEAD = 3, PH_CERT = 4;
+   // reverse sweep: a path whose first check was violated waits in PH_CERT for the certificate block at the top of the loop, which
+   // runs once holdC/8 of the live paths have gathered there (or nothing else can run in this pass)
+   constexpr bool CERT = (DIR == -1) && (PER == 1) && (S8_FF != 0) && (S8_CERT_PHASE != 0);
+   const int holdC = a.holdc;
    int phase = PH_ENDED;
    if (S8_CURVE_FULL(i)) { endStatus = BATOTP_ST_CAPACITY; phase = PH_DEAD; }
    double sN = 0, wN = 0;
@@ -311,6 +449,28 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
       const unsigned long long mWait = __ballot(phase < PH_CHECK);
       const bool startNow = (mWait == mAlive) || (__popcll(mWait) * 8 >= __popcll(mAlive) * hold);
       S8_CNT(0, 1); S8_CNT(13, __popcll(mAlive) / G);
+      if (CERT)
+      {
+         const unsigned long long mCert = __ballot(phase == PH_CERT);
+         if (mCert != 0)
+         {
+            // (will a prologue or a check run in this pass?  If not, the waiting certificates are all there is to do)
+            const bool progress = (startNow && mWait != 0) || ((mAlive & ~mWait & ~mCert) != 0);
+            if (__popcll(mCert) * 8 >= __popcll(mAlive) * holdC || !progress)
+            {
+               S8_TICK(tF0);
+               S8_CNT(11, 1); S8_CNT(15, __popcll(mCert) / G);
+               if (phase == PH_CERT)
+               {
+                  s8_certify(jOn[0], thD[0], thD2[0], rD[0], rOk[0], amax[0], thrV, thrA, sddotMax, lowFact, sdotH, sdotL, sdotTry, sdotGood,
+                             nGood, nIter);
+                  phase = PH_CHECK;
+               }
+               S8_TICK(tF1);
+               S8_CYC(14, tF0, tF1);
+            }
+         }
+      }
       S8_TICK(tA);
       if (startNow && mWait != 0)
       {
@@ -679,7 +839,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
          // ---- one pass of the loop of ba.cpp:1267-1321, as selects -----------------------------------------
          const bool first = (nIter == 0);
          const bool fin0 = !isViol && first; // the first check passes: the stage is done, nothing else happens
-         bool fin = fin0, failed = false;
+         bool fin = fin0, failed = false, toCert = false;
          // forward sweep: 99 % of the checks end here and the block is skipped; reverse sweep: three quarters of the time a
          // path is inside a bisection, the guard would nearly always be taken and only cost its ballot
          if (DIR == -1 || S8_ANY(!fin0))
@@ -713,126 +873,28 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
             nfail += failed ? 1 : 0;
             stageFailed = failed;
 #if S8_FF
-            // ---- CERTIFIED FAST-FORWARD of the bisection (the block of k_sweep1, sweep1.hip.h: its derivation and error analysis
-            // are there; this is the same certificate on the 8 lanes of a path) ------------------------------------------------
-            // The first check of the stage was violated and the loop goes on.  In x = sdot^2 every bound of the check is a line:
-            // joint q allows sddot in [-au_q - m_q x, au_q - m_q x] with au = amax_q / |theta'_q|, m = theta''_q / theta'_q, and
-            // [-sddotMax, sddotMax] is the line au = sddotMax, m = 0.  They stop intersecting at
-            //    x* = min over pairs (upper line i, lower line j, m_i > m_j) of (au_i + au_j) / (m_i - m_j),
-            // and a candidate c of the loop is violated iff c^2 > x* -- for certain when |c^2 - x*| exceeds the band 2^-40 R x*
-            // (R = 2 E / Smin: the rounding errors of the check against the width of the interval at x = 0).  The loop of
-            // ba.cpp:1267-1321 is advanced with its own update statements through every iteration whose outcome is certain and that
-            // neither ends it nor can take a failure exit; it stops in front of the first candidate inside the band, or the one
-            // that would end the loop: that one gets the real check in the next pass.  Anything unusual (a standing joint's
-            // threshold inside the band, non-finite or extreme values) leaves the state as it is.
-            // Where it pays: the forward sweep runs its 8 paths in lockstep and 0.6 % of its stages bisect -- a dozen passes in which
-            // seven paths wait for one.  In the reverse sweep (22 % of the stages bisect, the passes are shared by several paths) the
-            // block costs what it saves (profiles/r03_g_*, r04_j_*): it runs there only when asked for (a.ff & 2).
-            if ((DIR == 1 || S8_FF > 1) && PER == 1 && accOn)   // (compiled into the reverse kernel it costs 5 % switched off: -DS8_FF=2 for that A/B)
+            // ---- CERTIFIED FAST-FORWARD of the bisection (s8_certify above) -------------------------------------------------------
+            // The first check of the stage was violated and the loop goes on.  Forward sweep: the 8 paths of a wavefront run in
+            // lockstep and 0.6 % of the stages bisect -- a dozen passes in which seven paths wait for one: the certificate runs
+            // right here.  Reverse sweep: 22 % of the stages bisect and the passes are shared by several paths; run per arriving
+            // path the block costs more than the passes it removes (profiles/r03_g_*, r04_j_*: +27 %), so there the path moves to
+            // the phase PH_CERT and the block at the top of the loop serves the paths that have gathered in it (round 6).
+            if (PER == 1 && accOn)
             {
                const bool ffWant = (((DIR == 1) ? (a.ff & 1) : (a.ff & 2)) != 0) && first && isViol && !failed;
-               if (S8_ANY(ffWant))
+               if (CERT) toCert = ffWant;
+               else if (S8_ANY(ffWant))
                {
                   S8_CNT(11, 1);
                   if (ffWant)
-                  {
-                     auto fastRcp = [](double d) {
-                        double r = __builtin_amdgcn_rcp(d);
-                        r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-                        return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-                     };
-                     const double xTop = sdotH * sdotH;                 // the first candidate: no later one is larger
-                     const bool use = jOn[0] && !(fabs(thD[0]) < thrV);
-                     const double rv = fastRcp(use ? thD[0] : 1.0);
-                     double au = amax[0] * fabs(rv);
-                     double mj = thD2[0] * rv;
-                     double ej = au + fabs(mj) * xTop;
-                     // a line with a non-finite coefficient must stop the fast-forward: the min / max reductions would drop its NaN
-                     const bool lineFinite = !use || ((au == au) & (mj == mj) & (ej == ej) & (fabs(au) < kInf) & (fabs(mj) < kInf) & (ej < kInf));
-                     const unsigned long long mBad = __builtin_amdgcn_ballot_w64(!lineFinite);
-                     const bool allFinite = ((unsigned)(mBad >> (lane & ~7)) & 0xffu) == 0u;
-                     au = use ? au : kInf;
-                     mj = use ? mj : 0.0;
-                     ej = use ? ej : 0.0;
-                     double uMin = au, lMax = -au;
-                     grp_min_max<8>(uMin, lMax);
-                     const double eMax = grp_max<8>(ej);
-                     const double sMin2 = .5 * (dmin(uMin, sddotMax) - dmax(lMax, -sddotMax));
-                     const bool standing = jOn[0] && !use && !(fabs(thD2[0]) < thrA);
-                     const double xForce = grp_min<8>(standing ? amax[0] / fabs(thD2[0]) : kInf);
-                     // this lane's line against [-sddotMax, sddotMax]: as the upper line when m > 0, as the lower line when m < 0
-                     double xs = kInf;
-                     if (use && mj > 0.0) xs = (au + sddotMax) * fastRcp(mj);
-                     if (use && mj < 0.0) xs = (sddotMax + au) * fastRcp(-mj);
-                     // ... and as the upper line against every other joint's lower line (the partner computes the other orientation)
-#pragma unroll
-                     for (int k = 1; k < 8; ++k)
-                     {
-                        const double aui = __shfl_xor(au, k), mi = __shfl_xor(mj, k);
-                        const double dm = mj - mi;
-                        const double bnd = (au + aui) * fastRcp(dm > 0.0 ? dm : 1.0);
-                        xs = dmin(xs, (dm > 0.0 && use && aui < kInf) ? bnd : kInf);
-                     }
-                     xs = grp_min<8>(xs);
-                     const double xstar = dmin(xs, 4.0 * xTop);          // beyond 4 xTop: "never violated by the lines" just as well
-                     const double R = eMax * fastRcp(sMin2 > 0.0 ? sMin2 : 1.0);
-                     const double band = (R * 0x1p-40) * xstar;
-                     // a standing joint's threshold below the band around x* decides alone, and exactly; one above the band never
-                     // matters; one inside the band: no fast-forward
-                     const bool forceFirst = xForce < xstar - band;
-                     const double xThr = forceFirst ? xForce : xstar;
-                     const double bandThr = forceFirst ? -1.0 : band;
-                     const bool sane = allFinite & (eMax == eMax) & (xstar == xstar) & (R == R) & (R < 0x1p30) & (sMin2 > 1e-100) & (eMax < 1e100) &
-                                       (xTop > 1e-100) & (xTop < 1e100) & (xstar > 1e-100) & (forceFirst | (xForce > xstar + band));
-                     if (sane)
-                     {
-                        int it = nIter;
-                        bool inBand = false;
-                        // the search for a first feasible speed (ba.cpp:1281-1285): the bracket shrinks below every violated candidate
-#pragma unroll 1
-                        for (; it < 90; ++it)
-                        {
-                           const double c = sdotTry, d = c * c - xThr;   // c * c: sdotSQ of the check
-                           inBand = !((fabs(d) > bandThr) & (c > 1e-100));
-                           if (inBand | !(d > 0.0)) break;
-                           lowFact *= 2.0;
-                           sdotH = c;
-                           sdotL = dmax(.999 * 0.0, (1.0 - lowFact) * c);
-                           sdotTry = .5 * (sdotH + sdotL);
-                        }
-                        if (!inBand && it < 90)
-                        {
-                           // sdotTry is feasible for certain and the first such speed: ba.cpp:1294 compares it with sdotGood = 0 and
-                           // goes on.  From here the plain bisection (ba.cpp:1286-1303): sdotGood == sdotL throughout
-                           sdotGood = sdotTry; nGood = 1; sdotL = sdotTry;
-                           ++it;
-                           sdotTry = .5 * (sdotH + sdotL);
-                           // ba.cpp:1294 is false for certain when |c - sdotGood| > 1e-3 c (1 + 3e-14); otherwise this candidate is, or
-                           // may be, the last one and gets the real check and the real test
-                           const double convThr = 1e-3 * (1.0 + 3e-14);
-#pragma unroll 1
-                           for (; it < 90; ++it)
-                           {
-                              const double c = sdotTry, d = c * c - xThr;
-                              const bool viol = d > 0.0;
-                              inBand = !(fabs(d) > bandThr);
-                              const bool goesOn = viol | (fabs(c - sdotL) > convThr * c);
-                              if (inBand | !goesOn) break;
-                              sdotH = viol ? c : sdotH;
-                              sdotL = viol ? sdotL : c;
-                              sdotTry = .5 * (sdotH + sdotL);
-                           }
-                           sdotGood = sdotL;
-                        }
-                        nIter = it;
-                     }
-                  }
+                     s8_certify(jOn[0], thD[0], thD2[0], rD[0], rOk[0], amax[0], thrV, thrA, sddotMax, lowFact, sdotH, sdotL, sdotTry, sdotGood,
+                                nGood, nIter);
                }
             }
 #endif
          }
          wN = fin ? ((DIR == 1) ? sddotH : sddotL) : wN;
-         phase = (fin || failed) ? PH_ENDED : phase;
+         phase = (fin || failed) ? PH_ENDED : (toCert ? PH_CERT : phase);
       }
       S8_TICK(tC);
       S8_CYC(6, tB, tC);

@@ -363,9 +363,16 @@ int  batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on);
  * candidates within the error band, and the last one (whose sddot bounds are the result), get the real check.  Results are
  * identical with it on (default) and off (the parity tests run both).  on: 1 / 0.  Round 4: the batch kernel of the 8-lane layout
  * (batotp_amd/csrc/sweep8.hip.h) carries the same certificate in its forward sweep, where the eight paths of a wavefront run in
- * lockstep and wait for a path that bisects (bit 0 of `on`; bit 1 is reserved for the reverse sweep, where the block measured
- * slower and is not compiled in: profiles/r04_j_*). */
+ * lockstep and wait for a path that bisects; round 6: and in its reverse sweep (batotp_hip_set_cert_hold below). */
 int  batotp_hip_set_fast_forward(batotp_ctx *ctx, int32_t on);
+/* the same certificate in the REVERSE sweep of the 8-lane batch kernel (k_sweep8), where 22 % of the stages bisect and the passes of
+ * the flat loop are shared by the paths of a wavefront: run once per arriving path the certificate costs more than the checks it
+ * removes (profiles/r04_j_*), so a path whose first check of a stage (reference batotp/ba.cpp:1270-1280) was violated waits in a
+ * phase of its own and ONE certificate block serves the paths gathered there -- once hold/8 of the wavefront's live paths wait, or
+ * when nothing else can run.  hold: 1..8; 0 = no certificate in the reverse sweep (every iteration of ba.cpp:1267-1321 gets its
+ * check); -1 (default) = automatic (the measured optimum, profiles/r06_a_*).  batotp_hip_set_fast_forward(0) switches it off as
+ * well.  Never changes a result (tests/test_gpu_parity.py, tests/test_gpu_fuzz.py, tests/test_gpu_zz_as_worded.py run both). */
+int  batotp_hip_set_cert_hold(batotp_ctx *ctx, int32_t hold);
 /* which kernel evaluates the per-knot values (batotp_hip_pointwise_mvc) of velocity / acceleration-only problems: 1 (default)
  * k_pointwise_va, written for that constraint family (shared reciprocals, select-form passes, the certified fast-forward), 0 the
  * general kernel that runs the loop of reference ba.cpp:1267-1321 literally.  Same results bit for bit; the switch exists for
@@ -495,6 +502,11 @@ typedef struct batotp_output batotp_output;
 int  batotp_hip_output(batotp_batch *batch, const batotp_output_params *prm, int32_t path0, int32_t n_paths,
                        batotp_output **out);
 int  batotp_hip_output_destroy(batotp_output *o);
+/* known-answer test of one step of that stage, through the stage's own launch function: Spline::findInterpSegs' cursor never moves
+ * back (reference batotp/spline.cpp:56-99), i.e. the segment of an output site is the running maximum of the raw segment indices of
+ * the sites before it.  seg holds the raw indices of n_paths paths back to back (n1[k] sites each, >= 0) and returns their running
+ * maxima, one wavefront per path as in batotp_hip_output. */
+int  batotp_hip_out_segmax_kat(batotp_ctx *ctx, int32_t n_paths, const int32_t *n1, int32_t *seg);
 /* points per path (0 for a path whose sweep ended with an error status) and traj.sres of the output */
 int  batotp_hip_output_info(batotp_output *o, int64_t *n_pts /* [n_paths] */, double *sres /* [n_paths] */);
 /* rows per point: n_theta joint rows, then n_cart Cartesian rows and n_trq torque rows (0 and 0 for JOINT paths) */

@@ -324,7 +324,8 @@ def set_layout(ctx, layout):
     """sweep-kernel layout of a context: 0 (automatic), 1, 8, 16, 32 lanes per path, or "flatK": 8 lanes per path, 8 paths
     per wavefront and the flat stage / bisection loop with hold K in both directions (batotp_hip_set_sweep_hold; only
     problems with joint velocity / acceleration limits alone use it, the others run the nested loops whatever K is);
-    "64noff": 64 without the certified fast-forward of the bisection"""
+    "flatKcH": the same with the reverse sweep's certificate phase at hold H; "64noff": 64 without the certified fast-forward of the
+    bisection"""
     if isinstance(layout, str) and layout.startswith("oldflat"):
         # the flat instantiation of the general kernel instead of k_sweep8 (batotp_hip_set_flat_form 0)
         k = int(layout[7:])
@@ -333,10 +334,14 @@ def set_layout(ctx, layout):
         ctx.set_sweep_hold(k, k)
         ctx.set_flat_form(0)
     elif isinstance(layout, str) and layout.startswith("flat"):
-        k = int(layout[4:])
+        # "flat4": hold 4; "flat4c2": ... and the certificate phase of the reverse sweep with hold 2 (batotp_hip_set_cert_hold; c0: no
+        # certificate in the reverse sweep)
+        k, _, c = layout[4:].partition("c")
         ctx.set_sweep_group(8)
         ctx.set_paths_per_wave(8)
-        ctx.set_sweep_hold(k, k)
+        ctx.set_sweep_hold(int(k), int(k))
+        if c:
+            ctx.set_cert_hold(int(c))
     elif isinstance(layout, str) and layout.startswith("g"):
         # "g4flat3": 4 lanes per path (two joints per lane), every lane of the wavefront filled, flat loop with hold 3
         g, k = layout[1:].split("flat")

@@ -110,7 +110,9 @@ def test_certified_fast_forward_of_the_bisection_on_hard_problems(hip_lib, oracl
     nearly parallel), all eight joints in use -- against the oracle, bit for bit"""
     prob, ys, sres, cap, n_paths = _hard_problem(seed)
     ro, oo = _run(oracle_ctx, prob, ys, sres, cap)
-    for layout in (64, "64noff", "64x2"):
+    # (round 6: the batch kernel k_sweep8 carries the certificate in both directions -- the forward sweep in its check block, the
+    #  reverse sweep as a phase of its own that serves the paths gathered in it: flatKcH = hold K of the stage, hold H of that phase)
+    for layout in (64, "64noff", "64x2", "flat4", "flat4c1", "flat8c8", "flat0c2", "flat4c0"):
         ctx = capi.Context(hip_lib, 0)
         set_layout(ctx, layout)
         p2 = capi.Problem.from_buffer_copy(bytes(prob))
@@ -411,12 +413,13 @@ def test_flat_sweep_loop_on_stalled_velocity_acceleration_paths(hip_lib, oracle_
     p2 = capi.Problem.from_buffer_copy(bytes(prob))
     if compact:
         p2.flags |= capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES
-    for hold in (-1, 0, 2, 3, 4, 5, 6, 8):
+    # (hold of the stage, hold of the reverse sweep's certificate phase: -1 automatic, 0 none)
+    for hold, cert in ((-1, -1), (0, -1), (2, -1), (3, -1), (4, -1), (5, -1), (6, -1), (8, -1), (4, 0), (4, 1), (4, 8), (6, 2)):
         ctx = capi.Context(hip_lib, 0)
-        ctx.set_sweep_group(8); ctx.set_paths_per_wave(8); ctx.set_sweep_hold(hold, hold)
+        ctx.set_sweep_group(8); ctx.set_paths_per_wave(8); ctx.set_sweep_hold(hold, hold); ctx.set_cert_hold(cert)
         rh, ho = _run(ctx, p2, ys, sres, cap)
         for f in rh.dtype.names:
-            assert np.array_equal(rh[f], ro[f]), (seed, hold, f, rh[f], ro[f])
+            assert np.array_equal(rh[f], ro[f]), (seed, hold, cert, f, rh[f], ro[f])
         for k in range(len(ys)):
             for which in (0, 1):
                 assert_bit_equal(ho[k][which][0], oo[k][which][0], f"seed {seed} hold {hold} path {k} curve {which} s")

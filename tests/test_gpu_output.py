@@ -204,3 +204,25 @@ def test_long_series_on_the_lanes_of_a_wavefront(hip_ctx, oracle_ctx):
             assert_bit_equal(h.theta(k), o.theta(k), f"{what}: path {k}")
         h.close(); o.close()
     hb.close(); ob.close()
+
+
+@pytest.mark.parametrize("n_paths", [1, 2, 63, 64, 65, 200])
+def test_segment_cursor_never_moves_back_on_every_path_of_a_chunk(hip_ctx, oracle_ctx, n_paths):
+    """findInterpSegs' cursor (reference spline.cpp:56-99) as the stage runs it -- one wavefront per path, through the stage's own launch
+    function: raw segment indices that step BACK (an s(t) spline that overshoots) on every path of a chunk, lengths around the 256 sites a
+    wavefront takes per round, empty paths in between.  (Round 5 launched this kernel on a lane-per-path grid: only paths 0 ..
+    ceil(K / 64) - 1 were processed and no test saw it, every test curve being monotone.)"""
+    rng = np.random.default_rng(77 + n_paths)
+    segs = []
+    for k in range(n_paths):
+        n = int(rng.choice([0, 1, 3, 255, 256, 257, 511, 1024, 1500, 4099]))
+        raw = np.cumsum(rng.integers(0, 3, n)) - rng.integers(0, 4, n) * (rng.random(n) < 0.3)   # mostly rising, with dips
+        segs.append(np.maximum(raw, 0).astype(np.int32))
+    if sum(len(x) for x in segs) == 0:
+        segs[0] = np.array([3, 1, 2], dtype=np.int32)
+    want = [np.maximum.accumulate(x) if len(x) else x for x in segs]
+    assert any(not np.array_equal(w, x) for w, x in zip(want[1:], segs[1:])) or n_paths == 1
+    for ctx in (hip_ctx, oracle_ctx):
+        got = capi.out_segmax_kat(ctx, segs)
+        for k in range(n_paths):
+            assert np.array_equal(got[k], want[k]), (n_paths, k, len(segs[k]))

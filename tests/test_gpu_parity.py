@@ -281,11 +281,12 @@ def test_ragged_batch_with_pairs_for_all_channels(hip_lib, oracle_ctx):
     ctx.close()
 
 
-@pytest.mark.parametrize("hold", [(0, 0), (3, 5), (4, -1), (5, 3), (8, 8), (-1, 6), (-1, -1), (-2, -2)])
+@pytest.mark.parametrize("hold", [(0, 0), (3, 5), (4, -1), (5, 3), (8, 8), (-1, 6), (-1, -1), (-2, -2), (4, 8, 0), (4, 8, 1), (5, 8, 2), (0, 0, 8), (8, 8, 5)])
 @pytest.mark.parametrize("compact", [False, True])
 def test_flat_sweep_loop_with_paths_drifting_apart(hip_lib, oracle_ctx, hold, compact):
     """batotp_hip_set_sweep_hold: 8 different paths per wavefront in the flat stage / bisection loop (each at its own
-    stage and step), every hold: every path equals its single-path oracle run"""
+    stage and step), every hold -- and (third number) every hold of the reverse sweep's certificate phase, batotp_hip_set_cert_hold:
+    every path equals its single-path oracle run"""
     names = ["synth_gen7dof_s0", "GEN7DOF", "synth_gen7dof_s1_vel", "GEN7DOF", "synth_gen7dof_s0", "GEN7DOF", "GEN7DOF"]
     cases = [Case(n) for n in names]
     for c in cases:
@@ -293,7 +294,9 @@ def test_flat_sweep_loop_with_paths_drifting_apart(hip_lib, oracle_ctx, hold, co
     ctx = capi.Context(hip_lib, 0)
     ctx.set_sweep_group(8)
     ctx.set_paths_per_wave(8)
-    ctx.set_sweep_hold(*hold)
+    ctx.set_sweep_hold(*hold[:2])
+    if len(hold) > 2:
+        ctx.set_cert_hold(hold[2])
     extra = (capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES) if compact else 0
     cap = 4 * max(c.max_steps() for c in cases)
     many = run_pipeline(ctx, cases * 3, max_steps=cap, mvc=False, details=False, extra_flags=extra)   # 21 paths: 3 wavefronts, the last one partly filled

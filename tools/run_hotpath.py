@@ -15,10 +15,10 @@ ap.add_argument("--coefficient-rows", action="store_true")
 ap.add_argument("--lib", default=None, help="alternative build of the library (experiments)")
 ap.add_argument("--hold", type=int, nargs=2, default=None, help="sweep loop form, reverse forward (batotp_hip_set_sweep_hold)")
 ap.add_argument("--flat-form", type=int, default=None, help="0 = flat instantiation of k_sweep, 1 = k_sweep8 (batotp_hip_set_flat_form)")
-ap.add_argument("--fast-forward", type=int, default=None, help="batotp_hip_set_fast_forward: 0 off, 1 default (k_sweep8: forward), 3 (k_sweep8: both sweeps)")
+ap.add_argument("--fast-forward", type=int, default=None, help="batotp_hip_set_fast_forward: 0 off, 1 on (default)")
 ap.add_argument("--tag", default="", help="label printed in front of every line")
-ap.add_argument("--variants", default=None, help="A/B of sweep forms on ONE resident batch: comma-separated form:holdRev:holdFwd[:ppw] "
-                "(form 0 = k_sweep's flat instantiation, 1 = k_sweep8; hold -1 = nested loops); prints kernel times and digests of rows / curves")
+ap.add_argument("--variants", default=None, help="A/B of sweep forms on ONE resident batch: comma-separated form:holdRev:holdFwd[:ppw[:group[:certHold]]] "
+                "(form 0 = k_sweep's flat instantiation, 1 = k_sweep8; hold -1 = nested loops; certHold: batotp_hip_set_cert_hold); prints kernel times and digests of rows / curves")
 a = ap.parse_args()
 hip = capi.Context(capi.Library(a.lib) if a.lib else capi.load_hip(), 0)
 hip.set_sweep_group(a.group)
@@ -65,6 +65,7 @@ if a.variants:
         hip.set_flat_form(f[0]); hip.set_sweep_hold(f[1], f[2])
         if len(f) > 3: hip.set_paths_per_wave(f[3])
         if len(f) > 4: hip.set_sweep_group(f[4])
+        if len(f) > 5: hip.set_cert_hold(f[5])
         best = [1e30, 1e30]
         for _ in range(max(1, a.reps)):
             b.sweep(-1); best[0] = min(best[0], b.kernel_ms(3))

@@ -24,12 +24,15 @@ ap.add_argument("--paths", type=int, default=16384)
 ap.add_argument("--knots", type=int, default=100000)
 ap.add_argument("--distinct", type=int, default=256)
 ap.add_argument("--hold", type=int, nargs=2, default=None)
+ap.add_argument("--cert-hold", type=int, default=None, help="batotp_hip_set_cert_hold (reverse sweep: the certificate phase)")
 a = ap.parse_args()
 
 lib = capi.Library(a.lib)
 hip = capi.Context(lib, 0)
 if a.hold:
     hip.set_sweep_hold(*a.hold)
+if a.cert_hold is not None:
+    hip.set_cert_hold(a.cert_hold)
 if a.paths > a.distinct:
     hip.set_path_order(0)   # tiled copies of a path must not become neighbours in a wavefront (they would run in lockstep)
 inp = bench.Inputs(hip, a.workload, a.knots, [1000 + k for k in range(a.distinct)])
@@ -42,7 +45,7 @@ b.precompute(0)
 fn = lib.lib.batotp_hip_debug_sweep8_counters
 fn.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int64]
 names = ["passes", "prologue blocks", "paths served by them", "check blocks", "paths inside them", "cycles prologue", "cycles check",
-         "cycles loop", "step-end blocks", "segment-change blocks", "cursor walks", "fast-forward blocks", "literal-form blocks", "live paths x passes"]
+         "cycles loop", "step-end blocks", "segment-change blocks", "cursor walks", "fast-forward blocks", "literal-form blocks", "live paths x passes", "cycles certificate", "paths certified"]
 for rep in range(2):
     for d, name in ((-1, "reverse"), (+1, "forward")):
         b.sweep(d)
@@ -61,5 +64,7 @@ for rep in range(2):
         for k, nm in enumerate(names):
             print(f"   {nm:26s} {c[k]:.4e}   per wavefront-stage {c[k] / wstages:9.3f}")
         print(f"   paths per prologue block {c[2] / max(c[1], 1):.2f}, paths per check block {c[4] / max(c[3], 1):.2f}, live paths per pass {c[13] / max(c[0], 1):.2f}")
+        print(f"   cycles per certificate block {c[14] / max(c[11], 1):.0f}, paths per certificate block {c[15] / max(c[11], 1):.2f}, "
+              f"checks per path-stage {c[4] / (6.0 * steps):.3f}, share of loop cycles: certificate {c[14] / c[7]:.3f}")
         print(f"   cycles per prologue block {c[5] / max(c[1], 1):.0f}, per check block {c[6] / max(c[3], 1):.0f}; share of loop cycles: prologue "
               f"{c[5] / c[7]:.3f}, check {c[6] / c[7]:.3f}")
