@@ -199,6 +199,7 @@ class Library:
             "batotp_hip_batch_destroy": [P],
             "batotp_hip_upload_knots": [P, I32, I32, D, D],
             "batotp_hip_upload_knots_device": [P, I32, I32, P, D],
+            "batotp_hip_upload_knots_device_rows": [P, I32, I32, P, I32, D],
             "batotp_hip_upload_rr_trig": [P, I32, D],
             "batotp_hip_set_serial_model": [P, C.POINTER(SerialModel)],
             "batotp_hip_upload_joint_trig": [P, I32, D],
@@ -549,6 +550,12 @@ class Batch:
     def upload_knots_device(self, path0: int, n: int, dev_ptr: int, sres: Sequence[float]):
         sr = np.ascontiguousarray(sres, dtype=np.float64)
         self.L.check(self.lib.batotp_hip_upload_knots_device(self.handle, path0, n, C.c_void_p(dev_ptr), _dptr(sr)), "upload_knots_device")
+
+    def upload_knots_device_rows(self, path0: int, n: int, dev_ptr: int, src_rows: int, sres: Sequence[float]):
+        """paths [path0, path0 + n) from a device block whose paths carry src_rows rows each: the first n_joints + n_cart are taken"""
+        sr = np.ascontiguousarray(sres, dtype=np.float64)
+        self.L.check(self.lib.batotp_hip_upload_knots_device_rows(self.handle, path0, n, C.c_void_p(dev_ptr), int(src_rows), _dptr(sr)),
+                     "upload_knots_device_rows")
 
     def upload_rr_trig(self, path: int, trig: np.ndarray):
         t = np.ascontiguousarray(trig, dtype=np.float64)

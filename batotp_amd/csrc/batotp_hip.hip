@@ -784,9 +784,11 @@ static void setSres(batotp_batch *b, int p, double sres)
    pi.uniform = 1;
 }
 
-static int uploadKnotsImpl(batotp_batch *b, int32_t path0, int32_t n, const double *y, const double *sres, hipMemcpyKind kind)
+static int uploadKnotsImpl(batotp_batch *b, int32_t path0, int32_t n, const double *y, const double *sres, hipMemcpyKind kind, int srcRows = 0)
 {
    if (!b || !y || !sres || path0 < 0 || n < 1 || path0 + n > b->B) return BATOTP_ERR_ARG;
+   if (srcRows == 0) srcRows = b->P.Cin;
+   if (srcRows < b->P.Cin || (srcRows != b->P.Cin && kind != hipMemcpyDeviceToDevice)) return BATOTP_ERR_ARG;
    int rc = bind(b->ctx);
    if (rc) return rc;
    const int64_t first = b->pinfo[path0].koff;
@@ -798,13 +800,20 @@ static int uploadKnotsImpl(batotp_batch *b, int32_t path0, int32_t n, const doub
    }
    hipStream_t st = b->ctx->stream;
    const int Cin = b->P.Cin, bs = 256;
-   if (!b->compact)
+   if (!b->compact && srcRows == Cin)
       HIP_TRY(hipMemcpyAsync(b->dY + first * Cin, y, sizeof(double) * (size_t)((last - first) * Cin), kind, st));
+   else if (!b->compact)
+   {
+      // the caller's paths carry more rows than the batch keeps (the resampler's Cartesian rows of a problem without Cartesian limits)
+      const int64_t total = last - first;
+      hipLaunchKernelGGL(k_rows_take, dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, st, b->dPinfo, path0, n, Cin, srcRows, y, b->dY, total);
+      HIP_TRY(hipGetLastError());
+   }
    else if (kind == hipMemcpyDeviceToDevice)
    {
       // compact splines: the values go straight from the caller's device buffer into the pair array
       const int64_t total = last - first;
-      hipLaunchKernelGGL(k_pairs_from_rows, dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, st, b->dPinfo, path0, n, Cin, b->kmC, y, b->dKM, total);
+      hipLaunchKernelGGL(k_pairs_from_rows, dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, st, b->dPinfo, path0, n, Cin, srcRows, b->kmC, y, b->dKM, total);
       HIP_TRY(hipGetLastError());
    }
    else
@@ -827,7 +836,7 @@ static int uploadKnotsImpl(batotp_batch *b, int32_t path0, int32_t n, const doub
          if (q == p) return BATOTP_ERR_STATE;
          const int64_t off = b->pinfo[p].koff - first;
          HIP_TRY(hipMemcpyAsync(b->dUp, y + off * Cin, sizeof(double) * (size_t)(knots * Cin), hipMemcpyHostToDevice, st));
-         hipLaunchKernelGGL(k_pairs_from_rows, dim3((unsigned)((knots + bs - 1) / bs)), dim3(bs), 0, st, b->dPinfo, p, q - p, Cin, b->kmC, b->dUp, b->dKM, knots);
+         hipLaunchKernelGGL(k_pairs_from_rows, dim3((unsigned)((knots + bs - 1) / bs)), dim3(bs), 0, st, b->dPinfo, p, q - p, Cin, Cin, b->kmC, b->dUp, b->dKM, knots);
          HIP_TRY(hipGetLastError());
          HIP_TRY(hipStreamSynchronize(st)); // the staging buffer is reused by the next run
          p = q;
@@ -845,6 +854,11 @@ extern "C" int batotp_hip_upload_knots(batotp_batch *b, int32_t path0, int32_t n
 extern "C" int batotp_hip_upload_knots_device(batotp_batch *b, int32_t path0, int32_t n, const double *y_dev, const double *sres)
 {
    return uploadKnotsImpl(b, path0, n, y_dev, sres, hipMemcpyDeviceToDevice);
+}
+extern "C" int batotp_hip_upload_knots_device_rows(batotp_batch *b, int32_t path0, int32_t n, const double *y_dev, int32_t src_rows, const double *sres)
+{
+   if (src_rows < 1) return BATOTP_ERR_ARG;
+   return uploadKnotsImpl(b, path0, n, y_dev, sres, hipMemcpyDeviceToDevice, src_rows);
 }
 
 extern "C" int batotp_hip_upload_rr_trig(batotp_batch *b, int32_t path, const double *trig)

@@ -2349,9 +2349,9 @@ __global__ void k_coef_from_sol(const double *__restrict__ kmPath, int C, int dc
    if (i < N - 1) k = coeffs_from_sol(a[1], b[1], a[0], b[0]);
    out[i] = k.c0; out[N + i] = k.c1; out[2 * N + i] = k.c2; out[3 * N + i] = k.c3;
 }
-// knot values of paths [path0, path0+n) from the C-ABI layout (path after path, [C][N] each) into the value
-// slots of the pair array; one lane per knot
-__global__ void k_pairs_from_rows(const PathInfo *__restrict__ pinfo, int path0, int nPaths, int C, int kmC, const double *__restrict__ rows,
+// knot values of paths [path0, path0+n) from the C-ABI layout (path after path, [srcC][N] each, of which the first C rows are taken)
+// into the value slots of the pair array; one lane per knot
+__global__ void k_pairs_from_rows(const PathInfo *__restrict__ pinfo, int path0, int nPaths, int C, int srcC, int kmC, const double *__restrict__ rows,
                                   double *__restrict__ km, int64_t total)
 {
    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2364,9 +2364,27 @@ __global__ void k_pairs_from_rows(const PathInfo *__restrict__ pinfo, int path0,
       if (pinfo[mid].koff - base <= g) lo = mid; else hi = mid - 1;
    }
    const int64_t off = pinfo[lo].koff - base, N = pinfo[lo].n, i = g - off;
-   const double *src = rows + off * C + i;
+   const double *src = rows + off * srcC + i;
    double *dst = km + ((pinfo[lo].koff + i) * kmC) * 2; // kmC channels per knot in the pair array (C of them are input channels)
    for (int c = 0; c < C; ++c) dst[2 * c] = src[(int64_t)c * N];
+}
+// the same into the row layout ([C][N] per path): the first C of srcC rows of every path
+__global__ void k_rows_take(const PathInfo *__restrict__ pinfo, int path0, int nPaths, int C, int srcC, const double *__restrict__ rows,
+                            double *__restrict__ y, int64_t total)
+{
+   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= total) return;
+   const int64_t base = pinfo[path0].koff;
+   int lo = path0, hi = path0 + nPaths - 1;
+   while (lo < hi)
+   {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pinfo[mid].koff - base <= g) lo = mid; else hi = mid - 1;
+   }
+   const int64_t off = pinfo[lo].koff - base, N = pinfo[lo].n, i = g - off;
+   const double *src = rows + off * srcC + i;
+   double *dst = y + pinfo[lo].koff * C + i;
+   for (int c = 0; c < C; ++c) dst[(int64_t)c * N] = src[(int64_t)c * N];
 }
 __global__ void k_coef_scatter(double *__restrict__ coefPath, int C, int dc, int64_t N, const double *__restrict__ in)
 {

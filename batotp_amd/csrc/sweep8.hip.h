@@ -38,6 +38,7 @@ namespace bk
 {
 
 constexpr int S8_BLOCK = 256;
+__device__ __forceinline__ bool s8_div_window_fwd(double x) { return sdiv_window(x); }
 // "does any active lane ...": the i1 ballot intrinsic (HIP's __ballot goes through an integer compare: a v_cndmask + v_cmp per use)
 #define S8_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0)
 #define S8_RARE(x) __builtin_expect(S8_ANY(x), 0) // a guard whose block is off the straight-line code
@@ -56,12 +57,18 @@ constexpr int S8_BLOCK = 256;
 #endif
 #ifndef S8_TAU_RCP
 #define S8_TAU_RCP 0 // tau = (sCur - sSeg) / (sNext - sSeg) and the reverse-curve tau of the forward sweep through the refined reciprocal of
-                     // their segment's width (device_math.h: sdiv_rcp / sdiv_by, the bits of `/` inside the window), kept while the cursor
-                     // stays on the segment: 3 instead of ~30 instructions per stage on the dependent chain; the literal quotient behind
-                     // a wavefront-uniform guard where an operand leaves the window (a numerator of exactly 0: the cursor on a knot)
+                     // their segment's width (device_math.h: sdiv_rcp / sdiv_by, the bits of `/` inside the window and for a numerator of
+                     // +0), kept while the cursor stays on the segment: 3 instead of ~30 instructions per stage on the dependent chain.
+                     // Round 5 gave the literal quotient (an operand outside the window) a wavefront-uniform guard of its own and measured
+                     // 5-7 % SLOWER; round 6 let it share the guard of the segment change, which a third of the prologues enter anyway:
+                     // SLOWER again (reduced batch, same box: reverse 626 against 601 ms, forward 417 against 386 ms; profiles/r06_b_*).
+                     // The division is not what these wavefronts wait for.  Kept as an option, bit-identical.
 #endif
 #ifndef S8_FF
 #define S8_FF 1      // the certified fast-forward of the bisection (s8_certify), both directions (batotp_hip_set_fast_forward: bit 0 forward, bit 1 reverse)
+#endif
+#ifndef S8_FF_REV
+#define S8_FF_REV 1  // 0: the reverse kernel carries no certificate code at all (the kernel of rounds 4 and 5, for A/B runs)
 #endif
 #ifndef S8_CERT_PHASE
 #define S8_CERT_PHASE 1 // reverse sweep: the certificate as a phase of its own, served in batches (0: in the check block, per arriving path)
@@ -92,6 +99,10 @@ __device__ __forceinline__ void s8_ratio_lt_pair(double num1, double num2, doubl
    dec2 = ok & (lt2 | (num2 > den * (T2 * (1.0 + 1e-14))));
 }
 
+// numerator of a quotient by a cached reciprocal: inside the window, or +0 (0 * r = +0, the remainder fma(-den, +0, +0) = +0, the result
+// fma(+0, r, +0) = +0 = (+0) / den for the positive divisors this is used with; a numerator of -0 would come out as +0 and takes the
+// literal form)
+__device__ __forceinline__ bool s8_num_ok(double x) { return s8_div_window_fwd(x) | (__double_as_longlong(x) == 0ll); }
 // (the shared refined reciprocal of theta' -- sdiv_window / sdiv_rcp / sdiv_by -- lives in device_math.h.  In k_sweep1, the
 // one-path-per-wavefront kernel, the same technique measured 3-10 % SLOWER -- cfg 4: 961 against 874 ms -- and is not used there:
 // its window tests and ballot guards cost a lone wavefront more than the shorter quotients save; profiles/r04_b_*)
@@ -199,44 +210,54 @@ __device__ __forceinline__ void s8_certify(bool jOn, double thD, double thD2, do
                      (xTop > 1e-100) & (xTop < 1e100) & (xstar > 1e-100) & (forceFirst | (xForce > xstar + band));
    if (sane)
    {
+      // Both loops of the replay are wavefront-uniform loops ("while any lane goes on") with BRANCH-FREE bodies: a per-lane loop with a
+      // break, or an exec-masked update inside a uniform loop, makes the compiler structurize the whole loop as divergent and spend
+      // twice as many scalar instructions on mask bookkeeping as the loop has vector instructions (18 against 7 per iteration in the
+      // first round-6 build).  A lane that has stopped keeps its state through selects; its tests are re-evaluated on that unchanged
+      // state and give what they gave.  Invariant used below: sdotTry == .5 * (sdotH + sdotL) in every lane at every point (the check
+      // block's update, ba.cpp:1320, leaves it so, and every update here ends with that statement), so the midpoint needs no select.
       int it = nIter;
-      bool inBand = false;
+      bool inBand = false, more = true;
       // the search for a first feasible speed (ba.cpp:1281-1285): the bracket shrinks below every violated candidate
-#pragma unroll 1
-      for (; it < 90; ++it)
+      for (;;)
       {
          const double c = sdotTry, d = c * c - xThr;   // c * c: sdotSQ of the check
          inBand = !((fabs(d) > bandThr) & (c > 1e-100));
-         if (inBand | !(d > 0.0)) break;
-         lowFact *= 2.0;
-         sdotH = c;
-         sdotL = dmax(.999 * 0.0, (1.0 - lowFact) * c);
+         more = more & !inBand & (d > 0.0) & (it < 90);
+         if (!S8_ANY(more)) break;
+         const double lf2 = lowFact * 2.0;
+         const double lo = dmax(.999 * 0.0, (1.0 - lf2) * c);
+         lowFact = more ? lf2 : lowFact;
+         sdotH = more ? c : sdotH;
+         sdotL = more ? lo : sdotL;
          sdotTry = .5 * (sdotH + sdotL);
+         it += more ? 1 : 0;
       }
-      if (!inBand && it < 90)
+      // sdotTry is feasible for certain and the first such speed: ba.cpp:1294 compares it with sdotGood = 0 and goes on.  From
+      // here the plain bisection (ba.cpp:1286-1303): sdotGood == sdotL throughout
+      const bool bisect = !inBand & (it < 90);
+      sdotGood = bisect ? sdotTry : sdotGood;
+      nGood = bisect ? 1 : nGood;
+      sdotL = bisect ? sdotTry : sdotL;
+      it += bisect ? 1 : 0;
+      sdotTry = .5 * (sdotH + sdotL);
+      // ba.cpp:1294 is false for certain when |c - sdotGood| > 1e-3 c (1 + 3e-14); otherwise this candidate is, or may be, the
+      // last one and gets the real check and the real test
+      const double convThr = 1e-3 * (1.0 + 3e-14);
+      more = bisect;
+      for (;;)
       {
-         // sdotTry is feasible for certain and the first such speed: ba.cpp:1294 compares it with sdotGood = 0 and
-         // goes on.  From here the plain bisection (ba.cpp:1286-1303): sdotGood == sdotL throughout
-         sdotGood = sdotTry; nGood = 1; sdotL = sdotTry;
-         ++it;
+         const double c = sdotTry, d = c * c - xThr;
+         const bool viol = d > 0.0;
+         const bool goesOn = viol | (fabs(c - sdotL) > convThr * c);
+         more = more & (fabs(d) > bandThr) & goesOn & (it < 90);
+         if (!S8_ANY(more)) break;
+         sdotH = (more & viol) ? c : sdotH;
+         sdotL = (more & !viol) ? c : sdotL;
          sdotTry = .5 * (sdotH + sdotL);
-         // ba.cpp:1294 is false for certain when |c - sdotGood| > 1e-3 c (1 + 3e-14); otherwise this candidate is, or
-         // may be, the last one and gets the real check and the real test
-         const double convThr = 1e-3 * (1.0 + 3e-14);
-#pragma unroll 1
-         for (; it < 90; ++it)
-         {
-            const double c = sdotTry, d = c * c - xThr;
-            const bool viol = d > 0.0;
-            inBand = !(fabs(d) > bandThr);
-            const bool goesOn = viol | (fabs(c - sdotL) > convThr * c);
-            if (inBand | !goesOn) break;
-            sdotH = viol ? c : sdotH;
-            sdotL = viol ? sdotL : c;
-            sdotTry = .5 * (sdotH + sdotL);
-         }
-         sdotGood = sdotL;
+         it += more ? 1 : 0;
       }
+      sdotGood = bisect ? sdotL : sdotGood;
       nIter = it;
    }
 }
@@ -375,9 +396,12 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
    double sSeg = sres * (double)seg, sNext = sres * (double)(seg + 1); // sites of the cursor's segment
 #if S8_TAU_RCP
    double rSeg = s8_rcp_refined(sNext - sSeg); // refined reciprocal of the segment's width (renewed when the walk ran)
-   bool segOk = s8_div_window(sNext - sSeg);
+   bool segOk = s8_div_window(sNext - sSeg) & (sNext - sSeg > 0.0);
    double rM = 0;   // the same for the reverse-curve segment of the forward sweep
    bool mOk = false;
+   // forward sweep: what the literal form of evalsdot's quotient needs when it is redone behind the guard of the segment change
+   double numM = 0, denM = 1, vPre = 0;
+   bool fastM = true;
 #endif
    // reverse-curve cursor (forward sweep): segment and its two points
    int segM = 0;
@@ -388,7 +412,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
       const double2 qa = mvc[segM], qb = mvc[segM + 1];
       mS0 = qa.x; mD0 = qa.y; mS1 = qb.x; mD1 = qb.y;
 #if S8_TAU_RCP
-      rM = s8_rcp_refined(mS1 - mS0); mOk = s8_div_window(mS1 - mS0);
+      rM = s8_rcp_refined(mS1 - mS0); mOk = s8_div_window(mS1 - mS0) & (mS1 - mS0 > 0.0);
 #endif
    }
    unsigned status = t.status;
@@ -423,7 +447,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
    constexpr int PH_FIRST = 0, PH_ENDED = 1, PH_CHECK = 2, PH_DEAD = 3, PH_CERT = 4;
    // reverse sweep: a path whose first check was violated waits in PH_CERT for the certificate block at the top of the loop, which
    // runs once holdC/8 of the live paths have gathered there (or nothing else can run in this pass)
-   constexpr bool CERT = (DIR == -1) && (PER == 1) && (S8_FF != 0) && (S8_CERT_PHASE != 0);
+   constexpr bool CERT = (DIR == -1) && (PER == 1) && (S8_FF != 0) && (S8_FF_REV != 0) && (S8_CERT_PHASE != 0);
    const int holdC = a.holdc;
    int phase = PH_ENDED;
    if (S8_CURVE_FULL(i)) { endStatus = BATOTP_ST_CAPACITY; phase = PH_DEAD; }
@@ -602,13 +626,10 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                   // evalsdot, ba.cpp:1590-1607
 #include "sweep8_mvcwalk.inc"
 #if S8_TAU_RCP
-                  double tauM;
-                  {
-                     const double numM = sCur - mS0, denM = mS1 - mS0;
-                     const bool fastM = mOk & s8_div_window(numM);
-                     tauM = s8_div_by(numM, denM, rM);
-                     if (S8_RARE(!fastM)) tauM = fastM ? tauM : numM / denM;
-                  }
+                  numM = sCur - mS0; denM = mS1 - mS0;
+                  fastM = mOk & s8_num_ok(numM);
+                  vPre = vN;
+                  const double tauM = s8_div_by(numM, denM, rM);   // (a lane with !fastM is redone behind the guard of the segment change)
 #else
                   const double tauM = (sCur - mS0) / (mS1 - mS0);
 #endif
@@ -617,8 +638,8 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                }
                vN = dmin(vN, sdotCap);
                vN = dmax(vN, sdotMin);
+               double lim1 = kInf;
                {
-                  double lim1 = kInf;
 #pragma unroll
                   for (int q = 0; q < PER; ++q)
                   {
@@ -660,23 +681,39 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
                      if (!S8_ANY(mvUp | mvDn)) break;
                   }
 #if S8_TAU_RCP
-                  rSeg = s8_rcp_refined(sNext - sSeg); segOk = s8_div_window(sNext - sSeg);
+                  rSeg = s8_rcp_refined(sNext - sSeg); segOk = s8_div_window(sNext - sSeg) & (sNext - sSeg > 0.0);
 #endif
                }
 #if S8_TAU_RCP
-               double tau;
-               {
-                  const double numT = sCur - sSeg, denT = sNext - sSeg;
-                  const bool fastT = segOk & s8_div_window(numT);
-                  tau = s8_div_by(numT, denT, rSeg);
-                  if (S8_RARE(!fastT)) tau = fastT ? tau : numT / denT;
-               }
+               const double numT = sCur - sSeg, denT = sNext - sSeg;
+               const bool fastT = segOk & s8_num_ok(numT);
+               double tau = s8_div_by(numT, denT, rSeg);
+               const bool slowM = (DIR == 1) && !fastM;
 #else
-               const double tau = (sCur - sSeg) / (sNext - sSeg);
+               double tau = (sCur - sSeg) / (sNext - sSeg);
+               const bool fastT = true, slowM = false;
 #endif
                const bool chg = (seg != rowSeg);
-               if (S8_ANY(chg))
+               // one guard for the segment change and for the quotients that need their literal form
+               if (S8_ANY(chg | !fastT | slowM))
                {
+#if S8_TAU_RCP
+                  if (!fastT) tau = numT / denT;
+                  if (DIR == 1)
+                  {
+                     if (slowM)
+                     {
+                        // evalsdot and the rest of sdotLim once more with the literal quotient (ba.cpp:1590-1607, 1216-1229)
+                        const double tauM = numM / denM;
+                        const double sdotMVC = dmax(mD0 + tauM * (mD1 - mD0), sdotMin);
+                        double vR = (vPre > sdotMVC) ? sdotMVC : vPre;
+                        vR = dmin(vR, sdotCap);
+                        vR = dmax(vR, sdotMin);
+                        vR = dmin(vR, lim1);
+                        sdotCur = vR; sdotH = vR; sdotTry = vR;
+                     }
+                  }
+#endif
                   S8_CNT(9, 1);
                   if (chg)
                   {
@@ -879,7 +916,7 @@ __global__ void __launch_bounds__(S8_BLOCK, G == 8 ? 2 : 1) k_sweep8(SweepArgs a
             // right here.  Reverse sweep: 22 % of the stages bisect and the passes are shared by several paths; run per arriving
             // path the block costs more than the passes it removes (profiles/r03_g_*, r04_j_*: +27 %), so there the path moves to
             // the phase PH_CERT and the block at the top of the loop serves the paths that have gathered in it (round 6).
-            if (PER == 1 && accOn)
+            if (PER == 1 && accOn && (DIR == 1 || S8_FF_REV))
             {
                const bool ffWant = (((DIR == 1) ? (a.ff & 1) : (a.ff & 2)) != 0) && first && isViol && !failed;
                if (CERT) toCert = ffWant;

@@ -58,12 +58,16 @@ def gather_curves(batch: "capi.Batch", which: int, device=None, root: int = 0, o
     (batotp_hip_pack_curves), (3) one grouped send/recv moves the buffers device-to-device to the root -- direct peer-to-root
     transfers over the xGMI links of the root, no ring.  With `device` = None (gloo, CPU tests) the same code moves host
     tensors (the checker library's "device" memory is host memory).  on_device = True leaves the result where it arrived: the
-    root gets (list of per-rank (points, 2) tensors on its device, list of per-rank point-count arrays) instead of host arrays."""
+    root gets (list of per-rank (points, 2) tensors on its device, list of per-rank point-count arrays) instead of host arrays.
+    A rank whose share is empty passes batch = None: it takes part in the collectives and sends nothing."""
     import torch
     import torch.distributed as dist
 
-    res = batch.results()
-    counts_local = np.ascontiguousarray(res["n_fwd"] if which == 1 else res["n_rev"], dtype=np.int64)
+    if batch is None:
+        counts_local = np.zeros(0, dtype=np.int64)
+    else:
+        res = batch.results()
+        counts_local = np.ascontiguousarray(res["n_fwd"] if which == 1 else res["n_rev"], dtype=np.int64)
     dev = device if device is not None else torch.device("cpu")
     distributed = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size() if distributed else 1

@@ -108,6 +108,12 @@ CONFIGS = {
     "cfg5": dict(workload="cspr", knots=200000, paths=4096, scaling="strong", distinct=128, lean=True,
                  what="cfg5 as worded: CSPR3DOF cable robot with cable-tension constraints, N=200k, batch of 4096 sharded "
                       "across the GPUs"),
+    # the same configuration WITHOUT a curated sample: the first 2048 seeds as they come (4096 paths = those x2), only candidates that
+    # cannot finish at all are swapped and counted.  Random cable-robot paths have a heavy tail of barely feasible ones, and a launch
+    # lasts as long as its slowest path: this is the number a user with arbitrary paths sees (round 5: 16.7 s against 3.3 s)
+    "cfg5_distinct2048": dict(workload="cspr", knots=200000, paths=4096, scaling="strong", distinct=2048, lean=True, steps=1,
+                              what="cfg5 as worded with 2048 distinct seeds as they come (no curated sample): CSPR3DOF cable robot with "
+                                   "cable-tension constraints, N=200k, batch of 4096 sharded across the GPUs"),
 }
 
 
@@ -191,7 +197,10 @@ class Inputs:
     """K distinct synthetic paths of a workload for one rank: problem description, knot counts / spacing per distinct path
     and a way to put the knots of distinct path k into path p of a batch"""
 
-    CHUNK = 256   # distinct paths per call of the device resampler
+    # distinct paths per call of the device resampler (the library cuts a call into chunks that fit its scratch budget itself; what bounds
+    # this number is the host memory of the widened taught points -- gen7: 2.7 MB per path -- and the knots a call leaves resident:
+    # 8 MB per path).  Round 5 used 256: 129 calls for the headline's two passes, each with a 61 ms floor (one walk wavefront per path)
+    CHUNK = 1024
 
     def __init__(self, hip, workload, knots, seeds):
         self.hip, self.workload, self.K = hip, workload, len(seeds)
@@ -321,10 +330,10 @@ class Inputs:
             m = rs.n_knots.shape[0]
             ptr = rs.device_ptr()
             off = np.concatenate([[0], np.cumsum(rs.n_knots)]) * self.nC_in
-            if self.keep == self.nC_in and n_paths <= K:
-                hi = min(k0 + m, n_paths)     # consecutive paths are contiguous in the resampler's output
-                if hi > k0:
-                    batch.upload_knots_device(k0, hi - k0, ptr, list(rs.sres[: hi - k0]))
+            if n_paths <= K:
+                hi = min(k0 + m, n_paths)     # consecutive paths are contiguous in the resampler's output: ONE call for the block; the batch
+                if hi > k0:                   # keeps the first `keep` of the nC_in rows of a path (batotp_hip_upload_knots_device_rows)
+                    batch.upload_knots_device_rows(k0, hi - k0, ptr, self.nC_in, list(rs.sres[: hi - k0]))
             else:
                 for j in range(m):
                     # the first `keep` rows of a path are the first keep * N doubles of its block
@@ -544,7 +553,7 @@ def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=
     # the variable-length part of the gather: the forward curves of every path to rank 0, device to device
     # (size exchange + grouped send/recv); untimed side measurement of the sharded configurations
     curve_gather = None
-    if dist_ctx is not None and c["scaling"] == "strong" and batch is not None:
+    if dist_ctx is not None and c["scaling"] == "strong":     # (collective: a rank with an empty share takes part with batch = None)
         barrier()
         tg = time.perf_counter()
         got = bdist.gather_curves(batch, +1, dev, on_device=True)
@@ -648,7 +657,7 @@ def measure(hip, cfg_name, rank, world, steps, warmup, dist_ctx, paths_override=
     kept = None
     if keep:
         kept = dict(batch=batch, inp=inp, prob=prob, cap=cap, res=res, K=K, B=B, chunk0=chunk_sizes[0] if B else 0,
-                    knot_digests=inp.device_knot_digests(32) if (rank == 0 and B) else [])
+                    knot_digests=inp.device_knot_digests(64) if (rank == 0 and B) else [])
     elif batch is not None:
         batch.close()
     return out, kept
@@ -920,6 +929,18 @@ def main():
     workload = CONFIGS[args.config]["workload"]
     prob, batch = kept["prob"], kept["batch"]
     vel_acc_only = not (prob.flags & (capi.F_TRQ_ON | capi.F_CART_VEL_ON | capi.F_CART_ACC_ON))
+    # The headline's sweep kernel (k_sweep8, flat loop) is behind a gate: the toolchain the library was built with must be the one the
+    # loop was validated with, and a canary on this device must agree with the nested loops.  A closed gate silently costs a factor
+    # of 1.7 (the nested loops of the general kernel run instead, same results) -- so it is reported at the top level and on stderr.
+    gate = hip.flat_loop_status() if vel_acc_only else None
+    out["flat_loop_gate"] = {"status": gate, "meaning": {1: "open: k_sweep8 with the flat stage / bisection loop", -1: "CLOSED: library built by a toolchain "
+                             "the flat loop was not validated with (nested loops run instead, same results, ~1.7x slower)", -2: "CLOSED: the "
+                             "on-device canary disagreed with the nested loops", -3: "CLOSED: the canary could not run", None: "not applicable "
+                             "(torque or Cartesian limits: one path per wavefront)"}.get(gate, "?"),
+                             "toolchain_built_with_validated_with": list(hip.library.toolchain())}
+    if gate is not None and gate != 1 and rank == 0:
+        print(f"bench: WARNING: the gate of the flat sweep loop is CLOSED (batotp_hip_flat_loop_status = {gate}: {out['flat_loop_gate']['meaning']}); "
+              f"toolchain {hip.library.toolchain()}", file=sys.stderr)
 
     will_check = 1 if (not args.no_sides and batch is not None and vel_acc_only and kept["chunk0"] > 6144 and args.group in (0, 8)) else 0
     if dist_ctx is not None:
@@ -986,9 +1007,9 @@ def main():
     worded_host = {}
     if default_run and not args.no_as_worded:
         worded = {}
-        for name in ("cfg2", "cfg3", "cfg4", "cfg5"):
+        for name in ("cfg2", "cfg3", "cfg4", "cfg5", "cfg5_distinct2048"):
             try:
-                w, wk = measure(hip, name, rank, world, AS_WORDED_STEPS, 1, dist_ctx, keep=True)
+                w, wk = measure(hip, name, rank, world, CONFIGS[name].get("steps", AS_WORDED_STEPS), 1, dist_ctx, keep=True)
                 if wk is not None and wk.get("batch") is not None:
                     wk["batch"].close()
                 if rank == 0 and wk is not None and wk.get("chunk0"):
@@ -1013,7 +1034,7 @@ def main():
     # the last collective (the other ranks are done: nobody is parked in a barrier meanwhile), whatever the world size
     if rank == 0 and not args.no_cpu_baseline and not args.no_sides and kept_host is not None and kept_host["chunk0"]:
         out_prm, hip_out0 = cpu_job
-        info, err, mism, th0 = cpu_baseline(kept_host, args.cpu_seconds, out_prm, hip_out0 is not None)
+        info, err, mism, th0 = cpu_baseline(kept_host, args.cpu_seconds, out_prm, hip_out0 is not None, max_distinct=64)
         out["cpu_baseline"] = info
         out["vs_cpu_baseline"] = out["value"] / info["value"]
         out["traversal_time_err_s"] = err

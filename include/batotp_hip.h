@@ -212,6 +212,12 @@ int  batotp_hip_upload_knots(batotp_batch *batch, int32_t path0, int32_t n,
  * host array) */
 int  batotp_hip_upload_knots_device(batotp_batch *batch, int32_t path0, int32_t n,
                                     const double *y_dev, const double *sres);
+/* same for paths that carry MORE rows than the batch keeps: every path of the source is [src_rows][N] (src_rows >= n_joints +
+ * n_cart of the batch) and its first n_joints + n_cart rows are taken -- the knots of batotp_hip_resample (joint rows, then the
+ * Cartesian rows traj.cart of reference batotp/ba.cpp:247-262) into a batch of a problem without Cartesian limits, which carries no
+ * Cartesian channels (BA::deviceSweep): one call and one kernel for a block of paths instead of a call per path */
+int  batotp_hip_upload_knots_device_rows(batotp_batch *batch, int32_t path0, int32_t n,
+                                         const double *y_dev, int32_t src_rows, const double *sres);
 /* RR only (BATOTP_F_HOST_TRIG): trig[4][N] = cos(th1), cos(th2), cos(th1+th2), sin(th2) of the
  * knot samples of path p, evaluated with the host libm (robot.cpp:408-419). */
 int  batotp_hip_upload_rr_trig(batotp_batch *batch, int32_t path, const double *trig);

@@ -198,6 +198,23 @@ int batotp_hip_upload_knots_device(batotp_batch *b, int32_t path0, int32_t n, co
 {
     return batotp_hip_upload_knots(b, path0, n, y, sres);
 }
+int batotp_hip_upload_knots_device_rows(batotp_batch *b, int32_t path0, int32_t n, const double *y, int32_t src_rows, const double *sres)
+{
+    /* the first n_theta + n_cart of src_rows rows of every path (the checker's "device" memory is host memory) */
+    const double *src = y;
+    int32_t k;
+    if (!b || !y || !sres || path0 < 0 || n < 1 || path0 + n > b->n_paths) return BATOTP_ERR_ARG;
+    for (k = 0; k < n; k++) {
+        bo_path *p = b->path[path0 + k];
+        const int rows = p->n_theta + p->n_cart;
+        int rc;
+        if (src_rows < rows) return BATOTP_ERR_ARG;
+        rc = batotp_hip_upload_knots(b, path0 + k, 1, src, sres + k);
+        if (rc) return rc;
+        src += (size_t)src_rows * (size_t)p->n;
+    }
+    return BATOTP_OK;
+}
 int batotp_hip_upload_rr_trig(batotp_batch *b, int32_t path, const double *trig)
 {
     size_t cnt;

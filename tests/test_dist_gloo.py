@@ -37,11 +37,11 @@ def _worker(rank, world, port, names, q):
         local = np.array([o["result"] for o in outs], dtype=capi.RESULT_DTYPE) if outs else np.zeros(0, dtype=capi.RESULT_DTYPE)
         allres = bdist.gather_results(local)
         # the variable-length part: both curves of every path, to rank 0
-        b = capi.Batch(ctx, cases[0].problem if cases else helpers.Case(names[0]).problem, [c.n for c in cases] or [4],
-                       max([c.max_steps() for c in cases] or [8]))
-        for k, c in enumerate(cases):
-            b.upload_knots(k, [c.y], [c.sres])
+        b = None                 # (a rank without a share has no batch: it takes part in the collectives and sends nothing)
         if cases:
+            b = capi.Batch(ctx, cases[0].problem, [c.n for c in cases], max(c.max_steps() for c in cases))
+            for k, c in enumerate(cases):
+                b.upload_knots(k, [c.y], [c.sres])
             b.optimize()
         curves = {w: bdist.gather_curves(b, w) for w in (-1, 1)}
         if rank == 0:
@@ -91,6 +91,41 @@ def test_two_ranks_gather_matches_single_rank(oracle_ctx):
             assert curves[w][k][0] == o[key][0].tobytes() and curves[w][k][1] == o[key][1].tobytes(), (w, k)
 
 
+def test_eight_ranks_gather_rows_and_curves_with_empty_shards(oracle_ctx):
+    """the world size of BASELINE configs 4 / 5 (8 GPUs), on CPU: 11 paths over 8 ranks (blocks of 2, 2, 2, 1, 1, 1, 1, 1) and 5 paths
+    over 8 ranks (three ranks own nothing): result rows by all_gather in rank order, BOTH curves of every path to rank 0 by the size
+    exchange + grouped send/recv of batotp_amd.dist.gather_curves -- everything equal to the single-rank run, bit for bit"""
+    import torch.multiprocessing as mp
+    from batotp_amd import capi
+    pool = ["GEN7DOF", "synth_gen7dof_s0", "GEN7DOF"]
+    ref = {}
+    for names in ([pool[k % 3] for k in range(11)], [pool[k % 2] for k in range(5)]):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 8, port, names, q)) for r in range(8)]
+        for p in procs:
+            p.start()
+        raw, curves = q.get(timeout=600)
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        gathered = np.frombuffer(raw, dtype=capi.RESULT_DTYPE)
+        assert gathered.shape[0] == len(names)
+        for n in set(names):
+            if n not in ref:
+                c = helpers.Case(n)
+                c.problem = helpers.Case(names[0]).problem
+                ref[n] = helpers.run_pipeline(oracle_ctx, [c], mvc=False, details=False)[0]
+        for k, n in enumerate(names):
+            o = ref[n]
+            for f in capi.RESULT_DTYPE.names:
+                assert gathered[k][f] == o["result"][f], (len(names), k, f)
+            for w, key in ((-1, "rev"), (1, "fwd")):
+                assert len(curves[w]) == len(names)
+                assert curves[w][k][0] == o[key][0].tobytes() and curves[w][k][1] == o[key][1].tobytes(), (len(names), w, k)
+
+
 def _bench_line(args, env_extra=None):
     import json, subprocess
     env = dict(os.environ)
@@ -135,3 +170,18 @@ def test_bench_rehearses_config_5_on_four_ranks():
     # one GPU holds the whole batch in two chunks of whole multiples of the distinct paths
     r, line = _bench_line(["--gpus", "1", "--launch-check", "--config", "cfg5"])
     assert r.returncode == 0 and line["paths_per_rank"] == 4096 and line["chunks_per_rank"] == [2048] * 2
+
+
+@pytest.mark.parametrize("config, per_rank", [("cfg4", 128), ("cfg5", 512), ("cfg5_distinct2048", 512)])
+def test_bench_rehearses_the_sharded_configs_on_eight_ranks(config, per_rank):
+    """BASELINE configs 4 and 5 as worded on their 8 ranks without GPUs (--launch-check, gloo): contiguous blocks of 128 / 512 paths,
+    one chunk per GPU, rows gathered in rank order, the size exchange of the curve gather (rank 0 receives 7/8 of the curves)"""
+    r, line = _bench_line(["--gpus", "8", "--launch-check", "--config", config])
+    assert r.returncode == 0, r.stderr[-2000:]
+    total = 8 * per_rank
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["paths_total"] == total and line["gathered_rows"] == total
+    assert line["rows_in_rank_order"] and line["max_over_ranks"] == 8.0
+    assert line["paths_per_rank"] == per_rank and line["chunks_per_rank"] == [per_rank]
+    g = line["curve_gather"]
+    assert len(g["points_per_rank"]) == 8 and min(g["points_per_rank"]) > 0
+    assert abs(g["GB_to_rank0"] / (16e-9 * sum(g["points_per_rank"])) - 7.0 / 8.0) < 0.02

@@ -217,11 +217,15 @@ def test_segment_cursor_never_moves_back_on_every_path_of_a_chunk(hip_ctx, oracl
     for k in range(n_paths):
         n = int(rng.choice([0, 1, 3, 255, 256, 257, 511, 1024, 1500, 4099]))
         raw = np.cumsum(rng.integers(0, 3, n)) - rng.integers(0, 4, n) * (rng.random(n) < 0.3)   # mostly rising, with dips
-        segs.append(np.maximum(raw, 0).astype(np.int32))
+        raw = np.maximum(raw, 0).astype(np.int32)
+        if n >= 3:
+            raw[n // 2] = raw[n // 2 - 1] + 5      # a certain step back on every path: the site after a jump
+            raw[n // 2 + 1] = raw[n // 2 - 1]
+        segs.append(raw)
     if sum(len(x) for x in segs) == 0:
         segs[0] = np.array([3, 1, 2], dtype=np.int32)
     want = [np.maximum.accumulate(x) if len(x) else x for x in segs]
-    assert any(not np.array_equal(w, x) for w, x in zip(want[1:], segs[1:])) or n_paths == 1
+    assert all(len(x) < 3 or not np.array_equal(w, x) for w, x in zip(want, segs))
     for ctx in (hip_ctx, oracle_ctx):
         got = capi.out_segmax_kat(ctx, segs)
         for k in range(n_paths):

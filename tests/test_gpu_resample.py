@@ -177,6 +177,49 @@ def test_resampled_knots_feed_the_hot_path_on_the_device(hip_ctx):
     r.close()
 
 
+@pytest.mark.parametrize("compact", [False, True])
+def test_block_upload_of_paths_that_carry_more_rows_than_the_batch_keeps(hip_ctx, oracle_ctx, compact):
+    """batotp_hip_upload_knots_device_rows: the resampler leaves joint AND Cartesian rows per path, a problem without Cartesian limits
+    keeps the joint rows only -- one call for a ragged block of paths, rows and pairs layout: coefficients / curves / result rows equal
+    to a batch filled path by path from host arrays, and to the oracle's"""
+    name = "synth_gen7dof_s0"
+    c, rc = Case(name), ResampleCase(name)
+    nJ = c.problem.n_joints
+    xs = [rc.x, rc.x[:, : rc.x.shape[1] // 2].copy(), rc.x[:, ::-1].copy()]
+    r = capi.Resampled(hip_ctx, rc.params, xs, [rc.sres_in] * 3)
+    src_rows = r.knots(0).shape[0]
+    assert src_rows > nJ and not r.status.any()
+    prob = capi.Problem.from_buffer_copy(bytes(c.problem))
+    prob.n_cart = 0                                   # (no Cartesian limit: no Cartesian channels are carried)
+    prob.flags |= capi.F_NO_SAMPLES | (capi.F_COMPACT_SPLINES if compact else 0)
+    nk = [int(n) for n in r.n_knots]
+    rows = []
+    for mode in ("block", "per_path", "oracle"):
+        ctx = oracle_ctx if mode == "oracle" else hip_ctx
+        pr = capi.Problem.from_buffer_copy(bytes(prob))
+        if mode == "oracle":
+            pr.flags &= ~capi.F_COMPACT_SPLINES
+        b = capi.Batch(ctx, pr, nk, 4 * c.max_steps())
+        if mode == "block":
+            b.upload_knots_device_rows(0, 3, r.device_ptr(), src_rows, list(r.sres))
+        else:
+            for k in range(3):
+                b.upload_knots(k, [np.ascontiguousarray(r.knots(k)[:nJ])], [float(r.sres[k])])
+        b.optimize()
+        rows.append((b.results(), [b.curve(k, +1) for k in range(3)]))
+        b.close()
+    for other in rows[1:]:
+        assert rows[0][0].tobytes() == other[0].tobytes()
+        for k in range(3):
+            assert_bit_equal(rows[0][1][k][0], other[1][k][0], f"path {k} s")
+            assert_bit_equal(rows[0][1][k][1], other[1][k][1], f"path {k} sdot")
+    # too few source rows, host pointers: refused
+    b = capi.Batch(hip_ctx, prob, nk, 64)
+    with pytest.raises(capi.BatotpError):
+        b.upload_knots_device_rows(0, 3, r.device_ptr(), nJ - 1, list(r.sres))
+    b.close(); r.close()
+
+
 @pytest.mark.parametrize("name", ["synth_cspr_s3", "synth_gen7dof_s0", "synth_ur_s2", "GEN7DOF", "CSPR3DOF", "UR5", "KUKA-LWR-IV", "KUKA_cartacc", "RR", "RR_acc"])
 def test_product_batch_driver_on_gpu(tmp_path, name):
     """batotp_amd/host/_build/batest_batch (BA::optimizeBatch over the HIP library, device resampler and device output

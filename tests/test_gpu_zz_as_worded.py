@@ -104,6 +104,24 @@ def _batch_as_worded(hip_lib, oracle_ctx, config, n_paths, sample, distinct):
             s, sd = b.curve(p, which)
             assert_bit_equal(s, before[0], f"{config} path {p} curve {which} s, fast-forward off")
             assert_bit_equal(sd, before[1], f"{config} path {p} curve {which} sdot, fast-forward off")
+    if prob.flags & capi.F_COMPACT_SPLINES and not (prob.flags & (capi.F_TRQ_ON | capi.F_CART_VEL_ON | capi.F_CART_ACC_ON)):
+        # ... and through the batch kernel of the headline (k_sweep8: 8 lanes per path, 8 paths per wavefront, flat loop) with the
+        # certificate phase of its REVERSE sweep at the automatic hold, at hold 1 and switched off (batotp_hip_set_cert_hold), and with
+        # every fast-forward off: the rows of every path and the sampled curves are those of the one-path-per-wavefront kernel above
+        for cert, ff in ((-1, True), (1, True), (0, True), (-1, False)):
+            ctx.set_fast_forward(ff)
+            ctx.set_sweep_group(8); ctx.set_paths_per_wave(8); ctx.set_sweep_hold(4, 8); ctx.set_cert_hold(cert)
+            b.precompute(0); b.sweep(-1); b.sweep(+1)
+            assert b.last_sweep_launch(-1) == (8, 8, 4) and b.last_sweep_launch(+1) == (8, 8, 8)
+            res3 = b.results()
+            for f in res.dtype.names:
+                assert np.array_equal(res3[f], res[f]), (config, "k_sweep8, certificate hold", cert, "fast-forward", ff, f)
+            for p, (rev, fwd) in kept.items():
+                for which, before in ((-1, rev), (1, fwd)):
+                    s, sd = b.curve(p, which)
+                    assert_bit_equal(s, before[0], f"{config} path {p} curve {which} s, k_sweep8 cert {cert} ff {ff}")
+                    assert_bit_equal(sd, before[1], f"{config} path {p} curve {which} sdot, k_sweep8 cert {cert} ff {ff}")
+        ctx.set_sweep_group(0); ctx.set_paths_per_wave(0); ctx.set_sweep_hold(-2, -2); ctx.set_cert_hold(-1); ctx.set_fast_forward(True)
     b.close()
     if (prob.flags & capi.F_PARALLEL) and (prob.flags & capi.F_PAR2SER):
         # the layout bench.py runs this configuration in -- every channel as (value, second derivative) pairs, one curve buffer per
