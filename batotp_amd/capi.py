@@ -231,6 +231,7 @@ class Library:
             "batotp_hip_set_spline_tiles": [P, I32],
             "batotp_hip_set_fast_forward": [P, I32],
             "batotp_hip_set_cert_hold": [P, I32],
+            "batotp_hip_set_poison": [P, I32],
             "batotp_hip_set_k3_form": [P, I32],
             "batotp_hip_set_path_order": [P, I32],
             "batotp_hip_set_workspace_budget": [P, C.c_int64, C.c_int64],
@@ -287,11 +288,21 @@ class Library:
         return n.value
 
 
+# debug aid for test runs (tests/conftest.py, BATOTP_TEST_POISON=1): every context fills its workspaces with 0xFF bytes before use
+DEFAULT_POISON = False
+
+
 class Context:
     def __init__(self, library: Library, device: int = 0):
         self.library = library
         self.handle = C.c_void_p()
         library.check(library.lib.batotp_hip_ctx_create(device, C.byref(self.handle)), "batotp_hip_ctx_create")
+        if DEFAULT_POISON:
+            self.set_poison(True)
+
+    def set_poison(self, on: bool):
+        """debug aid: workspaces and batch arrays are filled with 0xFF bytes before use (include/batotp_hip.h)"""
+        self.library.check(self.library.lib.batotp_hip_set_poison(self.handle, 1 if on else 0), "set_poison")
 
     def close(self):
         if self.handle:

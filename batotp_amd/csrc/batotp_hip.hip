@@ -122,6 +122,7 @@ struct batotp_ctx
    int flatForm = 1;      // flat loop of the 8-lane layout: 1 = k_sweep8 (sweep8.hip.h), 0 = k_sweep's own flat instantiation (A/B, parity)
    int fastForward = 1;   // certified fast-forward of the bisection in the sweep kernels that have it (bisect_fast_forward)
    int certHold = -1;     // k_sweep8, reverse sweep: hold of the certificate phase (-1 automatic, 0 = no certificate there, 1..8)
+   int poison = 0;        // debug aid (batotp_hip_set_poison): every workspace / batch allocation is filled with 0xFF bytes before use
    int64_t rsBudget = 0, outBudget = 0; // scratch bytes a chunk of the resampler / output stage may take; 0 = from the free memory
    int pathOrder = 1;     // ragged batches: 1 = the sweeps take the paths longest first (SweepArgs::order), 0 = in the order given
    int k3Form = 1;        // per-knot evaluation of velocity / acceleration-only problems: 1 = k_pointwise_va (pointwise_va.hip.h), 0 = the general kernel
@@ -182,6 +183,15 @@ struct batotp_batch
    int lastLanes[2] = {0, 0}, lastPpw[2] = {0, 0}, lastHold[2] = {-1, -1}; // reverse, forward: what the last launch used
 };
 
+// debug aid (batotp_hip_set_poison): memory a stage is about to use is filled with 0xFF bytes -- NaNs as doubles, -1 as integers -- so
+// that a kernel that reads what nobody wrote gives a loud, reproducible wrong answer instead of one that depends on what the memory held
+static int poisonFill(const batotp_ctx *ctx, void *p, size_t bytes, hipStream_t st)
+{
+   if (!ctx->poison || !p || !bytes) return BATOTP_OK;
+   HIP_TRY(hipMemsetAsync(p, 0xFF, bytes, st));
+   return BATOTP_OK;
+}
+
 static int devAlloc(batotp_batch *b, void **p, size_t bytes)
 {
    if (bytes == 0) bytes = 8;
@@ -193,6 +203,11 @@ static int devAlloc(batotp_batch *b, void **p, size_t bytes)
       return BATOTP_ERR_ALLOC;
    }
    b->bytes += (int64_t)bytes;
+   if (b->ctx && b->ctx->poison)
+   {
+      e = hipMemset(*p, 0xFF, bytes);
+      if (e != hipSuccess) return hipFail(e, "hipMemset (poison)");
+   }
    return BATOTP_OK;
 }
 
@@ -414,6 +429,13 @@ extern "C" int batotp_hip_set_fast_forward(batotp_ctx *ctx, int32_t on)
 {
    if (!ctx) return BATOTP_ERR_ARG;
    ctx->fastForward = on != 0 ? 1 : 0;
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_set_poison(batotp_ctx *ctx, int32_t on)
+{
+   if (!ctx) return BATOTP_ERR_ARG;
+   ctx->poison = on ? 1 : 0;
    return BATOTP_OK;
 }
 

@@ -648,10 +648,16 @@ __global__ void __launch_bounds__(S1_BLOCK, ((FEAT == 2 && FF == 0 && PAIRS) || 
 #ifndef S1_FWD_PAIRS_FF
 #define S1_FWD_PAIRS_FF 0
 #endif
+#ifndef S1_FAIL_FF
+#define S1_FAIL_FF 1   // the certificate of a stage whose bisection cannot succeed (0: A/B, the kernels of round 5)
+#endif
       constexpr bool FF0 = FF == 0 && (S1_FWD_PAIRS_FF || !(PAIRS && DIR == 1));
-      bool ffApplies = FF0 && a.ff && !over && !cartAccOn && (FEAT == 2 || accOn);
+      // (round 6) the certificate of a stage that CANNOT succeed -- see below -- is a small part of the block and is compiled into every
+      // instantiation of this form, the forward kernel of a pair batch included
+      constexpr bool FFAIL0 = FF == 0 && (S1_FAIL_FF != 0);
+      bool ffApplies = (FF0 || FFAIL0) && a.ff && !over && !cartAccOn && (FEAT == 2 || accOn);
       if (FEAT == 2) ffApplies = ffApplies && nJ <= 4 && !S1_BALLOT(jv && !(a3pt == 0.0));
-      if (FF0 && ffApplies)
+      if ((FF0 || FFAIL0) && ffApplies)
       {
          // CERTIFIED FAST-FORWARD.  In x = sdot^2 every constraint of the check is an interval [l_q(x), u_q(x)] for sddot with
          //      u_q = au_q - m_q x,   l_q = al_q - m_q x:
@@ -722,6 +728,37 @@ __global__ void __launch_bounds__(S1_BLOCK, ((FEAT == 2 && FF == 0 && PAIRS) || 
          grp_min_max<8>(uMin, lMax);
          const double eMax = grp_max<8>(ej);
          const double sMin2 = .5 * (dmin(uMin, sddotMax) - dmax(lMax, -sddotMax));
+         if (FFAIL0 && S1_UNI(sMin2 < 0.0))
+         {
+            // CERTAIN FAILURE (round 6).  The sddot interval is empty already at x = 0: the path asks for something the limits do not
+            // admit at any speed (random cable-robot paths do: tensions outside [tmin, tmax] at rest).  The reference's
+            // loop (ba.cpp:1267-1321) then halves the speed a hundred times, every check violated, and returns -1 without touching
+            // sddot (:1307-1319; the caller ignores the code, :1091).  Whatever exit ends it -- the iteration count, a collapsed
+            // bracket, a negative speed -- what it leaves is the same: the status bit, the counter, sddot and sdotCur as they were.  So
+            // the hundred checks can be skipped when NO speed in [0, first candidate] can pass one: g(x) = min u - max l is at most the
+            // gap of any ONE pair of lines (i above, j below), (au_i - al_j) - (m_i - m_j) x, which is affine in x -- negative on the
+            // whole interval when it is negative at both ends.  The pair: the lines that bind at x = 0 (ties: the slopes that open the
+            // gap fastest; any tie is a valid witness).  The check's computed bounds are off by at most 4 eps e_q(x), e_q(x) <= e_q of
+            // the first candidate, these line coefficients by a few eps: demanded, at both ends, gap < -2^-40 E (the margin of the
+            // certificate below).  Every candidate of the loop lies in [0, first candidate]: each is violated for certain.
+            const double uB = dmin(uMin, sddotMax), lB = dmax(lMax, -sddotMax);
+            const double mU = (uMin < sddotMax) ? grp_max<8>((valid && au == uMin) ? mj : -kInf) : 0.0;   // (the clamp is a line of slope 0)
+            const double mL = (lMax > -sddotMax) ? grp_min<8>((valid && al == lMax) ? mj : kInf) : 0.0;
+            const double gap0 = uB - lB, gapTop = gap0 - (mU - mL) * xTop;
+            const double tolF = eMax * 0x1p-40;
+            const bool certain = allFinite & (eMax == eMax) & (eMax < 1e100) & (xTop < 1e100) & (sddotMax == sddotMax) & (fabs(mU) < 1e100) & (fabs(mL) < 1e100) &
+                                 (gap0 < -tolF) & (gapTop < -tolF);
+            if (S1_UNI(certain))
+            {
+               status |= BATOTP_ST_BISECT_FAIL;
+               nfail++;
+               BK_TICK(tpf);
+               BK_ACC(cyD, tp2, tpf);
+               return;
+            }
+         }
+         if (FF0)
+         {
          const bool standing = accOn && jv && !use && !(fabs(thD2) < thrA);
          double xForce = kInf;
          if (S1_BALLOT(standing)) xForce = grp_min<8>(standing ? amaxj / fabs(thD2) : kInf);
@@ -830,7 +867,8 @@ __global__ void __launch_bounds__(S1_BLOCK, ((FEAT == 2 && FF == 0 && PAIRS) || 
                return;
             }
          }
-      }
+               }
+}
       if (FEAT == 2 && FF == 1 && a.ff && !over && !cartAccOn)
       {
          // CERTIFIED FAST-FORWARD, general form for serial torque limits (a3 != 0: the KUKA chain's friction, the two-link arm; more

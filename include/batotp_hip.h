@@ -379,6 +379,12 @@ int  batotp_hip_set_fast_forward(batotp_ctx *ctx, int32_t on);
  * check); -1 (default) = automatic (the measured optimum, profiles/r06_a_*).  batotp_hip_set_fast_forward(0) switches it off as
  * well.  Never changes a result (tests/test_gpu_parity.py, tests/test_gpu_fuzz.py, tests/test_gpu_zz_as_worded.py run both). */
 int  batotp_hip_set_cert_hold(batotp_ctx *ctx, int32_t hold);
+/* debug aid: with on != 0 every workspace a stage is about to use (the resampler's and the output stage's scratch and result
+ * arrays, every array of a batch at its creation) is first filled with 0xFF bytes -- NaNs as doubles, -1 as integers -- so that a
+ * kernel that reads memory nobody wrote gives a reproducible wrong (or crashing) result instead of one that depends on what the
+ * memory happened to hold.  tests/ run the GPU suite once with it (BATOTP_TEST_POISON=1 python -m pytest -m gpu); results with and
+ * without it are identical.  Costs a memset per call; off by default. */
+int  batotp_hip_set_poison(batotp_ctx *ctx, int32_t on);
 /* which kernel evaluates the per-knot values (batotp_hip_pointwise_mvc) of velocity / acceleration-only problems: 1 (default)
  * k_pointwise_va, written for that constraint family (shared reciprocals, select-form passes, the certified fast-forward), 0 the
  * general kernel that runs the loop of reference ba.cpp:1267-1321 literally.  Same results bit for bit; the switch exists for

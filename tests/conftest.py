@@ -17,6 +17,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun)")
+    if os.environ.get("BATOTP_TEST_POISON") == "1":
+        # debug run: every context of the suite poisons its workspaces and batch arrays before use (batotp_hip_set_poison): a kernel
+        # that reads memory nobody wrote then fails a parity test instead of depending on what the memory held
+        from batotp_amd import capi
+        capi.DEFAULT_POISON = True
 
 
 def _ensure_oracle_built():

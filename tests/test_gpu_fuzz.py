@@ -270,6 +270,69 @@ def test_random_cable_robot_problems(hip_lib, oracle_ctx, seed, par2ser):
 
 
 @pytest.mark.parametrize("seed", range(4 * _SCALE))
+def test_cable_robot_paths_the_tension_limits_do_not_admit(hip_lib, oracle_ctx, seed):
+    """the cable robot in serial form on paths that leave the region where the tensions can stay inside [tmin, tmax]: there every
+    stage's bisection fails -- the reference halves the speed a hundred times, returns -1 without touching sddot and integrates on
+    (ba.cpp:1307-1319, :1091).  k_sweep1 certifies such a stage (no speed in [0, first candidate] can pass a check: sweep1.hip.h) and
+    skips the hundred checks.  Rows incl. the failure counts, curves and pointwise values against the oracle: fast-forward on / off,
+    coefficient rows and every channel as pairs, one and two paths per wavefront; the paths crawl, so some end by capacity"""
+    import helpers
+    rng = np.random.default_rng(9500 + seed)
+    base = helpers.Case("synth_cspr_s3").problem
+    prob = capi.Problem.from_buffer_copy(bytes(base))
+    prob.flags = capi.F_TRQ_ON | capi.F_PARALLEL | capi.F_PAR2SER | capi.F_JNT_ACC_ON | (capi.F_CART_VEL_ON if seed % 2 else 0)
+    for j in range(3):
+        prob.jnt_vel_max[j] = float(rng.uniform(2, 6)); prob.jnt_acc_max[j] = float(rng.uniform(4, 12))
+        prob.jnt_trq_max[j] = float(rng.uniform(8, 12)); prob.jnt_trq_min[j] = float(rng.uniform(1.0, 2.5))   # a narrow band
+    prob.cart_vel_max = float(rng.uniform(2, 5))
+    pm = np.array(list(prob.pmat)).reshape(3, 3)
+    ys, sres = [], []
+    for k in range(5):
+        n = int(rng.integers(60, 400))
+        t = np.linspace(0, 1, n)
+        # the platform wanders towards the edge of the anchor triangle and low under it, where one cable must go slack
+        amp = (1.0, 1.4, 1.8, 2.1, 2.4)[k]
+        cart = np.stack([amp * np.sin(2 * np.pi * t * rng.uniform(0.3, 1.2) + rng.uniform(0, 6)),
+                         amp * np.cos(2 * np.pi * t * rng.uniform(0.3, 1.2) + rng.uniform(0, 6)) + 0.4,
+                         3.0 + 0.8 * np.sin(2 * np.pi * t * rng.uniform(0.2, 1.0) + rng.uniform(0, 6))])
+        theta = np.stack([np.sqrt(((cart - pm[:, q:q + 1]) ** 2).sum(axis=0)) for q in range(3)])
+        ys.append(np.ascontiguousarray(np.vstack([theta, cart])))
+        sres.append(float(rng.uniform(0.005, 0.03)))
+
+    def run(c, pr):
+        b = capi.Batch(c, pr, [y.shape[1] for y in ys], 3000)
+        for k, y in enumerate(ys):
+            b.upload_knots(k, [y], [sres[k]])
+        b.precompute(0); b.pointwise_mvc()
+        mv = [np.stack(b.mvc(k)) for k in range(len(ys))]
+        b.sweep(-1); b.sweep(+1)
+        res = b.results()
+        cur = [(b.curve(k, -1), b.curve(k, +1)) if not ((res[k]["status_rev"] | res[k]["status_fwd"]) & ~np.uint32(capi.ST_BISECT_FAIL)) else None
+               for k in range(len(ys))]
+        b.close()
+        return res, cur, mv
+
+    ro, co, mo = run(oracle_ctx, prob)
+    fails = int(ro["n_bisect_fail_rev"].sum() + ro["n_bisect_fail_fwd"].sum())
+    assert fails > 1000, f"seed {seed}: the problem is meant to fail many bisections ({fails})"
+    pairs = capi.Problem.from_buffer_copy(bytes(prob))
+    pairs.flags |= capi.F_NO_SAMPLES | capi.F_COMPACT_SPLINES
+    for lanes, pr in ((64, prob), ("64noff", prob), (64, pairs), ("64x2", pairs), ("64noff", pairs), (0, prob)):
+        ctx = capi.Context(hip_lib, 0)
+        set_layout(ctx, lanes)
+        rh, ch, mh = run(ctx, pr)
+        for f in rh.dtype.names:
+            assert np.array_equal(rh[f], ro[f]), (seed, lanes, f, rh[f], ro[f])
+        for k in range(len(ys)):
+            assert_bit_equal(mh[k], mo[k], f"seed {seed} {lanes} path {k} pointwise")
+            if co[k] is not None:
+                for which in (0, 1):
+                    assert_bit_equal(ch[k][which][0], co[k][which][0], f"seed {seed} {lanes} path {k} curve {which} s")
+                    assert_bit_equal(ch[k][which][1], co[k][which][1], f"seed {seed} {lanes} path {k} curve {which} sdot")
+        ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(4 * _SCALE))
 def test_random_cartesian_constraint_problems(hip_lib, oracle_ctx, seed):
     """joint limits plus Cartesian speed and / or acceleration limits (solveQuadratic branch), random Cartesian channels"""
     rng = np.random.default_rng(7000 + seed)

@@ -22,9 +22,8 @@ pytestmark = pytest.mark.gpu
 
 def _batch_as_worded(hip_lib, oracle_ctx, config, n_paths, sample, distinct):
     """a BASELINE batch configuration as bench.py builds it (distinct seeded paths, taught points -> knots by the device
-    resampler): size-independent properties for every path; for about 200 of the distinct paths (all of a smaller set) the
-    knots bit-equal to the ORACLE resampler's and the result rows equal to the oracle's (fed by the oracle's resampler); curves
-    for a sample"""
+    resampler): size-independent properties for every path; for EVERY distinct path the knots bit-equal to the ORACLE
+    resampler's and the result rows equal to the oracle's (fed by the oracle's resampler); curves for a sample"""
     import bench
     ctx = capi.Context(hip_lib, 0)
     c = bench.CONFIGS[config]
@@ -44,13 +43,23 @@ def _batch_as_worded(hip_lib, oracle_ctx, config, n_paths, sample, distinct):
     # them must be equal -- in particular the set of paths that end with an error status (cable tensions the limits do not
     # admit: the reference grinds through such a path and returns -1) is exactly the oracle's, not "at most 3 %"
     import hashlib
-    # The oracle chain for a subset of the distinct paths -- every path of a small set, every `stride`-th of a large one plus the
-    # sampled ones: the driver gives the whole GPU suite 20 minutes, and a path costs the CPU about a second (resampling in a
-    # process of its own + both sweeps).  Which paths are checked does not depend on any result.
-    stride = max(1, K // 192)
-    checked = sorted(set(range(0, K, stride)) | {p % K for p in sample})
-    with cf.ThreadPoolExecutor(max_workers=min(len(checked), os.cpu_count() or 1, 64)) as ex:
-        hosts = dict(zip(checked, ex.map(inp.oracle_knots, checked)))      # CPU only: no device call in the checker's chain
+    # The oracle chain for EVERY distinct path (round 6; round 5 checked every fifth path of cfg 4): the oracle's resampler runs in this
+    # process over all host threads (oracle/abi_shim.c: OpenMP over the paths of a batch) instead of a dump_knots process per path, and so
+    # do its precompute and sweeps below.  Independent of the device from the taught points on.
+    checked = list(range(K))
+    hosts = {}
+    if inp.on_device:
+        step = 256
+        for k0 in range(0, K, step):
+            ks = checked[k0:k0 + step]
+            ors = capi.Resampled(oracle_ctx, inp.prm, [bench.widen(c["workload"], inp.taught[k]) for k in ks], [inp.sres_in] * len(ks))
+            assert not np.any(ors.status), (config, "oracle resampler status")
+            for i, k in enumerate(ks):
+                hosts[k] = (np.ascontiguousarray(ors.knots(i)[: inp.keep]), float(ors.sres[i]))
+            ors.close()
+    else:
+        with cf.ThreadPoolExecutor(max_workers=min(len(checked), os.cpu_count() or 1, 64)) as ex:
+            hosts = dict(zip(checked, ex.map(inp.oracle_knots, checked)))      # CPU only: no device call in the checker's chain
     # resampling at BASELINE size, device against oracle: the knots the batch holds, bit for bit
     digs = inp.device_knot_digests(K)
     for k in checked:
