@@ -248,6 +248,7 @@ class Library:
             "batotp_hip_resampled_knots_device": [P, C.POINTER(P), C.POINTER(C.c_int64)],
             "batotp_hip_resampled_download": [P, I32, D],
             "batotp_hip_resampled_ms": [P, C.POINTER(C.c_float)],
+            "batotp_hip_resampled_checksums": [P, C.POINTER(C.c_uint64)],
             "batotp_hip_output": [P, C.POINTER(OutputParams), I32, I32, C.POINTER(P)],
             "batotp_hip_output_destroy": [P],
             "batotp_hip_out_segmax_kat": [P, I32, C.POINTER(I32), C.POINTER(I32)],
@@ -434,6 +435,12 @@ class Resampled:
         v = C.c_float(0)
         self.L.check(self.lib.batotp_hip_resampled_ms(self.handle, C.byref(v)), "resampled_ms")
         return float(v.value)
+
+    def checksums(self) -> np.ndarray:
+        """order-independent 64-bit checksum of every path's knots, computed where the knots are (include/batotp_hip.h)"""
+        out = np.zeros(self.n_paths, dtype=np.uint64)
+        self.L.check(self.lib.batotp_hip_resampled_checksums(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint64))), "resampled_checksums")
+        return out
 
 
 class Output:

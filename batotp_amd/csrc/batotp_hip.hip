@@ -205,7 +205,10 @@ static int devAlloc(batotp_batch *b, void **p, size_t bytes)
    b->bytes += (int64_t)bytes;
    if (b->ctx && b->ctx->poison)
    {
-      e = hipMemset(*p, 0xFF, bytes);
+      // on the context's stream, and complete before anything else touches the allocation (a fill on the null stream is not ordered
+      // against the context's non-blocking stream: the first poison build "found" upload kernels racing with its own fill)
+      e = hipMemsetAsync(*p, 0xFF, bytes, b->ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(b->ctx->stream);
       if (e != hipSuccess) return hipFail(e, "hipMemset (poison)");
    }
    return BATOTP_OK;

@@ -925,4 +925,32 @@ __global__ void k_rs_zero_cart(RsParams P, const RsPath *__restrict__ paths, int
    for (int c = 0; c < P.nC; ++c) o[(int64_t)(P.nJ + c) * n + i] = 0.0;
 }
 
+// Order-independent 64-bit checksum of a path's knots (batotp_hip_resampled_checksums): the wrap-around sum over all values of
+// mix(bits of the value XOR a multiple of its index) -- addition commutes, so every decomposition gives the same number (the CPU
+// checker computes it serially: tests compare the two).  One block column per path (blockIdx.y), a grid-stride loop, one atomic add
+// per wavefront.
+__device__ __forceinline__ unsigned long long rs_mix64(unsigned long long x)
+{
+   x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+   x ^= x >> 27; x *= 0x94D049BB133111EBull;
+   x ^= x >> 31;
+   return x;
+}
+__global__ void k_rs_checksum(const int64_t *__restrict__ off, const int64_t *__restrict__ n, int C, const double *__restrict__ y,
+                              unsigned long long *__restrict__ out)
+{
+   const int p = blockIdx.y;
+   const int64_t total = n[p] * C;
+   const unsigned long long *__restrict__ v = reinterpret_cast<const unsigned long long *>(y + off[p] * C);
+   unsigned long long h = 0;
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+      h += rs_mix64(v[i] ^ ((unsigned long long)(i + 1) * 0x9E3779B97F4A7C15ull));
+   for (int o = 32; o; o >>= 1)
+   {
+      const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)h, o), hi = (unsigned)__shfl_xor((int)(unsigned)(h >> 32), o);
+      h += ((unsigned long long)hi << 32) | lo;
+   }
+   if ((threadIdx.x & 63) == 0 && h) atomicAdd(out + p, h);
+}
+
 } // namespace bk

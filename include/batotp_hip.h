@@ -486,6 +486,12 @@ int  batotp_hip_resampled_knots_device(batotp_resampled *r, const double **y_dev
 /* knots of one path to the host: y[n_joints + n_cart][n_knots] */
 int  batotp_hip_resampled_download(batotp_resampled *r, int32_t path, double *y);
 /* milliseconds the resampling kernels of this object took (HIP events on the context's stream) */
+/* an order-independent 64-bit checksum per path of the knots as they lie in HBM (0 for a path with a non-zero status): the wrap-around
+ * sum over the values of mix64(bits XOR (index + 1) * 0x9E3779B97F4A7C15), mix64 = the splitmix64 finaliser.  What it is for: the host
+ * library evaluates batotp_hip_resample TWICE for every call of BA::interpInputData / BA::optimizeBatch and uses the knots only when
+ * counts, spacings, status words and these sums agree (one unexplained wrong result in ~11 000 one-path calls of
+ * round 4) -- a many-path batch is compared in HBM, 8 bytes per path cross PCIe. */
+int  batotp_hip_resampled_checksums(batotp_resampled *r, uint64_t *sums);
 int  batotp_hip_resampled_ms(batotp_resampled *r, float *ms);
 
 /* ---- output stage behind the hot path ------------------------------------ */

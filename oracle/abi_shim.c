@@ -516,6 +516,32 @@ int batotp_hip_resampled_destroy(batotp_resampled *r)
     return BATOTP_OK;
 }
 
+/* TEST INFRASTRUCTURE: fault injection for the host library's "evaluate twice" guard (BA::interpInputData, BA::optimizeBatch).
+ * BATOTP_SHIM_RESAMPLE_FAULT = comma-separated call numbers (1-based, per process): those calls of batotp_hip_resample return knots with
+ * one value of the last path moved by one ulp and status 0 -- what the unexplained event of round 4 looked like from outside. */
+static void shim_inject_resample_fault(batotp_resampled *r, int64_t total)
+{
+    static int calls = 0;
+    const char *env = getenv("BATOTP_SHIM_RESAMPLE_FAULT");
+    int me;
+#pragma omp atomic capture
+    me = ++calls;
+    if (!env || total < 1) return;
+    while (*env) {
+        char *end;
+        const long k = strtol(env, &end, 10);
+        if (end == env) break;
+        if (k == me) {
+            const int p = r->n_paths - 1;
+            if (r->n[p] > 0 && !r->status[p]) {
+                double *v = r->y + r->off[p] * r->C + (r->n[p] * r->C) / 2;
+                *v = nextafter(*v, 1e300);
+            }
+        }
+        env = (*end == ',') ? end + 1 : end;
+    }
+}
+
 int batotp_hip_resample(batotp_ctx *ctx, const batotp_resample_params *prm, int32_t n_paths, const int64_t *n_in, const double *x,
                         const double *sres_in, batotp_resampled **out)
 {
@@ -562,6 +588,7 @@ int batotp_hip_resample(batotp_ctx *ctx, const batotp_resample_params *prm, int3
         free(ys[p]);
     }
     free(ys); free(xoff);
+    shim_inject_resample_fault(r, total);
     *out = r;
     return BATOTP_OK;
 }
@@ -602,6 +629,32 @@ int batotp_hip_resampled_download(batotp_resampled *r, int32_t path, double *y)
 {
     if (!r || !y || path < 0 || path >= r->n_paths) return BATOTP_ERR_ARG;
     memcpy(y, r->y + r->off[path] * r->C, sizeof(double) * (size_t)r->n[path] * r->C);
+    return BATOTP_OK;
+}
+
+static uint64_t shim_mix64(uint64_t x)
+{
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+int batotp_hip_resampled_checksums(batotp_resampled *r, uint64_t *sums)
+{
+    int32_t p;
+    if (!r || !sums) return BATOTP_ERR_ARG;
+    for (p = 0; p < r->n_paths; p++) {
+        const int64_t total = r->status[p] ? 0 : r->n[p] * r->C;
+        const double *y = r->y + r->off[p] * r->C;
+        uint64_t h = 0;
+        int64_t i;
+        for (i = 0; i < total; i++) {
+            uint64_t bits;
+            memcpy(&bits, y + i, sizeof(bits));
+            h += shim_mix64(bits ^ ((uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull));
+        }
+        sums[p] = h;
+    }
     return BATOTP_OK;
 }
 

@@ -190,3 +190,35 @@ def test_configurations_the_device_resampler_refuses(tmp_path, oracle_lib, what)
         assert r.returncode != 0, (what, tool, r.stdout[-1500:])
         assert "not covered by the device resampler" in r.stdout, (what, tool, r.stdout[-1500:])
         assert not os.path.exists(tmp_path / "traj_out.dat")
+
+
+@pytest.mark.parametrize("driver, copies", [("batest_oracle", None), ("batest_batch_oracle", "3")])
+def test_resampler_results_are_used_only_when_two_evaluations_agree(tmp_path, oracle_lib, driver, copies):
+    """BA::interpInputData and BA::optimizeBatch evaluate the resampler twice and compare (knots bit for bit resp. their checksums).
+    With a fault injected into the checker's resampler (BATOTP_SHIM_RESAMPLE_FAULT: the named calls return knots with one value moved
+    by an ulp and status 0 -- what round 4's unexplained event looked like): a single bad evaluation is reported, the path is evaluated
+    again and the files are the reference's; when no two consecutive evaluations agree the result is refused"""
+    src = os.path.join(helpers.GOLD, "synth_gen7dof_s0")
+    cmd = [os.path.join(helpers.BUILD, driver), "config.dat"] + ([copies] if copies else [])
+    outs = ("out_first", "out_last") if copies else (".",)
+    # (evaluations are compared in consecutive pairs, four at most: "1" -> 2 and 3 agree; "2" -> 3 and 4 agree; "1,3" and "2,4" -> good and
+    #  bad evaluations alternate, no pair agrees)
+    for fault in ("", "1", "2", "1,3", "2,4"):
+        work = tmp_path / f"run_{fault.replace(',', '_') or 'clean'}"
+        work.mkdir()
+        _stage(src, work)
+        env = dict(os.environ)
+        env["BATOTP_SHIM_RESAMPLE_FAULT"] = fault
+        r = subprocess.run(cmd, cwd=work, capture_output=True, text=True, env=env)
+        good = fault in ("", "1", "2")
+        assert (r.returncode == 0) == good, (fault, r.stdout[-2000:])
+        if fault:
+            assert "disagree" in r.stdout, (fault, r.stdout[-2000:])
+        else:
+            assert "disagree" not in r.stdout
+        if good:
+            for d in outs:
+                assert filecmp.cmp(work / d / "s-sdot.dat", os.path.join(src, "ref_s-sdot.dat"), shallow=False), fault
+                assert filecmp.cmp(work / d / "traj_out.dat", os.path.join(src, "ref_traj_out.dat"), shallow=False), fault
+        else:
+            assert "no two consecutive evaluations" in r.stdout, (fault, r.stdout[-2000:])

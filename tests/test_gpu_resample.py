@@ -177,6 +177,31 @@ def test_resampled_knots_feed_the_hot_path_on_the_device(hip_ctx):
     r.close()
 
 
+def test_knot_checksums_computed_in_hbm_equal_the_checkers(hip_ctx, oracle_ctx):
+    """batotp_hip_resampled_checksums: the per-path sums the host library compares between its two evaluations of the resampler,
+    computed on the device by k_rs_checksum (grid-stride, one atomic add per wavefront) against the checker's serial sums -- ragged batch
+    incl. a path that ends with a status (sum 0) and BASELINE-size paths"""
+    c = ResampleCase("synth_gen7dof_s0")
+    same = c.x.copy(); same[:, :] = same[:, :1]
+    big = [helpers_big_gen7(s) for s in (1, 2)]
+    xs = [c.x, c.x[:, : c.x.shape[1] // 2].copy(), same, c.x[:, ::-1].copy()] + big
+    sr = [c.sres_in] * len(xs)
+    h = capi.Resampled(hip_ctx, c.params, xs, sr)
+    o = capi.Resampled(oracle_ctx, c.params, xs, sr)
+    _same(h, o, "checksum batch")
+    hs, os_ = h.checksums(), o.checksums()
+    assert np.array_equal(hs, os_), (hs, os_)
+    assert int(hs[2]) == 0 and int(h.status[2]) != 0 and len(set(int(v) for v in hs)) == len(xs)
+    h.close(); o.close()
+
+
+def helpers_big_gen7(seed):
+    """taught points of a GEN7DOF path of ~5e4 knots (bench.py's generator), widened to the resampler's rows"""
+    import bench
+    taught, _ = bench.taught_points_f32("gen7", [seed], 50000)
+    return bench.widen("gen7", taught[0])
+
+
 @pytest.mark.parametrize("compact", [False, True])
 def test_block_upload_of_paths_that_carry_more_rows_than_the_batch_keeps(hip_ctx, oracle_ctx, compact):
     """batotp_hip_upload_knots_device_rows: the resampler leaves joint AND Cartesian rows per path, a problem without Cartesian limits

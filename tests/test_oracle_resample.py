@@ -95,3 +95,25 @@ def test_automatic_integration_resolution(octx, name):
     assert float(r.sres[0]) == float(z["sres"]) and int(r.n_knots[0]) == z["y"].shape[1]
     assert r.knots(0).tobytes() == np.ascontiguousarray(z["y"]).tobytes()
     r.close()
+
+
+def test_knot_checksums_are_the_sums_the_header_describes(oracle_ctx):
+    """batotp_hip_resampled_checksums (include/batotp_hip.h): per path the wrap-around sum of splitmix64-finalised (bits XOR (index + 1) *
+    golden ratio) over the knot values as they lie in memory; 0 for a path with a non-zero status"""
+    c = ResampleCase("synth_gen7dof_s0")
+    same = c.x.copy(); same[:, :] = same[:, :1]          # all points identical: the resampler reports a status
+    r = capi.Resampled(oracle_ctx, c.params, [c.x, c.x[:, : c.x.shape[1] // 2].copy(), same], [c.sres_in] * 3)
+    sums = r.checksums()
+    assert int(r.status[2]) != 0 and int(sums[2]) == 0
+
+    def mix(x):
+        x = x ^ (x >> np.uint64(30)); x = x * np.uint64(0xBF58476D1CE4E5B9)
+        x = x ^ (x >> np.uint64(27)); x = x * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+    with np.errstate(over="ignore"):
+        for k in range(2):
+            bits = np.ascontiguousarray(r.knots(k)).reshape(-1).view(np.uint64)
+            idx = (np.arange(bits.size, dtype=np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+            assert int(mix(bits ^ idx).sum(dtype=np.uint64)) == int(sums[k]), k
+    assert int(sums[0]) != int(sums[1])
+    r.close()
