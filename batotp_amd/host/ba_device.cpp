@@ -231,10 +231,11 @@ int BA::exportResampleParams(const Traj &traj, void *out) const
    // JOINT paths of the robots with forward kinematics (reference robot.cpp:73-96): the tool point is recomputed after
    // each resampling pass; its cos / sin come from the host libm (bit parity with the host resampler and the reference)
    const bool kin = _pathType == JOINT && _nCart == 3 && ((_robotType == KUKA && _nJoints == 7) || (_robotType == RR && _nJoints == 2));
-   // joints and tool poses taught together (the UR5 example): 6 pose rows, orientations as axis-angle -> quaternions
-   // (BA::aa2qVect, reference ba.cpp:327-369; sine / cosine of the half angle from the host libm)
-   const bool both = _pathType == BOTH && _nCart == 6;
-   if (kin || both) R.flags |= BATOTP_F_HOST_TRIG;
+   // joints and Cartesian rows taught together (reference ba.cpp:184-192, 245-262: both channel sets are resampled as taught).  Six
+   // Cartesian rows are tool poses (the UR5 example): orientations as axis-angle -> quaternions (BA::aa2qVect, ba.cpp:327-369; sine /
+   // cosine of the half angle from the host libm); any other count (tool positions without orientations) goes through unchanged
+   const bool both = _pathType == BOTH;
+   if (kin || (both && _nCart == 6)) R.flags |= BATOTP_F_HOST_TRIG;
    return (joint || cable || kin || both) ? 0 : -1;
 }
 
@@ -376,9 +377,9 @@ int BA::exportOutputParams(void *out) const
    // two-link arm's closed form or the chain model
    const bool kinRobot = _pathType == JOINT && _nCart == 3 && ((_robotType == KUKA && _nJoints == 7) || (_robotType == RR && _nJoints == 2));
    const bool kin = kinRobot && (!_isTrqConOn || (!_isParallelMechOrig && (_robotType == RR || const_cast<Robot &>(myRobot).serialModel() != nullptr)));
-   // joints and poses together: the pose rows are quaternions during the run (_nCart == 7) and leave as axis-angle
-   // (BA::q2aaVect, ba.cpp:384-403)
-   const bool both = _pathType == BOTH && (_nCart == 7 || _nCart == 6) && !_isTrqConOn;
+   // joints and Cartesian rows together (ba.cpp:1726-1736: the Cartesian rows are evaluated like the joints); pose rows are quaternions
+   // during the run (_nCart == 7) and leave as axis-angle (BA::q2aaVect, ba.cpp:384-403)
+   const bool both = _pathType == BOTH && _nCart >= 3 && _nCart <= BATOTP_MAX_CART && !_isTrqConOn;
    return (joint || cable || kin || both) ? 0 : -1;
 }
 

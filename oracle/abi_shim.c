@@ -719,10 +719,11 @@ int batotp_hip_output(batotp_batch *b, const batotp_output_params *prm, int32_t 
         const int serialTrq = jointPath && (b->prob.flags & BATOTP_F_TRQ_ON) && !(b->prob.flags & BATOTP_F_PARALLEL) &&
                               (b->has_serial || b->prob.robot_type == BATOTP_ROBOT_RR);
         const int joint = jointPath && (!(b->prob.flags & BATOTP_F_TRQ_ON) || serialTrq);
-        const int both = prm->path_type == BATOTP_PATH_BOTH && b->prob.n_cart == 7 && !(b->prob.flags & BATOTP_F_TRQ_ON);
+        const int both = prm->path_type == BATOTP_PATH_BOTH && b->prob.n_cart >= 3 && !(b->prob.flags & BATOTP_F_TRQ_ON);
+        const int pose = both && b->prob.n_cart == 7;
         if (!cable && !joint && !both) return BATOTP_ERR_ARG;
         o = (batotp_output *)calloc(1, sizeof(*o));
-        o->nTheta = prm->n_joints; o->nCart = cable ? 3 : (both ? 6 : (kin ? 3 : 0)); o->nTrq = cable ? 3 : (serialTrq ? prm->n_joints : 0);
+        o->nTheta = prm->n_joints; o->nCart = cable ? 3 : (pose ? 6 : (both ? b->prob.n_cart : (kin ? 3 : 0))); o->nTrq = cable ? 3 : (serialTrq ? prm->n_joints : 0);
     }
     o->n_paths = n_paths; o->nJ = o->nTheta + o->nCart + o->nTrq;
     o->n = (int64_t *)calloc((size_t)n_paths, sizeof(int64_t));

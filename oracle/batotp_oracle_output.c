@@ -103,11 +103,13 @@ int bo_output(const batotp_problem *prob, const batotp_output_params *prm, const
     const int serialTrq = jointPath && (prob->flags & BATOTP_F_TRQ_ON) && !(prob->flags & BATOTP_F_PARALLEL) &&
                           (p->serial != NULL || prob->robot_type == BATOTP_ROBOT_RR) && nJ == p->n_theta;
     const int joint = jointPath && (!(prob->flags & BATOTP_F_TRQ_ON) || serialTrq);
-    /* joints and tool poses taught together (path type BOTH, the UR5 example): 7 Cartesian rows (position + quaternion) are
-     * evaluated like the joints and turned back into axis-angle at the very end (ba.cpp:1709-1742, 1920-1927) */
-    const int both = prm->path_type == BATOTP_PATH_BOTH && p->n_cart == 7 && !(prob->flags & BATOTP_F_TRQ_ON);
+    /* joints and Cartesian rows taught together (path type BOTH): the Cartesian rows are evaluated like the joints (ba.cpp:1726-1736);
+     * seven of them are position + quaternion (the UR5 example after aa2qVect) and are turned back into axis-angle at the very end
+     * (ba.cpp:1920-1927) */
+    const int both = prm->path_type == BATOTP_PATH_BOTH && p->n_cart >= 3 && !(prob->flags & BATOTP_F_TRQ_ON);
+    const int pose = both && p->n_cart == 7;
     if (nJ < 1 || nJ > p->n_theta || n_fwd < 4 || (!cable && !joint && !both)) return -1;
-    const int nC = cable ? 3 : (both ? 7 : (kin ? 3 : 0)), nT = cable ? 3 : (serialTrq ? nJ : 0), C = nJ + nC + nT;
+    const int nC = cable ? 3 : (both ? p->n_cart : (kin ? 3 : 0)), nT = cable ? 3 : (serialTrq ? nJ : 0), C = nJ + nC + nT;
     double outRes = prm->out_res, smoothFact = prm->out_smooth_fact;
     const double outResUser = outRes;
     int reinterp = 0;
@@ -263,7 +265,7 @@ int bo_output(const batotp_problem *prob, const batotp_output_params *prm, const
         outRes = outResUser;
     }
     int nCout = nC;
-    if (both) {
+    if (pose) {
         /* BA::q2aaVect (ba.cpp:384-403): rows nJ+3 .. nJ+6 (quaternion) -> nJ+3 .. nJ+5 (axis-angle), the seventh row goes */
         bo_q2aa_rows(x + (size_t)(nJ + 3) * n, n, n);
         nCout = 6;

@@ -391,12 +391,15 @@ int bo_resample_auto(const bo_resample_params *prm, int64_t n_in, const double *
     /* JOINT path of a robot with forward kinematics (KUKA, RR): SURVEY.md 8 f-3 */
     const int kin = prm->path_type == BATOTP_PATH_JOINT && bo_fwdkin_trig_rows(prm->robot_type, prm->n_joints) != 0;
     const int cartOn = (prm->flags & (BATOTP_F_CART_VEL_ON | BATOTP_F_CART_ACC_ON)) != 0;
-    /* joints and tool poses taught together (the UR5 example): 6 pose rows in, 7 out (quaternions), nothing recomputed */
-    const int both = prm->path_type == BATOTP_PATH_BOTH && prm->n_cart == 6;
+    /* joints and Cartesian rows taught together (ba.cpp:184-192, 245-262: nothing is recomputed, both channel sets are resampled as
+     * taught).  With 6 Cartesian rows they are tool poses (the UR5 example): 6 rows in, 7 out (aa2qVect: quaternions); any other count
+     * (tool positions without orientations, ...) goes through unchanged */
+    const int both = prm->path_type == BATOTP_PATH_BOTH;
+    const int pose = both && prm->n_cart == 6;
     if ((!joint && !cable && !kin && !both) || n_in < 4 || prm->n_cart < 3) return -1;
     if (prm->s_weights[1] + prm->s_weights[2] < 1e-8) return -1; /* ba.cpp:416: nothing to do */
     rs_traj t;
-    t.nJ = prm->n_joints; t.nC = prm->n_cart + (both ? 1 : 0); t.C = t.nJ + t.nC; t.n = n_in; t.sres = sres_in;
+    t.nJ = prm->n_joints; t.nC = prm->n_cart + (pose ? 1 : 0); t.C = t.nJ + t.nC; t.n = n_in; t.sres = sres_in;
     t.x = (double *)calloc((size_t)n_in * t.C, sizeof(double));
     memcpy(t.x, x, sizeof(double) * (size_t)n_in * (t.nJ + prm->n_cart));
     if (joint) memset(t.x + (size_t)t.nJ * n_in, 0, sizeof(double) * (size_t)t.nC * n_in); /* ba.cpp:258-262 */
@@ -405,7 +408,7 @@ int bo_resample_auto(const bo_resample_params *prm, int64_t n_in, const double *
     else rs_rem_close(&t, 0, t.nJ, prm->jnt_thresh);
     if (t.n < 2) st |= BATOTP_RS_TOO_SHORT; /* "less than one site after remClosePts", ba.cpp:176-181 */
     else if (t.n < 4) rs_stretch_to_four(&t); /* ba.cpp:182-183 */
-    if (!st && both) bo_aa2q_rows(t.x + (size_t)(t.nJ + 3) * t.n, t.n, t.n); /* ba.cpp:186-193 */
+    if (!st && pose) bo_aa2q_rows(t.x + (size_t)(t.nJ + 3) * t.n, t.n, t.n); /* ba.cpp:186-193 */
     if (!st && (prm->input_decim_fact > 1 || prm->smooth_window > 1)) {
         /* driving rows: joints (JOINT), Cartesian rows (CART), both sets (BOTH), ba.cpp:197-241 */
         rs_decimate_smooth(&t, cable ? t.nJ : 0, cable ? t.nC : (both ? t.C : t.nJ), prm->input_decim_fact > 1 ? prm->input_decim_fact : 1, prm->smooth_window);

@@ -59,6 +59,18 @@ def shipped(robot_dir: str, subs=None):
     return build
 
 
+def shipped_ur5_positions_only():
+    """the shipped UR5 example (joints and tool poses taught together, path type BOTH) with the three position columns only:
+    nCart = 3, no orientations -- the reference then skips aa2qVect / q2aaVect and resamples both channel sets as taught
+    (ba.cpp:184-192, 245-262, 1726-1736, 1922)"""
+    def build(work):
+        src = os.path.join(REF, "input", "UR5")
+        rows = [", ".join(x.strip() for x in line.split(",")[:10]) for line in open(os.path.join(src, "trajUR.csv")).read().splitlines()]
+        open(os.path.join(work, "trajUR.csv"), "w").write("\n".join(rows) + "\n")      # timestamp, j1..j6, x, y, z
+        edit_config(os.path.join(src, "config.dat"), os.path.join(work, "config.dat"), {"nCart": 3})
+    return build
+
+
 def with_repeats(x, every):
     """repeat every `every`-th taught point and the last one (remClosePts has to drop them again; the repeated last
     point takes its tail rule)"""
@@ -125,6 +137,7 @@ CASES = {
     "CSPR3DOF_par": (shipped("CSPR3DOF", {"isPar2Ser": 0}), True),          # parallel-mechanism torque branch (LU solves)
     "RR_acc": (shipped("RR", {"isJntAccConOn": 1, "JntAccLims": "900 900"}), True),  # torque + joint accel
     "UR5_nocartacc": (shipped("UR5", {"isCartAccConOn": 0}), True),
+    "UR5_pos3": (shipped_ur5_positions_only(), True),                        # BOTH path with nCart = 3: positions without orientations
     "KUKA_cartacc": (shipped("KUKA-LWR-IV", {"isCartAccConOn": 1, "CartAccMax": 2.0}), True),
     # solveLinSys through Eigen's Jacobi SVD (util.cpp:421-438): per-knot conversion (isPar2Ser = 1) / every constraint check (0)
     "CSPR3DOF_svd": (shipped("CSPR3DOF", {"isSVD": 1}), True),

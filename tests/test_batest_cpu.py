@@ -30,7 +30,7 @@ def _stage(src, dst):
             shutil.copy(os.path.join(src, f), dst / f)
 
 
-@pytest.mark.parametrize("name", ["synth_cspr_s3", "synth_gen7dof_s1_vel", "synth_ur_s2", "GEN7DOF", "UR5", "RR", "RR_acc", "KUKA-LWR-IV", "KUKA_cartacc",
+@pytest.mark.parametrize("name", ["synth_cspr_s3", "synth_gen7dof_s1_vel", "synth_ur_s2", "GEN7DOF", "UR5", "UR5_pos3", "RR", "RR_acc", "KUKA-LWR-IV", "KUKA_cartacc",
                                   "CSPR3DOF", "CSPR3DOF_svd", "synth_gen7dof_s10_decim", "synth_cspr_s9_dup"])
 def test_batch_driver_files_equal_reference(tmp_path, oracle_lib, name):
     """BA::optimizeBatch (the many-path extension) writes, for every copy of the path, the files the reference binary wrote for
@@ -171,20 +171,18 @@ def test_default_ba_with_automatic_integration_resolution(tmp_path, oracle_lib, 
         assert filecmp.cmp(many / d / "traj_out.dat", one / "traj_out.dat", shallow=False)
 
 
-@pytest.mark.parametrize("what", ["cable robot without a cable limit", "JOINT path of a robot without forward kinematics", "BOTH path without orientations"])
+@pytest.mark.parametrize("what", ["cable robot without a cable limit", "JOINT path of a robot without forward kinematics"])
 def test_configurations_the_device_resampler_refuses(tmp_path, oracle_lib, what):
     """BA::exportResampleParams covers the path kinds of the shipped examples and the BASELINE configs; the rest is refused with
     a message and -1 instead of taking another code path (INTEGRATION.md 2 has the table and what the reference does with each:
-    a -1 of its own, undefined behaviour, or a configuration no shipped example uses)"""
+    a -1 of its own or undefined behaviour; BOTH paths without orientations, refused until round 5, are covered since round 6: golden
+    case UR5_pos3)"""
     if what == "cable robot without a cable limit":
         _stage(os.path.join(helpers.GOLD, "synth_cspr_s3"), tmp_path)
         _edit_config(tmp_path / "config.dat", {"isJntVelConOn": 0, "isJntAccConOn": 0, "isTrqConOn": 0})
-    elif what == "JOINT path of a robot without forward kinematics":
+    else:
         _stage(os.path.join(helpers.GOLD, "synth_ur_s2"), tmp_path)
         _edit_config(tmp_path / "config.dat", {"robotTypeStr": "UR"})
-    else:
-        _stage(os.path.join(helpers.GOLD, "UR5"), tmp_path)
-        _edit_config(tmp_path / "config.dat", {"nCart": 3})
     for tool, args in (("batest_oracle", ["config.dat"]), ("batest_batch_oracle", ["config.dat", "2"])):
         r = subprocess.run([os.path.join(helpers.BUILD, tool)] + args, cwd=tmp_path, capture_output=True, text=True)
         assert r.returncode != 0, (what, tool, r.stdout[-1500:])

@@ -245,7 +245,7 @@ def test_block_upload_of_paths_that_carry_more_rows_than_the_batch_keeps(hip_ctx
     b.close(); r.close()
 
 
-@pytest.mark.parametrize("name", ["synth_cspr_s3", "synth_gen7dof_s0", "synth_ur_s2", "GEN7DOF", "CSPR3DOF", "UR5", "KUKA-LWR-IV", "KUKA_cartacc", "RR", "RR_acc"])
+@pytest.mark.parametrize("name", ["synth_cspr_s3", "synth_gen7dof_s0", "synth_ur_s2", "GEN7DOF", "CSPR3DOF", "UR5", "UR5_pos3", "KUKA-LWR-IV", "KUKA_cartacc", "RR", "RR_acc"])
 def test_product_batch_driver_on_gpu(tmp_path, name):
     """batotp_amd/host/_build/batest_batch (BA::optimizeBatch over the HIP library, device resampler and device output
     stage where the configuration allows them) writes the reference binary's files for every copy of the path"""

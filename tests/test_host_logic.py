@@ -112,7 +112,9 @@ def test_which_configurations_the_device_stages_cover():
                                            # pose paths (path type BOTH: axis-angle <-> quaternion)
                                            "KUKA-LWR-IV", "KUKA_cartacc", "RR", "RR_acc", "UR5", "UR5_nocartacc",
                                            # the cable robot with solveLinSys through the Jacobi SVD (isSVD = 1)
-                                           "CSPR3DOF_svd", "CSPR3DOF_par_svd"}
+                                           "CSPR3DOF_svd", "CSPR3DOF_par_svd",
+                                           # round 6: joints and tool POSITIONS taught together (path type BOTH with nCart = 3, no orientations)
+                                           "UR5_pos3"}
     # paths whose s is the teach time (sWeights 1 0 0) need no resampling stage: adjust_s returns at once (ba.cpp:416) and the
     # knots are the taught points after the host filters (BA::keepTaughtSpacing); the output stage runs on the device for them too
     teach_time = {"synth_gen7dof_s14_teachtime", "synth_gen7dof_s15_teachtime_decim2"}
