@@ -232,6 +232,8 @@ class Library:
             "batotp_hip_set_fast_forward": [P, I32],
             "batotp_hip_set_cert_hold": [P, I32],
             "batotp_hip_set_poison": [P, I32],
+            "batotp_hip_set_resample_trace": [P, I32],
+            "batotp_hip_resampled_trace": [P, C.POINTER(C.c_uint64)],
             "batotp_hip_set_k3_form": [P, I32],
             "batotp_hip_set_path_order": [P, I32],
             "batotp_hip_set_workspace_budget": [P, C.c_int64, C.c_int64],
@@ -300,6 +302,10 @@ class Context:
         library.check(library.lib.batotp_hip_ctx_create(device, C.byref(self.handle)), "batotp_hip_ctx_create")
         if DEFAULT_POISON:
             self.set_poison(True)
+
+    def set_resample_trace(self, on: bool):
+        """one-path resample calls keep a checksum of every intermediate stage (Resampled.trace)"""
+        self.library.check(self.library.lib.batotp_hip_set_resample_trace(self.handle, 1 if on else 0), "set_resample_trace")
 
     def set_poison(self, on: bool):
         """debug aid: workspaces and batch arrays are filled with 0xFF bytes before use (include/batotp_hip.h)"""
@@ -435,6 +441,12 @@ class Resampled:
         v = C.c_float(0)
         self.L.check(self.lib.batotp_hip_resampled_ms(self.handle, C.byref(v)), "resampled_ms")
         return float(v.value)
+
+    def trace(self) -> np.ndarray:
+        """checksums of the eight intermediate stages of a traced one-path call (include/batotp_hip.h)"""
+        out = np.zeros(8, dtype=np.uint64)
+        self.L.check(self.lib.batotp_hip_resampled_trace(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint64))), "resampled_trace")
+        return out
 
     def checksums(self) -> np.ndarray:
         """order-independent 64-bit checksum of every path's knots, computed where the knots are (include/batotp_hip.h)"""

@@ -123,6 +123,9 @@ struct batotp_ctx
    int fastForward = 1;   // certified fast-forward of the bisection in the sweep kernels that have it (bisect_fast_forward)
    int certHold = -1;     // k_sweep8, reverse sweep: hold of the certificate phase (-1 automatic, 0 = no certificate there, 1..8)
    int poison = 0;        // debug aid (batotp_hip_set_poison): every workspace / batch allocation is filled with 0xFF bytes before use
+   int rsTrace = 0;       // diagnostic (batotp_hip_set_resample_trace): a one-path resample call keeps a checksum of every intermediate stage
+   uint64_t rsTraceSums[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // ... of the call in progress (copied into its batotp_resampled)
+   unsigned long long *dTrace = nullptr;               // ... device scratch of the checksum kernel (3 x 8 bytes)
    int64_t rsBudget = 0, outBudget = 0; // scratch bytes a chunk of the resampler / output stage may take; 0 = from the free memory
    int pathOrder = 1;     // ragged batches: 1 = the sweeps take the paths longest first (SweepArgs::order), 0 = in the order given
    int k3Form = 1;        // per-knot evaluation of velocity / acceleration-only problems: 1 = k_pointwise_va (pointwise_va.hip.h), 0 = the general kernel
@@ -354,6 +357,7 @@ extern "C" int batotp_hip_ctx_destroy(batotp_ctx *ctx)
    for (Arena &a : ctx->ws)
       if (a.p) hipFree(a.p);
    if (ctx->xfer.p) hipFree(ctx->xfer.p);
+   if (ctx->dTrace) hipFree(ctx->dTrace);
    delete ctx;
    return BATOTP_OK;
 }
@@ -432,6 +436,13 @@ extern "C" int batotp_hip_set_fast_forward(batotp_ctx *ctx, int32_t on)
 {
    if (!ctx) return BATOTP_ERR_ARG;
    ctx->fastForward = on != 0 ? 1 : 0;
+   return BATOTP_OK;
+}
+
+extern "C" int batotp_hip_set_resample_trace(batotp_ctx *ctx, int32_t on)
+{
+   if (!ctx) return BATOTP_ERR_ARG;
+   ctx->rsTrace = on ? 1 : 0;
    return BATOTP_OK;
 }
 

@@ -277,11 +277,21 @@ int BA::deviceResampleOne(Traj &traj)
    const bool poses = rsp.path_type == BATOTP_PATH_BOTH && _nCart == 6;
    const int rowsOut = (int)(_nJoints + _nCart) + (poses ? 1 : 0); // aa2qVect leaves position + quaternion rows (reference ba.cpp:335)
    bool agreed = false;
+   // every evaluation keeps a checksum of each of its intermediate stages (batotp_hip_set_resample_trace): two evaluations that
+   // disagree then say in which stage -- which kernel's output -- they first differ
+   static const char *const kStage[8] = {"taught points after close-point removal", "their sites (first adjust_s pass)", "their second derivatives",
+                                         "points emitted by interpSpecial", "those points in the second pass", "their sites (second pass)",
+                                         "their second derivatives", "knots"};
+   uint64_t trace[8] = {0, 0, 0, 0, 0, 0, 0, 0}, traceAgain[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+   bool haveTrace = false;
+   batotp_hip_set_resample_trace(_gpu->ctx, 1);
+   struct TraceOff { batotp_ctx *c; ~TraceOff() { batotp_hip_set_resample_trace(c, 0); } } traceOff{_gpu->ctx};
    for (int pass = 0; pass < 4 && !agreed; ++pass)
    {
       ResampledGuard rs;
       int rc = batotp_hip_resample(_gpu->ctx, &rsp, 1, &n, x.data(), &sresIn, &rs.r);
       if (rc) return fail("resample", rc);
+      const bool traced = batotp_hip_resampled_trace(rs.r, traceAgain) == BATOTP_OK;
       int64_t nK = 0;
       double sr = 0;
       uint32_t st = 0;
@@ -314,12 +324,23 @@ int BA::deviceResampleOne(Traj &traj)
                    "first different value at index %zu of %zu", pass, pass + 1, (long long)nKnots, (long long)nK, status, st, sres, sr, at, y.size());
             if (at < y.size() && at < yAgain.size()) printf(": %.17g / %.17g", y[at], yAgain[at]);
             printf(")%s\n", pass < 3 ? ": evaluating again." : ".");
+            if (traced && haveTrace)
+            {
+               int firstStage = -1;
+               for (int k = 0; k < 8 && firstStage < 0; ++k)
+                  if (trace[k] != traceAgain[k]) firstStage = k;
+               printf("interpInputData(): stage checksums of the two evaluations:");
+               for (int k = 0; k < 8; ++k) printf(" [%d] %016llx/%016llx", k, (unsigned long long)trace[k], (unsigned long long)traceAgain[k]);
+               printf("; first difference in stage %d (%s).\n", firstStage, firstStage >= 0 ? kStage[firstStage] : "none: the difference lies outside the traced arrays");
+            }
          }
       }
       // the latest evaluation is the one the next is compared with (and the one that is used once two in a row agree)
       nKnots = nK; sres = sr; status = st; integ = integP; scale = scaleP;
       for (int k = 0; k < 3; ++k) sw[k] = swP[k];
       y.swap(yAgain);
+      haveTrace = traced;
+      for (int k = 0; k < 8; ++k) trace[k] = traceAgain[k];
       batotp_hip_resampled_ms(rs.r, &ms);
    }
    if (!agreed)

@@ -492,6 +492,14 @@ int  batotp_hip_resampled_download(batotp_resampled *r, int32_t path, double *y)
  * counts, spacings, status words and these sums agree (one unexplained wrong result in ~11 000 one-path calls of
  * round 4) -- a many-path batch is compared in HBM, 8 bytes per path cross PCIe. */
 int  batotp_hip_resampled_checksums(batotp_resampled *r, uint64_t *sums);
+/* diagnostic of that protection: with batotp_hip_set_resample_trace(ctx, 1) a ONE-PATH call of batotp_hip_resample also keeps the same
+ * kind of checksum of every intermediate stage -- [0] the taught points after close-point removal / filtering (ba.cpp:160-242), [1] their
+ * sites s (adjust_s, first pass), [2] their second derivatives, [3] the points interpSpecial emitted (ba.cpp:651-781), [4] those points as
+ * the second pass sees them, [5] their sites, [6] their second derivatives, [7] the knots -- so that two evaluations that disagree can
+ * name the stage where they first differ.  batotp_hip_resampled_trace returns BATOTP_ERR_STATE for a call that was not traced.
+ * BA::interpInputData switches it on for its evaluations (milliseconds per path). */
+int  batotp_hip_set_resample_trace(batotp_ctx *ctx, int32_t on);
+int  batotp_hip_resampled_trace(batotp_resampled *r, uint64_t *sums /* [8] */);
 int  batotp_hip_resampled_ms(batotp_resampled *r, float *ms);
 
 /* ---- output stage behind the hot path ------------------------------------ */

@@ -195,6 +195,33 @@ def test_knot_checksums_computed_in_hbm_equal_the_checkers(hip_ctx, oracle_ctx):
     h.close(); o.close()
 
 
+def test_one_path_calls_can_keep_a_checksum_of_every_intermediate_stage(hip_lib):
+    """batotp_hip_set_resample_trace: the diagnostic behind the two-evaluations guard of BA::interpInputData -- eight stage checksums of a
+    one-path call, the same from call to call, the last one the checksum of the knots; a call with more than one path keeps none"""
+    ctx = capi.Context(hip_lib, 0)
+    ctx.set_resample_trace(True)
+    traces = []
+    for name in ("synth_gen7dof_s0", "synth_cspr_s3", "UR5_pos3"):
+        c = ResampleCase(name)
+        per_case = []
+        for _ in range(3):
+            r = capi.Resampled(ctx, c.params, [c.x], [c.sres_in])
+            t = r.trace()
+            assert int(t[7]) == int(r.checksums()[0]) and all(int(v) != 0 for v in t), (name, t)
+            assert_bit_equal(r.knots(0), c.y, name)
+            per_case.append(t.tobytes())
+            r.close()
+        assert len(set(per_case)) == 1, name
+        traces.append(per_case[0])
+    assert len(set(traces)) == 3
+    c = ResampleCase("synth_gen7dof_s0")
+    r = capi.Resampled(ctx, c.params, [c.x, c.x], [c.sres_in] * 2)
+    with pytest.raises(capi.BatotpError):
+        r.trace()
+    r.close()
+    ctx.close()
+
+
 def helpers_big_gen7(seed):
     """taught points of a GEN7DOF path of ~5e4 knots (bench.py's generator), widened to the resampler's rows"""
     import bench

@@ -47,7 +47,9 @@ def run_tool(tool, work, env=None):
     r = subprocess.run([tool, "config.dat"], cwd=work, capture_output=True, text=True, env=env)
     if r.returncode != 0:
         return None, r.stdout[-500:] + r.stderr[-500:]
-    return open(os.path.join(work, "knots.bin"), "rb").read(), r.stdout[-300:]
+    # (round 6: BA::interpInputData evaluates the resampler until two consecutive evaluations agree and reports a disagreement)
+    report = [l for l in r.stdout.splitlines() if "disagree" in l or "stage checksums" in l]
+    return open(os.path.join(work, "knots.bin"), "rb").read(), ("[DISAGREE] " + " || ".join(report) + " || " if report else "") + r.stdout[-300:]
 
 
 def parse(kb):
@@ -164,6 +166,8 @@ def main():
             # a second attempt right away, alone: does the same input come out right?
             kb2, _ = run_tool(BAKNOTS, work)
             rec["retry_equal_oracle"] = bool(kb2 is not None and hashlib.sha256(kb2).hexdigest() == want[seed][0])
+        elif msg.startswith("[DISAGREE]"):
+            rec = dict(round=rnd, seed=seed, kind="right knots after the guard reported two evaluations that disagree", msg=msg)
         shutil.rmtree(work, ignore_errors=True)
         return rec
 
