@@ -183,7 +183,7 @@ def test_knot_checksums_computed_in_hbm_equal_the_checkers(hip_ctx, oracle_ctx):
     incl. a path that ends with a status (sum 0) and BASELINE-size paths"""
     c = ResampleCase("synth_gen7dof_s0")
     same = c.x.copy(); same[:, :] = same[:, :1]
-    big = [helpers_big_gen7(s) for s in (1, 2)]
+    big = [_big_gen7_taught_points(s) for s in (1, 2)]
     xs = [c.x, c.x[:, : c.x.shape[1] // 2].copy(), same, c.x[:, ::-1].copy()] + big
     sr = [c.sres_in] * len(xs)
     h = capi.Resampled(hip_ctx, c.params, xs, sr)
@@ -222,7 +222,7 @@ def test_one_path_calls_can_keep_a_checksum_of_every_intermediate_stage(hip_lib)
     ctx.close()
 
 
-def helpers_big_gen7(seed):
+def _big_gen7_taught_points(seed):
     """taught points of a GEN7DOF path of ~5e4 knots (bench.py's generator), widened to the resampler's rows"""
     import bench
     taught, _ = bench.taught_points_f32("gen7", [seed], 50000)
