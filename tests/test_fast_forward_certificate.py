@@ -255,3 +255,94 @@ def test_the_division_free_check_of_the_general_form_certifies_the_real_one():
                     worst = max(worst, abs(d) / band)
     assert used > 200 and probes > 10000, (used, probes)
     assert worst < 0.1          # wrong signs of the approximate check occur only deep inside the band
+
+
+def _certain_failure(rng, x_top, A, v, D, thr_v, thr_a, sddot_max, trq):
+    """the certificate of a stage whose bisection cannot succeed (sweep1.hip.h, CERTAIN FAILURE; round 6): the sddot interval is empty at
+    x = 0 and the two lines that bind there have a negative gap at x_top as well -- both by more than 2^-40 E.  True / False."""
+    lines = []                                               # (au, al, m, e)
+    for q in range(len(A)):
+        if not (abs(v[q]) < thr_v):
+            rv = _rcp(rng, v[q])
+            au = A[q] * abs(rv)
+            m = D[q] * rv
+            lines.append((au, -au, m, au + abs(m) * x_top))
+    if trq is not None:
+        a1, a2, a4, tmax, tmin = trq
+        for q in range(len(a1)):
+            if not (abs(a1[q]) < thr_v):
+                r1 = _rcp(rng, a1[q])
+                q0, q1 = (tmax[q] - a4[q]) * r1, (tmin[q] - a4[q]) * r1
+                lines.append((max(q0, q1), min(q0, q1), a2[q] * r1,
+                              (abs(tmax[q]) + abs(tmin[q]) + 2.0 * abs(a4[q]) + abs(a2[q]) * x_top) * abs(r1)))
+    if not lines:
+        return False
+    u_min = min(l[0] for l in lines)
+    l_max = max(l[1] for l in lines)
+    e_max = max(l[3] for l in lines)
+    uB, lB = min(u_min, sddot_max), max(l_max, -sddot_max)
+    if not (0.5 * (uB - lB) < 0.0):
+        return False
+    mU = max(l[2] for l in lines if l[0] == u_min) if u_min < sddot_max else 0.0
+    mL = min(l[2] for l in lines if l[1] == l_max) if l_max > -sddot_max else 0.0
+    gap0 = uB - lB
+    gap_top = gap0 - (mU - mL) * x_top
+    tol = e_max * 2.0 ** -40
+    return bool(e_max < 1e100 and x_top < 1e100 and abs(mU) < 1e100 and abs(mL) < 1e100 and gap0 < -tol and gap_top < -tol)
+
+
+def test_a_certified_failure_fails_every_candidate_of_the_loop():
+    """torque lines whose limits cannot be met at rest (the cable robot outside its tension-feasible region): where the certificate says
+    "no speed in [0, first candidate] can pass a check", the real check (ba.cpp:1495-1534) must be violated at EVERY candidate of the
+    reference's loop (ba.cpp:1276-1320: the bracket shrinks below each violated candidate, then the speed is halved a hundred times) and
+    at random speeds in between; and the certificate must decline problems that are feasible somewhere in the interval"""
+    rng = np.random.default_rng(606)
+    certified = declined_feasible = probes = 0
+    for trial in range(3000):
+        nJ = int(rng.integers(1, 5))
+        A = 10.0 ** rng.uniform(-1, 2, nJ)
+        v = rng.normal(size=nJ) * 10.0 ** rng.uniform(-1, 1)
+        D = rng.normal(size=nJ) * 10.0 ** rng.uniform(-1, 2)
+        thr_v, thr_a = 1e-6, 1e-6
+        sddot_max = 10.0 ** rng.uniform(2, 8)
+        n = nJ
+        a1 = rng.normal(size=n) * 10.0 ** rng.uniform(-1, 1)
+        a2 = rng.normal(size=n) * 10.0 ** rng.uniform(-2, 1)
+        a4 = rng.normal(size=n) * 10.0
+        # tension-like limits [tmin, tmax] that a4 (gravity) may or may not fit into: sometimes infeasible at rest by a wide margin,
+        # sometimes barely, sometimes feasible
+        tmin = np.full(n, 1.0); tmax = np.full(n, 12.0)
+        shift = rng.choice([0.0, 0.0, 5.0, 20.0, 1e-9, 1e-13])
+        if rng.random() < 0.7:
+            k = rng.integers(0, n)
+            a4[k] = (tmax[k] + shift) if rng.random() < 0.5 else (tmin[k] - shift)    # a1 * sddot must then make up for it ...
+            j = (k + 1) % n
+            if n > 1 and rng.random() < 0.8:
+                # ... while another row with the opposite sign of a1 and no slack forbids that direction
+                a1[j] = -np.sign(a1[k]) * abs(a1[j]) if rng.random() < 0.5 else np.sign(a1[k]) * abs(a1[j])
+                a4[j] = (tmin[j] - shift) if a4[k] > tmax[k] - 1e-12 else (tmax[j] + shift)
+        trq = (a1, a2, a4, tmax, tmin)
+        c0 = 10.0 ** rng.uniform(-2, 1)
+        chk = lambda c: _real_check(c * c, c, A, v, D, thr_v, thr_a, sddot_max, trq)
+        if not chk(c0):
+            continue                                  # the certificate is only consulted after a violated first check
+        cert = _certain_failure(rng, c0 * c0, A, v, D, thr_v, thr_a, sddot_max, trq)
+        # the candidates of the reference's loop when every check is violated
+        cands, low, c = [c0], 0.01, c0
+        for _ in range(100):
+            low *= 2.0
+            lo = max(0.0, (1.0 - low) * c)
+            c = 0.5 * (c + lo)
+            cands.append(c)
+        extra = list(c0 * rng.uniform(0, 1, 40)) + [0.0, 1e-300, 1e-160]
+        feasible_somewhere = any(not chk(x) for x in cands + extra)
+        if cert:
+            certified += 1
+            for x in cands + extra:
+                probes += 1
+                assert chk(x), ("certified failure, but this speed passes the check", trial, x, c0)
+        elif not feasible_somewhere:
+            pass                                      # declining is always allowed (the hundred checks run)
+        else:
+            declined_feasible += 1
+    assert certified > 300 and declined_feasible > 100 and probes > 40000, (certified, declined_feasible, probes)
