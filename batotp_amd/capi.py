@@ -234,6 +234,7 @@ class Library:
             "batotp_hip_set_poison": [P, I32],
             "batotp_hip_set_resample_trace": [P, I32],
             "batotp_hip_resampled_trace": [P, C.POINTER(C.c_uint64)],
+            "batotp_hip_resampled_trace_data": [P, I32, D, I64, C.POINTER(I64)],
             "batotp_hip_set_k3_form": [P, I32],
             "batotp_hip_set_path_order": [P, I32],
             "batotp_hip_set_workspace_budget": [P, C.c_int64, C.c_int64],
@@ -446,6 +447,15 @@ class Resampled:
         """checksums of the eight intermediate stages of a traced one-path call (include/batotp_hip.h)"""
         out = np.zeros(8, dtype=np.uint64)
         self.L.check(self.lib.batotp_hip_resampled_trace(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint64))), "resampled_trace")
+        return out
+
+    def trace_data(self, stage: int) -> np.ndarray:
+        """the array of a traced stage that is kept on the host (2, 3); empty for the others"""
+        n = C.c_int64(0)
+        self.L.check(self.lib.batotp_hip_resampled_trace_data(self.handle, stage, None, 0, C.byref(n)), "resampled_trace_data")
+        out = np.empty(int(n.value), dtype=np.float64)
+        if n.value:
+            self.L.check(self.lib.batotp_hip_resampled_trace_data(self.handle, stage, _dptr(out), n.value, C.byref(n)), "resampled_trace_data")
         return out
 
     def checksums(self) -> np.ndarray:

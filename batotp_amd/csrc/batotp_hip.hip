@@ -126,6 +126,7 @@ struct batotp_ctx
    int rsTrace = 0;       // diagnostic (batotp_hip_set_resample_trace): a one-path resample call keeps a checksum of every intermediate stage
    uint64_t rsTraceSums[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // ... of the call in progress (copied into its batotp_resampled)
    unsigned long long *dTrace = nullptr;               // ... device scratch of the checksum kernel (3 x 8 bytes)
+   std::vector<double> rsTraceData[8];                 // ... and host copies of the stages a caller may want to look at (2, 3: see rsTraceSum)
    int64_t rsBudget = 0, outBudget = 0; // scratch bytes a chunk of the resampler / output stage may take; 0 = from the free memory
    int pathOrder = 1;     // ragged batches: 1 = the sweeps take the paths longest first (SweepArgs::order), 0 = in the order given
    int k3Form = 1;        // per-knot evaluation of velocity / acceleration-only problems: 1 = k_pointwise_va (pointwise_va.hip.h), 0 = the general kernel

@@ -284,6 +284,7 @@ int BA::deviceResampleOne(Traj &traj)
                                          "their second derivatives", "knots"};
    uint64_t trace[8] = {0, 0, 0, 0, 0, 0, 0, 0}, traceAgain[8] = {0, 0, 0, 0, 0, 0, 0, 0};
    bool haveTrace = false;
+   std::vector<double> stageKept[2];       // stages 2 and 3 of the previous evaluation
    batotp_hip_set_resample_trace(_gpu->ctx, 1);
    struct TraceOff { batotp_ctx *c; ~TraceOff() { batotp_hip_set_resample_trace(c, 0); } } traceOff{_gpu->ctx};
    for (int pass = 0; pass < 4 && !agreed; ++pass)
@@ -292,6 +293,17 @@ int BA::deviceResampleOne(Traj &traj)
       int rc = batotp_hip_resample(_gpu->ctx, &rsp, 1, &n, x.data(), &sresIn, &rs.r);
       if (rc) return fail("resample", rc);
       const bool traced = batotp_hip_resampled_trace(rs.r, traceAgain) == BATOTP_OK;
+      std::vector<double> stageAgain[2];   // stages 2 and 3 of this evaluation (a few MB)
+      if (traced)
+         for (int k = 0; k < 2; ++k)
+         {
+            int64_t cnt = 0;
+            if (batotp_hip_resampled_trace_data(rs.r, 2 + k, nullptr, 0, &cnt) == BATOTP_OK && cnt > 0)
+            {
+               stageAgain[k].resize((size_t)cnt);
+               batotp_hip_resampled_trace_data(rs.r, 2 + k, stageAgain[k].data(), cnt, &cnt);
+            }
+         }
       int64_t nK = 0;
       double sr = 0;
       uint32_t st = 0;
@@ -332,6 +344,24 @@ int BA::deviceResampleOne(Traj &traj)
                printf("interpInputData(): stage checksums of the two evaluations:");
                for (int k = 0; k < 8; ++k) printf(" [%d] %016llx/%016llx", k, (unsigned long long)trace[k], (unsigned long long)traceAgain[k]);
                printf("; first difference in stage %d (%s).\n", firstStage, firstStage >= 0 ? kStage[firstStage] : "none: the difference lies outside the traced arrays");
+               if (firstStage == 2 || firstStage == 3)
+               {
+                  // both evaluations' arrays of that stage, for a look at WHERE they differ
+                  const std::vector<double> &a = stageKept[firstStage - 2], &b = stageAgain[firstStage - 2];
+                  size_t nd = 0, first = 0, last = 0;
+                  for (size_t i = 0; i < a.size() && i < b.size(); ++i)
+                     if (std::memcmp(&a[i], &b[i], sizeof(double)) != 0) { if (!nd) first = i; last = i; ++nd; }
+                  printf("interpInputData(): stage %d arrays: %zu / %zu values, %zu differ, first at %zu, last at %zu", firstStage, a.size(), b.size(), nd, first, last);
+                  char name[96];
+                  for (int w = 0; w < 2; ++w)
+                  {
+                     std::snprintf(name, sizeof(name), "resampler_disagreement_stage%d_eval%d.bin", firstStage, pass + w);
+                     FILE *f = std::fopen(name, "wb");
+                     const std::vector<double> &v = w ? b : a;
+                     if (f) { std::fwrite(v.data(), sizeof(double), v.size(), f); std::fclose(f); }
+                  }
+                  printf("; written to resampler_disagreement_stage%d_eval%d.bin / _eval%d.bin.\n", firstStage, pass, pass + 1);
+               }
             }
          }
       }
@@ -341,6 +371,7 @@ int BA::deviceResampleOne(Traj &traj)
       y.swap(yAgain);
       haveTrace = traced;
       for (int k = 0; k < 8; ++k) trace[k] = traceAgain[k];
+      stageKept[0].swap(stageAgain[0]); stageKept[1].swap(stageAgain[1]);
       batotp_hip_resampled_ms(rs.r, &ms);
    }
    if (!agreed)

@@ -500,6 +500,10 @@ int  batotp_hip_resampled_checksums(batotp_resampled *r, uint64_t *sums);
  * BA::interpInputData switches it on for its evaluations (milliseconds per path). */
 int  batotp_hip_set_resample_trace(batotp_ctx *ctx, int32_t on);
 int  batotp_hip_resampled_trace(batotp_resampled *r, uint64_t *sums /* [8] */);
+/* ... and, for the stages kept on the host as well (2: the second derivatives of the taught points, channel-major; 3: the points
+ * interpSpecial emitted, point-major), the array itself: *count doubles (0 for a stage that is not kept); out may be NULL to ask for the
+ * count.  BA::interpInputData writes both evaluations' arrays to files when two evaluations first differ in one of these stages. */
+int  batotp_hip_resampled_trace_data(batotp_resampled *r, int32_t stage, double *out, int64_t cap, int64_t *count);
 int  batotp_hip_resampled_ms(batotp_resampled *r, float *ms);
 
 /* ---- output stage behind the hot path ------------------------------------ */

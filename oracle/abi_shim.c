@@ -94,6 +94,11 @@ int batotp_hip_set_poison(batotp_ctx *ctx, int32_t on) { (void)ctx; (void)on; re
 int batotp_hip_set_resample_trace(batotp_ctx *ctx, int32_t on) { (void)ctx; (void)on; return BATOTP_OK; }
 /* (the checker keeps no intermediate stages: its resampler is one sequential function per path) */
 int batotp_hip_resampled_trace(batotp_resampled *r, uint64_t *sums) { (void)r; (void)sums; return BATOTP_ERR_STATE; }
+int batotp_hip_resampled_trace_data(batotp_resampled *r, int32_t stage, double *out, int64_t cap, int64_t *count)
+{
+    (void)r; (void)stage; (void)out; (void)cap; (void)count;
+    return BATOTP_ERR_STATE;
+}
 int batotp_hip_set_cert_hold(batotp_ctx *ctx, int32_t hold) { (void)ctx; return (hold >= -1 && hold <= 8) ? BATOTP_OK : BATOTP_ERR_ARG; }
 int batotp_hip_set_path_order(batotp_ctx *ctx, int32_t mode) { (void)ctx; return (mode == 0 || mode == 1) ? BATOTP_OK : BATOTP_ERR_ARG; }
 int batotp_hip_set_workspace_budget(batotp_ctx *ctx, int64_t resample_bytes, int64_t output_bytes) { (void)ctx; return (resample_bytes < 0 || output_bytes < 0) ? BATOTP_ERR_ARG : BATOTP_OK; }

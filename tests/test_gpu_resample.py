@@ -208,6 +208,10 @@ def test_one_path_calls_can_keep_a_checksum_of_every_intermediate_stage(hip_lib)
             r = capi.Resampled(ctx, c.params, [c.x], [c.sres_in])
             t = r.trace()
             assert int(t[7]) == int(r.checksums()[0]) and all(int(v) != 0 for v in t), (name, t)
+            # the arrays of stages 2 and 3 are kept on the host as well: second derivatives of the taught points, the emitted points
+            n_taught_kept = r.trace_data(2).size // c.y.shape[0]
+            assert r.trace_data(2).size % c.y.shape[0] == 0 and 4 <= n_taught_kept <= c.x.shape[1] and r.trace_data(3).size % c.y.shape[0] == 0
+            assert r.trace_data(0).size == 0 and not np.isnan(r.trace_data(2)).any() and not np.isnan(r.trace_data(3)).any()
             assert_bit_equal(r.knots(0), c.y, name)
             per_case.append(t.tobytes())
             r.close()

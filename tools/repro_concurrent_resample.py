@@ -168,6 +168,11 @@ def main():
             rec["retry_equal_oracle"] = bool(kb2 is not None and hashlib.sha256(kb2).hexdigest() == want[seed][0])
         elif msg.startswith("[DISAGREE]"):
             rec = dict(round=rnd, seed=seed, kind="right knots after the guard reported two evaluations that disagree", msg=msg)
+            keep = os.path.join(a.out, f"r{rnd}_s{seed}")
+            os.makedirs(keep, exist_ok=True)
+            for f in os.listdir(work):
+                if f.startswith("resampler_disagreement_") or f in ("path.dat", "config.dat"):
+                    shutil.copy(os.path.join(work, f), keep)
         shutil.rmtree(work, ignore_errors=True)
         return rec
 
