@@ -64,6 +64,10 @@ __device__ __forceinline__ bool s8_div_window_fwd(double x) { return sdiv_window
                      // SLOWER again (reduced batch, same box: reverse 626 against 601 ms, forward 417 against 386 ms; profiles/r06_b_*).
                      // The division is not what these wavefronts wait for.  Kept as an option, bit-identical.
 #endif
+#ifndef S8_SPEC_MID
+#define S8_SPEC_MID 0  // s8_certify's bisection replay forms both possible next candidates beside the test: a shorter dependent chain, four more
+                       // fp64 instructions per iteration -- bit-identical, reverse sweep 2.3 % SLOWER (profiles/r06_p_*): the block is issue-bound
+#endif
 #ifndef S8_FF
 #define S8_FF 1      // the certified fast-forward of the bisection (s8_certify), both directions (batotp_hip_set_fast_forward: bit 0 forward, bit 1 reverse)
 #endif
@@ -248,13 +252,24 @@ __device__ __forceinline__ void s8_certify(bool jOn, double thD, double thD2, do
       for (;;)
       {
          const double c = sdotTry, d = c * c - xThr;
+#if S8_SPEC_MID
+         // both possible next candidates, computed beside the test instead of behind it (the same sums as ba.cpp:1320 forms after the
+         // update: .5 * (c + sdotL) when c becomes sdotH, .5 * (sdotH + c) when it becomes sdotL; a lane that has stopped keeps c, which
+         // IS .5 * (sdotH + sdotL) by the invariant): the dependent chain of an iteration is square - subtract - compare - select
+         // instead of square - subtract - compare - select - add - halve
+         const double nextV = .5 * (c + sdotL), nextG = .5 * (sdotH + c);
+#endif
          const bool viol = d > 0.0;
          const bool goesOn = viol | (fabs(c - sdotL) > convThr * c);
          more = more & (fabs(d) > bandThr) & goesOn & (it < 90);
          if (!S8_ANY(more)) break;
          sdotH = (more & viol) ? c : sdotH;
          sdotL = (more & !viol) ? c : sdotL;
+#if S8_SPEC_MID
+         sdotTry = more ? (viol ? nextV : nextG) : c;
+#else
          sdotTry = .5 * (sdotH + sdotL);
+#endif
          it += more ? 1 : 0;
       }
       sdotGood = bisect ? sdotL : sdotGood;
