@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--resident", type=int, default=1024, help="paths of a resident batch sweeping meanwhile (0: none)")
     ap.add_argument("--idle", action="store_true", help="the resident batch sweeps once and then sits idle (what the red test had)")
+    ap.add_argument("--no-oracle", action="store_true", help="skip the oracle's knots (5 min of host time for 1024 seeds): detection rests on the "
+                    "report of the two-evaluations guard alone")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "repro"))
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
@@ -97,8 +99,11 @@ def main():
         shutil.rmtree(work)
     print(f"serial generation of {len(seeds)} inputs in {time.time() - t0:.1f} s", flush=True)
 
-    with cf.ThreadPoolExecutor(max_workers=min(a.jobs, os.cpu_count() or 1)) as ex:
-        want = dict(zip(seeds, ex.map(oracle_one, seeds)))
+    if a.no_oracle:
+        want = {s_: (None, 0, serial[s_]) for s_ in seeds}
+    else:
+        with cf.ThreadPoolExecutor(max_workers=min(a.jobs, os.cpu_count() or 1)) as ex:
+            want = dict(zip(seeds, ex.map(oracle_one, seeds)))
     by_digest = {v[0]: s for s, v in want.items()}
     gen_bad = [s for s in seeds if want[s][2] != serial[s]]
     print(f"generator in {a.jobs} threads against serial generation: {len(gen_bad)} different inputs {gen_bad[:8]}", flush=True)
@@ -143,7 +148,7 @@ def main():
             rec = dict(round=rnd, seed=seed, kind="generator produced a different input in this thread")
         elif kb is None:
             rec = dict(round=rnd, seed=seed, kind="failed", msg=msg)
-        elif hashlib.sha256(kb).hexdigest() != want[seed][0]:
+        elif want[seed][0] is not None and hashlib.sha256(kb).hexdigest() != want[seed][0]:
             keep = os.path.join(a.out, f"r{rnd}_s{seed}")
             os.makedirs(keep, exist_ok=True)
             open(os.path.join(keep, "device_knots.bin"), "wb").write(kb)
