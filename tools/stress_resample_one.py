@@ -12,7 +12,7 @@ The resampler is a deterministic function of its input: ANY difference is a faul
 the process and of the context in calls, the first stage whose checksum differs, and -- from the host copies of the stage-2 and stage-3 arrays
 the trace keeps -- how many values differ, in which rows, first / last index, the size of the difference; both arrays go to --out as .npy.
 
-usage: stress_resample_one.py [--jobs 64] [--seconds 300] [--life 60] [--calls-per-context 8] [--knots 50000] [--resident 1024] [--out gpurun_out/stress_rs]
+usage: stress_resample_one.py [--alternate] [--jobs 64] [--seconds 300] [--life 60] [--calls-per-context 8] [--knots 50000] [--resident 1024] [--out gpurun_out/stress_rs]
 """
 import argparse
 import json
@@ -30,29 +30,36 @@ sys.path.insert(0, ROOT)
 STAGES = ["taught points", "their sites", "their second derivatives", "emitted points", "stage-1 points", "stage-1 sites", "stage-1 second derivatives", "knots"]
 
 
-def worker(k, wave, knots, life, per_ctx, out, q):
+def worker(k, wave, knots, life, per_ctx, out, q, alternate=False):
     import bench
     from batotp_amd import capi
     seed = 7000 + k
-    taught, sres_in = bench.taught_points_f32("gen7", [seed], knots)
-    x = bench.widen("gen7", taught[0])
+    # --alternate: two different paths take turns, so that every address of the workspaces holds the OTHER path's data from the call
+    # before -- a repetition of ONE path cannot see a stale read (a cache line or a buffer that was not refreshed holds the right values
+    # anyway); the soak's wrong evaluations were both the second of their process, the one whose workspaces have just moved
+    seeds = [seed, seed + 5000] if alternate else [seed]
+    taught, sres_in = bench.taught_points_f32("gen7", seeds, knots)
+    xs = [bench.widen("gen7", t) for t in taught]
     prm = bench.resample_params("gen7", capi.Problem())      # (a joint path of a generic robot: the pose matrix is not used)
     lib = capi.load_hip()
-    calls, ctxs, bad, ref, ref_data = 0, 0, [], None, None
+    calls, ctxs, bad = 0, 0, []
+    refs, refs_data = [None] * len(xs), [None] * len(xs)
     t0 = time.time()
     while time.time() - t0 < life:
         ctx = capi.Context(lib, 0)
         ctx.set_resample_trace(True)
         ctxs += 1
         for j in range(per_ctx):
+            w = calls % len(xs)
+            x, ref, ref_data = xs[w], refs[w], refs_data[w]
             r = capi.Resampled(ctx, prm, [x], [sres_in])
             t = r.trace()
             calls += 1
             if ref is None:
-                ref, ref_data = t.copy(), (r.trace_data(2), r.trace_data(3), int(r.n_knots[0]), float(r.sres[0]))
+                refs[w], refs_data[w] = t.copy(), (r.trace_data(2), r.trace_data(3), int(r.n_knots[0]), float(r.sres[0]))
             elif t.tobytes() != ref.tobytes():
                 first = int(np.nonzero(t != ref)[0][0])
-                rec = dict(worker=k, wave=wave, seed=seed, call_of_process=calls, call_of_context=j + 1, context_of_process=ctxs,
+                rec = dict(worker=k, wave=wave, seed=seeds[w], call_of_process=calls, call_of_context=j + 1, context_of_process=ctxs,
                            first_stage=first, first_stage_name=STAGES[first], stages_differ=[int(v) for v in np.nonzero(t != ref)[0]],
                            n_knots=[ref_data[2], int(r.n_knots[0])], sres=[ref_data[3], float(r.sres[0])], status=int(r.status[0]))
                 for st, good in ((2, ref_data[0]), (3, ref_data[1])):
@@ -87,6 +94,7 @@ def main():
     ap.add_argument("--life", type=float, default=60.0)
     ap.add_argument("--calls-per-context", type=int, default=8)
     ap.add_argument("--knots", type=int, default=50000)
+    ap.add_argument("--alternate", action="store_true", help="every process alternates between two different paths (sees stale reads)")
     ap.add_argument("--resident", type=int, default=1024, help="paths of a resident batch sweeping meanwhile (0: none)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "stress_rs"))
     a = ap.parse_args()
@@ -115,7 +123,7 @@ def main():
     wave, calls, ctxs, procs_n, bad = 0, 0, 0, 0, []
     while time.time() - t0 < a.seconds:
         q = mpc.Queue()
-        procs = [mpc.Process(target=worker, args=(k, wave, a.knots, a.life, a.calls_per_context, a.out, q)) for k in range(a.jobs)]
+        procs = [mpc.Process(target=worker, args=(k, wave, a.knots, a.life, a.calls_per_context, a.out, q, a.alternate)) for k in range(a.jobs)]
         for p in procs:
             p.start()
         res = [q.get(timeout=a.life * 4 + 600) for _ in procs]
