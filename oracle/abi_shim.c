@@ -17,7 +17,7 @@
 #include "batotp_models.h" /* robot parameter tables: data, shared with the product */
 #include "batotp_oracle.h"
 
-struct batotp_ctx { int device; };
+struct batotp_ctx { int device; int rs_trace; };
 
 struct batotp_batch {
     batotp_problem prob;
@@ -91,14 +91,9 @@ int batotp_hip_set_spline_tiles(batotp_ctx *ctx, int32_t on) { (void)ctx; (void)
 int batotp_hip_set_flat_form(batotp_ctx *ctx, int32_t form) { (void)ctx; (void)form; return BATOTP_OK; }
 int batotp_hip_set_fast_forward(batotp_ctx *ctx, int32_t on) { (void)ctx; (void)on; return BATOTP_OK; }
 int batotp_hip_set_poison(batotp_ctx *ctx, int32_t on) { (void)ctx; (void)on; return BATOTP_OK; }
-int batotp_hip_set_resample_trace(batotp_ctx *ctx, int32_t on) { (void)ctx; (void)on; return BATOTP_OK; }
-/* (the checker keeps no intermediate stages: its resampler is one sequential function per path) */
-int batotp_hip_resampled_trace(batotp_resampled *r, uint64_t *sums) { (void)r; (void)sums; return BATOTP_ERR_STATE; }
-int batotp_hip_resampled_trace_data(batotp_resampled *r, int32_t stage, double *out, int64_t cap, int64_t *count)
-{
-    (void)r; (void)stage; (void)out; (void)cap; (void)count;
-    return BATOTP_ERR_STATE;
-}
+/* the stage trace of one-path calls (batotp_hip_resampled_trace / _trace_data further down, beside the resampler): the checker observes
+ * the stages of its own sequential resampler (bo_resample_set_stage_observer) */
+int batotp_hip_set_resample_trace(batotp_ctx *ctx, int32_t on) { if (!ctx) return BATOTP_ERR_ARG; ctx->rs_trace = on != 0; return BATOTP_OK; }
 int batotp_hip_set_cert_hold(batotp_ctx *ctx, int32_t hold) { (void)ctx; return (hold >= -1 && hold <= 8) ? BATOTP_OK : BATOTP_ERR_ARG; }
 int batotp_hip_set_path_order(batotp_ctx *ctx, int32_t mode) { (void)ctx; return (mode == 0 || mode == 1) ? BATOTP_OK : BATOTP_ERR_ARG; }
 int batotp_hip_set_workspace_budget(batotp_ctx *ctx, int64_t resample_bytes, int64_t output_bytes) { (void)ctx; return (resample_bytes < 0 || output_bytes < 0) ? BATOTP_ERR_ARG : BATOTP_OK; }
@@ -511,7 +506,38 @@ struct batotp_resampled {
     double *y; /* concatenated knots, the layout batotp_hip_upload_knots expects */
     double *au; /* per path: integ_res, s_weights[3], scale_type (automatic integration resolution) */
     float ms;
+    /* stage trace of a one-path call (batotp_hip_set_resample_trace): the checksum of every stage, copies of stages 2 and 3 */
+    int traced;
+    uint64_t trace[8];
+    double *tdata[2];
+    int64_t tcnt[2];
 };
+
+static uint64_t shim_mix64(uint64_t x);
+static uint64_t shim_checksum(const double *y, int64_t total)
+{
+    uint64_t h = 0;
+    int64_t i;
+    for (i = 0; i < total; i++) {
+        uint64_t bits;
+        memcpy(&bits, y + i, sizeof(bits));
+        h += shim_mix64(bits ^ ((uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull));
+    }
+    return h;
+}
+static void shim_observe_stage(void *user, int stage, const double *data, int64_t count)
+{
+    batotp_resampled *r = (batotp_resampled *)user;
+    if (stage < 0 || stage > 7 || count < 0) return;
+    r->trace[stage] = shim_checksum(data, count);
+    if (stage == 2 || stage == 3) {
+        const int k = stage - 2;
+        free(r->tdata[k]);
+        r->tdata[k] = (double *)malloc(sizeof(double) * (size_t)(count ? count : 1));
+        memcpy(r->tdata[k], data, sizeof(double) * (size_t)count);
+        r->tcnt[k] = count;
+    }
+}
 
 int batotp_hip_set_overlap(batotp_ctx *ctx, int32_t on) { (void)on; return ctx ? BATOTP_OK : BATOTP_ERR_ARG; }
 int batotp_hip_ctx_trim(batotp_ctx *ctx) { return ctx ? BATOTP_OK : BATOTP_ERR_ARG; }
@@ -520,6 +546,7 @@ int batotp_hip_resampled_destroy(batotp_resampled *r)
 {
     if (!r) return BATOTP_OK;
     free(r->n); free(r->off); free(r->sres); free(r->status); free(r->y); free(r->au);
+    free(r->tdata[0]); free(r->tdata[1]);
     free(r);
     return BATOTP_OK;
 }
@@ -544,6 +571,18 @@ static void shim_inject_resample_fault(batotp_resampled *r, int64_t total)
             if (r->n[p] > 0 && !r->status[p]) {
                 double *v = r->y + r->off[p] * r->C + (r->n[p] * r->C) / 2;
                 *v = nextafter(*v, 1e300);
+                if (r->traced) {
+                    /* a traced call shows the fault the way the event of round 6 looked: stages 0 and 1 as they were, one value of
+                     * stage 2 moved by an ulp, every later stage different */
+                    int k;
+                    if (r->tcnt[0] > 0) {
+                        double *w = r->tdata[0] + r->tcnt[0] / 2;
+                        *w = nextafter(*w, 1e300);
+                        r->trace[2] = shim_checksum(r->tdata[0], r->tcnt[0]);
+                    }
+                    for (k = 3; k < 7; ++k) r->trace[k] ^= 1;
+                    r->trace[7] = shim_checksum(r->y + r->off[p] * r->C, r->n[p] * r->C);
+                }
             }
         }
         env = (*end == ',') ? end + 1 : end;
@@ -575,6 +614,13 @@ int batotp_hip_resample(batotp_ctx *ctx, const batotp_resample_params *prm, int3
     xoff = (int64_t *)calloc((size_t)n_paths, sizeof(int64_t));
     for (p = 1; p < n_paths; ++p) xoff[p] = xoff[p - 1] + n_in[p - 1] * Cin;
     clock_gettime(CLOCK_MONOTONIC, &t0);
+    r->traced = ctx->rs_trace && n_paths == 1;
+    if (r->traced) {
+        /* one path, on the calling thread, its stages observed */
+        bo_resample_set_stage_observer(shim_observe_stage, r);
+        if (bo_resample_auto(prm, n_in[0], x, sres_in[0], &ys[0], &r->n[0], &r->sres[0], &r->status[0], r->au) != 0) bad = 1;
+        bo_resample_set_stage_observer(NULL, NULL);
+    } else
 #pragma omp parallel for schedule(dynamic, 1)
     for (p = 0; p < n_paths; ++p)
         if (bo_resample_auto(prm, n_in[p], x + xoff[p], sres_in[p], &ys[p], &r->n[p], &r->sres[p], &r->status[p], r->au + 5 * (size_t)p) != 0) {
@@ -662,6 +708,26 @@ int batotp_hip_resampled_checksums(batotp_resampled *r, uint64_t *sums)
             h += shim_mix64(bits ^ ((uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull));
         }
         sums[p] = h;
+    }
+    return BATOTP_OK;
+}
+
+int batotp_hip_resampled_trace(batotp_resampled *r, uint64_t *sums)
+{
+    int k;
+    if (!r || !sums) return BATOTP_ERR_ARG;
+    if (!r->traced) return BATOTP_ERR_STATE;
+    for (k = 0; k < 8; ++k) sums[k] = r->trace[k];
+    return BATOTP_OK;
+}
+int batotp_hip_resampled_trace_data(batotp_resampled *r, int32_t stage, double *out, int64_t cap, int64_t *count)
+{
+    if (!r || !count || stage < 0 || stage > 7) return BATOTP_ERR_ARG;
+    if (!r->traced) return BATOTP_ERR_STATE;
+    *count = (stage == 2 || stage == 3) ? r->tcnt[stage - 2] : 0;
+    if (out) {
+        if (cap < *count) return BATOTP_ERR_ARG;
+        if (*count) memcpy(out, r->tdata[stage - 2], sizeof(double) * (size_t)*count);
     }
     return BATOTP_OK;
 }

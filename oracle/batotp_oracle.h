@@ -122,6 +122,13 @@ int  bo_resample(const bo_resample_params *prm, int64_t n_in, const double *x, d
                  double **y_out, int64_t *n_out, double *sres_out, uint32_t *status);
 int  bo_resample_auto(const bo_resample_params *prm, int64_t n_in, const double *x, double sres_in, double **y_out, int64_t *n_out,
                       double *sres_out, uint32_t *status, double auto_out[5]);
+/* Observer of the resampler's intermediate stages, for the CALLING THREAD (NULL: none): while set, bo_resample / bo_resample_auto hand it
+ * the arrays the stage trace of the product names (batotp_hip_set_resample_trace, include/batotp_hip.h) -- 0: taught points after
+ * close-point removal, 1: their sites, 2: their spline coefficients ([C][4][n]; the product keeps second derivatives), 3: the points
+ * interpSpecial emitted, 4-6: the same three of the second pass, 7: the knots.  The checker's ABI shim uses it to exercise the reporting
+ * path of the host library's two-evaluations guard on the CPU. */
+typedef void (*bo_resample_stage_fn)(void *user, int stage, const double *data, int64_t count);
+void bo_resample_set_stage_observer(bo_resample_stage_fn fn, void *user);
 
 /* Output stage behind the hot path: BA::interpOutputData (ba.cpp:1661-1931) for JOINT paths
  * without kinematic model and without torque constraints.  p: the path as precomputed for the sweep;

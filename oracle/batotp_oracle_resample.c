@@ -16,6 +16,12 @@
 
 #include "batotp_oracle.h"
 
+/* stage observer of the calling thread (batotp_oracle.h) */
+static __thread bo_resample_stage_fn rs_obs = NULL;
+static __thread void *rs_obs_user = NULL;
+void bo_resample_set_stage_observer(bo_resample_stage_fn fn, void *user) { rs_obs = fn; rs_obs_user = user; }
+#define RS_STAGE(k, ptr, cnt) do { if (rs_obs) rs_obs(rs_obs_user, (k), (ptr), (int64_t)(cnt)); } while (0)
+
 typedef struct rs_traj {
     int     nJ, nC, C;
     int64_t n;
@@ -263,6 +269,7 @@ static unsigned rs_special(const bo_resample_params *prm, rs_traj *t, const doub
     const int nJ = t->nJ, nC = t->nC, C = t->C;
     const int cartEval = (prm->flags & (BATOTP_F_CART_VEL_ON | BATOTP_F_CART_ACC_ON)) != 0;
     double *coef = rs_all_coeffs(t);
+    RS_STAGE(2, coef, (int64_t)C * 4 * n);
     int64_t chunk = (int64_t)ceil(sc->sLast / sc->sResNew) + 1; /* ba.cpp:666-667 */
     if (chunk < 4) chunk = 4;
     int64_t cap = chunk;
@@ -361,6 +368,7 @@ static unsigned rs_regular(rs_traj *t, const double *sC, const rs_scale *sc)
     if (bo_find_interp_segs(sC, n, sites, nNew, seg, tau) != 0) st = BATOTP_RS_SEG_ERROR;
     if (!st) {
         double *coef = rs_all_coeffs(t);
+        RS_STAGE(6, coef, (int64_t)C * 4 * n);
         double *y = (double *)malloc(sizeof(double) * (size_t)nNew * C);
         double *d1 = (double *)malloc(sizeof(double) * (size_t)nNew), *d2 = (double *)malloc(sizeof(double) * (size_t)nNew);
         for (int c = 0; c < C; ++c) bo_interp1_spline(coef + (size_t)c * 4 * n, n, seg, tau, nNew, oldRes, y + c * nNew, d1, d2);
@@ -422,11 +430,14 @@ int bo_resample_auto(const bo_resample_params *prm, int64_t n_in, const double *
     for (int pass = 0; pass < 2 && !st; ++pass) {
         double *sC = (double *)malloc(sizeof(double) * (size_t)t.n);
         rs_scale sc;
+        RS_STAGE(pass ? 4 : 0, t.x, (int64_t)t.C * t.n);
         st |= rs_arclen(prm, &t, pass == 0, sC, &sc, &au);
+        if (!st) RS_STAGE(pass ? 5 : 1, sC, t.n);
         if (!st) st |= pass == 0 ? rs_special(prm, &t, sC, &sc) : rs_regular(&t, sC, &sc);
         free(sC);
         if (!st && cable) rs_invkin_cspr(&t, prm->pmat); /* ba.cpp:630 */
         if (!st && kin) rs_fwdkin(&t, prm->robot_type);   /* ba.cpp:626-628: after either pass, whatever the constraints */
+        if (!st) RS_STAGE(pass ? 7 : 3, t.x, (int64_t)t.C * t.n);
     }
     auto_out[0] = au.integRes; auto_out[1] = prm->s_weights[0]; auto_out[2] = au.sw1; auto_out[3] = au.sw2; auto_out[4] = (double)au.scaleType;
     *status = st;

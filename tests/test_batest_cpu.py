@@ -220,3 +220,15 @@ def test_resampler_results_are_used_only_when_two_evaluations_agree(tmp_path, or
                 assert filecmp.cmp(work / d / "traj_out.dat", os.path.join(src, "ref_traj_out.dat"), shallow=False), fault
         else:
             assert "no two consecutive evaluations" in r.stdout, (fault, r.stdout[-2000:])
+        if not copies and fault == "2":
+            # the one-path route traces its stages: the report names the first stage whose checksum differs (the injected fault looks
+            # like the event of round 6: taught points and sites identical, one value of stage 2 moved) and keeps both evaluations'
+            # arrays of that stage -- evaluation 2 against 1, then 3 against 2
+            import numpy as np
+            assert "stage checksums of the two evaluations" in r.stdout and "first difference in stage 2 (their second derivatives)" in r.stdout, r.stdout[-3000:]
+            ev = [np.fromfile(work / f"resampler_disagreement_stage2_eval{k}.bin", dtype=np.uint64) for k in (1, 2, 3)]
+            assert ev[0].size == ev[1].size == ev[2].size > 0
+            assert np.array_equal(ev[0], ev[2]) and int((ev[0] != ev[1]).sum()) == 1
+            assert f"{ev[0].size} / {ev[0].size} values, 1 differ, first at {ev[0].size // 2}, last at {ev[0].size // 2}" in r.stdout, r.stdout[-3000:]
+        if not copies and not fault:
+            assert not [f for f in os.listdir(work) if f.startswith("resampler_disagreement")]

@@ -117,3 +117,41 @@ def test_knot_checksums_are_the_sums_the_header_describes(oracle_ctx):
             assert int(mix(bits ^ idx).sum(dtype=np.uint64)) == int(sums[k]), k
     assert int(sums[0]) != int(sums[1])
     r.close()
+
+
+def test_checker_keeps_the_stage_trace_of_one_path_calls(oracle_lib):
+    """batotp_hip_set_resample_trace through the checker (its resampler's stages observed: bo_resample_set_stage_observer): eight stage
+    checksums of a one-path call, the same from call to call, the last one the checksum of the knots; stages 2 and 3 are kept as arrays;
+    the knots are those of an untraced call; a call with more than one path keeps none (the product: tests/test_gpu_resample.py)"""
+    ctx = capi.Context(oracle_lib, 0)
+    plain = {}
+    for name in ("synth_gen7dof_s0", "synth_cspr_s3", "UR5_pos3"):
+        c = ResampleCase(name)
+        r = capi.Resampled(ctx, c.params, [c.x], [c.sres_in])
+        plain[name] = r.knots(0).tobytes()
+        with pytest.raises(capi.BatotpError):
+            r.trace()
+        r.close()
+    ctx.set_resample_trace(True)
+    seen = set()
+    for name in plain:
+        c = ResampleCase(name)
+        per_case = []
+        for _ in range(2):
+            r = capi.Resampled(ctx, c.params, [c.x], [c.sres_in])
+            t = r.trace()
+            assert int(t[7]) == int(r.checksums()[0]) and all(int(v) != 0 for v in t), (name, t)
+            assert r.trace_data(2).size > 0 and r.trace_data(3).size % c.y.shape[0] == 0 and r.trace_data(0).size == 0
+            assert r.knots(0).tobytes() == plain[name]
+            per_case.append(t.tobytes())
+            r.close()
+        assert len(set(per_case)) == 1, name
+        seen.add(per_case[0])
+    assert len(seen) == 3
+    c = ResampleCase("synth_gen7dof_s0")
+    r = capi.Resampled(ctx, c.params, [c.x, c.x], [c.sres_in] * 2)
+    with pytest.raises(capi.BatotpError):
+        r.trace()
+    r.close()
+    ctx.set_resample_trace(False)
+    ctx.close()
