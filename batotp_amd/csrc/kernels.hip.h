@@ -140,6 +140,19 @@ __device__ __forceinline__ void emit_segment(double *__restrict__ cf, int64_t i,
    *reinterpret_cast<Coef4 *>(cf + (i * C + dc) * 4) = o;
 }
 
+// The solve kernels PARK the eliminated right-hand sides in global memory and load them back in the back substitution, tens of thousands
+// of steps later in the same launch.  BK_PARK_RELOAD_AGENT = 1 makes that reload an agent-scope load (served by L2, never by a CU's vector
+// L1): bit-identical by construction, prepared as the first mitigation to measure against the transient wrong-knots event of rounds 4 and 6
+// (profiles/r06_i_*, last section).  Default 0: the shipped code is the code every measurement and parity run of round 6 used.
+#ifndef BK_PARK_RELOAD_AGENT
+#define BK_PARK_RELOAD_AGENT 0
+#endif
+#if BK_PARK_RELOAD_AGENT
+#define BK_PARK_RELOAD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define BK_PARK_RELOAD(ptr) (*(ptr))
+#endif
+
 // The Thomas solve of one series of N values (spline.cpp:252-276) and what follows it: SOL = false emits the
 // coefficient rows (emit_segment), SOL = true leaves the second derivatives sol[0..N-1] in dpark.
 // STRIDED = false: y and dpark are contiguous; true: element i of y is y[i*ys], of dpark dpark[i*ds].
@@ -209,7 +222,7 @@ __device__ __forceinline__ void thomas_series(int N, const double *__restrict__ 
 #pragma unroll
       for (int k = 0; k < CH; ++k)
       {
-         dd[k] = dpark[(i - 1 - k) * ds];
+         dd[k] = BK_PARK_RELOAD(&dpark[(i - 1 - k) * ds]);
          yy[k] = y[(i - 1 - k) * ys];
       }
 #pragma unroll
@@ -226,7 +239,7 @@ __device__ __forceinline__ void thomas_series(int N, const double *__restrict__ 
    {
       const double ci = (i - 1) < CONV ? c_ctab[i - 1] : cInf;
       const double yL = y[(i - 1) * ys];
-      const double solL = dpark[(i - 1) * ds] - ci * solR;
+      const double solL = BK_PARK_RELOAD(&dpark[(i - 1) * ds]) - ci * solR;
       if (SOL) dpark[(i - 1) * ds] = solL;
       else emit_segment(cf, i - 1, C, dc, solL, solR, yL, yR);
       solR = solL;

@@ -124,7 +124,7 @@ __device__ __forceinline__ bool thomas_series_lanes(int N, const double *__restr
       {
          int idx = j - k;
          idx = idx >= 1 ? idx : 1;
-         dd[k] = sol[idx];
+         dd[k] = BK_PARK_RELOAD(&sol[idx]); // (kernels.hip.h: optionally an agent-scope load)
       }
 #pragma unroll
       for (int k = 0; k < SL_CH; ++k)
@@ -146,7 +146,7 @@ __device__ __forceinline__ bool thomas_series_lanes(int N, const double *__restr
    {
       for (j = CONV - 1; j >= 1; --j) // the rows whose c[j] has not converged yet
       {
-         const double s = sol[j] - c_ctab[j] * sNext;
+         const double s = BK_PARK_RELOAD(&sol[j]) - c_ctab[j] * sNext;
          sol[j] = s;
          sNext = s;
       }
